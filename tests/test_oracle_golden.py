@@ -1,0 +1,199 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself (tools/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import equivariant as eq
+from oracle import graph as gr
+from oracle import trpl as tr
+from geometry_rl_amd import synthetic as syn
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def close(a, b, tol=1e-6, rel=1e-5):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs().max().item() if a.numel() else 0.0
+    scale = max(1.0, b.double().abs().max().item()) if b.numel() else 1.0
+    assert err <= tol + rel * scale, f"max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def test_grids_poly_softplus(golden_dir):
+    z = load(golden_dir, "tier1_basics.npz")
+    close(eq.make_grid(2, 16), z["grid_s1_16"], 1e-7)
+    close(eq.make_grid(3, 16), z["grid_s2_16"], 1e-7)
+    close(eq.make_grid(3, 16, True), z["grid_s2_16_upper"], 1e-7)
+    close(eq.make_grid(3, 20), z["grid_s2_20"], 1e-7)
+    close(eq.polynomial_features(z["poly_in2"]), z["poly_out2"], 1e-7)
+    close(eq.polynomial_features(z["poly_in1"]), z["poly_out1"], 1e-7)
+    close(tr.inverse_softplus(z["inv_softplus_in"]), z["inv_softplus_out"], 1e-7)
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_ponita_forward_backward_calibration(golden_dir, dim):
+    z = load(golden_dir, f"tier1_ponita_dim{dim}.npz")
+    P = {"ponita." + k[5:]: v.clone() for k, v in z.items() if k.startswith("init.")}
+    # first (calibrating) training call
+    y0 = eq.ponita_forward(P, z["x"], z["pos"], z["edge_index"], 2, "ponita", calibrate=True)
+    close(y0, z["y_first_call"], 2e-6)
+    for k, v in z.items():
+        if k.startswith("cal.") and v.dtype.is_floating_point:
+            close(P["ponita." + k[4:]], v, 2e-6)
+    # steady state forward/backward with the reference's calibrated weights
+    P = {"ponita." + k[4:]: v.clone().requires_grad_(v.dtype.is_floating_point and "ori_grid" not in k)
+         for k, v in z.items() if k.startswith("cal.")}
+    x = z["x"].clone().requires_grad_(True)
+    y = eq.ponita_forward(P, x, z["pos"], z["edge_index"], 2, "ponita")
+    close(y, z["y"], 2e-6)
+    (y * z["R"]).sum().backward()
+    close(x.grad, z["grad.x"], 1e-5, 1e-4)
+    n = 0
+    for k, v in z.items():
+        if k.startswith("grad.") and k != "grad.x":
+            close(P["ponita." + k[5:]].grad, v, 1e-5, 1e-4)
+            n += 1
+    assert n >= 20
+
+
+CASES = {
+    "rigid_g1": dict(spec=lambda: gr.rigid_spec(P=8, G=1, E_mesh=4), dim=3, od=2, ov=2),
+    "rigid_g2": dict(spec=lambda: gr.rigid_spec(P=8, G=2, E_mesh=4, angular_velocity=False, object_velocity=False),
+                     dim=3, od=1, ov=1),
+    "rope_dim2": dict(spec=lambda: gr.rope_spec(n_links=7, G=2), dim=2, od=1, ov=1),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_hepi_forward_backward_calibration(golden_dir, name):
+    c = CASES[name]
+    spec = c["spec"]()
+    z = load(golden_dir, f"tier2b_hepi_{name}.npz")
+    obs = {k[4:]: v for k, v in z.items() if k.startswith("obs.")}
+    split = gr.split_obs(spec, obs)
+    topo = gr.build_topology(spec, split, full_graph_obs=False)
+    for et, ei in topo["edge_index"].items():
+        assert torch.equal(ei, z["edge_index." + "|".join(et)])
+    graph, s, v = gr.build_features(spec, topo, split, dist_as_pos=True)
+    graph["output_mask_key"] = "grippers"
+    rounds = eq.hepi_schedule(spec.edge_types, spec.edge_levels, [[1, 0], [0, 1], [0, 1]])
+    kw = dict(dim=c["dim"], output_dim=c["od"], output_dim_vec=c["ov"], rounds=rounds)
+
+    P = {k[5:]: val.clone() for k, val in z.items() if k.startswith("init.")}
+    out0, hid0 = eq.hepi_forward(P, graph, s, v, calibrate=True, **kw)
+    close(out0, z["out_first_call"], 2e-6)
+    close(hid0, z["hidden_first_call"], 2e-6)
+    for k, val in z.items():
+        if k.startswith("cal.") and val.dtype.is_floating_point:
+            close(P[k[4:]], val, 2e-6)
+
+    P = {k[4:]: val.clone().requires_grad_(val.dtype.is_floating_point and "ori_grid" not in k)
+         for k, val in z.items() if k.startswith("cal.")}
+    out, hid = eq.hepi_forward(P, graph, s, v, **kw)
+    close(out, z["out"], 2e-6)
+    close(hid, z["hidden"], 2e-6)
+    ((out * z["R_out"]).sum() + (hid * z["R_hidden"]).sum()).backward()
+    n = 0
+    for k, val in z.items():
+        if k.startswith("grad."):
+            close(P[k[5:]].grad, val, 1e-5, 1e-4)
+            n += 1
+    assert n >= 20
+
+
+def test_projection_helpers(golden_dir):
+    z = load(golden_dir, "tier2_projection.npz")
+    B = z["hidden"].shape[0]
+    std = tr.std_head(z["hidden"], z["pre_std.weight"], z["pre_std.bias"], 1.0, 1e-5, B)
+    close(std ** 2, z["cov"].diagonal(dim1=-2, dim2=-1), 1e-6)
+    close(z["gnn_out"].reshape(B, -1), z["loc"], 0)
+    S, So = z["S"].diagonal(dim1=-2, dim2=-1), z["S_o"].diagonal(dim1=-2, dim2=-1)
+    close(tr.maha(z["mean"], z["mean_o"], So), z["maha"], 1e-5)
+    close(tr.log_determinant(S), z["logdet"], 1e-6)
+    close(tr.entropy_std(S), z["entropy"], 1e-6)
+    # log_probability(p, x) = -0.5 (maha + k log 2pi + logdet)   (gnn_gaussian_policy_diag.py:100-109)
+    lp = -0.5 * (tr.maha(z["x"], z["mean"], S) + S.shape[-1] * np.log(2 * np.pi) + tr.log_determinant(S))
+    close(lp, z["log_prob"], 1e-5)
+    mp, cp = tr.gaussian_kl((z["mean"], S), (z["mean_o"], So))
+    close(mp, z["kl_mean"], 1e-5)
+    close(cp, z["kl_cov"], 1e-5)
+    close(tr.mean_projection(z["mean"], z["mean_o"], mp, z["eps_mean"]), z["proj_mean"], 1e-6)
+    close(tr.mean_projection(z["mean"], z["mean_o"], mp, torch.tensor(1e6)), z["proj_mean_noop"], 0)
+    # trust-region loss + gradients (base_projection_layer.py:292-327), coefficient 4.0
+    m = z["mean"].clone().requires_grad_(True)
+    s = S.clone().requires_grad_(True)
+    pS = z["tr_proj_S"].diagonal(dim1=-2, dim2=-1)
+    a, b = tr.gaussian_kl((m, s), (z["proj_mean"], pS))
+    loss = (a + b).mean() * 4.0
+    loss.backward()
+    close(loss, z["tr_loss"], 1e-5)
+    close(m.grad, z["tr_grad_mean"], 1e-6)
+    close(s.grad, z["tr_grad_S"].diagonal(dim1=-2, dim2=-1), 1e-6)
+    # metrics (base_projection_layer.py:332-384)
+    mk, ck = tr.gaussian_kl((z["mean"], S), (z["proj_mean"], pS))
+    close((mk + ck).mean(), z["metric.kl"], 1e-5)
+    close(mk.mean(), z["metric.mean_constraint"], 1e-5)
+    close(mk.max(), z["metric.mean_constraint_max"], 1e-5)
+    close(ck.mean(), z["metric.cov_constraint"], 1e-5)
+    close(ck.max(), z["metric.cov_constraint_max"], 1e-5)
+    close(tr.entropy_std(S).mean(), z["metric.entropy"], 1e-5)
+    close((tr.entropy_std(pS) - tr.entropy_std(S)).mean(), z["metric.entropy_diff"], 1e-5)
+    # identity entropy projection with bound -inf
+    close(z["base_call_mean"], z["mean"], 0)
+    close(z["base_call_S"], z["S"], 0)
+
+
+def test_mvn_closed_form_matches_torch_distributions():
+    g = torch.Generator().manual_seed(0)
+    mean, var, x = torch.randn(7, 6, generator=g), torch.rand(7, 6, generator=g) + 0.3, torch.randn(7, 6, generator=g)
+    d = torch.distributions.MultivariateNormal(mean, covariance_matrix=var.diag_embed())
+    close(tr.mvn_diag_log_prob(x, mean, var), d.log_prob(x), 1e-5)
+    close(tr.mvn_diag_entropy(var), d.entropy(), 1e-5)
+
+
+def test_cov_projection_kkt_and_gradients():
+    """ITPAL restatement (parity unpinned): constraint residual <= 1e-6, identity inside the bound, FD gradient check."""
+    g = torch.Generator().manual_seed(2)
+    B, A, eps = 12, 6, 0.0025
+    S = (torch.rand(B, A, generator=g, dtype=torch.float64) + 0.5)
+    So = (torch.rand(B, A, generator=g, dtype=torch.float64) + 0.5)
+    S[0] = So[0] * 1.001  # inactive sample
+    proj = tr.project_cov_diag_kl(S, So, eps)
+    v, o = proj.pow(2), So.pow(2)
+    kl = 0.5 * (v / o - 1 - v.log() + o.log()).sum(-1)
+    assert torch.allclose(proj[0], S[0], atol=1e-12)
+    assert (kl[1:] - eps).abs().max() < 1e-6
+    assert kl[0] <= eps
+    Sg = S.clone().requires_grad_(True)
+    w = torch.randn(B, A, generator=g, dtype=torch.float64)
+    (tr.project_cov_diag_kl(Sg, So, eps) * w).sum().backward()
+    h = 1e-6
+    for (i, j) in [(1, 0), (3, 2), (7, 5), (0, 1)]:
+        Sp, Sm = S.clone(), S.clone()
+        Sp[i, j] += h
+        Sm[i, j] -= h
+        fd = ((tr.project_cov_diag_kl(Sp, So, eps) - tr.project_cov_diag_kl(Sm, So, eps)) * w).sum() / (2 * h)
+        assert abs(fd - Sg.grad[i, j]) < 1e-5 * max(1.0, abs(fd)), (i, j, fd, Sg.grad[i, j])
+
+
+def test_gae_shifted_matches_recursion():
+    d = syn.make_gae_inputs(5, 230, seed=1)
+    d["terminated"][:, 57] = True
+    d["done"][:, 57] = True
+    adv, tgt = tr.gae_shifted(d["reward"], d["done"], d["terminated"], d["values"])
+    # independent scalar recursion
+    r, dn, tm, v = (d[k].double() for k in ["reward", "done", "terminated", "values"])
+    ref = torch.zeros(5, 230, dtype=torch.float64)
+    for n in range(5):
+        run = 0.0
+        for t in reversed(range(230)):
+            delta = r[n, t] + 0.99 * (1 - tm[n, t]) * v[n, t + 1] - v[n, t]
+            run = delta + 0.99 * 0.95 * (1 - dn[n, t]) * run
+            ref[n, t] = run
+    close(adv, ref.float(), 1e-5)
+    close(tgt, (ref + v[:, :-1]).float(), 1e-5)

@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the oracle by importing the reference IN THIS CONTAINER.
+
+Run:  python tools/make_golden.py            (needs /root/reference; writes tests/golden/*.npz)
+
+The reference cannot be imported end-to-end here (PyG, torch_scatter, torchrl, tensordict, ITPAL are absent, SURVEY.md
+section 8c), so three tiers are used:
+
+  tier 1  modules that import unmodified (ponita.py, to_from_sphere.py, torch_utils.py): grids, polynomial features,
+          the full Ponita (EMPN core) forward/backward, calibration.
+  tier 2  modules imported under NAME-ONLY stubs for gymnasium / stable_baselines3 (no arithmetic in the stubs):
+          gaussian_kl, mean_projection, get_trust_region_loss, compute_metrics, GNNGaussianPolicyDiag helpers + std head.
+  tier 2b HEPi.one_step / FiberBundleConv / HeteroFiberConv run as reference code under stubs of the PyG container
+          classes.  These stubs DO carry the three PyG semantics the call sites rely on -- gather x_src[edge_index[0]],
+          scatter-sum over edge_index[1], sum of per-edge-type outputs -- restated from PyG 2.5.2; fixtures from this
+          tier are flagged ``tier2b`` and pin everything else in those files (invariants, bases, message, einsum,
+          calibration order, node MLP, readout).
+
+Only inputs/outputs (arrays) are written; no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
+
+
+def npd(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+# ----------------------------------------------------------------------------------------------- stubs
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Env:  # gymnasium.Env (name only)
+        pass
+
+    mod("gymnasium", Env=_Env)
+    mod("stable_baselines3")
+    mod("stable_baselines3.common")
+    mod("stable_baselines3.common.vec_env", VecEnvWrapper=object, VecNormalize=object)
+
+    # --- PyG containers (tier 2b) -------------------------------------------------------------
+    class MessagePassing(nn.Module):
+        def __init__(self, node_dim=0, aggr="add", aggr_kwargs=None, **kw):
+            super().__init__()
+
+        def propagate(self, edge_index, size=None, x=None, kernel=None, dim_size=None, **kw):
+            x_src, x_dst = x
+            x_j = x_src[edge_index[0]]
+            x_i = x_dst[edge_index[1]]
+            msg = self.message(x_i=x_i, x_j=x_j, kernel=kernel)
+            return self.aggregate(msg, edge_index, dim_size=dim_size)
+
+    def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
+        assert reduce in ("sum", "add") and dim == 0
+        out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+        return out.index_add(0, index, src)
+
+    class _TupleModuleDict(nn.ModuleDict):
+        def __init__(self, modules):
+            super().__init__()
+            self._keys_orig = {}
+            for k, v in modules.items():
+                ik = "<" + "___".join(k) + ">"
+                self._keys_orig[ik] = tuple(k)
+                self[ik] = v
+
+        def items(self):
+            return [(self._keys_orig[k], v) for k, v in super().items()]
+
+    class HeteroConv(nn.Module):
+        def __init__(self, convs, aggr="sum"):
+            super().__init__()
+            self.convs = _TupleModuleDict(convs)
+            self.aggr = aggr
+
+    def group(xs, aggr):
+        assert aggr == "sum"
+        return xs[0] if len(xs) == 1 else torch.stack(xs, 0).sum(0)
+
+    class Data:
+        pass
+
+    class HeteroData:
+        pass
+
+    tg = mod("torch_geometric")
+    tg.nn = mod("torch_geometric.nn", MessagePassing=MessagePassing, MLP=object)
+    tg.data = mod("torch_geometric.data", Data=Data, HeteroData=HeteroData)
+    conv = mod("torch_geometric.nn.conv", MessagePassing=MessagePassing, HeteroConv=HeteroConv)
+    mod("torch_geometric.nn.conv.hetero_conv", group=group)
+    mod("torch_geometric.typing", EdgeType=tuple, NodeType=str)
+    mod("torch_scatter", scatter=scatter)
+    tg.nn.conv = conv
+
+
+# ----------------------------------------------------------------------------------------------- tier 1
+def tier1():
+    from geometry_rl.modules.pyg_models.ponita.ponita import GridGenerator, PolynomialFeatures, Ponita
+    from geometry_rl.algorithms.trust_region_projections.utils.torch_utils import inverse_softplus
+
+    out = {}
+    out["grid_s1_16"] = GridGenerator(2, 16)()
+    out["grid_s2_16"] = GridGenerator(3, 16)()
+    out["grid_s2_16_upper"] = GridGenerator(3, 16, only_upper_hemisphere=True)()
+    out["grid_s2_20"] = GridGenerator(3, 20)()
+    g = torch.Generator().manual_seed(1)
+    x2 = torch.randn(5, 16, 2, generator=g)
+    x1 = torch.randn(4, 4, 1, generator=g)
+    out["poly_in2"], out["poly_out2"] = x2, PolynomialFeatures(2)(x2)
+    out["poly_in1"], out["poly_out1"] = x1, PolynomialFeatures(2)(x1)
+    xs = torch.tensor([0.3, 1.0, 2.5])
+    out["inv_softplus_in"], out["inv_softplus_out"] = xs, inverse_softplus(xs)
+    np.savez(os.path.join(OUT, "tier1_basics.npz"), **npd(out))
+
+    for dim in (3, 2):
+        torch.manual_seed(10 + dim)
+        net = Ponita(input_dim=7, hidden_dim=64, output_dim=1, num_layers=2, output_dim_vec=1, dim=dim, num_ori=16,
+                     degree=2, widening_factor=4, layer_scale=None, task_level="node")
+        N, E = 14, 40
+        x = torch.randn(N, 16, 7, generator=g)
+        pos = torch.randn(N, dim, generator=g)
+        ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)])
+        R = torch.randn(N, 16, 64, generator=g)
+        rec = {"x": x, "pos": pos, "edge_index": ei, "R": R}
+        rec.update({"init." + k: v.clone() for k, v in net.state_dict().items()})
+        net.train()
+        y0 = net(x, pos, ei)  # first training call: calibrates (ponita.py:178-180)
+        rec["y_first_call"] = y0
+        rec.update({"cal." + k: v.clone() for k, v in net.state_dict().items()})
+        net.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        y = net(xg, pos, ei)
+        (y * R).sum().backward()
+        rec["y"] = y
+        rec["grad.x"] = xg.grad
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                rec["grad." + k] = p.grad
+        np.savez(os.path.join(OUT, f"tier1_ponita_dim{dim}.npz"), **npd(rec))
+
+
+# ----------------------------------------------------------------------------------------------- tier 2
+def tier2():
+    from geometry_rl.algorithms.trust_region_projections.projections.base_projection_layer import (
+        BaseProjectionLayer, mean_projection)
+    from geometry_rl.algorithms.trust_region_projections.utils.projection_utils import gaussian_kl
+    from geometry_rl.algorithms.trust_region_projections.models.policy.gnn_gaussian_policy_diag import (
+        GNNGaussianPolicyDiag)
+
+    g = torch.Generator().manual_seed(5)
+    B, A = 9, 6
+
+    class FakeGNN(nn.Module):
+        device = "cpu"
+
+        def one_step(self, data, input_vector):
+            return data
+
+    class FakeData:
+        def build_data(self, *args, train=True):
+            return self.payload, None
+
+    torch.manual_seed(3)
+    fd = FakeData()
+    policy = GNNGaussianPolicyDiag(gnn=FakeGNN(), hyper_data=fd, action_dim=A, num_actuators=1, init="orthogonal",
+                                   hidden_sizes=(64, 64), contextual_std=True, init_std=1.0, minimal_std=1e-5,
+                                   share_action_dim=True, post_fc=False)
+    hidden = torch.randn(B, 64, generator=g)
+    mean_in = torch.randn(B * 2, 3, generator=g)
+    fd.payload = (mean_in, hidden)
+    with torch.no_grad():
+        policy._pre_std.weight.mul_(30.0)  # make the contextual std visibly state dependent
+    loc, cov = policy(torch.zeros(B, 1), train=True)
+    rec = {"hidden": hidden, "gnn_out": mean_in, "loc": loc, "cov": cov,
+           "pre_std.weight": policy._pre_std.weight, "pre_std.bias": policy._pre_std.bias}
+
+    mean = torch.randn(B, A, generator=g)
+    S = (torch.rand(B, A, generator=g) + 0.5).diag_embed()
+    mean_o = mean + 0.3 * torch.randn(B, A, generator=g)
+    mean_o[0] = mean[0] + 1e-3  # one sample inside the mean bound
+    S_o = (torch.rand(B, A, generator=g) + 0.5).diag_embed()
+    x = torch.randn(B, A, generator=g)
+    p, q = (mean, S), (mean_o, S_o)
+    rec.update({"mean": mean, "S": S, "mean_o": mean_o, "S_o": S_o, "x": x})
+    rec["maha"] = policy.maha(mean, mean_o, S_o)
+    rec["logdet"] = policy.log_determinant(S)
+    rec["entropy"] = policy.entropy(p)
+    rec["log_prob"] = policy.log_probability(p, x)
+    rec["covariance"] = policy.covariance(S)
+    rec["precision"] = policy.precision(S)
+    mp, cp = gaussian_kl(policy, p, q)
+    rec["kl_mean"], rec["kl_cov"] = mp, cp
+    eps = torch.tensor(0.05)
+    rec["eps_mean"] = eps
+    rec["proj_mean"] = mean_projection(mean, mean_o, mp, eps)
+    rec["proj_mean_noop"] = mean_projection(mean, mean_o, mp, torch.tensor(1e6))
+    layer = BaseProjectionLayer(proj_type="kl", mean_bound=0.05, cov_bound=0.0025, trust_region_coeff=4.0,
+                                scale_prec=True, entropy_schedule=False, action_dim=A, total_train_steps=100,
+                                cpu=True, dtype=torch.float32)
+    proj = (rec["proj_mean"], (S * 0.9 + S_o * 0.1))
+    mean_g = mean.clone().requires_grad_(True)
+    S_g = S.clone().requires_grad_(True)
+    trl = layer.get_trust_region_loss(policy, (mean_g, S_g), proj)
+    trl.backward()
+    rec["tr_proj_S"] = proj[1]
+    rec["tr_loss"], rec["tr_grad_mean"], rec["tr_grad_S"] = trl, mean_g.grad, S_g.grad
+    m = layer.compute_metrics(policy, p, proj, step=0)
+    for k, v in m.items():
+        rec["metric." + k] = v
+    # base_projection_layer.__call__ with the base (identity) trust-region hook: entropy projection with bound -inf
+    out_p = layer(policy, p, q, 0)
+    rec["base_call_mean"], rec["base_call_S"] = out_p
+    np.savez(os.path.join(OUT, "tier2_projection.npz"), **npd(rec))
+
+
+# ----------------------------------------------------------------------------------------------- tier 2b
+def tier2b():
+    from geometry_rl.modules.pyg_models.hepi import HEPi
+    from geometry_rl.modules.pyg_models.ponita.conv import FiberBundleConv
+    from oracle import graph as gr
+    from geometry_rl_amd import synthetic as syn
+
+    cases = {
+        "rigid_g1": dict(spec=gr.rigid_spec(P=8, G=1, E_mesh=4), obs=lambda s: syn.make_rigid_obs(5, P=8, G=1, E_mesh=4, seed=s),
+                         dim=3, upper=True, od=2, ov=2),
+        "rigid_g2": dict(spec=gr.rigid_spec(P=8, G=2, E_mesh=4, angular_velocity=False, object_velocity=False),
+                         obs=lambda s: syn.make_rigid_obs(4, P=8, G=2, E_mesh=4, angular_velocity=False,
+                                                          object_velocity=False, seed=s),
+                         dim=3, upper=False, od=1, ov=1),
+        "rope_dim2": dict(spec=gr.rope_spec(n_links=7, G=2), obs=lambda s: syn.make_rope_obs(3, n_links=7, G=2, seed=s),
+                          dim=2, upper=False, od=1, ov=1),
+    }
+    codes = [[1, 0], [0, 1], [0, 1]]
+    for name, c in cases.items():
+        spec = c["spec"]
+        obs = c["obs"](21)
+        split = gr.split_obs(spec, obs)
+        topo = gr.build_topology(spec, split, full_graph_obs=False)
+        graph, s_dict, v_dict = gr.build_features(spec, topo, split, dist_as_pos=True)
+
+        torch.manual_seed(77)
+        mp = []
+        for lvl in range(3):
+            mp.append([FiberBundleConv(64, 64, 64, groups=64, separable=True, widening_factor=4) if codes[lvl][k] else None
+                       for k in range(2)])
+        n_in = len(spec.node_types) + spec.n_vec
+        net = HEPi(input_dim_node=n_in, input_dim_edge=0, hidden_dim=64, latent_dim=64, output_dim=c["od"],
+                   output_dim_vec=c["ov"], node_encoder_layers=2, edge_encoder_layers=2, node_decoder_layers=2,
+                   node_type_mapping=None, edge_type_mapping=[tuple(e) for e in spec.edge_types],
+                   edge_level_mapping=spec.edge_levels, message_passing=mp, num_messages=2, device="cpu", num_ori=16,
+                   degree=2, ponita_dim=c["dim"], only_upper_hemisphere=c["upper"])
+
+        class NS:
+            pass
+
+        class G:
+            def __getitem__(self, k):
+                n = NS()
+                n.pos = graph["pos"][k]
+                return n
+
+        hg = G()
+        hg.node_types = graph["node_types"]
+        hg.edge_types = list(graph["edge_index"].keys())
+        hg.edge_index_dict = graph["edge_index"]
+        hg.output_mask_key = "grippers"
+
+        rec = {"obs." + k: v for k, v in obs.items()}
+        for et, ei in graph["edge_index"].items():
+            rec["edge_index." + "|".join(et)] = ei
+        rec.update({"init." + k: v.clone() for k, v in net.state_dict().items()})
+        net.train()
+        out0, hid0 = net.one_step(hg, (s_dict, v_dict))  # calibrating call (conv.py:104-105)
+        rec["out_first_call"], rec["hidden_first_call"] = out0, hid0
+        rec.update({"cal." + k: v.clone() for k, v in net.state_dict().items()})
+        net.zero_grad()
+        out, hid = net.one_step(hg, (s_dict, v_dict))
+        g = torch.Generator().manual_seed(9)
+        Ro, Rh = torch.randn(out.shape, generator=g), torch.randn(hid.shape, generator=g)
+        ((out * Ro).sum() + (hid * Rh).sum()).backward()
+        rec.update({"out": out, "hidden": hid, "R_out": Ro, "R_hidden": Rh})
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                rec["grad." + k] = p.grad
+        np.savez(os.path.join(OUT, f"tier2b_hepi_{name}.npz"), **npd(rec))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    tier1()
+    install_stubs()
+    tier2()
+    tier2b()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
