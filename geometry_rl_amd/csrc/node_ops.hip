@@ -1,0 +1,244 @@
+// HBM-bound node-side kernels of the HEPi / EMPN actor:
+//   lift + node encoder            (reference hepi.py:136-143, to_from_sphere.py:4-9)
+//   depthwise fiber convolution    (reference conv.py:88-90,108-109: x2[n,p,c] = 1/16 sum_o x1[n,o,c] fk[o,p,c] + bias[c])
+//   slab reduction of per-workgroup weight-gradient partials
+// All are streaming kernels: one coalesced pass over [N,16,64] fp32 node tensors, weights held in registers / LDS.
+#include "grl_common.h"
+
+namespace {
+
+constexpr int C = 64, O = 16;
+constexpr int KF_MAX = 8;  // scalars + vectors per node (7 in every reference config)
+
+// ------------------------------------------------------------------------------------------------ lift + encode
+// x[n,o,c] = sum_s scal[n,s] W[c,s] + sum_v (vec[n,v,:] . grid[o,:]) W[c,S+v]
+__global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
+                                                              const float* __restrict__ grid, const float* __restrict__ Wenc,
+                                                              float* __restrict__ x, int N, int S, int V) {
+  __shared__ float Ws[C * KF_MAX];
+  __shared__ float gs[O * 3];
+  const int KF = S + V;
+  for (int i = threadIdx.x; i < C * KF; i += blockDim.x) Ws[i] = Wenc[i];
+  for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
+  __syncthreads();
+  const size_t total = (size_t)N * O * (C / 4);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = idx & 15;
+    const size_t row = idx >> 4;
+    const int o = row & 15;
+    const size_t n = row >> 4;
+    float feat[KF_MAX];
+#pragma unroll
+    for (int k = 0; k < KF_MAX; ++k) {
+      if (k < S) feat[k] = scal[n * S + k];
+      else if (k < KF) {
+        const float* v = vec + (n * V + (k - S)) * 3;
+        feat[k] = v[0] * gs[3 * o] + v[1] * gs[3 * o + 1] + v[2] * gs[3 * o + 2];
+      } else feat[k] = 0.f;
+    }
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* w = Ws + (4 * c4 + j) * KF;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < KF_MAX; ++k)
+        if (k < KF) acc += feat[k] * w[k];
+      out[j] = acc;
+    }
+    reinterpret_cast<float4*>(x)[idx] = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF]
+__global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
+                                                              const float* __restrict__ grid, const float* __restrict__ dx,
+                                                              float* __restrict__ partial, int N, int S, int V) {
+  __shared__ float gs[O * 3];
+  __shared__ float red[4 * C * KF_MAX];
+  const int KF = S + V;
+  for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
+  __syncthreads();
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float dw[KF_MAX];
+#pragma unroll
+  for (int k = 0; k < KF_MAX; ++k) dw[k] = 0.f;
+  const size_t rows = (size_t)N * O;
+  for (size_t row = (size_t)blockIdx.x * 4 + part; row < rows; row += (size_t)gridDim.x * 4) {
+    const int o = row & 15;
+    const size_t n = row >> 4;
+    const float d = dx[row * C + c];
+#pragma unroll
+    for (int k = 0; k < KF_MAX; ++k) {
+      float f = 0.f;
+      if (k < S) f = scal[n * S + k];
+      else if (k < KF) {
+        const float* v = vec + (n * V + (k - S)) * 3;
+        f = v[0] * gs[3 * o] + v[1] * gs[3 * o + 1] + v[2] * gs[3 * o + 2];
+      }
+      dw[k] += d * f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KF_MAX; ++k) red[(part * C + c) * KF_MAX + k] = dw[k];
+  __syncthreads();
+  if (part == 0) {
+    for (int k = 0; k < KF; ++k) {
+      const float v = red[c * KF_MAX + k] + red[(C + c) * KF_MAX + k] + red[(2 * C + c) * KF_MAX + k] +
+                      red[(3 * C + c) * KF_MAX + k];
+      partial[(size_t)blockIdx.x * C * KF + c * KF + k] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fiber conv
+// thread (c, q): owns channel c and the output-orientation quad p = 4q..4q+3; fk[o][p][c] slice lives in registers.
+__global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ fk,
+                                                             const float* __restrict__ bias, float* __restrict__ x2, int N) {
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  float k[O][4];
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[o][j] = fk[(o * O + 4 * q + j) * C + c] * (1.f / O);
+  const float b = bias[c];
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    const float* xin = x1 + (size_t)n * O * C + c;
+    float acc[4] = {b, b, b, b};
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float v = xin[o * C];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += v * k[o][j];
+    }
+    float* xo = x2 + (size_t)n * O * C + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xo[(4 * q + j) * C] = acc[j];
+  }
+}
+
+// partial[block] = [dfk 16*16*64 | dbias 64]
+constexpr int FIBER_PARTIAL = O * O * C + C;
+__global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ fk,
+                                                             const float* __restrict__ dx2, float* __restrict__ dx1,
+                                                             float* __restrict__ partial, int N) {
+  __shared__ float red[4 * C];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  float kq[4][O];   // fk[o = 4q+j][p][c] / 16   (rows this thread back-propagates to)
+  float dk[O][4];   // d fk[o][p = 4q+j][c]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int p = 0; p < O; ++p) kq[j][p] = fk[((4 * q + j) * O + p) * C + c] * (1.f / O);
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dk[o][j] = 0.f;
+  float db = 0.f;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    const float* xin = x1 + (size_t)n * O * C + c;
+    const float* din = dx2 + (size_t)n * O * C + c;
+    float xv[O], dv[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) { xv[o] = xin[o * C]; dv[o] = din[o * C]; }
+    float* dxo = dx1 + (size_t)n * O * C + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int p = 0; p < O; ++p) acc += dv[p] * kq[j][p];
+      dxo[(4 * q + j) * C] = acc;
+      db += dv[4 * q + j];
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dk[o][j] += xv[o] * dv[4 * q + j];
+  }
+  float* out = partial + (size_t)blockIdx.x * FIBER_PARTIAL;
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[(o * O + 4 * q + j) * C + c] = dk[o][j] * (1.f / O);
+  red[q * C + c] = db;
+  __syncthreads();
+  if (q == 0) out[O * O * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
+}
+
+// ------------------------------------------------------------------------------------------------ slab reduce
+// out[j] (+)= sum_w partial[w][j]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int n_rows, int n, int rows_per_block) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int w0 = blockIdx.y * rows_per_block, w1 = min(w0 + rows_per_block, n_rows);
+  float acc = 0.f;
+  for (int w = w0; w < w1; ++w) acc += partial[(size_t)w * n + j];
+  atomicAdd(out + j, acc);
+}
+
+int cap_blocks(long long work, int per_block, int cap) {
+  long long b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  return (int)(b < cap ? b : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int grl_fiber_partial_size() { return FIBER_PARTIAL; }
+int grl_fiber_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
+int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks((long long)n_nodes * O, 64, 1024); }
+
+int grl_lift_encode_fwd(const float* scal, const float* vec, const float* grid, const float* Wenc, float* x, int n_nodes,
+                        int n_scal, int n_vec, hipStream_t stream) {
+  if (n_nodes <= 0) return 0;
+  if (n_scal + n_vec > KF_MAX) return -2;
+  const int blocks = cap_blocks((long long)n_nodes * O * 16, 256, 2048);
+  hipLaunchKernelGGL(lift_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, scal, vec, grid, Wenc, x, n_nodes, n_scal,
+                     n_vec);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// partial: [grl_lift_bwd_blocks(n_nodes)][64*(n_scal+n_vec)]
+int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, const float* dx, float* partial, int n_nodes,
+                        int n_scal, int n_vec, hipStream_t stream) {
+  if (n_nodes <= 0) return 0;
+  if (n_scal + n_vec > KF_MAX) return -2;
+  hipLaunchKernelGGL(lift_encode_bwd_kernel, dim3(grl_lift_bwd_blocks(n_nodes)), dim3(256), 0, stream, scal, vec, grid, dx,
+                     partial, n_nodes, n_scal, n_vec);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int grl_fiber_conv_fwd(const float* x1, const float* fk, const float* bias, float* x2, int n_nodes, hipStream_t stream) {
+  if (n_nodes <= 0) return 0;
+  hipLaunchKernelGGL(fiber_conv_fwd_kernel, dim3(cap_blocks(n_nodes, 4, 2048)), dim3(256), 0, stream, x1, fk, bias, x2,
+                     n_nodes);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// partial: [grl_fiber_bwd_blocks(n_nodes)][grl_fiber_partial_size()]
+int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float* dx1, float* partial, int n_nodes,
+                       hipStream_t stream) {
+  if (n_nodes <= 0) return 0;
+  hipLaunchKernelGGL(fiber_conv_bwd_kernel, dim3(grl_fiber_bwd_blocks(n_nodes)), dim3(256), 0, stream, x1, fk, dx2, dx1,
+                     partial, n_nodes);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[j] += sum over the n_rows partial rows (out must be initialised by the caller)
+int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hipStream_t stream) {
+  if (n_rows <= 0 || n <= 0) return 0;
+  const int rpb = 32;
+  dim3 grid((n + 255) / 256, (n_rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, stream, partial, out, n_rows, n, rpb);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+"""ctypes binding of the C-ABI kernel library ``libgrl_hip.so`` (declared in include/grl_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved the import of this module (and
+therefore every op of the package) raises.  Tensors are passed as raw device pointers + the current HIP stream.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+from typing import Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
+SOURCES = ["edge_conv.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
+
+
+def build(verbose: bool = True, force: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link libgrl_hip.so in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "grl_common.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d)
+                                                    for d in [s, os.path.join(CSRC, "grl_common.h")]):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'). "
+                "geometry_rl_amd has no CPU or PyTorch fallback path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def _arg(a):
+    if torch.is_tensor(a):
+        if not a.is_contiguous():
+            raise ValueError("non-contiguous tensor passed to a HIP kernel")
+        return ctypes.c_void_p(a.data_ptr())
+    if a is None:
+        return ctypes.c_void_p(0)
+    if isinstance(a, bool):
+        return ctypes.c_int(int(a))
+    if isinstance(a, int):
+        return ctypes.c_int(a)
+    if isinstance(a, float):
+        return ctypes.c_float(a)
+    return a
+
+
+def stream_ptr() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name: str, *args, stream=None) -> None:
+    """Launch C-ABI entry point ``name`` on the current stream; raises on a non-zero status."""
+    fn = getattr(lib(), name)
+    fn.restype = ctypes.c_int
+    rc = fn(*[_arg(a) for a in args], stream if stream is not None else stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}")
+
+
+def query(name: str, *args) -> int:
+    """Call a pure host-side query entry point (no stream argument)."""
+    fn = getattr(lib(), name)
+    fn.restype = ctypes.c_int
+    return fn(*[_arg(a) for a in args])
+
+
+def check_f32(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+            raise TypeError(f"expected a CUDA float32 tensor, got {t.dtype} on {t.device}")

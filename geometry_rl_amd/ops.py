@@ -1,0 +1,169 @@
+"""torch.autograd.Function wrappers around the C-ABI HIP kernels (include/grl_hip.h).
+
+Only plumbing lives here: argument checks, workspace allocation with torch's caching allocator, and wiring each
+forward/backward kernel pair into autograd so the modules in ``geometry_rl_amd.modules`` behave like ordinary
+``nn.Module``s.  No arithmetic of the hot path is done in Python/PyTorch.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import hip
+
+
+@dataclass
+class EdgeSet:
+    """One edge type of the batched graph in both anchor orders (int32, device resident).
+
+    Forward kernels walk edges grouped by destination, backward kernels the same edges grouped by source
+    (see csrc/edge_conv.hip)."""
+    n_src: int
+    n_dst: int
+    n_edges: int
+    rowptr_d: torch.Tensor
+    src_d: torch.Tensor
+    dst_d: torch.Tensor
+    rowptr_s: torch.Tensor
+    src_s: torch.Tensor
+    dst_s: torch.Tensor
+
+
+def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
+    """edge_index [2,E] (row 0 = source, row 1 = destination) -> CSR by dst and CSR by src.  Runs once per cached topology."""
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    dev = edge_index.device
+
+    def csr(anchor, other, n_anchor):
+        order = torch.argsort(anchor * (int(other.max().item()) + 1 if other.numel() else 1) + other)
+        a, o = anchor[order], other[order]
+        rowptr = torch.zeros(n_anchor + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(a, minlength=n_anchor), 0)
+        return rowptr.int().contiguous(), a.int().contiguous(), o.int().contiguous()
+
+    rp_d, dst_d, src_d = csr(dst, src, n_dst)
+    rp_s, src_s, dst_s = csr(src, dst, n_src)
+    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s, src_s, dst_s)
+
+
+def _reduce(partial: torch.Tensor, out: torch.Tensor):
+    hip.call("grl_reduce_partials", partial, out, partial.shape[0], out.numel())
+
+
+class LiftEncode(torch.autograd.Function):
+    """x[n,o,:] = [scalars | vectors . grid_o] W_enc^T   (reference hepi.py:136-143)."""
+
+    @staticmethod
+    def forward(ctx, scal, vec, grid3, w_enc):
+        hip.check_f32(scal, vec, grid3, w_enc)
+        n, s = scal.shape
+        v = vec.shape[1]
+        x = torch.empty(n, 16, 64, device=scal.device, dtype=torch.float32)
+        hip.call("grl_lift_encode_fwd", scal, vec, grid3, w_enc.contiguous(), x, n, s, v)
+        ctx.save_for_backward(scal, vec, grid3)
+        ctx.kf = s + v
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        scal, vec, grid3 = ctx.saved_tensors
+        n, s = scal.shape
+        v = vec.shape[1]
+        blocks = hip.query("grl_lift_bwd_blocks", n)
+        partial = torch.empty(blocks, 64 * ctx.kf, device=dx.device, dtype=torch.float32)
+        hip.call("grl_lift_encode_bwd", scal, vec, grid3, dx.contiguous(), partial, n, s, v)
+        dw = torch.zeros(64, ctx.kf, device=dx.device, dtype=torch.float32)
+        _reduce(partial, dw)
+        return None, None, None, dw
+
+
+class EdgeConv(torch.autograd.Function):
+    """x1[d] = sum_{e->d} Wk(basis_mlp(invariants_e)) * x_src[src(e)]   (reference hepi.py:145-157, conv.py:79-86,115-149)."""
+
+    @staticmethod
+    def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int):
+        hip.check_f32(x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
+        x1 = torch.zeros(edges.n_dst, 16, 64, device=x_src.device, dtype=torch.float32)
+        args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
+        hip.call("grl_edge_conv_fwd", x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
+                 dim, *args, x1)
+        ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
+        ctx.edges, ctx.dim = edges, dim
+        return x1
+
+    @staticmethod
+    def backward(ctx, dx1):
+        x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk = ctx.saved_tensors
+        e = ctx.edges
+        dev = dx1.device
+        blocks = hip.query("grl_edge_bwd_blocks", e.n_src)
+        psize = hip.query("grl_edge_partial_size")
+        partial = torch.empty(blocks * 4, psize, device=dev, dtype=torch.float32)
+        dx_src = torch.zeros_like(x_src)
+        hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_s, e.src_s, e.dst_s, e.n_src, grid3, ctx.dim, w1, b1,
+                 w2, b2, wk, dx1.contiguous(), dx_src, partial)
+        flat = torch.zeros(psize, device=dev, dtype=torch.float32)
+        _reduce(partial, flat)
+        dw1, db1, dw2, db2, dwk = torch.split(flat, [64 * 14, 64, 64 * 64, 64, 64 * 64])
+        return (dx_src, None, None, None, dw1.view(64, 14), db1, dw2.view(64, 64), db2, dwk.view(64, 64), None, None)
+
+
+class FiberConv(torch.autograd.Function):
+    """x2[n,p,c] = 1/16 sum_o x1[n,o,c] fk[o,p,c] + bias[c]   (reference conv.py:88-90,108-109)."""
+
+    @staticmethod
+    def forward(ctx, x1, fk, bias):
+        hip.check_f32(x1, fk, bias)
+        x2 = torch.empty_like(x1)
+        fk = fk.contiguous()
+        hip.call("grl_fiber_conv_fwd", x1, fk, bias.contiguous(), x2, x1.shape[0])
+        ctx.save_for_backward(x1, fk)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x1, fk = ctx.saved_tensors
+        n = x1.shape[0]
+        blocks = hip.query("grl_fiber_bwd_blocks", n)
+        psize = hip.query("grl_fiber_partial_size")
+        partial = torch.empty(blocks, psize, device=dx2.device, dtype=torch.float32)
+        dx1 = torch.empty_like(x1)
+        hip.call("grl_fiber_conv_bwd", x1, fk, dx2.contiguous(), dx1, partial, n)
+        flat = torch.zeros(psize, device=dx2.device, dtype=torch.float32)
+        _reduce(partial, flat)
+        return dx1, flat[: 16 * 16 * 64].view(16, 16, 64), flat[16 * 16 * 64:]
+
+
+class NodeMLP(torch.autograd.Function):
+    """out = [prev +] x_dst + W4 GELU(W3 LN(x2) + b3) + b4   (reference conv.py:64-69,112; hetero_fiber_conv.py:63-64)."""
+
+    @staticmethod
+    def forward(ctx, x2, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor]):
+        hip.check_f32(x2, x_dst, gamma, beta, w3, b3, w4, b4)
+        ws = [a.contiguous() for a in (w3, b3, w4, b4, gamma, beta)]
+        n_rows = x2.shape[0] * 16
+        out = prev.clone() if prev is not None else torch.empty_like(x2)
+        hip.call("grl_node_mlp_fwd", x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0)
+        ctx.save_for_backward(x2, *ws)
+        ctx.has_prev = prev is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, w3, b3, w4, b4, gamma, beta = ctx.saved_tensors
+        dev = dout.device
+        dout = dout.contiguous()
+        n_rows = x2.shape[0] * 16
+        dx2 = torch.empty_like(x2)
+        xhat = torch.empty(n_rows, 64, device=dev, dtype=torch.float32)
+        da = torch.empty(n_rows, 64, device=dev, dtype=torch.float32)
+        hbuf = torch.empty(n_rows, 256, device=dev, dtype=torch.float32)
+        dz = torch.empty(n_rows, 256, device=dev, dtype=torch.float32)
+        blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
+        psize = hip.query("grl_node_mlp_partial_size")
+        partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
+        hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, xhat, da, hbuf, dz, partial, n_rows)
+        flat = torch.zeros(psize, device=dev, dtype=torch.float32)
+        _reduce(partial, flat)
+        dw3, db3, dw4, db4, dgam, dbet = torch.split(flat, [256 * 64, 256, 64 * 256, 64, 64, 64])
+        return (dx2, dout, dgam, dbet, dw3.view(256, 64), db3, dw4.view(64, 256), db4, dout if ctx.has_prev else None)
