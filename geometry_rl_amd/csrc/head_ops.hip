@@ -1,0 +1,426 @@
+// Actor read-out + contextual-std head, and the fused TRPL objective (forward values AND analytic gradients).
+//
+// Read-out (reference hepi.py:173-190 == ponita_gcn.py:129-146; std head gnn_gaussian_policy_diag.py:65-87):
+//   y = lat W_dec^T + b (per orientation); scalar part averaged over the grid, vector part projected on the grid,
+//   mean[v,:] = vec[v,:] * scal[v]; hidden = mean_o lat; sigma = softplus(hidden W_s^T + b_s + shift) + min_std.
+// TRPL (reference objectives/trpl.py:231-321, projections/base_projection_layer.py:71-100,292-384,
+//   projections/kl_projection_layer.py:15-111, utils/projection_utils.py:34-67, objectives/utils.py:5-28; ITPAL's diagonal
+//   covariance projection restated from its KKT system): one thread per frame, fp64 inside.
+#include "grl_common.h"
+
+namespace {
+
+constexpr int C = 64, O = 16;
+constexpr int JMAX = 4;   // output_dim + output_dim_vec
+constexpr int APER_MAX = 6;
+
+GRL_DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+GRL_DEVINL float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+GRL_DEVINL float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// one wave per actuator node
+__global__ __launch_bounds__(64) void readout_fwd_kernel(const float* __restrict__ lat, const float* __restrict__ grid,
+                                                        const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                        const float* __restrict__ Ws, const float* __restrict__ bs, float shift,
+                                                        float min_std, float* __restrict__ mean, float* __restrict__ sigma,
+                                                        float* __restrict__ hidden, int n_nodes, int od, int ov) {
+  const int c = threadIdx.x;
+  const int J = od + ov, aper = 3 * ov;
+  float wd[JMAX], ws[APER_MAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) wd[j] = j < J ? Wd[j * C + c] : 0.f;
+#pragma unroll
+  for (int a = 0; a < APER_MAX; ++a) ws[a] = a < aper ? Ws[a * C + c] : 0.f;
+  for (int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
+    const float* l = lat + (size_t)n * O * C + c;
+    float hsum = 0.f;
+    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f};      // sum_o y[o][j]          (j < od)
+    float vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f}, vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float v = l[o * C];
+      hsum += v;
+      const float gx = grid[3 * o], gy = grid[3 * o + 1], gz = grid[3 * o + 2];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        if (j < J) {
+          const float y = wave_sum(v * wd[j]) + bd[j];
+          if (j < od) sc[j] += y;
+          else { vx[j - od] += y * gx; vy[j - od] += y * gy; vz[j - od] += y * gz; }
+        }
+      }
+    }
+    const float hid = hsum * (1.f / O);
+    hidden[(size_t)n * C + c] = hid;
+#pragma unroll
+    for (int a = 0; a < APER_MAX; ++a) {
+      if (a < aper) {
+        const float pre = wave_sum(hid * ws[a]) + bs[a];
+        if (c == 0) sigma[(size_t)n * aper + a] = softplus_f(pre + shift) + min_std;
+      }
+    }
+    if (c == 0) {
+      for (int v = 0; v < ov; ++v) {
+        const float s = sc[v] * (1.f / O);
+        mean[((size_t)n * ov + v) * 3 + 0] = vx[v] * (1.f / O) * s;
+        mean[((size_t)n * ov + v) * 3 + 1] = vy[v] * (1.f / O) * s;
+        mean[((size_t)n * ov + v) * 3 + 2] = vz[v] * (1.f / O) * s;
+      }
+    }
+  }
+}
+
+// partial row: [dWd JMAX*64 | dbd JMAX | dWs APER_MAX*64 | dbs APER_MAX]
+constexpr int RO_PARTIAL = JMAX * C + JMAX + APER_MAX * C + APER_MAX;
+__global__ __launch_bounds__(64) void readout_bwd_kernel(const float* __restrict__ lat, const float* __restrict__ grid,
+                                                        const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                        const float* __restrict__ Ws, const float* __restrict__ bs, float shift,
+                                                        const float* __restrict__ dmean, const float* __restrict__ dsigma,
+                                                        const float* __restrict__ dhidden_ext, float* __restrict__ dlat,
+                                                        float* __restrict__ partial, int n_nodes, int od, int ov) {
+  const int c = threadIdx.x;
+  const int J = od + ov, aper = 3 * ov;
+  float wd[JMAX], ws[APER_MAX], dwd[JMAX], dws[APER_MAX], dbd[JMAX], dbs[APER_MAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) { wd[j] = j < J ? Wd[j * C + c] : 0.f; dwd[j] = 0.f; dbd[j] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < APER_MAX; ++a) { ws[a] = a < aper ? Ws[a * C + c] : 0.f; dws[a] = 0.f; dbs[a] = 0.f; }
+  for (int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
+    const float* l = lat + (size_t)n * O * C + c;
+    float lv[O], hsum = 0.f;
+    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f}, vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f},
+          vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      lv[o] = l[o * C];
+      hsum += lv[o];
+      const float gx = grid[3 * o], gy = grid[3 * o + 1], gz = grid[3 * o + 2];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        if (j < J) {
+          const float y = wave_sum(lv[o] * wd[j]) + bd[j];
+          if (j < od) sc[j] += y;
+          else { vx[j - od] += y * gx; vy[j - od] += y * gy; vz[j - od] += y * gz; }
+        }
+      }
+    }
+    const float hid = hsum * (1.f / O);
+    // std head
+    float dhid = dhidden_ext ? dhidden_ext[(size_t)n * C + c] : 0.f;
+#pragma unroll
+    for (int a = 0; a < APER_MAX; ++a) {
+      if (a < aper) {
+        const float pre = wave_sum(hid * ws[a]) + bs[a];
+        const float dpre = dsigma[(size_t)n * aper + a] * sigmoid_f(pre + shift);
+        dws[a] += dpre * hid;
+        dbs[a] += dpre;
+        dhid += dpre * ws[a];
+      }
+    }
+    // mean = vec * scal
+    float ds[JMAX] = {0.f, 0.f, 0.f, 0.f}, dvx[JMAX], dvy[JMAX], dvz[JMAX];
+#pragma unroll
+    for (int v = 0; v < JMAX; ++v) {
+      dvx[v] = dvy[v] = dvz[v] = 0.f;
+      if (v < ov) {
+        const float s = sc[v] * (1.f / O);
+        const float* dm = dmean + ((size_t)n * ov + v) * 3;
+        ds[v] = (dm[0] * vx[v] + dm[1] * vy[v] + dm[2] * vz[v]) * (1.f / O);
+        dvx[v] = dm[0] * s; dvy[v] = dm[1] * s; dvz[v] = dm[2] * s;
+      }
+    }
+    float* dl = dlat + (size_t)n * O * C + c;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float gx = grid[3 * o], gy = grid[3 * o + 1], gz = grid[3 * o + 2];
+      float g = dhid * (1.f / O);
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        if (j < J) {
+          const float dy = (j < od) ? ds[j] * (1.f / O) : (dvx[j - od] * gx + dvy[j - od] * gy + dvz[j - od] * gz) * (1.f / O);
+          g += dy * wd[j];
+          dwd[j] += dy * lv[o];
+          dbd[j] += dy;
+        }
+      }
+      dl[o * C] = g;
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * RO_PARTIAL;
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) out[j * C + c] = dwd[j];
+#pragma unroll
+  for (int a = 0; a < APER_MAX; ++a) out[JMAX * C + JMAX + a * C + c] = dws[a];
+  if (c == 0) {
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) out[JMAX * C + j] = dbd[j];
+#pragma unroll
+    for (int a = 0; a < APER_MAX; ++a) out[JMAX * C + JMAX + APER_MAX * C + a] = dbs[a];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ TRPL
+constexpr int AMAX = 12;
+// sums layout (fp64): 0 loss_objective 1 loss_trust_region 2 entropy(dist) 3 loss_critic 4 sum exp(lw) 5 sum exp(2 lw)
+//                     6 mean_constraint 7 cov_constraint 8 entropy(p) 9 entropy_diff 10 count
+// maxes layout (fp32 bits, values >= 0): 0 mean_constraint_max 1 cov_constraint_max
+struct TrplCfg {
+  double mean_bound, cov_bound, tr_coeff, ent_coef, critic_coef, clip_value, inv_batch, adv_count;
+  int A;
+};
+
+GRL_DEVINL double kl_of_eta(double eta, const double* t, const double* o, int A) {
+  double kl = 0.0;
+  for (int i = 0; i < A; ++i) {
+    const double v = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]);
+    kl += v / o[i] - 1.0 - log(v) + log(o[i]);
+  }
+  return 0.5 * kl;
+}
+
+__global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __restrict__ mean, const float* __restrict__ sigma,
+                                                  const float* __restrict__ action, const float* __restrict__ old_mean,
+                                                  const float* __restrict__ old_var, const float* __restrict__ old_logp,
+                                                  const float* __restrict__ advantage, const float* __restrict__ value,
+                                                  const float* __restrict__ old_value, const float* __restrict__ value_target,
+                                                  float* __restrict__ dmean, float* __restrict__ dsigma, float* __restrict__ dvalue,
+                                                  float* __restrict__ proj_mean_out, float* __restrict__ proj_var_out,
+                                                  const double* __restrict__ adv_stats, double* __restrict__ sums,
+                                                  unsigned int* __restrict__ maxes, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int A = cfg.A;
+  double acc[10];
+  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+  float mmax = 0.f, cmax = 0.f;
+  if (b < B) {
+    double mu[AMAX], S[AMAX], mo[AMAX], So[AMAX], t[AMAX], o[AMAX], a[AMAX];
+    for (int i = 0; i < A; ++i) {
+      mu[i] = mean[(size_t)b * A + i];
+      const double sg = sigma[(size_t)b * A + i];
+      S[i] = sg * sg;                      // policy covariance diagonal == "std" seen by the projection (trpl.py:241)
+      mo[i] = old_mean[(size_t)b * A + i];
+      So[i] = old_var[(size_t)b * A + i];
+      a[i] = action[(size_t)b * A + i];
+      t[i] = S[i] * S[i];                  // kl_projection_layer.py:60-63: covariance(std) = std**2
+      o[i] = So[i] * So[i];
+    }
+    // ---- mean projection (base_projection_layer.py:71-100)
+    double mp = 0.0;
+    for (int i = 0; i < A; ++i) { const double d = (mu[i] - mo[i]) / So[i]; mp += d * d; }
+    mp *= 0.5;
+    const bool m_act = mp > cfg.mean_bound;
+    double omega = 0.0, D = 1.0, pm[AMAX];
+    if (m_act) { omega = sqrt(mp / cfg.mean_bound) - 1.0; D = 1.0 + omega + 1e-16; }
+    for (int i = 0; i < A; ++i) pm[i] = m_act ? (mu[i] + omega * mo[i]) / D : mu[i];
+    // ---- covariance projection: eta >= 0 with KL_cov(eta) = cov_bound (monotone decreasing in eta)
+    double eta = 0.0;
+    const bool c_act = kl_of_eta(0.0, t, o, A) > cfg.cov_bound;
+    if (c_act) {
+      double lo = 0.0, hi = 1.0;
+      for (int it = 0; it < 200 && kl_of_eta(hi, t, o, A) > cfg.cov_bound; ++it) { lo = hi; hi *= 2.0; }
+      for (int it = 0; it < 100; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (kl_of_eta(mid, t, o, A) > cfg.cov_bound) lo = mid; else hi = mid;
+      }
+      eta = 0.5 * (lo + hi);
+    }
+    double v[AMAX], pS[AMAX];
+    for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }
+    // ---- log-prob under the projected distribution (covariance = pS), importance weight, objective
+    const double LOG2PI = 1.8378770664093454836;
+    double q = 0.0, sl = 0.0;
+    for (int i = 0; i < A; ++i) { const double d = a[i] - pm[i]; q += d * d / pS[i]; sl += log(pS[i]); }
+    const double lw = -0.5 * (q + A * LOG2PI + sl) - (double)old_logp[b];
+    const double ratio = exp(lw);
+    // advantage normalisation (trpl.py:286-289): batch mean / unbiased std (clamped at 1e-6) from the device-side sums
+    double adv = (double)advantage[b];
+    if (adv_stats && cfg.adv_count > 1.0) {
+      const double am = adv_stats[0] / cfg.adv_count;
+      double var = (adv_stats[1] - cfg.adv_count * am * am) / (cfg.adv_count - 1.0);
+      double sd = var > 0.0 ? sqrt(var) : 0.0;
+      if (sd < 1e-6) sd = 1e-6;
+      adv = (adv - am) / sd;
+    }
+    acc[0] = -ratio * adv;
+    acc[4] = ratio;
+    acc[5] = ratio * ratio;
+    const double ent = 0.5 * (A * (1.0 + LOG2PI) + sl);
+    acc[2] = ent;
+    // ---- trust-region regression loss and metrics: gaussian_kl(p, stopgrad(proj_p))
+    double mk = 0.0, ck = 0.0, ldS = 0.0, ldP = 0.0;
+    for (int i = 0; i < A; ++i) {
+      const double d = (mu[i] - pm[i]) / pS[i];
+      mk += d * d;
+      const double rr = S[i] / pS[i];
+      ck += rr * rr;
+      ldS += log(S[i]);
+      ldP += log(pS[i]);
+    }
+    mk *= 0.5;
+    ck = 0.5 * (ck - A + 2.0 * ldP - 2.0 * ldS);
+    acc[1] = (mk + ck) * cfg.tr_coeff;
+    acc[6] = mk;
+    acc[7] = ck;
+    const double c_ent = 0.5 * A * 2.8378770664093454836;  // 0.5 k log(2 pi e)
+    acc[8] = c_ent + ldS;                                   // policy.entropy(p) with S as "std"
+    acc[9] = (c_ent + ldP) - (c_ent + ldS);
+    mmax = (float)mk;
+    cmax = (float)fmax(ck, 0.0);
+    // ---- gradients of actor_loss = objective + entropy bonus + trust region  (all already scaled by 1/B)
+    const double w_obj = -ratio * adv * cfg.inv_batch;
+    double g_pm[AMAX], g_pS[AMAX];
+    for (int i = 0; i < A; ++i) {
+      const double d = a[i] - pm[i];
+      g_pm[i] = w_obj * d / pS[i];
+      g_pS[i] = w_obj * 0.5 * (d * d / (pS[i] * pS[i]) - 1.0 / pS[i]) - cfg.ent_coef * cfg.inv_batch * 0.5 / pS[i];
+    }
+    double gmu[AMAX], gS[AMAX];
+    if (m_act) {
+      double dot = 0.0;
+      for (int i = 0; i < A; ++i) dot += g_pm[i] * (mo[i] - pm[i]) / D;
+      const double k = dot / (2.0 * (omega + 1.0) * cfg.mean_bound);
+      for (int i = 0; i < A; ++i) gmu[i] = g_pm[i] / D + k * (mu[i] - mo[i]) / (So[i] * So[i]);
+    } else {
+      for (int i = 0; i < A; ++i) gmu[i] = g_pm[i];
+    }
+    {
+      double gv[AMAX];
+      for (int i = 0; i < A; ++i) gv[i] = g_pS[i] / (2.0 * pS[i]);
+      if (c_act) {
+        double dvt[AMAX], dve[AMAX], gk[AMAX], denom = 0.0, num = 0.0;
+        for (int i = 0; i < A; ++i) {
+          dvt[i] = v[i] * v[i] / (t[i] * t[i] * (eta + 1.0));
+          dve[i] = -v[i] * v[i] * (1.0 / o[i] - 1.0 / t[i]) / ((eta + 1.0) * (eta + 1.0));
+          gk[i] = 0.5 * (1.0 / o[i] - 1.0 / v[i]);
+          denom += gk[i] * dve[i];
+          num += gv[i] * dve[i];
+        }
+        for (int i = 0; i < A; ++i) {
+          const double gt = gv[i] * dvt[i] - num * gk[i] * dvt[i] / denom;
+          gS[i] = gt * 2.0 * S[i];
+        }
+      } else {
+        for (int i = 0; i < A; ++i) gS[i] = gv[i] * 2.0 * S[i];
+      }
+    }
+    const double ctr = cfg.tr_coeff * cfg.inv_batch;
+    for (int i = 0; i < A; ++i) {
+      gmu[i] += ctr * (mu[i] - pm[i]) / (pS[i] * pS[i]);
+      gS[i] += ctr * (S[i] / (pS[i] * pS[i]) - 1.0 / S[i]);
+      dmean[(size_t)b * A + i] = (float)gmu[i];
+      dsigma[(size_t)b * A + i] = (float)(gS[i] * 2.0 * (double)sigma[(size_t)b * A + i]);
+      if (proj_mean_out) { proj_mean_out[(size_t)b * A + i] = (float)pm[i]; proj_var_out[(size_t)b * A + i] = (float)pS[i]; }
+    }
+    // ---- clipped value loss (trpl.py:213-228, objectives/utils.py:5-28), l2
+    if (value) {
+      const double V = value[b], Vo = old_value[b], R = value_target[b];
+      const double l1 = (V - R) * (V - R);
+      double l = l1, g = 2.0 * (V - R);
+      if (cfg.clip_value > 0.0) {
+        const double dlt = V - Vo;
+        const bool inside = dlt >= -cfg.clip_value && dlt <= cfg.clip_value;
+        const double Vc = Vo + fmin(fmax(dlt, -cfg.clip_value), cfg.clip_value);
+        const double l2 = (Vc - R) * (Vc - R);
+        if (l2 > l1) { l = l2; g = inside ? 2.0 * (Vc - R) : 0.0; }
+      }
+      acc[3] = l * cfg.critic_coef;
+      dvalue[b] = (float)(g * cfg.critic_coef * cfg.inv_batch);
+    }
+  }
+  // block reduction (2 waves) -> fp64 atomics
+  __shared__ double red[2][10];
+  __shared__ float redm[2][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = 0; i < 10; ++i) {
+    double x = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    if (lane == 0) red[wv][i] = x;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mmax = fmaxf(mmax, __shfl_xor(mmax, off, 64));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, off, 64));
+  }
+  if (lane == 0) { redm[wv][0] = mmax; redm[wv][1] = cmax; }
+  __syncthreads();
+  if (threadIdx.x < 10) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x]);
+  if (threadIdx.x == 10) {
+    const int n_here = min(B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x);
+    atomicAdd(sums + 10, (double)(n_here > 0 ? n_here : 0));
+  }
+  if (threadIdx.x == 11) atomicMax(maxes, __float_as_uint(fmaxf(redm[0][0], redm[1][0])));
+  if (threadIdx.x == 12) atomicMax(maxes + 1, __float_as_uint(fmaxf(redm[0][1], redm[1][1])));
+}
+
+// sum and sum of squares of the advantages (fp64) -> stats[0..1]
+__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, double* __restrict__ stats, int B) {
+  double s0 = 0, s1 = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+    const double a = adv[i];
+    s0 += a;
+    s1 += a * a;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(stats, s0); atomicAdd(stats + 1, s1); }
+}
+
+}  // namespace
+
+extern "C" {
+
+int grl_readout_partial_size() { return RO_PARTIAL; }
+int grl_readout_blocks(int n_nodes) { return n_nodes < 1024 ? (n_nodes < 1 ? 1 : n_nodes) : 1024; }
+
+int grl_readout_fwd(const float* lat, const float* grid, const float* Wd, const float* bd, const float* Ws, const float* bs,
+                    float shift, float min_std, float* mean, float* sigma, float* hidden, int n_nodes, int output_dim,
+                    int output_dim_vec, hipStream_t stream) {
+  if (output_dim != output_dim_vec || output_dim + output_dim_vec > JMAX || 3 * output_dim_vec > APER_MAX) return -2;
+  hipLaunchKernelGGL(readout_fwd_kernel, dim3(n_nodes < 4096 ? n_nodes : 4096), dim3(64), 0, stream, lat, grid, Wd, bd, Ws, bs,
+                     shift, min_std, mean, sigma, hidden, n_nodes, output_dim, output_dim_vec);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// partial: [grl_readout_blocks(n_nodes)][grl_readout_partial_size()]; dhidden_ext may be NULL
+int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const float* bd, const float* Ws, const float* bs,
+                    float shift, const float* dmean, const float* dsigma, const float* dhidden_ext, float* dlat, float* partial,
+                    int n_nodes, int output_dim, int output_dim_vec, hipStream_t stream) {
+  if (output_dim != output_dim_vec || output_dim + output_dim_vec > JMAX || 3 * output_dim_vec > APER_MAX) return -2;
+  hipLaunchKernelGGL(readout_bwd_kernel, dim3(grl_readout_blocks(n_nodes)), dim3(64), 0, stream, lat, grid, Wd, bd, Ws, bs, shift,
+                     dmean, dsigma, dhidden_ext, dlat, partial, n_nodes, output_dim, output_dim_vec);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream) {
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(batch < 65536 ? (batch + 255) / 256 : 256), dim3(256), 0, stream, advantage, stats,
+                     batch);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// cfg8 (HOST pointer): 8 doubles {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
+// 1/B_global, B_global}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
+// grl_adv_stats, all-reduced when data parallel) or NULL for no normalisation.  sums: fp64[11], maxes: u32[2], zeroed by the caller.  value/old_value/value_target/dvalue may be
+// NULL together (actor-only call); proj_mean/proj_var may be NULL.
+int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, const float* sigma, const float* action,
+                     const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
+                     const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
+                     float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
+                     unsigned int* maxes, int batch, hipStream_t stream) {
+  if (action_dim > AMAX || action_dim < 1) return -2;
+  TrplCfg c{cfg8[0], cfg8[1], cfg8[2], cfg8[3], cfg8[4], cfg8[5], cfg8[6], cfg8[7], action_dim};
+  hipLaunchKernelGGL(trpl_kernel, dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean, old_var,
+                     old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, sums,
+                     maxes, batch);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

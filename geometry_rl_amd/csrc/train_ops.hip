@@ -1,0 +1,166 @@
+// Training-loop kernels around the loss: fused Adam over a flat parameter buffer (reference examples/torchrl/train.py:145-146,
+// 313-316: two torch.optim.Adam(lr, eps=1e-5) -> one launch over the concatenated actor+critic buffer), the shifted GAE
+// scan (train.py:134-140,249-251; torchrl GAE(shifted=True, average_gae=False)), global grad-norm clipping
+// (train.py:308-310) and the per-sample kNN topology (rigid_tasks_data.py:285-287).
+#include "grl_common.h"
+
+namespace {
+
+// torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps).   scale = optional gradient pre-scale (1/world, clip coefficient)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
+                                                  float bc1, float bc2_sqrt, const float* __restrict__ scale_dev,
+                                                  float scale_host) {
+  const float scale = scale_host * (scale_dev ? scale_dev[0] : 1.f);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+// clip coefficient of torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g||_2 + 1e-6))
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int n, double* __restrict__ out) {
+  double s = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += (double)g[i] * g[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+__global__ void clip_coef_kernel(const double* __restrict__ sq, float max_norm, float* __restrict__ coef) {
+  const float nrm = (float)sqrt(sq[0]);
+  coef[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
+}
+
+// One thread per environment, sequential over time (the recursion is inherently serial in t; N envs run in parallel).
+// Inputs are [N, T] row-major (values [N, T+1]); a 64x(T) tile is transposed through LDS so global accesses stay coalesced.
+constexpr int GAE_TT = 64;
+__global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ reward, const unsigned char* __restrict__ done,
+                                                const unsigned char* __restrict__ terminated, const float* __restrict__ values,
+                                                float* __restrict__ adv, float* __restrict__ target, int N, int T, float gamma,
+                                                float lmbda) {
+  __shared__ float s_r[64][GAE_TT + 1], s_v[64][GAE_TT + 2], s_a[64][GAE_TT + 1];
+  __shared__ unsigned char s_d[64][GAE_TT + 4], s_t[64][GAE_TT + 4];
+  const int env0 = blockIdx.x * 64, lane = threadIdx.x;
+  float run = 0.f;
+  for (int t1 = T; t1 > 0; t1 -= GAE_TT) {
+    const int t0 = max(t1 - GAE_TT, 0), len = t1 - t0;
+    // cooperative coalesced load: row e of the tile is env0+e, columns t0..t1 (values: t0..t1 inclusive)
+    for (int e = 0; e < 64; ++e) {
+      const int env = env0 + e;
+      if (env >= N) break;
+      if (lane < len) {
+        s_r[e][lane] = reward[(size_t)env * T + t0 + lane];
+        s_d[e][lane] = done[(size_t)env * T + t0 + lane];
+        s_t[e][lane] = terminated[(size_t)env * T + t0 + lane];
+      }
+      if (lane < len) s_v[e][lane] = values[(size_t)env * (T + 1) + t0 + lane];
+      if (lane == 0) s_v[e][len] = values[(size_t)env * (T + 1) + t0 + len];  // the 65th value of a full 64-step tile
+    }
+    __syncthreads();
+    if (env0 + lane < N) {
+      for (int k = len - 1; k >= 0; --k) {
+        const float nt = s_t[lane][k] ? 0.f : 1.f, nd = s_d[lane][k] ? 0.f : 1.f;
+        const float delta = s_r[lane][k] + gamma * nt * s_v[lane][k + 1] - s_v[lane][k];
+        run = delta + gamma * lmbda * nd * run;
+        s_a[lane][k] = run;
+      }
+    }
+    __syncthreads();
+    for (int e = 0; e < 64; ++e) {
+      const int env = env0 + e;
+      if (env >= N) break;
+      if (lane < len) {
+        const float a = s_a[e][lane];
+        adv[(size_t)env * T + t0 + lane] = a;
+        target[(size_t)env * T + t0 + lane] = a + s_v[e][lane];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Brute-force k nearest OTHER points among the first n_valid[b] of P points of each sample (P <= 128).
+// out_nbr [B, P, k] (local indices, -1 where fewer than k neighbours exist / point is padding).  Ties: lower index first.
+constexpr int KNN_PMAX = 128;
+__global__ __launch_bounds__(128) void knn_kernel(const float* __restrict__ pos /*[B,P,3]*/, const int* __restrict__ n_valid,
+                                                 int* __restrict__ out_nbr, int B, int P, int k) {
+  __shared__ float px[KNN_PMAX], py[KNN_PMAX], pz[KNN_PMAX];
+  const int b = blockIdx.x, i = threadIdx.x;
+  const int nv = n_valid ? min(n_valid[b], P) : P;
+  if (i < P) {
+    px[i] = pos[((size_t)b * P + i) * 3];
+    py[i] = pos[((size_t)b * P + i) * 3 + 1];
+    pz[i] = pos[((size_t)b * P + i) * 3 + 2];
+  }
+  __syncthreads();
+  if (i >= P) return;
+  int chosen[8];
+  for (int s = 0; s < k; ++s) {
+    int best = -1;
+    float bd = 3.4e38f;
+    if (i < nv) {
+      for (int j = 0; j < nv; ++j) {
+        if (j == i) continue;
+        bool used = false;
+        for (int u = 0; u < s; ++u) used |= (chosen[u] == j);
+        if (used) continue;
+        const float dx = px[j] - px[i], dy = py[j] - py[i], dz = pz[j] - pz[i];
+        const float d = dx * dx + dy * dy + dz * dz;
+        if (d < bd) { bd = d; best = j; }
+      }
+    }
+    chosen[s] = best;
+    out_nbr[((size_t)b * P + i) * k + s] = best;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// step = 1-based Adam step count.  scale_dev: optional device scalar multiplied into the gradient (clip coefficient).
+int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
+                  float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                     bc1, bc2s, scale_dev, scale_host);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// sqnorm: device fp64[1] zeroed by the caller; coef: device float[1]
+int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream) {
+  const int blocks = (n + 255) / 256 < 256 ? (n + 255) / 256 : 256;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, stream, grads, n, sqnorm);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sqnorm, max_norm, coef);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// reward [N,T] f32, done/terminated [N,T] u8 (torch.bool), values [N,T+1] -> advantage, value_target [N,T]
+int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned char* terminated, const float* values,
+                 float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream) {
+  if (n_env <= 0 || n_steps <= 0) return 0;
+  hipLaunchKernelGGL(gae_kernel, dim3((n_env + 63) / 64), dim3(64), 0, stream, reward, done, terminated, values, advantage,
+                     value_target, n_env, n_steps, gamma, lmbda);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream) {
+  if (n_points > KNN_PMAX || k > 8 || k < 1) return -2;
+  hipLaunchKernelGGL(knn_kernel, dim3(batch), dim3(128), 0, stream, pos, n_valid, out_nbr, batch, n_points, k);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+"""Batched hetero point-cloud graphs for the HIP actor/critic: the MI355X-side counterpart of
+``geometry_rl/modules/pyg_data/{base,rigid_tasks,cloth_tasks,rope_tasks}_data.py``.
+
+Differences from the reference that do not change any output:
+  * no PyG containers: a :class:`GraphBatch` is plain device tensors -- per node type a compact node list, per edge
+    type an :class:`~geometry_rl_amd.ops.EdgeSet` (CSR by destination and by source, int32);
+  * zero-padded object points (reference orbit/tasks/common/utils.py:193-211) are dropped from the ACTOR graph: they have
+    no edges (rigid_tasks_data.py:285-287,313-319), so their latents never reach the actuator read-out.  The critic
+    (DeepSets) still sees every padded point, exactly like the reference (deepsets.py:44-51);
+  * edge attributes (HeteroCartesian/HeteroDistance, transforms.py:122-163) are not materialised: no model on the hot
+    path reads them.
+The topology is built once per batch size and reused for every later batch of that size, like the reference cache
+(rigid_tasks_data.py:254-255).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import hip, ops
+
+EdgeType = Tuple[str, str, str]
+
+
+@dataclass
+class TaskSpec:
+    family: str
+    node_types: List[str]
+    edge_types: List[EdgeType]
+    edge_levels: List[str]
+    obs_names: Dict[str, List[str]]
+    obs_dims: Dict[str, List[int]]
+    num_actuators: int
+    knn_k: int = 3
+    angular_velocity: bool = True
+    n_vec: int = 4
+    in_features: List[str] = field(default_factory=list)
+
+    @property
+    def actuator(self) -> str:
+        return "grippers"
+
+
+_IN6 = ["scalars", "position_vectors", "velocity_vectors", "norm_position_vectors", "norm_velocity_vectors", "infos"]
+
+
+def rigid_spec(P=32, G=1, E_mesh=180, angular_velocity=True, object_velocity=True) -> TaskSpec:
+    """rigid_tasks_data.py:21-48 + rigid_tasks/config/common_cfg/observations_cfg.py:143-192,254-273."""
+    vel = ["grippers"] + (["grippers_angular"] if angular_velocity else [])
+    if object_velocity:
+        vel += ["object_geometry"] + (["object_geometry_angular"] if angular_velocity else [])
+    return TaskSpec(
+        "rigid", ["object_geometry", "grippers", "target_geometry"],
+        [("object_geometry", "internal", "object_geometry"), ("grippers", "agent", "grippers"),
+         ("object_geometry", "task", "grippers")], ["internal", "task", "agent"],
+        {"scalars": ["object_target_distances"], "position_vectors": ["grippers", "object_geometry", "target_geometry"],
+         "velocity_vectors": vel, "infos": ["object_num_points", "object_geometry_edges", "object_num_edges"]},
+        {"scalars": [1], "position_vectors": [3 * G, 3 * P, 3 * P],
+         "velocity_vectors": [3 * G if n.startswith("grippers") else 3 for n in vel], "infos": [1, 2 * E_mesh, 1]},
+        G, angular_velocity=angular_velocity, n_vec=4, in_features=list(_IN6))
+
+
+def cloth_spec(n_particles=225, n_hole=10, G=4, E_cloth=600) -> TaskSpec:
+    """cloth_tasks_data.py:19-47 + cloth_tasks/config/common_cfg/observations_cfg.py:150-193."""
+    return TaskSpec(
+        "cloth", ["particles", "grippers", "hole_boundary", "target_hook"],
+        [("hole_boundary", "internal", "hole_boundary"), ("grippers", "agent", "grippers"),
+         ("hole_boundary", "task", "grippers")], ["internal", "task", "agent"],
+        {"scalars": ["hole_target_distances", "cloth_edges_length"],
+         "position_vectors": ["grippers", "particles", "init_particles", "hole_boundary", "target_hook"],
+         "velocity_vectors": ["grippers", "particles"]},
+        {"scalars": [n_hole, E_cloth], "position_vectors": [3 * G, 3 * n_particles, 3 * n_particles, 3 * n_hole, 3],
+         "velocity_vectors": [3 * G, 3 * n_particles]},
+        G, n_vec=3, in_features=_IN6[:5])
+
+
+def rope_spec(n_links=80, G=2) -> TaskSpec:
+    """rope_tasks_data.py:21-46 + rope_tasks/config/common_cfg/observations_cfg.py:131-160."""
+    return TaskSpec(
+        "rope", ["links", "grippers", "target_geometry"],
+        [("links", "internal", "links"), ("grippers", "agent", "grippers"), ("links", "task", "grippers")],
+        ["internal", "task", "agent"],
+        {"scalars": ["links_target_distances"], "position_vectors": ["grippers", "links", "target_geometry"],
+         "velocity_vectors": ["grippers", "links"]},
+        {"scalars": [1], "position_vectors": [3 * G, 3 * n_links, 3 * n_links], "velocity_vectors": [3 * G, 3 * n_links]},
+        G, n_vec=3, in_features=_IN6[:5])
+
+
+@dataclass
+class GraphBatch:
+    """What ``build_data`` hands to ``gnn.one_step`` (the reference passes a PyG HeteroData batch)."""
+    batch_size: int
+    node_types: List[str]
+    num_nodes: Dict[str, int]
+    pos: Dict[str, torch.Tensor]  # raw positions [N_t, 3] (invariants use un-normalised positions, hepi.py:148-149)
+    edges: Dict[EdgeType, "ops.EdgeSet"]
+    output_mask_key: Optional[str]
+    nodes_per_sample: Dict[str, int]
+    compact: bool  # True: padded points removed (actor graph)
+
+    @property
+    def edge_types(self):
+        return list(self.edges.keys())
+
+
+class HyperData:
+    """Mirror of RigidTasksData / ClothTasksData / RopeTasksData (constructor kwargs of rigid_tasks_data.py:53-67).
+
+    ``build_data(*obs, train)`` returns ``(graph, input_vector)`` with ``input_vector`` either
+    ``(scalar_dict, vector_dict)`` (concat_input_vector=False, actor) or the dense critic input ``[B, n_all, d]``
+    (concat_input_vector=True; the reference returns the per-type dict that DeepSets concatenates, deepsets.py:41-49)."""
+
+    def __init__(self, spec: TaskSpec, *, full_graph_obs=False, dist_as_pos=False, output_mask_key=None, training_noise=False,
+                 training_noise_std=1e-2, concat_input_vector=True, drop_padding=True, **ignored):
+        if training_noise:
+            raise NotImplementedError("training_noise is False in every reference config on the hot path")
+        self.spec = spec
+        self.full_graph_obs = full_graph_obs
+        self.dist_as_pos = dist_as_pos
+        self._output_mask_key = output_mask_key
+        self.concat_input_vector = concat_input_vector
+        self.drop_padding = drop_padding and not concat_input_vector
+        fam = spec.family
+        if fam == "rigid":
+            self.node_type_list = [t for t in spec.node_types if t != "target_geometry"]
+        elif fam == "cloth":
+            keep = [t for t in spec.node_types if t != "target_hook"]
+            self.node_type_list = keep if full_graph_obs else [t for t in keep if t != "particles"]
+        else:
+            self.node_type_list = list(spec.node_types)
+        self._cache = {}
+
+    # ---- observation split (rigid_tasks_data.py:93-150)
+    def _split(self, obs: Dict[str, torch.Tensor]):
+        B = obs["scalars"].shape[0]
+        out = {}
+        for group, x in obs.items():
+            base = group.replace("norm_", "")
+            if base not in self.spec.obs_dims:
+                continue
+            parts = torch.split(x, self.spec.obs_dims[base], dim=1)
+            out[group] = {name: (p.reshape(B, -1, 3) if "vectors" in group else p)
+                          for name, p in zip(self.spec.obs_names[base], parts)}
+        return out
+
+    # ---- topology (cached per batch size)
+    def _topology(self, split, B: int, dev):
+        key = B
+        if key in self._cache:
+            return self._cache[key]
+        spec = self.spec
+        posv = split["position_vectors"]
+        n_per = {t: posv[t].shape[1] for t in self.node_type_list}
+        G = n_per["grippers"]
+        main = spec.edge_types[0][0]  # particle-like node type carrying the internal edges
+        P = n_per[main]
+        if spec.family == "rigid":
+            n_valid = split["infos"]["object_num_points"].reshape(B).long().clamp(max=P)
+        else:
+            n_valid = torch.full((B,), P, dtype=torch.long, device=dev)
+        ar = torch.arange(P, device=dev)
+        valid = ar[None, :] < n_valid[:, None]  # [B,P]
+        if self.drop_padding:
+            offset = torch.cumsum(n_valid, 0) - n_valid  # compact id of (b, 0)
+            gather_main = torch.nonzero(valid.reshape(-1)).reshape(-1)  # index into [B*P]
+        else:
+            offset = torch.arange(B, device=dev) * P
+            gather_main = torch.arange(B * P, device=dev)
+        n_main = int(gather_main.numel())
+        b_of = torch.arange(B, device=dev)[:, None].expand(B, P)[valid]  # sample of every valid point
+        j_of = ar[None, :].expand(B, P)[valid]
+        cid = offset[b_of] + j_of  # compact id of every valid point
+        edges = {}
+        et_int, et_agent, et_task = spec.edge_types
+        need_edges = not self.concat_input_vector  # the DeepSets critic never reads the edges
+        # internal edges
+        if not need_edges:
+            pass
+        elif spec.family == "cloth":  # fully connected hole boundary (cloth_tasks_data.py:252-260)
+            jj, kk = torch.meshgrid(ar, ar, indexing="ij")
+            m = jj != kk
+            src = (offset[:, None] + jj[m][None, :]).reshape(-1)
+            dst = (offset[:, None] + kk[m][None, :]).reshape(-1)
+        else:  # kNN among the valid points (rigid_tasks_data.py:285-287, rope_tasks_data.py:251)
+            k = spec.knn_k
+            nbr = torch.empty(B, P, k, dtype=torch.int32, device=dev)
+            hip.call("grl_knn_topology", posv[main].contiguous().float(), n_valid.int().contiguous(), nbr, B, P, k)
+            nb = nbr.long()[valid]  # [n_valid_total, k]
+            ok = nb >= 0
+            src = (offset[b_of][:, None] + nb)[ok]
+            dst = cid[:, None].expand_as(nb)[ok]
+        if need_edges and et_int[0] in self.node_type_list:
+            edges[et_int] = ops.build_edge_set(torch.stack([src, dst]), n_main, n_main)
+        # agent edges: j != k among the actuators of a sample
+        if not need_edges:
+            pass
+        elif G > 1:
+            gj, gk = torch.meshgrid(torch.arange(G, device=dev), torch.arange(G, device=dev), indexing="ij")
+            m = gj != gk
+            base = (torch.arange(B, device=dev) * G)[:, None]
+            edges[et_agent] = ops.build_edge_set(torch.stack([(base + gj[m][None]).reshape(-1), (base + gk[m][None]).reshape(-1)]),
+                                                 B * G, B * G)
+        else:
+            edges[et_agent] = None  # empty edge set: the conv is skipped (hetero_fiber_conv.py:48-49)
+        # task edges: every valid point -> every actuator of its sample
+        if need_edges and et_task[0] in self.node_type_list:
+            src = cid[:, None].expand(-1, G).reshape(-1)
+            dst = (b_of[:, None] * G + torch.arange(G, device=dev)[None, :]).reshape(-1)
+            edges[et_task] = ops.build_edge_set(torch.stack([src, dst]), n_main, B * G)
+        n_types = len(spec.node_types)
+        one_hot = {}
+        for t in self.node_type_list:
+            n_t = n_main if t == main else B * n_per[t]
+            oh = torch.zeros(n_t, n_types, device=dev)
+            oh[:, spec.node_types.index(t)] = 1  # transforms.py:52-66
+            one_hot[t] = oh
+        topo = dict(n_per=n_per, main=main, gather_main=gather_main, n_main=n_main, edges={k: v for k, v in edges.items() if v is not None},
+                    one_hot=one_hot, G=G, n_valid=n_valid)
+        self._cache[key] = topo
+        return topo
+
+    def build_data(self, *args, train=True, **kw):
+        """rigid_tasks_data.py / base_data.py:45-55.  Positional obs tensors in ``spec.in_features`` order."""
+        spec = self.spec
+        obs = dict(zip(spec.in_features, args))
+        B = obs["scalars"].shape[0]
+        dev = obs["scalars"].device
+        with torch.no_grad():
+            split = self._split(obs)
+            topo = self._topology(split, B, dev)
+            npos, nvel, pos = split["norm_position_vectors"], split["norm_velocity_vectors"], split["position_vectors"]
+            main, gm = topo["main"], topo["gather_main"]
+            full = topo["n_main"] == B * topo["n_per"][main]
+
+            def rows(x, t):  # [B,n,3] -> node rows (compact for the main type)
+                x = x.reshape(-1, 3)
+                return x if (t != main or full) else x[gm]
+
+            graph_pos, scalar_dict, vector_dict = {}, {}, {}
+            for t in self.node_type_list:
+                graph_pos[t] = rows(pos[t], t).contiguous()
+                norm_pos = rows(npos[t], t)
+                zeros = torch.zeros_like(norm_pos)
+                fam = spec.family
+                if fam == "rigid":
+                    if t == "object_geometry":
+                        target = rows(npos["target_geometry"], t)
+                        corr = norm_pos - target if self.dist_as_pos else target
+                    else:
+                        corr = zeros
+                    if t in nvel:
+                        n_t = npos[t].shape[1]
+                        vel = rows(nvel[t].expand(-1, n_t, -1) if t == main else nvel[t], t)
+                        if spec.angular_velocity:
+                            a = nvel[f"{t}_angular"]
+                            ang = rows(a.expand(-1, n_t, -1) if t == main else a, t)
+                        else:
+                            ang = torch.zeros_like(vel)
+                    else:
+                        vel, ang = zeros, zeros
+                    vecs = [norm_pos, corr, vel, ang]
+                elif fam == "cloth":
+                    if t == "particles":
+                        init = npos["init_particles"].reshape(-1, 3)
+                        corr = norm_pos - init if self.dist_as_pos else init
+                    elif t == "hole_boundary":
+                        target = rows(npos["target_hook"].expand(-1, npos[t].shape[1], -1), t)
+                        corr = norm_pos - target if self.dist_as_pos else target
+                    else:
+                        corr = zeros
+                    vecs = [norm_pos, corr, nvel[t].reshape(-1, 3) if t in nvel else zeros]
+                else:
+                    if t == "links":
+                        target = rows(npos["target_geometry"], t)
+                        corr = norm_pos - target if self.dist_as_pos else target
+                    else:
+                        corr = zeros
+                    vecs = [norm_pos, corr, rows(nvel[t], t) if t in nvel else zeros]
+                scalar_dict[t] = topo["one_hot"][t]
+                vector_dict[t] = torch.stack(vecs, dim=1).contiguous()  # [N_t, n_vec, 3]
+            graph = GraphBatch(B, list(self.node_type_list), {t: graph_pos[t].shape[0] for t in self.node_type_list}, graph_pos,
+                               topo["edges"], self._output_mask_key, topo["n_per"], self.drop_padding)
+            if self.concat_input_vector:
+                xs = [torch.cat([scalar_dict[t], vector_dict[t].reshape(vector_dict[t].shape[0], -1)], dim=1).reshape(B, -1, len(
+                    spec.node_types) + 3 * spec.n_vec) for t in self.node_type_list]
+                return graph, torch.cat(xs, dim=1).contiguous()
+            return graph, (scalar_dict, vector_dict)

@@ -1,0 +1,199 @@
+"""HEPi actor GNN on the HIP kernels -- drop-in for ``geometry_rl/modules/pyg_models/hepi.py`` (+ ponita/conv.py,
+ponita/hetero_fiber_conv.py).  Same constructor kwargs, same ``one_step(graph, u_dict)`` contract, same ``state_dict``
+names (PyG's tuple-key mangling ``<src___rel___dst>`` included) so reference checkpoints load.
+
+The nn.Linear / LayerNorm children are parameter containers only: their weights are handed to the fused HIP kernels
+(geometry_rl_amd.ops); torch never runs them."""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import EdgeType, GraphBatch
+
+
+def make_grid(dim: int, n: int, only_upper_hemisphere: bool = False) -> torch.Tensor:
+    """S1 uniform / S2 Fibonacci lattice orientation grid (reference ponita.py:53-97)."""
+    if dim == 2:
+        ang = torch.linspace(0, 2 * math.pi - (2 * math.pi / n), n)
+        return torch.stack((torch.cos(ang), torch.sin(ang)), dim=1)
+    if dim != 3:
+        raise ValueError("Only S1 and S2 are supported.")
+    i = torch.arange(n)
+    theta = (math.pi * i * (1 + math.sqrt(5))) % (2 * math.pi)
+    phi = torch.acos(1 - (1.0 if only_upper_hemisphere else 2.0) * (i + 0.5) / (n - 1 + 1.0))
+    return torch.stack((torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)), dim=-1)
+
+
+class PolynomialFeatures(nn.Module):
+    """Parameter-free placeholder so ``basis_fn.1`` / ``basis_fn.3`` keep the reference indices (ponita.py:233-244)."""
+
+    def __init__(self, degree):
+        super().__init__()
+        self.degree = degree
+
+    def forward(self, x):
+        polys = [x]
+        for _ in range(self.degree):
+            polys.append(torch.einsum("...i,...j->...ij", polys[-1], x).flatten(-2, -1))
+        return torch.cat(polys, -1)
+
+
+def basis_sequential(in_dim: int, hidden: int, basis: int, degree: int) -> nn.Sequential:
+    return nn.Sequential(PolynomialFeatures(degree), nn.Linear(in_dim, hidden), nn.GELU(), nn.Linear(hidden, basis), nn.GELU())
+
+
+class FiberBundleConv(nn.Module):
+    """Parameter holder with the reference's names/shapes (conv.py:10-69); separable + depthwise only."""
+
+    def __init__(self, in_channels, out_channels, attr_dim, bias=True, aggr="add", separable=True, groups=1, widening_factor=4):
+        super().__init__()
+        if not (separable and groups == in_channels == out_channels == 64 and attr_dim == 64 and widening_factor == 4 and bias):
+            raise NotImplementedError("the HIP path implements the separable depth-wise 64-channel configuration of every "
+                                      "reference config (configs/algorithm/pyg_agent/model/hepi.yaml:19-48)")
+        if aggr != "add":
+            raise NotImplementedError("AttentionalAggregation is outside the hot path (SURVEY.md section 8f.4)")
+        self.kernel = nn.Linear(attr_dim, in_channels, bias=False)
+        self.fiber_kernel = nn.Linear(attr_dim, in_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.register_buffer("callibrated", torch.tensor(False))
+        self.node_mlp = nn.Sequential(nn.LayerNorm(in_channels), nn.Linear(in_channels, out_channels * widening_factor), nn.GELU(),
+                                      nn.Linear(out_channels * widening_factor, out_channels))
+
+
+def conv_key(edge_type: EdgeType) -> str:
+    return "<" + "___".join(edge_type) + ">"
+
+
+class HeteroFiberConv(nn.Module):
+    """One message-passing round: a FiberBundleConv per edge type, outputs summed per destination type
+    (hetero_fiber_conv.py:10-66)."""
+
+    def __init__(self, convs: Dict[EdgeType, FiberBundleConv]):
+        super().__init__()
+        self.edge_types = [tuple(k) for k in convs]
+        self.convs = nn.ModuleDict({conv_key(tuple(k)): v for k, v in convs.items()})
+
+    def items(self):
+        return [(et, self.convs[conv_key(et)]) for et in self.edge_types]
+
+
+class HEPi(nn.Module):
+    def __init__(self, input_dim_node, input_dim_edge, hidden_dim, latent_dim, output_dim, output_dim_vec, node_encoder_layers=2,
+                 edge_encoder_layers=2, node_decoder_layers=2, node_type_mapping=None, edge_type_mapping=None,
+                 edge_level_mapping=None, message_passing=None, num_messages=2, concat_global=False, shared_processor=False,
+                 shared_node_encoder=True, shared_edge_encoder=True, device="cuda", num_ori=16, basis_dim=None, degree=2,
+                 ponita_dim=3, only_upper_hemisphere=False, **ignored):
+        super().__init__()
+        if hidden_dim != 64 or latent_dim != 64 or num_ori != 16 or degree != 2 or concat_global or shared_processor:
+            raise NotImplementedError("HIP kernels are specialised for hidden=latent=64, 16 orientations, degree 2")
+        self.input_dim_node, self.output_dim, self.output_dim_vec = input_dim_node, output_dim, output_dim_vec
+        self.latent_dim, self.hidden_dim, self.num_messages = latent_dim, hidden_dim, num_messages
+        self.device = device
+        self.dim, self.num_ori = ponita_dim, num_ori
+        self.register_buffer("ori_grid", make_grid(ponita_dim, num_ori, only_upper_hemisphere))
+        self.basis_fn = basis_sequential(14, hidden_dim, hidden_dim, degree)
+        self.fiber_basis_fn = basis_sequential(3, hidden_dim, hidden_dim, degree)
+        self.node_encoder = nn.Linear(input_dim_node, latent_dim, False)
+        self.processor = nn.ModuleList()
+        for k in range(num_messages):  # hepi.py:93-104
+            level = {}
+            for l, edge_level in enumerate(edge_level_mapping):
+                pl = message_passing[l][k]
+                if pl is not None:
+                    for et in edge_type_mapping:
+                        if et[1] == edge_level:
+                            level[tuple(et)] = pl
+            self.processor.append(HeteroFiberConv(level))
+        self.decoder = nn.Linear(latent_dim, output_dim + output_dim_vec)
+        self.to(device)
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def grid3(self) -> torch.Tensor:
+        g = self.ori_grid
+        return F.pad(g, (0, 3 - g.shape[1])).contiguous()
+
+    @property
+    def calibrated(self) -> bool:
+        return all(bool(c.callibrated) for r in self.processor for _, c in r.items())
+
+    def fiber_basis(self) -> torch.Tensor:
+        """Phi[o,p,:] = fiber_basis_fn(o_o . o_p)  (hepi.py:119,157): 256 parameter-only rows, plain torch."""
+        g = self.ori_grid
+        inv = (g[None, :, :] * g[:, None, :]).sum(-1, keepdim=True)
+        return self.fiber_basis_fn(inv)
+
+    def _needed_types(self, graph: GraphBatch):
+        need = {graph.output_mask_key} if graph.output_mask_key else set(graph.node_types)
+        for r in self.processor:
+            for (s, _, d), _c in r.items():
+                if (s, _, d) in graph.edges:
+                    need.update((s, d))
+        return [t for t in graph.node_types if t in need]
+
+    def _conv(self, conv, x_src, x_dst, graph, et, grid3, phi, prev):
+        es = graph.edges[et]
+        s, _, d = et
+        b = self.basis_fn
+        x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
+                                conv.kernel.weight, es, self.dim)
+        fk = F.linear(phi, conv.fiber_kernel.weight)
+        x2 = ops.FiberConv.apply(x1, fk, conv.bias)
+        m = conv.node_mlp
+        return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev), x1, fk
+
+    # ------------------------------------------------------------------ forward
+    def latent_step(self, graph: GraphBatch, u_dict) -> torch.Tensor:
+        """hepi.py:125-173: lift/encode, message-passing rounds; returns the actuator latents [B*G, 16, 64]."""
+        scalar_dict, vector_dict = u_dict
+        grid3 = self.grid3
+        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight)
+             for t in self._needed_types(graph)}
+        phi = self.fiber_basis()
+        for rnd in self.processor:
+            outs = {}
+            for et, conv in rnd.items():
+                if et not in graph.edges:  # empty edge set: skipped like hetero_fiber_conv.py:48-49
+                    continue
+                s, _, d = et
+                outs[d], _, _ = self._conv(conv, x[s], x[d], graph, et, grid3, phi, outs.get(d))
+            x.update(outs)
+        return x[graph.output_mask_key]
+
+    def one_step(self, graph: GraphBatch, u_dict, u=None, u_properties=None):
+        """Reference contract: -> (out [B*G*out_vec, 3], hidden [B*G, 64])."""
+        lat = self.latent_step(graph, u_dict)
+        zw = lat.new_zeros(3 * self.output_dim_vec, 64)
+        zb = lat.new_zeros(3 * self.output_dim_vec)
+        mean, _, hidden = ops.Readout.apply(lat, self.grid3, self.decoder.weight, self.decoder.bias, zw, zb, 0.0, 0.0,
+                                            self.output_dim, self.output_dim_vec)
+        return mean.reshape(-1, 3), hidden
+
+    @torch.no_grad()
+    def calibrate(self, graph_full: GraphBatch, u_dict) -> None:
+        """First-training-call re-initialisation (conv.py:104-105,151-157) on the FULL (padded) graph: kernel.weight *=
+        std(x_dst)/std(x_1), fiber_kernel.weight *= std(x_1)/std(x_2) with x_2 taken before the bias; the call that
+        calibrates continues with the un-rescaled activations, so later rounds see the same inputs as in the reference."""
+        scalar_dict, vector_dict = u_dict
+        grid3 = self.grid3
+        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight) for t in graph_full.node_types}
+        phi = self.fiber_basis()
+        for rnd in self.processor:
+            outs = {}
+            for et, conv in rnd.items():
+                if et not in graph_full.edges:
+                    continue
+                s, _, d = et
+                out, x1, fk = self._conv(conv, x[s], x[d], graph_full, et, grid3, phi, outs.get(d))
+                if not bool(conv.callibrated):
+                    x2 = ops.FiberConv.apply(x1, fk, torch.zeros_like(conv.bias))
+                    s_in, s_1, s_2 = x[d].std(), x1.std(), x2.std()
+                    conv.kernel.weight.mul_(s_in / s_1)
+                    conv.fiber_kernel.weight.mul_(s_1 / s_2)
+                    conv.callibrated.fill_(True)
+                outs[d] = out
+            x.update(outs)

@@ -167,3 +167,152 @@ class NodeMLP(torch.autograd.Function):
         _reduce(partial, flat)
         dw3, db3, dw4, db4, dgam, dbet = torch.split(flat, [256 * 64, 256, 64 * 256, 64, 64, 64])
         return (dx2, dout, dgam, dbet, dw3.view(256, 64), db3, dw4.view(64, 256), db4, dout if ctx.has_prev else None)
+
+
+class Readout(torch.autograd.Function):
+    """Decoder + orientation pooling + contextual std head on the actuator nodes
+    (reference hepi.py:173-190, gnn_gaussian_policy_diag.py:65-87) -> (mean [N, ov, 3], sigma [N, 3 ov], hidden [N, 64])."""
+
+    @staticmethod
+    def forward(ctx, lat, grid3, wd, bd, ws, bs, shift: float, min_std: float, od: int, ov: int):
+        hip.check_f32(lat, grid3, wd, bd, ws, bs)
+        n = lat.shape[0]
+        dev = lat.device
+        mean = torch.empty(n, ov, 3, device=dev, dtype=torch.float32)
+        sigma = torch.empty(n, 3 * ov, device=dev, dtype=torch.float32)
+        hidden = torch.empty(n, 64, device=dev, dtype=torch.float32)
+        ws_, bs_ = ws.contiguous(), bs.contiguous()
+        wd_, bd_ = wd.contiguous(), bd.contiguous()
+        hip.call("grl_readout_fwd", lat, grid3, wd_, bd_, ws_, bs_, float(shift), float(min_std), mean, sigma, hidden, n, od, ov)
+        ctx.save_for_backward(lat, grid3, wd_, bd_, ws_, bs_)
+        ctx.cfg = (float(shift), od, ov)
+        return mean, sigma, hidden
+
+    @staticmethod
+    def backward(ctx, dmean, dsigma, dhidden):
+        lat, grid3, wd, bd, ws, bs = ctx.saved_tensors
+        shift, od, ov = ctx.cfg
+        n = lat.shape[0]
+        dev = lat.device
+        blocks = hip.query("grl_readout_blocks", n)
+        psize = hip.query("grl_readout_partial_size")
+        partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
+        dlat = torch.empty_like(lat)
+        dmean = torch.zeros(n, ov, 3, device=dev) if dmean is None else dmean.contiguous()
+        dsigma = torch.zeros(n, 3 * ov, device=dev) if dsigma is None else dsigma.contiguous()
+        dh = dhidden.contiguous() if dhidden is not None else None
+        hip.call("grl_readout_bwd", lat, grid3, wd, bd, ws, bs, shift, dmean, dsigma, dh, dlat, partial, n, od, ov)
+        flat = torch.zeros(psize, device=dev, dtype=torch.float32)
+        _reduce(partial, flat)
+        J, aper = od + ov, 3 * ov
+        dwd = flat[: 4 * 64].view(4, 64)[:J]
+        dbd = flat[4 * 64: 4 * 64 + 4][:J]
+        dws = flat[4 * 64 + 4: 4 * 64 + 4 + 6 * 64].view(6, 64)[:aper]
+        dbs = flat[4 * 64 + 4 + 6 * 64:][:aper]
+        return dlat, None, dwd, dbd, dws, dbs, None, None, None, None
+
+
+class DeepSetsValue(torch.autograd.Function):
+    """DeepSets critic + value head (reference deepsets.py:34-53, gnn_vf_net.py:50-86): x [B, n, d] -> V [B].
+
+    ``group``: optional torch.distributed process group; the whole-tensor LayerNorm statistics (and their backward
+    counterparts) are all-reduced over it so a sharded minibatch reproduces the single-device result."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv, group):
+        hip.check_f32(x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)
+        B, n, d = x.shape
+        dev = x.device
+        x = x.contiguous()
+        P = [t.contiguous() for t in (w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)]
+        w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = P
+        world = 1
+        if group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+        stats = torch.zeros(4, device=dev, dtype=torch.float64)  # [sum h1, sum h1^2, sum u1, sum u1^2]
+        h1 = torch.empty(B, n, 64, device=dev, dtype=torch.float32)
+        z = torch.empty(B, 64, device=dev, dtype=torch.float32)
+        u1 = torch.empty(B, 64, device=dev, dtype=torch.float32)
+        value = torch.empty(B, device=dev, dtype=torch.float32)
+        c1, c2 = float(B * world * n * 64), float(B * world * 64)
+        hip.call("grl_deepsets_fwd1", x, w1, b1, h1, stats[0:2], B, n, d)
+        if world > 1:
+            dist.all_reduce(stats[0:2], group=group)
+        hip.call("grl_deepsets_fwd2", h1, stats[0:2], ctypes_double(c1), g1, be1, w2, b2, w3, b3, z, u1, stats[2:4], B, n)
+        if world > 1:
+            dist.all_reduce(stats[2:4], group=group)
+        hip.call("grl_deepsets_fwd3", u1, stats[2:4], ctypes_double(c2), g2, be2, w4, b4, wv, bv, value, B)
+        ctx.save_for_backward(x, h1, z, u1, stats, *P)
+        ctx.meta = (B, n, d, c1, c2, group, world)
+        return value
+
+    @staticmethod
+    def backward(ctx, dvalue):
+        x, h1, z, u1, stats, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = ctx.saved_tensors
+        B, n, d, c1, c2, group, world = ctx.meta
+        dev = x.device
+        blocks = hip.query("grl_deepsets_blocks", B)
+        p3, p2 = hip.query("grl_deepsets_partial3"), hip.query("grl_deepsets_partial2")
+        p1 = 64 * d + 64
+        part3 = torch.empty(blocks, p3, device=dev)
+        part2 = torch.empty(blocks, p2, device=dev)
+        part1 = torch.empty(blocks, p1, device=dev)
+        bst = torch.zeros(4, device=dev, dtype=torch.float64)  # [sum q2, sum q2 xh2, sum q1, sum q1 xh1]
+        q2 = torch.empty(B, 64, device=dev)
+        q1 = torch.empty(B, n, 64, device=dev)
+        hip.call("grl_deepsets_bwd3", u1, stats[2:4], ctypes_double(c2), g2, be2, w4, b4, wv, dvalue.contiguous(), q2, bst[0:2],
+                 part3, B)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(bst[0:2], group=group)
+        hip.call("grl_deepsets_bwd2", h1, stats[0:2], ctypes_double(c1), g1, be1, w2, w3, z, u1, stats[2:4], ctypes_double(c2), q2,
+                 bst[0:2], q1, bst[2:4], part2, B, n)
+        if world > 1:
+            dist.all_reduce(bst[2:4], group=group)
+        hip.call("grl_deepsets_bwd1", x, h1, stats[0:2], ctypes_double(c1), q1, bst[2:4], part1, B, n, d)
+        f3 = torch.zeros(p3, device=dev)
+        f2 = torch.zeros(p2, device=dev)
+        f1 = torch.zeros(p1, device=dev)
+        _reduce(part3, f3)
+        _reduce(part2, f2)
+        _reduce(part1, f1)
+        dw4, db4, dwv, dbv, dg2, dbe2 = torch.split(f3, [4096, 64, 64, 1, 64, 64])
+        dw3, db3, dw2, db2, dg1, dbe1 = torch.split(f2, [4096, 64, 4096, 64, 64, 64])
+        dw1, db1 = torch.split(f1, [64 * d, 64])
+        return (None, dw1.view(64, d), db1, dg1, dbe1, dw2.view(64, 64), db2, dw3.view(64, 64), db3, dg2, dbe2,
+                dw4.view(64, 64), db4, dwv.view(1, 64), dbv, None)
+
+
+def ctypes_double(v: float):
+    import ctypes
+    return ctypes.c_double(v)
+
+
+TRPL_SUM_KEYS = ("loss_objective", "loss_trust_region", "entropy_dist", "loss_critic", "sum_w", "sum_w2", "mean_constraint",
+                 "cov_constraint", "entropy", "entropy_diff", "count")
+
+
+def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
+                 global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False):
+    """Launches the fused TRPL kernel.  Returns (sums fp64[11], maxes u32[2], dloc, dsigma, dvalue, proj_mean, proj_var)."""
+    import ctypes
+    hip.check_f32(loc, sigma)
+    B, A = loc.shape
+    dev = loc.device
+    cfg = (ctypes.c_double * 8)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
+                                clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch))
+    sums = torch.zeros(11, device=dev, dtype=torch.float64)
+    maxes = torch.zeros(2, device=dev, dtype=torch.int32)
+    dloc, dsigma = torch.empty_like(loc), torch.empty_like(sigma)
+    dvalue = torch.empty(B, device=dev, dtype=torch.float32) if value is not None else None
+    pm = torch.empty_like(loc) if want_projection else None
+    pv = torch.empty_like(loc) if want_projection else None
+    f = lambda t: t.reshape(B, -1).contiguous() if t.dim() > 1 else t.contiguous()
+    hip.call("grl_trpl_fwd_bwd", cfg, A, loc.contiguous(), sigma.contiguous(), f(batch["action"]), f(batch["loc"]), f(batch["var"]),
+             batch["sample_log_prob"].reshape(B).contiguous(), batch["advantage"].reshape(B).contiguous(),
+             value.reshape(B).contiguous() if value is not None else None,
+             batch["state_value"].reshape(B).contiguous() if value is not None else None,
+             batch["value_target"].reshape(B).contiguous() if value is not None else None,
+             dloc, dsigma, dvalue, pm, pv, adv_stats, sums, maxes, B)
+    return sums, maxes, dloc, dsigma, dvalue, pm, pv

@@ -1,0 +1,193 @@
+"""Policy / value heads around the HIP GNNs -- drop-ins for
+``geometry_rl/algorithms/trust_region_projections/models/policy/gnn_gaussian_policy_diag.py`` (GNNGaussianPolicyDiag),
+``.../models/value/gnn_vf_net.py`` (GNNVFNet), ``.../models/value/critic.py`` (BaseCritic) and
+``geometry_rl/modules/pyg_models/deepsets.py`` (DeepSets).  Same constructor kwargs, forward signatures and state_dict names."""
+import math
+from typing import Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .graph import HyperData
+
+
+def inverse_softplus(x: torch.Tensor) -> torch.Tensor:
+    """utils/torch_utils.py:361-370."""
+    return (x.exp() - 1.0).log()
+
+
+def _orthogonal_linear(in_f, out_f, gain):
+    lin = nn.Linear(in_f, out_f)
+    nn.init.orthogonal_(lin.weight, gain=gain)  # network_utils.py:66-70 ("orthogonal": weights orthogonal, biases zero)
+    nn.init.zeros_(lin.bias)
+    return lin
+
+
+class GNNGaussianPolicyDiag(nn.Module):
+    """forward(*obs, train=True) -> (loc [B,A], covariance_matrix [B,A,A] = diag(sigma)**2)   (gnn_gaussian_policy_diag.py:26-87).
+
+    ``forward_diag`` is the allocation-free variant used by TRPLLoss: (loc [B,A], sigma [B,A])."""
+
+    def __init__(self, gnn, hyper_data: HyperData, action_dim, num_actuators, init="orthogonal", hidden_sizes=(64, 64),
+                 activation="tanh", layer_norm=False, contextual_std=True, trainable_std=True, init_std=1.0, use_tanh_mean=False,
+                 share_weights=False, vf_model=None, minimal_std=1e-5, scale=1e-4, gain=0.01, share_action_dim=True, post_fc=False,
+                 **kwargs):
+        super().__init__()
+        if not contextual_std or post_fc or not share_action_dim or isinstance(action_dim, list) or use_tanh_mean:
+            raise NotImplementedError("HIP policy head implements the HEPi/EMPN configuration: contextual_std=True, post_fc=False, "
+                                      "share_action_dim=True (configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:85-99)")
+        if init != "orthogonal":
+            raise NotImplementedError("only the 'orthogonal' initialisation of configs/algorithm/policy/default.yaml is mirrored")
+        self.action_dim, self.num_actuators = action_dim, num_actuators
+        self.contextual_std, self.post_fc = contextual_std, post_fc
+        self.minimal_std = torch.tensor(minimal_std)
+        self.init_std = torch.tensor(init_std)
+        a_shared = action_dim // num_actuators
+        self._pre_activation_shift = inverse_softplus(self.init_std - self.minimal_std)  # abstract_gaussian_policy.py:124-134
+        self._mean = _orthogonal_linear(hidden_sizes[-1], a_shared, gain)  # unused when post_fc=False, kept for state_dict parity
+        self._pre_std = _orthogonal_linear(hidden_sizes[-1], a_shared, gain)
+        self.hyper_data = hyper_data
+        self.gnn = gnn
+        self._calib_data = None
+        self.to(next(gnn.parameters()).device)
+
+    @property
+    def is_diag(self):
+        return True
+
+    def _maybe_calibrate(self, args):
+        gnn = self.gnn
+        if hasattr(gnn, "calibrated") and not gnn.calibrated:
+            if self._calib_data is None:
+                hd = self.hyper_data
+                self._calib_data = HyperData(hd.spec, full_graph_obs=hd.full_graph_obs, dist_as_pos=hd.dist_as_pos,
+                                             output_mask_key=hd._output_mask_key, concat_input_vector=False, drop_padding=False)
+            graph, u = self._calib_data.build_data(*args, train=True)
+            gnn.calibrate(graph, u)
+            self._calib_data = None
+
+    def forward_diag(self, *args, train=True) -> Tuple[torch.Tensor, torch.Tensor]:
+        self.train(train)
+        B = args[0].shape[0]
+        if train:
+            self._maybe_calibrate(args)
+        graph, u = self.hyper_data.build_data(*args, train=train)
+        gnn = self.gnn
+        lat = gnn.latent_step(graph, u)
+        dec = gnn.decoder
+        mean, sigma, _ = ops.Readout.apply(lat, gnn.grid3, dec.weight, dec.bias, self._pre_std.weight, self._pre_std.bias,
+                                           float(self._pre_activation_shift), float(self.minimal_std), gnn.output_dim,
+                                           gnn.output_dim_vec)
+        return mean.reshape(B, -1), sigma.reshape(B, -1)
+
+    def forward(self, *args, train=True):
+        loc, sigma = self.forward_diag(*args, train=train)
+        return loc, sigma.diag_embed() ** 2
+
+    # ---- diag-Gaussian helpers with the reference's "std matrix" API (gnn_gaussian_policy_diag.py:89-148)
+    def sample(self, p, n=1):
+        return self.rsample(p, n).detach()
+
+    def rsample(self, p, n=1):
+        means, std = p
+        std = std.diagonal(dim1=-2, dim2=-1)
+        eps = torch.randn((n,) + means.shape, dtype=std.dtype, device=std.device)
+        return (means + eps * std).squeeze(0)
+
+    def log_determinant(self, std):
+        return 2 * std.diagonal(dim1=-2, dim2=-1).log().sum(-1)
+
+    def maha(self, mean, mean_other, std):
+        return ((mean - mean_other) / std.diagonal(dim1=-2, dim2=-1)).pow(2).sum(-1)
+
+    def log_probability(self, p, x, **kwargs):
+        mean, std = p
+        k = x.shape[-1]
+        return -0.5 * (self.maha(x, mean, std) + np.log(2.0 * np.pi) * k + self.log_determinant(std))
+
+    def entropy(self, p):
+        _, std = p
+        return 0.5 * (std.shape[-1] * np.log(2 * np.e * np.pi) + self.log_determinant(std))
+
+    def covariance(self, std):
+        return std.pow(2)
+
+    def precision(self, std):
+        return (1 / self.covariance(std).diagonal(dim1=-2, dim2=-1)).diag_embed()
+
+    def set_std(self, std):
+        raise AssertionError("set_std requires a non-contextual std (gnn_gaussian_policy_diag.py:137-142)")
+
+
+class _PygLinearNames(nn.Module):
+    """PyG ``MLP([a, b, c], norm='layer_norm')`` parameter layout [upstream PyG 2.5.2]: lins.0, norms.0, lins.1."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.lins = nn.ModuleList([nn.Linear(dims[0], dims[1]), nn.Linear(dims[1], dims[2])])
+        self.norms = nn.ModuleList([nn.LayerNorm(dims[1])])  # used as whole-tensor ("graph" mode) LayerNorm by the kernels
+
+
+class DeepSets(nn.Module):
+    """deepsets.py:11-53 (norm = ['layer_norm', 'layer_norm'], configs/algorithm/pyg_agent/model/deepsets.yaml)."""
+
+    def __init__(self, input_dim_node, output_dim=64, hidden_dim=64, norm=("layer_norm", "layer_norm"), device="cuda", **ignored):
+        super().__init__()
+        if hidden_dim != 64 or output_dim != 64 or list(norm) != ["layer_norm", "layer_norm"]:
+            raise NotImplementedError("HIP DeepSets is specialised for hidden=output=64 with graph-mode LayerNorm")
+        self.input_dim = input_dim_node
+        self.mlp_inner = _PygLinearNames([input_dim_node, hidden_dim, hidden_dim])
+        self.mlp_outer = _PygLinearNames([hidden_dim, hidden_dim, output_dim])
+        self.to(device)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class GNNVFNet(nn.Module):
+    """gnn_vf_net.py:8-102: critic GNN + Linear(64,1).  2-D inputs -> [B,1]; 3-D [N,T,.] inputs loop over T like the reference."""
+
+    def __init__(self, gnn: DeepSets, hyper_data: HyperData, init="orthogonal", hidden_sizes=(64, 64), **kwargs):
+        super().__init__()
+        self.hyper_data, self.gnn = hyper_data, gnn
+        self.final = nn.Linear(hidden_sizes[-1], 1)
+        nn.init.orthogonal_(self.final.weight, 0.01)  # builders/utils_algo_graph.py:195-198
+        nn.init.zeros_(self.final.bias)
+        self.group = None  # torch.distributed group for the whole-batch LayerNorm statistics (data parallel)
+        self.to(gnn.device)
+
+    def _values(self, args, train):
+        _, x = self.hyper_data.build_data(*args, train=train)
+        g = self.gnn
+        a, b = g.mlp_inner, g.mlp_outer
+        return ops.DeepSetsValue.apply(x, a.lins[0].weight, a.lins[0].bias, a.norms[0].weight, a.norms[0].bias, a.lins[1].weight,
+                                       a.lins[1].bias, b.lins[0].weight, b.lins[0].bias, b.norms[0].weight, b.norms[0].bias,
+                                       b.lins[1].weight, b.lins[1].bias, self.final.weight, self.final.bias, self.group)
+
+    def forward(self, *args, train=True):
+        self.train(train)
+        if args[0].dim() == 3:
+            T = args[0].shape[1]
+            return torch.stack([self._values([a[:, i] for a in args], train) for i in range(T)], dim=1).unsqueeze(-1)
+        return self._values(args, train).unsqueeze(-1)
+
+
+class BaseCritic(nn.Module):
+    """critic.py:4-32."""
+
+    def __init__(self, vf):
+        super().__init__()
+        self._network1 = vf
+
+    def forward(self, x, *args, **kwargs):
+        return self._network1(x, *args, **kwargs)
+
+    def q1(self, x, *args, **kwargs):
+        return self._network1(x, *args, **kwargs)
+
+    @property
+    def is_vf(self):
+        return True

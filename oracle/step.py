@@ -118,11 +118,11 @@ class OracleAgent:
         actor_loss = out["loss_objective"] + out["loss_entropy"] + out["loss_trust_region"]
         actor_loss.backward()
         out["loss_critic"].backward()
+        grads = {"actor": {k: v.grad.clone() for k, v in self.actor.items() if v.grad is not None},
+                 "critic": {k: v.grad.clone() for k, v in self.critic.items() if v.grad is not None}}  # before clipping
         if self.cfg.clip_grad_norm:
             torch.nn.utils.clip_grad_norm_(self._actor_leaves(), self.cfg.max_grad_norm)
             torch.nn.utils.clip_grad_norm_(list(self.critic.values()), self.cfg.max_grad_norm)
-        grads = {"actor": {k: v.grad.clone() for k, v in self.actor.items() if v.grad is not None},
-                 "critic": {k: v.grad.clone() for k, v in self.critic.items() if v.grad is not None}}
         self.actor_optim.step()
         self.critic_optim.step()
         self.actor_optim.zero_grad()
