@@ -79,11 +79,33 @@ GRL_DEVINL void acc_to_frag(const f32x16& a, float4& f0, float4& f1, float4& f2,
   f3 = make_float4(a[12], a[13], a[14], a[15]);
 }
 
-// exact (erf) GELU and its derivative -- torch.nn.GELU() default, reference hepi.py:73, conv.py:67
-GRL_DEVINL float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (torch.nn.GELU() default; reference hepi.py:73, conv.py:67) and its derivative, branch-free:
+//   erf(z) = sign(z) (1 - (a1 t + .. + a5 t^5) exp(-z^2)),  t = 1/(1 + p |z|)     (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
+// with z = x/sqrt(2), so exp(-z^2) = exp(-x^2/2) is also the Gaussian pdf factor the derivative needs: one v_exp_f32 and
+// one v_rcp_f32 per element give both gelu(x) and gelu'(x).  (libm erff costs ~3x the instructions and diverges.)
+GRL_DEVINL void gelu_both(float x, float& g, float& gp) {
+  const float az = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  const float e = __expf(-0.5f * x * x);
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float erf_abs = fmaf(-poly, e, 1.0f);
+  const float cdf = fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
+  g = x * cdf;
+  gp = fmaf(x * e, 0.39894228040143267794f, cdf);
+}
+GRL_DEVINL float gelu_f(float x) {
+  float g, gp;
+  gelu_both(x, g, gp);
+  return g;
+}
 GRL_DEVINL float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-  return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float g, gp;
+  gelu_both(x, g, gp);
+  return gp;
 }
 
 GRL_DEVINL float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }

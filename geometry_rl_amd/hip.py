@@ -81,13 +81,31 @@ def stream_ptr() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-entry-point timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+# KERNEL_TIMES maps name -> list of (start_event, end_event); enable with ``hip.KERNEL_TIMES = {}``.
+KERNEL_TIMES = None
+
+
 def call(name: str, *args, stream=None) -> None:
     """Launch C-ABI entry point ``name`` on the current stream; raises on a non-zero status."""
     fn = getattr(lib(), name)
     fn.restype = ctypes.c_int
+    timing = KERNEL_TIMES is not None
+    if timing:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = fn(*[_arg(a) for a in args], stream if stream is not None else stream_ptr())
+    if timing:
+        e1.record()
+        KERNEL_TIMES.setdefault(name, []).append((e0, e1))
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc}")
+
+
+def kernel_time_summary():
+    """-> {name: (n_calls, total_ms)} from the recorded events (synchronises)."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (KERNEL_TIMES or {}).items()}
 
 
 def query(name: str, *args) -> int:

@@ -50,7 +50,7 @@ class GNNGaussianPolicyDiag(nn.Module):
         self._pre_std = _orthogonal_linear(hidden_sizes[-1], a_shared, gain)
         self.hyper_data = hyper_data
         self.gnn = gnn
-        self._calib_data = None
+        self._calib_checked = False  # host-side latch: the per-conv `callibrated` buffers are inspected once, not every step
         self.to(next(gnn.parameters()).device)
 
     @property
@@ -58,20 +58,25 @@ class GNNGaussianPolicyDiag(nn.Module):
         return True
 
     def _maybe_calibrate(self, args):
+        """First training call: data-dependent re-initialisation of every conv that sees edges (conv.py:104-105).  Convs whose
+        edge set is empty are skipped by the reference too (hetero_fiber_conv.py:48-49) and stay un-calibrated."""
         gnn = self.gnn
+        self._calib_checked = True
         if hasattr(gnn, "calibrated") and not gnn.calibrated:
-            if self._calib_data is None:
-                hd = self.hyper_data
-                self._calib_data = HyperData(hd.spec, full_graph_obs=hd.full_graph_obs, dist_as_pos=hd.dist_as_pos,
-                                             output_mask_key=hd._output_mask_key, concat_input_vector=False, drop_padding=False)
-            graph, u = self._calib_data.build_data(*args, train=True)
+            hd = self.hyper_data
+            full = HyperData(hd.spec, full_graph_obs=hd.full_graph_obs, dist_as_pos=hd.dist_as_pos,
+                             output_mask_key=hd._output_mask_key, concat_input_vector=False, drop_padding=False)
+            graph, u = full.build_data(*args, train=True)
             gnn.calibrate(graph, u)
-            self._calib_data = None
+
+    def load_state_dict(self, *a, **k):
+        self._calib_checked = False
+        return super().load_state_dict(*a, **k)
 
     def forward_diag(self, *args, train=True) -> Tuple[torch.Tensor, torch.Tensor]:
         self.train(train)
         B = args[0].shape[0]
-        if train:
+        if train and not self._calib_checked:
             self._maybe_calibrate(args)
         graph, u = self.hyper_data.build_data(*args, train=train)
         gnn = self.gnn

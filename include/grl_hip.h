@@ -1,0 +1,120 @@
+/* grl_hip.h -- C ABI of libgrl_hip.so: hand-written gfx950 (MI355X) kernels for the policy-update hot path of
+ * thobotics/geometry_rl (HEPi / EMPN actor, DeepSets critic, TRPL objective, GAE, Adam).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the call unless marked HOST; the caller allocates
+ *     every output and workspace; fp32 row-major tensors; index arrays are int32;
+ *   - launches are asynchronous on `stream`; return value 0 = enqueued, -2 = unsupported shape, <= -1000 = -(1000+hipError_t);
+ *   - no global mutable state: thread-safe per stream;
+ *   - "partial" buffers are per-workgroup weight-gradient rows [n_rows][partial_size]; sum them with grl_reduce_partials.
+ * The reference has no native ABI for this path (it is Python on PyG / torch_scatter / ITPAL); each group below cites the
+ * reference code it replaces (paths relative to the reference checkout).
+ */
+#pragma once
+#include <hip/hip_runtime_api.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
+ * x[n,o,:] = [scal[n,:] | vec[n,v,:] . grid[o,:]] W_enc^T ;  scal [N,S], vec [N,V,3], grid [16,3] (z = 0 for S1), W_enc [64,S+V] */
+int grl_lift_encode_fwd(const float* scal, const float* vec, const float* grid, const float* Wenc, float* x, int n_nodes,
+                        int n_scal, int n_vec, hipStream_t stream);
+int grl_lift_bwd_blocks(int n_nodes);
+int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, const float* dx, float* partial, int n_nodes,
+                        int n_scal, int n_vec, hipStream_t stream);
+
+/* ---- fused edge pipeline: hepi.py:76-82,109-123,145-157 (invariants, PolynomialFeatures, basis MLP),
+ *      ponita/conv.py:79-86,115-149 (kernel Linear, message, torch_scatter sum)  ==  ponita/ponita.py:153,161,327-345 ------
+ * forward : rowptr/e_src/e_dst = CSR by DESTINATION; x1 [n_dst,16,64] (must be zero-initialised for edge-less nodes)
+ * backward: rowptr/e_src/e_dst = CSR by SOURCE of the same edges; dx_src [n_src,16,64];
+ *           partial [grl_edge_bwd_blocks(n_src)*4][grl_edge_partial_size()] = [dW1 64x14 | db1 64 | dW2 64x64 | db2 64 | dWk 64x64] */
+int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                      const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
+                      const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
+int grl_edge_partial_size(void);
+int grl_edge_bwd_blocks(int n_anchor);
+int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr_s,
+                      const int* e_src_s, const int* e_dst_s, int n_src, const float* grid, int dim, const float* W1,
+                      const float* b1, const float* W2, const float* b2, const float* Wk, const float* dx1, float* dx_src,
+                      float* partial, hipStream_t stream);
+
+/* ---- depthwise fiber convolution + bias: ponita/conv.py:88-90,108-109 (ponita.py:164-166,183) ----------------------------
+ * x2[n,p,c] = 1/16 sum_o x1[n,o,c] fk[o,p,c] + bias[c];  partial [grl_fiber_bwd_blocks][grl_fiber_partial_size] = [dfk | dbias] */
+int grl_fiber_conv_fwd(const float* x1, const float* fk, const float* bias, float* x2, int n_nodes, hipStream_t stream);
+int grl_fiber_partial_size(void);
+int grl_fiber_bwd_blocks(int n_nodes);
+int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float* dx1, float* partial, int n_nodes,
+                       hipStream_t stream);
+
+/* ---- ConvNeXt node block: ponita/conv.py:64-69,112 (ponita.py:219-230); hetero sum hetero_fiber_conv.py:63-64 -------------
+ * out = (accumulate ? out : 0) + x_dst + W4 GELU(W3 LN(x2) + b3) + b4 ; n_rows = n_nodes*16
+ * bwd scratch: xhat_buf, da_buf [n_rows,64]; h_buf, dz_buf [n_rows,256];
+ * partial [grl_node_mlp_bwd_blocks(n_rows)][grl_node_mlp_partial_size()] = [dW3 | db3 | dW4 | db4 | dgamma | dbeta] */
+int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream);
+int grl_node_mlp_partial_size(void);
+int grl_node_mlp_bwd_blocks(int n_rows);
+int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, float* dx2, float* xhat_buf, float* da_buf, float* h_buf,
+                     float* dz_buf, float* partial, int n_rows, hipStream_t stream);
+
+/* ---- read-out + contextual std head: hepi.py:173-190 (ponita_gcn.py:129-146),
+ *      algorithms/trust_region_projections/models/policy/gnn_gaussian_policy_diag.py:65-87 ------------------------------------
+ * mean [n,ov,3], sigma [n,3 ov], hidden [n,64]; partial [grl_readout_blocks][grl_readout_partial_size] */
+int grl_readout_fwd(const float* lat, const float* grid, const float* Wd, const float* bd, const float* Ws, const float* bs,
+                    float shift, float min_std, float* mean, float* sigma, float* hidden, int n_nodes, int output_dim,
+                    int output_dim_vec, hipStream_t stream);
+int grl_readout_partial_size(void);
+int grl_readout_blocks(int n_nodes);
+int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const float* bd, const float* Ws, const float* bs,
+                    float shift, const float* dmean, const float* dsigma, const float* dhidden_ext, float* dlat, float* partial,
+                    int n_nodes, int output_dim, int output_dim_vec, hipStream_t stream);
+
+/* ---- TRPL objective: objectives/trpl.py:231-321, projections/base_projection_layer.py:71-100,292-384,
+ *      projections/kl_projection_layer.py:15-111 (+ ITPAL BatchedDiagCovOnlyProjection), utils/projection_utils.py:34-67,
+ *      objectives/utils.py:5-28 ---------------------------------------------------------------------------------------------
+ * cfg8 (HOST): {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value, 1/B_global, B_global}
+ * sums fp64[11]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
+ *               cov_constraint, entropy(p), entropy_diff, count  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
+int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream);
+int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, const float* sigma, const float* action,
+                     const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
+                     const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
+                     float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
+                     unsigned int* maxes, int batch, hipStream_t stream);
+
+/* ---- DeepSets critic: geometry_rl/modules/pyg_models/deepsets.py:34-53, models/value/gnn_vf_net.py:50-86 ---------------------
+ * three forward and three backward stages around the whole-tensor LayerNorm statistics (PyG LayerNorm mode="graph") */
+int grl_deepsets_blocks(int batch);
+int grl_deepsets_partial3(void);
+int grl_deepsets_partial2(void);
+int grl_deepsets_fwd1(const float* x, const float* W1, const float* b1, float* h1, double* stats1, int batch, int n_nodes, int d,
+                      hipStream_t stream);
+int grl_deepsets_fwd2(const float* h1, const double* stats1, double count1, const float* g1, const float* be1, const float* W2,
+                      const float* b2, const float* W3, const float* b3, float* z, float* u1, double* stats2, int batch,
+                      int n_nodes, hipStream_t stream);
+int grl_deepsets_fwd3(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
+                      const float* b4, const float* wv, const float* bv, float* value, int batch, hipStream_t stream);
+int grl_deepsets_bwd3(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
+                      const float* b4, const float* wv, const float* dvalue, float* q2, double* bstats2, float* partial,
+                      int batch, hipStream_t stream);
+int grl_deepsets_bwd2(const float* h1, const double* stats1, double count1, const float* g1, const float* be1, const float* W2,
+                      const float* W3, const float* z, const float* u1, const double* stats2, double count2, const float* q2,
+                      const double* bstats2, float* q1, double* bstats1, float* partial, int batch, int n_nodes,
+                      hipStream_t stream);
+int grl_deepsets_bwd1(const float* x, const float* h1, const double* stats1, double count1, const float* q1,
+                      const double* bstats1, float* partial, int batch, int n_nodes, int d, hipStream_t stream);
+
+/* ---- training loop: examples/torchrl/train.py:134-146,249-251,308-316; pyg_data/rigid_tasks_data.py:285-287 ------------- */
+int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hipStream_t stream);
+int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
+                  float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
+int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream);
+int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned char* terminated, const float* values,
+                 float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream);
+int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif

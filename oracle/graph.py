@@ -253,15 +253,17 @@ def graph_layer_norm(x, w, b, eps=1e-5, stats=None):
     return (x - mean) / (std + eps) * w + b
 
 
-def deepsets_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, prefix="gnn"):
+def deepsets_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, prefix="gnn", stats_fn=None):
     """deepsets.py:34-53 + PyG MLP([in,64,64], norm="layer_norm") [upstream]: Linear, graph-LN, ReLU, Linear; sum over nodes;
     second MLP.  x [B, n_all, d] -> [B, 64]."""
     h = F.linear(x, P[f"{prefix}.mlp_inner.lins.0.weight"], P[f"{prefix}.mlp_inner.lins.0.bias"])
-    h = F.relu(graph_layer_norm(h, P[f"{prefix}.mlp_inner.norms.0.weight"], P[f"{prefix}.mlp_inner.norms.0.bias"]))
+    st = stats_fn(h) if stats_fn else None  # data-parallel check: statistics of the GLOBAL batch
+    h = F.relu(graph_layer_norm(h, P[f"{prefix}.mlp_inner.norms.0.weight"], P[f"{prefix}.mlp_inner.norms.0.bias"], stats=st))
     h = F.linear(h, P[f"{prefix}.mlp_inner.lins.1.weight"], P[f"{prefix}.mlp_inner.lins.1.bias"])
     z = h.sum(dim=1)  # deepsets.py:51
     u = F.linear(z, P[f"{prefix}.mlp_outer.lins.0.weight"], P[f"{prefix}.mlp_outer.lins.0.bias"])
-    u = F.relu(graph_layer_norm(u, P[f"{prefix}.mlp_outer.norms.0.weight"], P[f"{prefix}.mlp_outer.norms.0.bias"]))
+    st = stats_fn(u) if stats_fn else None
+    u = F.relu(graph_layer_norm(u, P[f"{prefix}.mlp_outer.norms.0.weight"], P[f"{prefix}.mlp_outer.norms.0.bias"], stats=st))
     return F.linear(u, P[f"{prefix}.mlp_outer.lins.1.weight"], P[f"{prefix}.mlp_outer.lins.1.bias"])
 
 
@@ -275,9 +277,9 @@ def critic_input(topo: dict, scalar_dict, vector_dict) -> torch.Tensor:
     return torch.cat(xs, dim=1)
 
 
-def value_forward(P: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+def value_forward(P: Dict[str, torch.Tensor], x: torch.Tensor, stats_fn=None) -> torch.Tensor:
     """vf.py:50-86 GNNVFNet.forward for a 2-D batch: DeepSets -> Linear(64,1).  [B, n_all, d] -> [B, 1]."""
-    return F.linear(deepsets_forward(P, x, "gnn"), P["final.weight"], P["final.bias"])
+    return F.linear(deepsets_forward(P, x, "gnn", stats_fn), P["final.weight"], P["final.bias"])
 
 
 def init_critic_params(in_dim: int, hidden=64, seed=1) -> Dict[str, torch.Tensor]:

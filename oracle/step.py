@@ -96,16 +96,16 @@ class OracleAgent:
                           c.minimal_std, B)
         return out.reshape(B, -1), std ** 2  # diag of diag_embed(std)**2
 
-    def critic_forward(self, obs):
+    def critic_forward(self, obs, stats_fn=None):
         topo, graph, s, v = self._graph(obs, full_graph_obs=True, dist_as_pos=False)
-        return gr.value_forward(self.critic, gr.critic_input(topo, s, v))
+        return gr.value_forward(self.critic, gr.critic_input(topo, s, v), stats_fn)
 
-    def loss(self, batch: Dict[str, torch.Tensor], adv_stats=None):
+    def loss(self, batch: Dict[str, torch.Tensor], adv_stats=None, stats_fn=None):
         c = self.cfg
         b = {k: (v.to(self.dtype) if v.is_floating_point() else v) for k, v in batch.items()}
         obs = {k: b[k] for k in self.spec.in_features}
         loc, var = self.actor_forward(obs)
-        value = self.critic_forward(obs)
+        value = self.critic_forward(obs, stats_fn)
         out = tr.trpl_loss(loc, var, b, value, mean_bound=c.mean_bound, cov_bound=c.cov_bound,
                            trust_region_coeff=c.trust_region_coeff, entropy_coef=c.entropy_coef,
                            critic_coef=c.critic_coef, clip_value=c.clip_value, adv_stats=adv_stats)

@@ -1,0 +1,82 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/grl_hip.h declares; host logic without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "grl_hip.h")).read()
+    return sorted(set(re.findall(r"\bint\s+(grl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from geometry_rl_amd import hip
+    path = hip.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/grl_hip.h but not exported by libgrl_hip.so"
+    # host-only queries are callable without a GPU
+    lib.grl_edge_partial_size.restype = ctypes.c_int
+    assert lib.grl_edge_partial_size() == 64 * 14 + 64 + 4096 + 64 + 4096
+    assert lib.grl_node_mlp_partial_size() == 256 * 64 + 256 + 64 * 256 + 64 * 3
+    assert lib.grl_fiber_partial_size() == 16 * 16 * 64 + 64
+
+
+def test_no_oracle_import_in_product():
+    """The product package must never route through the CPU oracle."""
+    pkg = os.path.join(ROOT, "geometry_rl_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py") and fn != "smoke.py":
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("CPU oracle", ""), fn
+
+
+def test_product_fails_loudly_without_extension(monkeypatch, tmp_path):
+    from geometry_rl_amd import hip
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(hip, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        hip.lib()
+
+
+def test_module_state_dict_names_match_reference_layout():
+    """SURVEY Appendix B names (incl. PyG tuple-key mangling) so reference checkpoints load."""
+    from geometry_rl_amd import agent, graph
+    spec = graph.rigid_spec()
+    cfg = agent.AgentConfig(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
+    actor, critic, proj, loss = agent.build_agent(spec, cfg, device="cpu")
+    sd = actor.state_dict()
+    for k in ["gnn.ori_grid", "gnn.basis_fn.1.weight", "gnn.basis_fn.3.bias", "gnn.fiber_basis_fn.1.weight", "gnn.node_encoder.weight",
+              "gnn.processor.0.convs.<object_geometry___internal___object_geometry>.kernel.weight",
+              "gnn.processor.1.convs.<object_geometry___task___grippers>.node_mlp.3.bias",
+              "gnn.processor.1.convs.<grippers___agent___grippers>.callibrated", "gnn.decoder.weight", "_pre_std.weight", "_mean.bias"]:
+        assert k in sd, k
+    n_train = sum(p.numel() for p in actor.parameters())
+    assert n_train == 135440
+    assert sum(p.numel() for p in critic.parameters()) == 13825
+    csd = critic.state_dict()
+    for k in ["_network1.gnn.mlp_inner.lins.0.weight", "_network1.gnn.mlp_inner.norms.0.weight", "_network1.gnn.mlp_outer.lins.1.bias",
+              "_network1.final.weight"]:
+        assert k in csd, k
+    assert tuple(sd["gnn.node_encoder.weight"].shape) == (64, 7)
+
+
+def test_synthetic_shapes_follow_reference_layout():
+    from geometry_rl_amd import graph, synthetic as syn
+    spec = graph.rigid_spec()
+    obs = syn.make_rigid_obs(5)
+    for g in spec.in_features:
+        base = g.replace("norm_", "")
+        assert obs[g].shape == (5, sum(spec.obs_dims[base])), g
+    assert obs["position_vectors"].shape[1] == 195 and obs["velocity_vectors"].shape[1] == 12
+    c = syn.make_cloth_obs(3)
+    assert c["position_vectors"].shape[1] == 1395 and c["velocity_vectors"].shape[1] == 687
+    r = syn.make_rope_obs(3)
+    assert r["position_vectors"].shape[1] == 486 and r["velocity_vectors"].shape[1] == 246
