@@ -2,15 +2,22 @@
 //   invariants -> PolynomialFeatures(2) -> Linear(14,64)+GELU -> Linear(64,64)+GELU        (hepi.py:76-82,109-123,145-157)
 //   -> kernel Linear(64,64, no bias) -> message = kernel * x_src[src]                      (conv.py:79,115-117)
 //   -> sum over the edges of each destination node                                         (conv.py:141-147)
-// Nothing per-edge ever reaches HBM.  Forward walks edges grouped by destination (CSR by dst), backward walks the same
-// edges grouped by SOURCE so that d x_src accumulates in an LDS tile too -- no global atomics in either direction.
+// Nothing per-edge ever reaches HBM.  Every wave works alone on 32 rows (2 edges x 16 orientations) per pass, in
+// destination-sorted edge order:
+//   forward : a wave owns TD = 2 consecutive destination nodes, sums their messages in registers and stores the finished rows
+//             with plain stores (no atomics, no workgroup barrier in the loop);
+//   backward: recomputes the chain, accumulates the five weight gradients in registers for the whole launch, stores each
+//             edge's d x_src row once ([E,16,64] scratch) and sums them per source node in a second streaming pass
+//             (store pass + per-destination sum pass, cdna_hip_programming.md "Scatter / gather"): no atomics anywhere.
+// The next pass's indices / positions and this pass's x_src rows are requested before the MFMA chain starts, so the gather
+// latency hides behind it.
 #include "grl_common.h"
 
 namespace {
 
 constexpr int C = 64;            // channels
 constexpr int O = 16;            // orientations
-constexpr int GROUP = 8;         // anchor nodes per workgroup iteration
+constexpr int TD = 2;            // destination nodes per wave tile (forward)
 constexpr int LDT = C + 4;       // padded row of an LDS activation tile
 constexpr int LDW = GRL_LD(64);  // 68
 constexpr int LDW1 = GRL_LD(16); // 20
@@ -52,7 +59,7 @@ GRL_DEVINL void poly_frags(float a, float b, int h, float4& f0, float4& f1) {
 template <bool BWD>
 GRL_DEVINL void edge_chain(const float* W1s, const float* b1s, const float* W2s, const float* b2s, const float* Wks,
                            float a, float b, float4 (&kf)[8], float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8],
-                           float4 (&gp2)[8], float4 (&phi)[2]) {
+                           float4 (&gp2)[8], float4 (&phi)[2], float* g1_rows = nullptr, float* g2_rows = nullptr) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   poly_frags(a, b, h, phi[0], phi[1]);
 #pragma unroll
@@ -72,6 +79,7 @@ GRL_DEVINL void edge_chain(const float* W1s, const float* b1s, const float* W2s,
                                       gelu_grad_f(acc[4 * q + 3]));
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     f32x16 acc;
@@ -79,6 +87,10 @@ GRL_DEVINL void edge_chain(const float* W1s, const float* b1s, const float* W2s,
     for (int q = 0; q < 4; ++q) {
       const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * nt + 8 * q + 4 * h);
       acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
+    }
+    if (BWD && nt == 0) {  // backward: g1 goes to its LDS tile (row-major [r][c]) now and leaves the registers after layer 2
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g1_rows + 8 * t) = g1[t];
     }
     mma_wx<64>(W2s + (32 * nt + i) * LDW + 4 * h, g1, acc);
 #pragma unroll
@@ -89,23 +101,18 @@ GRL_DEVINL void edge_chain(const float* W1s, const float* b1s, const float* W2s,
                                       gelu_grad_f(acc[4 * q + 3]));
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     f32x16 acc = zero16();
+    if (BWD && nt == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g2_rows + 8 * t) = g2[t];
+    }
     mma_wx<64>(Wks + (32 * nt + i) * LDW + 4 * h, g2, acc);
     acc_to_frag(acc, kf[4 * nt], kf[4 * nt + 1], kf[4 * nt + 2], kf[4 * nt + 3]);
   }
-}
-
-GRL_DEVINL void edge_invariants(const EdgeParams& p, const float* grid_s, int e, int o, float& a, float& b) {
-  const int s = p.e_src[e], d = p.e_dst[e];
-  float rx = p.pos_src[3 * s] - p.pos_dst[3 * d];
-  float ry = p.pos_src[3 * s + 1] - p.pos_dst[3 * d + 1];
-  float rz = (p.dim == 2) ? 0.f : p.pos_src[3 * s + 2] - p.pos_dst[3 * d + 2];
-  const float gx = grid_s[3 * o], gy = grid_s[3 * o + 1], gz = grid_s[3 * o + 2];
-  a = rx * gx + ry * gy + rz * gz;                      // hepi.py:115
-  rx -= a * gx; ry -= a * gy; rz -= a * gz;
-  b = sqrtf(rx * rx + ry * ry + rz * rz);               // hepi.py:117
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // LDS: weights + the anchor tile
@@ -132,59 +139,93 @@ GRL_DEVINL void load_weights(Smem& s, const EdgeParams& p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ per-pass metadata
+struct PassMeta {
+  int src, dst;   // node ids of this lane's edge
+  float a, b;     // spatial invariants for this lane's (edge, orientation)
+  bool valid;
+};
+
+GRL_DEVINL void meta_indices(const EdgeParams& p, int e, int e_end, PassMeta& m) {
+  m.valid = e < e_end;
+  const int ee = m.valid ? e : e_end - 1;
+  m.src = p.e_src[ee];
+  m.dst = p.e_dst[ee];
+}
+GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o, PassMeta& m) {
+  float rx = p.pos_src[3 * m.src] - p.pos_dst[3 * m.dst];
+  float ry = p.pos_src[3 * m.src + 1] - p.pos_dst[3 * m.dst + 1];
+  float rz = (p.dim == 2) ? 0.f : p.pos_src[3 * m.src + 2] - p.pos_dst[3 * m.dst + 2];
+  const float gx = grid_s[3 * o], gy = grid_s[3 * o + 1], gz = grid_s[3 * o + 2];
+  m.a = rx * gx + ry * gy + rz * gz;                      // hepi.py:115
+  rx -= m.a * gx; ry -= m.a * gy; rz -= m.a * gz;
+  m.b = sqrtf(rx * rx + ry * ry + rz * rz);               // hepi.py:117
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void edge_conv_fwd_kernel(EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
+// A wave owns TD = 2 consecutive destination nodes (A, B).  Each lane keeps two register accumulators (one per node) for
+// its (edge slot, orientation) row; after the last pass the two edge slots are folded with one cross-lane exchange
+// (lane r <-> r^16) and the rows leave with plain stores.  No LDS traffic besides the weights (LDS float atomics cost
+// ~200 LDS cycles per wave instruction on gfx950 -- measured, profiles/r01_*pmc* -- and made the first version LDS-bound).
+constexpr int FWD_WAVES = 4;
+__global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel(EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   Smem& s = *reinterpret_cast<Smem*>(smem_raw);
-  float* tile = smem_raw + sizeof(Smem) / 4;  // [GROUP*16][LDT]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   load_weights(s, p);
-  for (int idx = threadIdx.x; idx < GROUP * O * LDT; idx += blockDim.x) tile[idx] = 0.f;
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
-  const int n_groups = (p.n_anchor + GROUP - 1) / GROUP;
-  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int d0 = g * GROUP, d1 = min(d0 + GROUP, p.n_anchor);
+  const int n_tiles = (p.n_anchor + TD - 1) / TD;
+  for (int tl = blockIdx.x * FWD_WAVES + wave; tl < n_tiles; tl += gridDim.x * FWD_WAVES) {
+    const int d0 = tl * TD, d1 = min(d0 + TD, p.n_anchor);
     const int e0 = p.rowptr[d0], e1 = p.rowptr[d1];
-    const int n_pass = (e1 - e0 + 1) >> 1;
-    for (int ps = wave; ps < n_pass; ps += 4) {
-      const int e = e0 + 2 * ps + el;
-      const bool valid = e < e1;
-      const int ee = valid ? e : e0;
-      float a, b;
-      edge_invariants(p, s.grid_s, ee, o, a, b);
-      float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-      edge_chain<false>(s.W1s, s.b1s, s.W2s, s.b2s, s.Wks, a, b, kf, g1, gp1, g2, gp2, phi);
-      if (valid) {
-        const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)p.e_src[ee] * O + o) * C) + h;
-        float* trow = tile + ((p.e_dst[ee] - d0) * O + o) * LDT + 4 * h;
+    float4 accA[8], accB[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { accA[t] = make_float4(0.f, 0.f, 0.f, 0.f); accB[t] = accA[t]; }
+    if (e1 > e0) {
+      PassMeta cur;
+      meta_indices(p, e0 + el, e1, cur);
+      meta_invariants(p, s.grid_s, o, cur);
+#pragma unroll 1
+      for (int e = e0; e < e1; e += 2) {
+        PassMeta nxt;
+        const bool more = e + 2 < e1;
+        if (more) meta_indices(p, e + 2 + el, e1, nxt);                       // next pass: indices in flight
+        const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
+        float4 xv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];                         // this pass: x_src row in flight
+        float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
+        edge_chain<false>(s.W1s, s.b1s, s.W2s, s.b2s, s.Wks, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi);
+        if (more) meta_invariants(p, s.grid_s, o, nxt);                       // next pass: positions -> (a, b)
+        const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
+        const float wb = (cur.valid && cur.dst != d0) ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const float4 m = f4_mul(kf[t], xs[2 * t]);  // float4 index 2t + h  <->  floats 8t + 4h
-          atomicAdd(trow + 8 * t, m.x);
-          atomicAdd(trow + 8 * t + 1, m.y);
-          atomicAdd(trow + 8 * t + 2, m.z);
-          atomicAdd(trow + 8 * t + 3, m.w);
+          const float4 m = f4_mul(kf[t], xv[t]);
+          accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
+          accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
         }
+        cur = nxt;
       }
     }
-    __syncthreads();
-    // flush the tile (coalesced float4 rows) and clear it
-    const int n_rows = (d1 - d0) * O;
-    for (int idx = threadIdx.x; idx < n_rows * (C / 4); idx += blockDim.x) {
-      const int row = idx >> 4, c4 = idx & 15;
-      float4* src = reinterpret_cast<float4*>(tile + row * LDT) + c4;
-      reinterpret_cast<float4*>(x1 + ((size_t)d0 * O + row) * C)[c4] = *src;
-      *src = make_float4(0.f, 0.f, 0.f, 0.f);
+    // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's
+    const int node = d0 + el;
+    float4* dstp = reinterpret_cast<float4*>(x1 + ((size_t)node * O + o) * C) + h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float4 a = accA[t], b = accB[t];
+      a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
+      b.x += __shfl_xor(b.x, 16, 64); b.y += __shfl_xor(b.y, 16, 64); b.z += __shfl_xor(b.z, 16, 64); b.w += __shfl_xor(b.w, 16, 64);
+      if (node < d1) dstp[2 * t] = el == 0 ? a : b;
     }
-    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Walks edges grouped by SOURCE node.  Per pass (2 edges x 16 orientations = 32 rows per wave):
-//   recompute chain; dM = d x1[dst]; dK = dM * x_src; d x_src += dM * K (LDS tile);
+// Per pass (2 edges x 16 orientations = 32 rows per wave):
+//   recompute chain; dM = d x1[dst]; dK = dM * x_src; d x_src[src] += dM * K (row-shaped global atomics);
 //   dWk += dK^T g2; dG2 = dK Wk; dZ2 = dG2 * gelu'(z2); dW2 += dZ2^T g1; db2 += colsum dZ2;
 //   dG1 = dZ2 W2; dZ1 = dG1 * gelu'(z1); dW1 += dZ1^T phi; db1 += colsum dZ1.
 // Weight-gradient accumulators live in registers for the whole kernel (one wave per SIMD, 512-VGPR budget) and are
@@ -197,20 +238,19 @@ GRL_DEVINL void store_frags_rowmajor(float* buf /*wave-private [32][LDT]*/, int 
 }
 
 __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                float* __restrict__ dx_src /*[Ns,16,64]*/,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ dxe /*[E,16,64] per-edge d x_src rows*/,
+                                                                float* __restrict__ partial, int n_edges) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   Smem& s = *reinterpret_cast<Smem*>(smem_raw);
-  float* tile = smem_raw + sizeof(Smem) / 4;          // [GROUP*16][LDT]  d x_src accumulators
-  float* tbuf = tile + GROUP * O * LDT;               // 4 waves x 2 x [32][LDT]
+  float* tbuf = smem_raw + sizeof(Smem) / 4;          // 4 waves x 3 x [32][LDT]
   load_weights(s, p);
-  for (int idx = threadIdx.x; idx < GROUP * O * LDT; idx += blockDim.x) tile[idx] = 0.f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
-  float* T0 = tbuf + wave * 2 * 32 * LDT;
-  float* T1 = T0 + 32 * LDT;
+  float* T0 = tbuf + wave * 3 * 32 * LDT;  // gradient-side operand (d x_src, dK, dZ2, dZ1 in turn)
+  float* T1 = T0 + 32 * LDT;               // g2 (written inside the chain), later phi
+  float* T2 = T1 + 32 * LDT;               // g1 (written inside the chain)
 
   f32x16 dWk[2][2], dW2[2][2], dW1[2];
 #pragma unroll
@@ -221,100 +261,97 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
   }
   float db1 = 0.f, db2 = 0.f;  // lane = column (64 columns)
 
-  const int n_groups = (p.n_anchor + GROUP - 1) / GROUP;
-  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int s0 = g * GROUP, s1 = min(s0 + GROUP, p.n_anchor);
-    const int e0 = p.rowptr[s0], e1 = p.rowptr[s1];
-    const int n_pass = (e1 - e0 + 1) >> 1;
-    for (int ps = wave; ps < n_pass; ps += 4) {
-      const int e = e0 + 2 * ps + el;
-      const bool valid = e < e1;
-      const int ee = valid ? e : e0;
-      float a, b;
-      edge_invariants(p, s.grid_s, ee, o, a, b);
-      float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-      edge_chain<true>(s.W1s, s.b1s, s.W2s, s.b2s, s.Wks, a, b, kf, g1, gp1, g2, gp2, phi);
+  const int n_pass = (n_edges + 1) >> 1;
+  const int stride = gridDim.x * 4;
+  int ps = blockIdx.x * 4 + wave;
+  PassMeta cur;
+  if (ps < n_pass) {
+    meta_indices(p, 2 * ps + el, n_edges, cur);
+    meta_invariants(p, s.grid_s, o, cur);
+  }
+  for (; ps < n_pass; ps += stride) {
+    PassMeta nxt;
+    const bool more = ps + stride < n_pass;
+    if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
+    const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
+    const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
+    float4 xv[8], dv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }
+    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
+    edge_chain<true>(s.W1s, s.b1s, s.W2s, s.b2s, s.Wks, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi, T2 + r * LDT + 4 * h,
+                     T1 + r * LDT + 4 * h);
+    if (more) meta_invariants(p, s.grid_s, o, nxt);
 
-      const int src = p.e_src[ee], dst = p.e_dst[ee];
-      const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)src * O + o) * C) + h;
-      const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)dst * O + o) * C) + h;
-      float4 dK[8];
-      float* trow = tile + ((src - s0) * O + o) * LDT + 4 * h;
+    float4 dK[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float4 d = dm[2 * t];
-        if (!valid) d = make_float4(0.f, 0.f, 0.f, 0.f);
-        dK[t] = f4_mul(d, xs[2 * t]);
-        const float4 dx = f4_mul(d, kf[t]);
-        if (valid) {
-          atomicAdd(trow + 8 * t, dx.x);
-          atomicAdd(trow + 8 * t + 1, dx.y);
-          atomicAdd(trow + 8 * t + 2, dx.z);
-          atomicAdd(trow + 8 * t + 3, dx.w);
-        }
-      }
-      // ---- Wk: dWk[c][k] += sum_r dK[r][c] g2[r][k]
-      store_frags_rowmajor(T0, r, h, dK);
-      store_frags_rowmajor(T1, r, h, g2);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          mma_tn<32>(T0 + 4 * h * LDT + 32 * ct + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dWk[ct][kt]);
-      // ---- dZ2 = (dK Wk) * gelu'(z2)
-      float4 dz2[8];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x16 acc = zero16();
-        mma_wTy<64>(s.Wks + 4 * h * LDW + 32 * kt + r, LDW, dK, acc);
-        float4 f0, f1, f2, f3;
-        acc_to_frag(acc, f0, f1, f2, f3);
-        dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
-        dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
-        dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
-        dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
-      }
-      store_frags_rowmajor(T0, r, h, dz2);
-      store_frags_rowmajor(T1, r, h, g1);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dW2[nt][kt]);
-#pragma unroll
-      for (int rr = 0; rr < 32; ++rr) db2 += T0[rr * LDT + lane];
-      // ---- dZ1 = (dZ2 W2) * gelu'(z1)
-      float4 dz1[8];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x16 acc = zero16();
-        mma_wTy<64>(s.W2s + 4 * h * LDW + 32 * kt + r, LDW, dz2, acc);
-        float4 f0, f1, f2, f3;
-        acc_to_frag(acc, f0, f1, f2, f3);
-        dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
-        dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
-        dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
-        dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
-      }
-      store_frags_rowmajor(T0, r, h, dz1);
-      // phi as row-major [32][16] inside T1 (columns 16..31 of the tile are never used downstream)
-      *reinterpret_cast<float4*>(T1 + r * LDT + 4 * h) = phi[0];
-      *reinterpret_cast<float4*>(T1 + r * LDT + 8 + 4 * h) = phi[1];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + r, LDT, dW1[nt]);
-#pragma unroll
-      for (int rr = 0; rr < 32; ++rr) db1 += T0[rr * LDT + lane];
+    for (int t = 0; t < 8; ++t) {
+      if (!cur.valid) dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dK[t] = f4_mul(dv[t], xv[t]);
+      kf[t] = f4_mul(dv[t], kf[t]);  // d x_src fragment
     }
-    __syncthreads();
-    const int n_rows = (s1 - s0) * O;
-    for (int idx = threadIdx.x; idx < n_rows * (C / 4); idx += blockDim.x) {
-      const int row = idx >> 4, c4 = idx & 15;
-      float4* src = reinterpret_cast<float4*>(tile + row * LDT) + c4;
-      reinterpret_cast<float4*>(dx_src + ((size_t)s0 * O + row) * C)[c4] = *src;
-      *src = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- d x_src contribution of this lane's (edge, orientation) row: plain stores of the per-edge rows; the per-source sum
+    //      is a separate streaming pass (edge_gather_sum_kernel) -- no atomics, bitwise reproducible
+    if (cur.valid) {
+      float4* de = reinterpret_cast<float4*>(dxe + ((size_t)(2 * ps + el) * O + o) * C) + h;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) de[2 * t] = kf[t];
     }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Wk: dWk[c][k] += sum_r dK[r][c] g2[r][k]
+    store_frags_rowmajor(T0, r, h, dK);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        mma_tn<32>(T0 + 4 * h * LDT + 32 * ct + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dWk[ct][kt]);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dZ2 = (dK Wk) * gelu'(z2)
+    float4 dz2[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 acc = zero16();
+      mma_wTy<64>(s.Wks + 4 * h * LDW + 32 * kt + r, LDW, dK, acc);
+      float4 f0, f1, f2, f3;
+      acc_to_frag(acc, f0, f1, f2, f3);
+      dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
+      dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
+      dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
+      dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
+    }
+    store_frags_rowmajor(T0, r, h, dz2);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T2 + 4 * h * LDT + 32 * kt + r, LDT, dW2[nt][kt]);
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) db2 += T0[rr * LDT + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- dZ1 = (dZ2 W2) * gelu'(z1)
+    float4 dz1[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 acc = zero16();
+      mma_wTy<64>(s.W2s + 4 * h * LDW + 32 * kt + r, LDW, dz2, acc);
+      float4 f0, f1, f2, f3;
+      acc_to_frag(acc, f0, f1, f2, f3);
+      dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
+      dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
+      dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
+      dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_frags_rowmajor(T0, r, h, dz1);
+    // phi as row-major [32][16] inside T1 (columns 16..31 of the tile are never used downstream)
+    *reinterpret_cast<float4*>(T1 + r * LDT + 4 * h) = phi[0];
+    *reinterpret_cast<float4*>(T1 + r * LDT + 8 + 4 * h) = phi[1];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + r, LDT, dW1[nt]);
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) db1 += T0[rr * LDT + lane];
+    cur = nxt;
   }
 
   // ---- write this wave's weight-gradient partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
@@ -336,14 +373,34 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
   ob2[lane] = db2;
 }
 
+// dx_src[n] = sum over the out-edges of source node n of the per-edge rows dxe[eid]  (CSR by source: rowptr_s, eid_s)
+__global__ __launch_bounds__(256) void edge_gather_sum_kernel(const float* __restrict__ dxe, const int* __restrict__ rowptr_s,
+                                                              const int* __restrict__ eid_s, float* __restrict__ dx_src, int n_src) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = blockIdx.x * 4 + wave; n < n_src; n += gridDim.x * 4) {
+    float4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j0 = rowptr_s[n], j1 = rowptr_s[n + 1];
+    for (int j = j0; j < j1; ++j) {
+      const float4* row = reinterpret_cast<const float4*>(dxe + (size_t)eid_s[j] * O * C) + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = f4_add(acc[q], row[64 * q]);
+    }
+    float4* out = reinterpret_cast<float4*>(dx_src + (size_t)n * O * C) + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[64 * q] = acc[q];
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 int grl_edge_partial_size() { return EDGE_PARTIAL; }
-int grl_edge_bwd_blocks(int n_anchor) {
-  const int n_groups = (n_anchor + GROUP - 1) / GROUP;
-  return n_groups < 256 ? n_groups : 256;
+int grl_edge_bwd_blocks(int n_edges) {
+  const int b = ((n_edges + 1) / 2 + 3) / 4;
+  return b < 1 ? 1 : (b < 256 ? b : 256);
 }
 
 int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
@@ -351,35 +408,40 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
                       const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream) {
   if (n_dst <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-  const int n_groups = (n_dst + GROUP - 1) / GROUP;
-  const int blocks = n_groups < 512 ? n_groups : 512;
-  const size_t smem = sizeof(Smem) + sizeof(float) * GROUP * O * LDT;
+  const int n_tiles = (n_dst + TD - 1) / TD;
+  int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
+  if (blocks > 256) blocks = 256;
+  const size_t smem = sizeof(Smem);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL(edge_conv_fwd_kernel, dim3(blocks), dim3(256), smem, stream, p, x1);
+  hipLaunchKernelGGL(edge_conv_fwd_kernel, dim3(blocks), dim3(64 * FWD_WAVES), smem, stream, p, x1);
   GRL_CHECK_LAUNCH();
   return 0;
 }
 
-// rowptr/e_src/e_dst here are the SOURCE-sorted CSR of the same edge set.  partial must hold
-// grl_edge_bwd_blocks(n_src)*4 rows of grl_edge_partial_size() floats.
-int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr_s,
-                      const int* e_src_s, const int* e_dst_s, int n_src, const float* grid, int dim, const float* W1,
-                      const float* b1, const float* W2, const float* b2, const float* Wk, const float* dx1, float* dx_src,
-                      float* partial, hipStream_t stream) {
-  if (n_src <= 0) return 0;
-  EdgeParams p{x_src, pos_src, pos_dst, rowptr_s, e_src_s, e_dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
-  const int blocks = grl_edge_bwd_blocks(n_src);
-  const size_t smem = sizeof(Smem) + sizeof(float) * (GROUP * O * LDT + 4 * 2 * 32 * LDT);
+// Same destination-sorted edge arrays as the forward, plus the by-source index (rowptr_s [n_src+1], eid_s [E] = position of
+// each out-edge in the destination-sorted order).  dxe: scratch [n_edges,16,64]; dx_src [n_src,16,64] is fully overwritten.
+// partial must hold grl_edge_bwd_blocks(n_edges)*4 rows of grl_edge_partial_size() floats.
+int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* eid_s, int n_src,
+                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                      const float* Wk, const float* dx1, float* dxe, float* dx_src, float* partial, hipStream_t stream) {
+  if (n_edges <= 0) return 0;
+  EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+  const int blocks = grl_edge_bwd_blocks(n_edges);
+  const size_t smem = sizeof(Smem) + sizeof(float) * (4 * 3 * 32 * LDT);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL(edge_conv_bwd_kernel, dim3(blocks), dim3(256), smem, stream, p, dx1, dx_src, partial);
+  hipLaunchKernelGGL(edge_conv_bwd_kernel, dim3(blocks), dim3(256), smem, stream, p, dx1, dxe, partial, n_edges);
+  GRL_CHECK_LAUNCH();
+  const int gblocks = (n_src + 3) / 4 < 2048 ? (n_src + 3) / 4 : 2048;
+  hipLaunchKernelGGL(edge_gather_sum_kernel, dim3(gblocks), dim3(256), 0, stream, dxe, rowptr_s, eid_s, dx_src, n_src);
   GRL_CHECK_LAUNCH();
   return 0;
 }

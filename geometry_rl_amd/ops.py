@@ -14,23 +14,20 @@ from . import hip
 
 @dataclass
 class EdgeSet:
-    """One edge type of the batched graph in both anchor orders (int32, device resident).
-
-    Forward kernels walk edges grouped by destination, backward kernels the same edges grouped by source
-    (see csrc/edge_conv.hip)."""
+    """One edge type of the batched graph as a destination-sorted CSR (int32, device resident); forward and backward
+    kernels walk the same arrays (see csrc/edge_conv.hip)."""
     n_src: int
     n_dst: int
     n_edges: int
     rowptr_d: torch.Tensor
     src_d: torch.Tensor
     dst_d: torch.Tensor
-    rowptr_s: torch.Tensor
-    src_s: torch.Tensor
-    dst_s: torch.Tensor
+    rowptr_s: torch.Tensor  # by-source index for the backward's gather-sum pass
+    eid_s: torch.Tensor     # position (in destination-sorted order) of every out-edge, grouped by source
 
 
 def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
-    """edge_index [2,E] (row 0 = source, row 1 = destination) -> CSR by dst and CSR by src.  Runs once per cached topology."""
+    """edge_index [2,E] (row 0 = source, row 1 = destination) -> CSR by destination.  Runs once per cached topology."""
     src, dst = edge_index[0].long(), edge_index[1].long()
     dev = edge_index.device
 
@@ -42,8 +39,10 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         return rowptr.int().contiguous(), a.int().contiguous(), o.int().contiguous()
 
     rp_d, dst_d, src_d = csr(dst, src, n_dst)
-    rp_s, src_s, dst_s = csr(src, dst, n_src)
-    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s, src_s, dst_s)
+    eid_s = torch.argsort(src_d.long(), stable=True)
+    rp_s = torch.zeros(n_src + 1, dtype=torch.int64, device=dev)
+    rp_s[1:] = torch.cumsum(torch.bincount(src_d.long(), minlength=n_src), 0)
+    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s.int().contiguous(), eid_s.int().contiguous())
 
 
 def _reduce(partial: torch.Tensor, out: torch.Tensor):
@@ -83,7 +82,7 @@ class EdgeConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int):
         hip.check_f32(x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
-        x1 = torch.zeros(edges.n_dst, 16, 64, device=x_src.device, dtype=torch.float32)
+        x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=torch.float32)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
         hip.call("grl_edge_conv_fwd", x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
                  dim, *args, x1)
@@ -96,12 +95,13 @@ class EdgeConv(torch.autograd.Function):
         x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk = ctx.saved_tensors
         e = ctx.edges
         dev = dx1.device
-        blocks = hip.query("grl_edge_bwd_blocks", e.n_src)
+        blocks = hip.query("grl_edge_bwd_blocks", e.n_edges)
         psize = hip.query("grl_edge_partial_size")
         partial = torch.empty(blocks * 4, psize, device=dev, dtype=torch.float32)
-        dx_src = torch.zeros_like(x_src)
-        hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_s, e.src_s, e.dst_s, e.n_src, grid3, ctx.dim, w1, b1,
-                 w2, b2, wk, dx1.contiguous(), dx_src, partial)
+        dx_src = torch.empty_like(x_src)
+        dxe = torch.empty(e.n_edges, 16, 64, device=dev, dtype=torch.float32)
+        hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.eid_s,
+                 e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dxe, dx_src, partial)
         flat = torch.zeros(psize, device=dev, dtype=torch.float32)
         _reduce(partial, flat)
         dw1, db1, dw2, db2, dwk = torch.split(flat, [64 * 14, 64, 64 * 64, 64, 64 * 64])
