@@ -167,13 +167,16 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 // its (edge slot, orientation) row; after the last pass the two edge slots are folded with one cross-lane exchange
 // (lane r <-> r^16) and the rows leave with plain stores.  No LDS traffic besides the weights (LDS float atomics cost
 // ~200 LDS cycles per wave instruction on gfx950 -- measured, profiles/r01_*pmc* -- and made the first version LDS-bound).
-constexpr int FWD_WAVES = 4;
+constexpr int FWD_WAVES = 8;
 __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel(EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   Smem& s = *reinterpret_cast<Smem*>(smem_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   load_weights(s, p);
   __syncthreads();
+  // the two waves of a SIMD (w, w+4) run the same program; starting the second one half a pass late keeps one of them in
+  // its MFMA phase while the other is in its VALU phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 9)
+  if (wave >= 4) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(32); }
 
   const int o = r & 15, el = r >> 4;
   const int n_tiles = (p.n_anchor + TD - 1) / TD;

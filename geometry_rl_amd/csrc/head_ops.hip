@@ -216,17 +216,28 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     double omega = 0.0, D = 1.0, pm[AMAX];
     if (m_act) { omega = sqrt(mp / cfg.mean_bound) - 1.0; D = 1.0 + omega + 1e-16; }
     for (int i = 0; i < A; ++i) pm[i] = m_act ? (mu[i] + omega * mo[i]) / D : mu[i];
-    // ---- covariance projection: eta >= 0 with KL_cov(eta) = cov_bound (monotone decreasing in eta)
+    // ---- covariance projection: eta >= 0 with KL_cov(eta) = cov_bound.  With rho_i = v_i/o_i = (eta+1)/(eta+c_i), c_i = o_i/t_i:
+    //      KL = 1/2 sum(rho_i - 1 - log rho_i),  dKL/deta = -1/2 sum (1-c_i)^2 / ((eta+1)(eta+c_i)^2) < 0, KL convex in eta:
+    //      Newton from eta = 0 approaches the root monotonically from the left (never overshoots).
     double eta = 0.0;
     const bool c_act = kl_of_eta(0.0, t, o, A) > cfg.cov_bound;
     if (c_act) {
-      double lo = 0.0, hi = 1.0;
-      for (int it = 0; it < 200 && kl_of_eta(hi, t, o, A) > cfg.cov_bound; ++it) { lo = hi; hi *= 2.0; }
+      double cr[AMAX];
+      for (int i = 0; i < A; ++i) cr[i] = o[i] / t[i];
       for (int it = 0; it < 100; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (kl_of_eta(mid, t, o, A) > cfg.cov_bound) lo = mid; else hi = mid;
+        double f = 0.0, df = 0.0;
+        for (int i = 0; i < A; ++i) {
+          const double den = eta + cr[i], rho = (eta + 1.0) / den, om = 1.0 - cr[i];
+          f += rho - 1.0 - log(rho);
+          df += om * om / ((eta + 1.0) * den * den);
+        }
+        f = 0.5 * f - cfg.cov_bound;
+        df *= 0.5;
+        if (f <= 0.0 || df <= 0.0) break;
+        const double step = f / df;
+        eta += step;
+        if (step <= 1e-15 * eta) break;
       }
-      eta = 0.5 * (lo + hi);
     }
     double v[AMAX], pS[AMAX];
     for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }

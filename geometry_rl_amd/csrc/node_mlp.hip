@@ -227,34 +227,50 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* 
   dW3[0] = zero16(); dW3[1] = zero16(); dW4[0] = zero16(); dW4[1] = zero16();
   float colsum = 0.f;  // tid<256: db3[tid]; 256..319: db4; 320..383: dgamma; 384..447: dbeta
   const int n_chunks = (n_rows + 31) >> 5;
-  for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+  // register-staged software pipeline: the next chunk's rows are requested before this chunk's MFMAs and written to LDS
+  // after them, so the HBM latency of the hand-off buffers hides behind the matrix work (one LDS image, two barriers/chunk)
+  float4 pw_dz[4], pw_h[4], p_xh, p_da, p_dy;
+  const int nr = tid >> 4, nc4 = tid & 15;
+  auto fetch = [&](int ch) {
     const int row0 = ch * 32;
-    __syncthreads();
-    for (int idx = tid; idx < 32 * (W / 4); idx += 512) {  // 2048 float4 per wide buffer
-      const int rr = idx >> 6, c4 = idx & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 512 * q, rr = idx >> 6, c4 = idx & 63;
       const bool ok = row0 + rr < n_rows;
       const size_t g = (size_t)(ok ? row0 + rr : 0) * W + 4 * c4;
-      float4 v = *reinterpret_cast<const float4*>(dz_buf + g), w = *reinterpret_cast<const float4*>(h_buf + g);
-      if (!ok) { v = make_float4(0.f, 0.f, 0.f, 0.f); w = v; }
-      *reinterpret_cast<float4*>(DZ + rr * LDH + 4 * c4) = v;
-      *reinterpret_cast<float4*>(H + rr * LDH + 4 * c4) = w;
+      pw_dz[q] = *reinterpret_cast<const float4*>(dz_buf + g);
+      pw_h[q] = *reinterpret_cast<const float4*>(h_buf + g);
+      if (!ok) { pw_dz[q] = make_float4(0.f, 0.f, 0.f, 0.f); pw_h[q] = pw_dz[q]; }
+    }
+    const bool ok = row0 + nr < n_rows;
+    const size_t g = (size_t)(ok ? row0 + nr : 0) * C + 4 * nc4;
+    p_xh = *reinterpret_cast<const float4*>(xhat_buf + g);
+    p_da = *reinterpret_cast<const float4*>(da_buf + g);
+    p_dy = *reinterpret_cast<const float4*>(dout + g);
+    if (!ok) { p_xh = make_float4(0.f, 0.f, 0.f, 0.f); p_da = p_xh; p_dy = p_xh; }
+  };
+  const float4 gm = *reinterpret_cast<const float4*>(gam + 4 * nc4), bt = *reinterpret_cast<const float4*>(bet + 4 * nc4);
+  int ch = blockIdx.x;
+  if (ch < n_chunks) fetch(ch);
+  for (; ch < n_chunks; ch += gridDim.x) {
+    const bool ok_row = ch * 32 + nr < n_rows;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 512 * q, rr = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<float4*>(DZ + rr * LDH + 4 * c4) = pw_dz[q];
+      *reinterpret_cast<float4*>(H + rr * LDH + 4 * c4) = pw_h[q];
     }
     {
-      const int rr = tid >> 4, c4 = tid & 15;  // 512 float4 per narrow buffer
-      const bool ok = row0 + rr < n_rows;
-      const size_t g = (size_t)(ok ? row0 + rr : 0) * C + 4 * c4;
-      float4 xh = *reinterpret_cast<const float4*>(xhat_buf + g), da = *reinterpret_cast<const float4*>(da_buf + g);
-      float4 dy = *reinterpret_cast<const float4*>(dout + g);
-      if (!ok) { xh = make_float4(0.f, 0.f, 0.f, 0.f); da = xh; dy = xh; }
-      const float4 gm = *reinterpret_cast<const float4*>(gam + 4 * c4), bt = *reinterpret_cast<const float4*>(bet + 4 * c4);
-      float4 a = make_float4(xh.x * gm.x + bt.x, xh.y * gm.y + bt.y, xh.z * gm.z + bt.z, xh.w * gm.w + bt.w);
-      if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(A + rr * LDA + 4 * c4) = a;
-      *reinterpret_cast<float4*>(DO + rr * LDA + 4 * c4) = dy;
-      *reinterpret_cast<float4*>(DA + rr * LDA + 4 * c4) = da;
-      *reinterpret_cast<float4*>(XH + rr * LDA + 4 * c4) = xh;
+      float4 a = make_float4(p_xh.x * gm.x + bt.x, p_xh.y * gm.y + bt.y, p_xh.z * gm.z + bt.z, p_xh.w * gm.w + bt.w);
+      if (!ok_row) a = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(A + nr * LDA + 4 * nc4) = a;
+      *reinterpret_cast<float4*>(DO + nr * LDA + 4 * nc4) = p_dy;
+      *reinterpret_cast<float4*>(DA + nr * LDA + 4 * nc4) = p_da;
+      *reinterpret_cast<float4*>(XH + nr * LDA + 4 * nc4) = p_xh;
     }
     __syncthreads();
+    if (ch + (int)gridDim.x < n_chunks) fetch(ch + gridDim.x);
     // wave w owns hidden tile nt = w:  dW3[32w..32w+31][0..63] and dW4[0..63][32w..32w+31]
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {

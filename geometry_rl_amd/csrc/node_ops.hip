@@ -50,33 +50,48 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
   }
 }
 
-// dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF]
+// dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF].  A block streams 64-row tiles of dx: 64 threads build the
+// tile's lifted features once into LDS, then thread (c, part) folds its 16 rows (dx read coalesced, features broadcast).
 __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const float* __restrict__ dx,
                                                               float* __restrict__ partial, int N, int S, int V) {
   __shared__ float gs[O * 3];
+  __shared__ float feat[64][KF_MAX];
   __shared__ float red[4 * C * KF_MAX];
   const int KF = S + V;
   for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
-  __syncthreads();
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   float dw[KF_MAX];
 #pragma unroll
   for (int k = 0; k < KF_MAX; ++k) dw[k] = 0.f;
   const size_t rows = (size_t)N * O;
-  for (size_t row = (size_t)blockIdx.x * 4 + part; row < rows; row += (size_t)gridDim.x * 4) {
-    const int o = row & 15;
-    const size_t n = row >> 4;
-    const float d = dx[row * C + c];
+  const size_t n_tiles = (rows + 63) / 64;
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const size_t row = tile * 64 + threadIdx.x;
+      const int o = row & 15;
+      const size_t n = row >> 4;
 #pragma unroll
-    for (int k = 0; k < KF_MAX; ++k) {
-      float f = 0.f;
-      if (k < S) f = scal[n * S + k];
-      else if (k < KF) {
-        const float* v = vec + (n * V + (k - S)) * 3;
-        f = v[0] * gs[3 * o] + v[1] * gs[3 * o + 1] + v[2] * gs[3 * o + 2];
+      for (int k = 0; k < KF_MAX; ++k) {
+        float f = 0.f;
+        if (row < rows) {
+          if (k < S) f = scal[n * S + k];
+          else if (k < KF) {
+            const float* v = vec + (n * V + (k - S)) * 3;
+            f = v[0] * gs[3 * o] + v[1] * gs[3 * o + 1] + v[2] * gs[3 * o + 2];
+          }
+        }
+        feat[threadIdx.x][k] = f;
       }
-      dw[k] += d * f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = part * 16; rr < part * 16 + 16; ++rr) {
+      const size_t row = tile * 64 + rr;
+      const float d = row < rows ? dx[row * C + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KF_MAX; ++k) dw[k] += d * feat[rr][k];
     }
   }
 #pragma unroll
