@@ -12,6 +12,11 @@
 // The next pass's indices / positions and this pass's x_src rows are requested before the MFMA chain starts, so the gather
 // latency hides behind it.
 #include "grl_common.h"
+#ifdef GRL_NO_SCHED_BARRIER
+#define GRL_SCHED_BARRIER()
+#else
+#define GRL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace {
 
@@ -19,8 +24,9 @@ constexpr int C = 64;            // channels
 constexpr int O = 16;            // orientations
 constexpr int TD = 2;            // destination nodes per wave tile (forward)
 constexpr int LDT = C + 4;       // padded row of an LDS activation tile
-constexpr int LDW = GRL_LD(64);  // 68
-constexpr int LDW1 = GRL_LD(16); // 20
+constexpr int LDW = GRL_LD(64);  // 68   fp32 images (backward: column reads)
+constexpr int LDB = GRL_LDB(64); // 72   split-bf16 images (chain)
+constexpr int LDB1 = GRL_LDB(16);// 24
 
 struct EdgeParams {
   const float* x_src;    // [Ns,16,64]
@@ -56,82 +62,98 @@ GRL_DEVINL void poly_frags(float a, float b, int h, float4& f0, float4& f1) {
 
 // One pass of the chain for this lane's row.  Returns the kernel fragments K (8 float4); optionally keeps the
 // pre-activation derivatives for the backward pass.
-template <bool BWD>
-GRL_DEVINL void edge_chain(const float* W1s, const float* b1s, const float* W2s, const float* b2s, const float* Wks,
-                           float a, float b, float4 (&kf)[8], float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8],
-                           float4 (&gp2)[8], float4 (&phi)[2], float* g1_rows = nullptr, float* g2_rows = nullptr) {
-  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  poly_frags(a, b, h, phi[0], phi[1]);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bb = *reinterpret_cast<const float4*>(b1s + 32 * nt + 8 * q + 4 * h);
-      acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
-    }
-    mma_wx<16>(W1s + (32 * nt + i) * LDW1 + 4 * h, phi, acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      g1[4 * nt + q] = make_float4(gelu_f(acc[4 * q]), gelu_f(acc[4 * q + 1]), gelu_f(acc[4 * q + 2]), gelu_f(acc[4 * q + 3]));
-      if (BWD)
-        gp1[4 * nt + q] = make_float4(gelu_grad_f(acc[4 * q]), gelu_grad_f(acc[4 * q + 1]), gelu_grad_f(acc[4 * q + 2]),
-                                      gelu_grad_f(acc[4 * q + 3]));
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bb = *reinterpret_cast<const float4*>(b2s + 32 * nt + 8 * q + 4 * h);
-      acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
-    }
-    if (BWD && nt == 0) {  // backward: g1 goes to its LDS tile (row-major [r][c]) now and leaves the registers after layer 2
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g1_rows + 8 * t) = g1[t];
-    }
-    mma_wx<64>(W2s + (32 * nt + i) * LDW + 4 * h, g1, acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      g2[4 * nt + q] = make_float4(gelu_f(acc[4 * q]), gelu_f(acc[4 * q + 1]), gelu_f(acc[4 * q + 2]), gelu_f(acc[4 * q + 3]));
-      if (BWD)
-        gp2[4 * nt + q] = make_float4(gelu_grad_f(acc[4 * q]), gelu_grad_f(acc[4 * q + 1]), gelu_grad_f(acc[4 * q + 2]),
-                                      gelu_grad_f(acc[4 * q + 3]));
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    f32x16 acc = zero16();
-    if (BWD && nt == 0) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g2_rows + 8 * t) = g2[t];
-    }
-    mma_wx<64>(Wks + (32 * nt + i) * LDW + 4 * h, g2, acc);
-    acc_to_frag(acc, kf[4 * nt], kf[4 * nt + 1], kf[4 * nt + 2], kf[4 * nt + 3]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// LDS: weights + the anchor tile
-struct Smem {
-  float W1s[64 * LDW1];
-  float W2s[64 * LDW];
-  float Wks[64 * LDW];
+// Weight images of the chain in LDS: bf16 hi/lo rows (grl_common.h "split-bf16 MFMA path")
+struct ChainW {
+  unsigned short W1h[64 * LDB1], W1l[64 * LDB1];
+  unsigned short W2h[64 * LDB], W2l[64 * LDB];
+  unsigned short Wkh[64 * LDB], Wkl[64 * LDB];
   float b1s[64];
   float b2s[64];
   float grid_s[64];
 };
 
-GRL_DEVINL void load_weights(Smem& s, const EdgeParams& p) {
-  for (int idx = threadIdx.x; idx < 64 * LDW1; idx += blockDim.x) {
-    const int r = idx / LDW1, c = idx - r * LDW1;
-    s.W1s[idx] = (c < 14) ? p.W1[r * 14 + c] : 0.f;
+template <bool BWD>
+GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8],
+                           float4 (&gp2)[8], float4 (&phi)[2], float* g2_rows = nullptr) {
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  poly_frags(a, b, h, phi[0], phi[1]);
+  bf16x8 ph[1], pl[1];
+  split_frags<16>(phi, ph, pl);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bb = *reinterpret_cast<const float4*>(w.b1s + 32 * nt + 8 * q + 4 * h);
+      acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
+    }
+    mma_wx_bf<16>(w.W1h + (32 * nt + i) * LDB1 + 8 * h, w.W1l + (32 * nt + i) * LDB1 + 8 * h, ph, pl, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float gx, gy, gz, gw, px, py, pz, pw;
+      gelu_both(acc[4 * q], gx, px); gelu_both(acc[4 * q + 1], gy, py); gelu_both(acc[4 * q + 2], gz, pz); gelu_both(acc[4 * q + 3], gw, pw);
+      g1[4 * nt + q] = make_float4(gx, gy, gz, gw);
+      if (BWD) gp1[4 * nt + q] = make_float4(px, py, pz, pw);
+    }
   }
-  stage_matrix(s.W2s, p.W2, 64, 64, LDW);
-  stage_matrix(s.Wks, p.Wk, 64, 64, LDW);
+  bf16x8 g1h[4], g1l[4];
+  split_frags<64>(g1, g1h, g1l);
+  GRL_SCHED_BARRIER();
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bb = *reinterpret_cast<const float4*>(w.b2s + 32 * nt + 8 * q + 4 * h);
+      acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
+    }
+    mma_wx_bf<64>(w.W2h + (32 * nt + i) * LDB + 8 * h, w.W2l + (32 * nt + i) * LDB + 8 * h, g1h, g1l, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float gx, gy, gz, gw, px, py, pz, pw;
+      gelu_both(acc[4 * q], gx, px); gelu_both(acc[4 * q + 1], gy, py); gelu_both(acc[4 * q + 2], gz, pz); gelu_both(acc[4 * q + 3], gw, pw);
+      g2[4 * nt + q] = make_float4(gx, gy, gz, gw);
+      if (BWD) gp2[4 * nt + q] = make_float4(px, py, pz, pw);
+    }
+  }
+  if (BWD) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g2_rows + 8 * t) = g2[t];
+  }
+  bf16x8 g2h[4], g2l[4];
+  split_frags<64>(g2, g2h, g2l);
+  GRL_SCHED_BARRIER();
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    f32x16 acc = zero16();
+    mma_wx_bf<64>(w.Wkh + (32 * nt + i) * LDB + 8 * h, w.Wkl + (32 * nt + i) * LDB + 8 * h, g2h, g2l, acc);
+    acc_to_frag(acc, kf[4 * nt], kf[4 * nt + 1], kf[4 * nt + 2], kf[4 * nt + 3]);
+  }
+  GRL_SCHED_BARRIER();
+}
+
+// backward additionally keeps split-bf16 images of W2^T / Wk^T for dG = dZ W (rows of the transposed matrix = columns of W)
+struct BwdW {
+  unsigned short W2Th[64 * LDB], W2Tl[64 * LDB];
+  unsigned short WkTh[64 * LDB], WkTl[64 * LDB];
+};
+
+// like stage_split for the TRANSPOSE of src [64][64]: image row k holds src[.][k]
+GRL_DEVINL void stage_split_T(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int ld) {
+  for (int idx = threadIdx.x; idx < 64 * 64; idx += blockDim.x) {
+    const int k = idx >> 6, p = idx & 63;
+    const int q = (p >> 2) & 3;
+    const int n = (p & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q) + (p & 3);
+    const float w = src[n * 64 + k];
+    hi[k * ld + p] = (unsigned short)(__float_as_uint(w) >> 16);
+    lo[k * ld + p] = (unsigned short)(pack_rn(w - trunc_bf16(w), 0.f) & 0xFFFFu);
+  }
+}
+
+GRL_DEVINL void load_chain_weights(ChainW& s, const EdgeParams& p) {
+  stage_split(s.W1h, s.W1l, p.W1, 64, 16, 14, LDB1);
+  stage_split(s.W2h, s.W2l, p.W2, 64, 64, 64, LDB);
+  stage_split(s.Wkh, s.Wkl, p.Wk, 64, 64, 64, LDB);
   for (int idx = threadIdx.x; idx < 64; idx += blockDim.x) {
     s.b1s[idx] = p.b1[idx];
     s.b2s[idx] = p.b2[idx];
@@ -167,20 +189,35 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 // its (edge slot, orientation) row; after the last pass the two edge slots are folded with one cross-lane exchange
 // (lane r <-> r^16) and the rows leave with plain stores.  No LDS traffic besides the weights (LDS float atomics cost
 // ~200 LDS cycles per wave instruction on gfx950 -- measured, profiles/r01_*pmc* -- and made the first version LDS-bound).
-constexpr int FWD_WAVES = 8;
-__global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel(EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
+#ifndef GRL_FWD_WAVES
+#define GRL_FWD_WAVES 4
+#endif
+constexpr int FWD_WAVES = GRL_FWD_WAVES;
+#ifdef GRL_LB1
+__global__ __launch_bounds__(64 * FWD_WAVES) void edge_conv_fwd_kernel
+#else
+__global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
+#endif
+(EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  Smem& s = *reinterpret_cast<Smem*>(smem_raw);
+  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  load_weights(s, p);
+  load_chain_weights(s, p);
   __syncthreads();
   // the two waves of a SIMD (w, w+4) run the same program; starting the second one half a pass late keeps one of them in
   // its MFMA phase while the other is in its VALU phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 9)
+#ifndef GRL_NO_STAGGER
   if (wave >= 4) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(32); }
+#endif
 
   const int o = r & 15, el = r >> 4;
   const int n_tiles = (p.n_anchor + TD - 1) / TD;
+#ifdef GRL_DBG_HALF_IDLE
+  if (wave >= 4) return;
+  for (int tl = blockIdx.x * 4 + wave; tl < n_tiles; tl += gridDim.x * 4) {
+#else
   for (int tl = blockIdx.x * FWD_WAVES + wave; tl < n_tiles; tl += gridDim.x * FWD_WAVES) {
+#endif
     const int d0 = tl * TD, d1 = min(d0 + TD, p.n_anchor);
     const int e0 = p.rowptr[d0], e1 = p.rowptr[d1];
     float4 accA[8], accB[8];
@@ -200,7 +237,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel(EdgePa
 #pragma unroll
         for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];                         // this pass: x_src row in flight
         float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-        edge_chain<false>(s.W1s, s.b1s, s.W2s, s.b2s, s.Wks, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi);
+        edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi);
         if (more) meta_invariants(p, s.grid_s, o, nxt);                       // next pass: positions -> (a, b)
         const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
         const float wb = (cur.valid && cur.dst != d0) ? 1.f : 0.f;
@@ -221,7 +258,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel(EdgePa
       float4 a = accA[t], b = accB[t];
       a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
       b.x += __shfl_xor(b.x, 16, 64); b.y += __shfl_xor(b.y, 16, 64); b.z += __shfl_xor(b.z, 16, 64); b.w += __shfl_xor(b.w, 16, 64);
-      if (node < d1) dstp[2 * t] = el == 0 ? a : b;
+      // component-wise select: a struct-level `el == 0 ? a : b` is lowered through scratch memory by hipcc (store both, load
+      // one by index) -- slow, and the store->load ordering proved unreliable with two waves of a block per SIMD
+      const bool is_a = el == 0;
+      const float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
+      if (node < d1) dstp[2 * t] = v;
     }
   }
 }
@@ -244,16 +285,18 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
                                                                 float* __restrict__ dxe /*[E,16,64] per-edge d x_src rows*/,
                                                                 float* __restrict__ partial, int n_edges) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  Smem& s = *reinterpret_cast<Smem*>(smem_raw);
-  float* tbuf = smem_raw + sizeof(Smem) / 4;          // 4 waves x 3 x [32][LDT]
-  load_weights(s, p);
+  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
+  BwdW& sb = *reinterpret_cast<BwdW*>(smem_raw + sizeof(ChainW) / 4);
+  float* tbuf = smem_raw + (sizeof(ChainW) + sizeof(BwdW)) / 4;          // 4 waves x 2 x [32][LDT]
+  load_chain_weights(s, p);
+  stage_split_T(sb.W2Th, sb.W2Tl, p.W2, LDB);
+  stage_split_T(sb.WkTh, sb.WkTl, p.Wk, LDB);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
-  float* T0 = tbuf + wave * 3 * 32 * LDT;  // gradient-side operand (d x_src, dK, dZ2, dZ1 in turn)
-  float* T1 = T0 + 32 * LDT;               // g2 (written inside the chain), later phi
-  float* T2 = T1 + 32 * LDT;               // g1 (written inside the chain)
+  float* T0 = tbuf + wave * 2 * 32 * LDT;  // gradient-side operand of the row-reduction GEMMs (dK, dZ2, dZ1 in turn)
+  float* T1 = T0 + 32 * LDT;               // activation-side operand (g2 written inside the chain, then g1, then phi)
 
   f32x16 dWk[2][2], dW2[2][2], dW1[2];
 #pragma unroll
@@ -278,12 +321,13 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
     if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
     const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
     const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
+    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
+    edge_chain<true>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi, T1 + r * LDT + 4 * h);
+    // x_src / d x1 rows are requested only now: one wave per SIMD is register-bound (160 accumulator registers), and holding
+    // 64 more registers across the chain costs more in scratch traffic than the exposed L2 latency
     float4 xv[8], dv[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }
-    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-    edge_chain<true>(s.W1s, s.b1s, s.W2s, s.b2s, s.Wks, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi, T2 + r * LDT + 4 * h,
-                     T1 + r * LDT + 4 * h);
     if (more) meta_invariants(p, s.grid_s, o, nxt);
 
     float4 dK[8];
@@ -300,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
 #pragma unroll
       for (int t = 0; t < 8; ++t) de[2 * t] = kf[t];
     }
-    __builtin_amdgcn_sched_barrier(0);
+    GRL_SCHED_BARRIER();
     // ---- Wk: dWk[c][k] += sum_r dK[r][c] g2[r][k]
     store_frags_rowmajor(T0, r, h, dK);
 #pragma unroll
@@ -308,43 +352,52 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
         mma_tn<32>(T0 + 4 * h * LDT + 32 * ct + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dWk[ct][kt]);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- dZ2 = (dK Wk) * gelu'(z2)
+    GRL_SCHED_BARRIER();
+    // ---- dZ2 = (dK Wk) * gelu'(z2)      (split-bf16: rows of Wk^T)
     float4 dz2[8];
+    {
+      bf16x8 dh_[4], dl_[4];
+      split_frags<64>(dK, dh_, dl_);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      f32x16 acc = zero16();
-      mma_wTy<64>(s.Wks + 4 * h * LDW + 32 * kt + r, LDW, dK, acc);
-      float4 f0, f1, f2, f3;
-      acc_to_frag(acc, f0, f1, f2, f3);
-      dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
-      dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
-      dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
-      dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x16 acc = zero16();
+        mma_wx_bf<64>(sb.WkTh + (32 * kt + r) * LDB + 8 * h, sb.WkTl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
+        float4 f0, f1, f2, f3;
+        acc_to_frag(acc, f0, f1, f2, f3);
+        dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
+        dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
+        dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
+        dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
+      }
     }
     store_frags_rowmajor(T0, r, h, dz2);
+    store_frags_rowmajor(T1, r, h, g1);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
-        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T2 + 4 * h * LDT + 32 * kt + r, LDT, dW2[nt][kt]);
+        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dW2[nt][kt]);
 #pragma unroll
     for (int rr = 0; rr < 32; ++rr) db2 += T0[rr * LDT + lane];
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- dZ1 = (dZ2 W2) * gelu'(z1)
+    GRL_SCHED_BARRIER();
+    // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
     float4 dz1[8];
+    {
+      bf16x8 dh_[4], dl_[4];
+      split_frags<64>(dz2, dh_, dl_);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      f32x16 acc = zero16();
-      mma_wTy<64>(s.W2s + 4 * h * LDW + 32 * kt + r, LDW, dz2, acc);
-      float4 f0, f1, f2, f3;
-      acc_to_frag(acc, f0, f1, f2, f3);
-      dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
-      dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
-      dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
-      dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x16 acc = zero16();
+        mma_wx_bf<64>(sb.W2Th + (32 * kt + r) * LDB + 8 * h, sb.W2Tl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
+        float4 f0, f1, f2, f3;
+        acc_to_frag(acc, f0, f1, f2, f3);
+        dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
+        dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
+        dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
+        dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    GRL_SCHED_BARRIER();
     store_frags_rowmajor(T0, r, h, dz1);
     // phi as row-major [32][16] inside T1 (columns 16..31 of the tile are never used downstream)
     *reinterpret_cast<float4*>(T1 + r * LDT + 4 * h) = phi[0];
@@ -414,7 +467,7 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
   const int n_tiles = (n_dst + TD - 1) / TD;
   int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
   if (blocks > 256) blocks = 256;
-  const size_t smem = sizeof(Smem);
+  const size_t smem = sizeof(ChainW);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -435,7 +488,7 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
   if (n_edges <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int blocks = grl_edge_bwd_blocks(n_edges);
-  const size_t smem = sizeof(Smem) + sizeof(float) * (4 * 3 * 32 * LDT);
+  const size_t smem = sizeof(ChainW) + sizeof(BwdW) + sizeof(float) * (4 * 2 * 32 * LDT);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -125,3 +125,75 @@ GRL_DEVINL void stage_matrix(float* dst, const float* __restrict__ src, int rows
     hipError_t e_ = hipGetLastError();           \
     if (e_ != hipSuccess) return -1000 - (int)e_; \
   } while (0)
+
+// ------------------------------------------------------------------------------------------------ split-bf16 MFMA path
+// fp32 GEMMs on the bf16 matrix pipe: x = hi + lo with hi = upper 16 bits of x (truncation, exact), lo = bf16(x - hi);
+// a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo  (three v_mfma_f32_32x32x16_bf16 at 16x the fp32-MFMA rate; dropped term and the
+// rounding of lo are ~2^-17 relative -- measured <= 4e-5 absolute on O(5) activations, tests keep the 1e-4 bar).
+// Operand maps of v_mfma_f32_32x32x16_bf16: lane (i = l&31, h = l>>5) supplies A[i][8h+j], B[8h+j][i], j = 0..7; C/D as the
+// fp32 32x32 form.  To keep the "accumulator is the next operand" chain, element j of lane half h of K-step s stands for
+// k = 16s + 8(j>>2) + 4h + (j&3): exactly fragments x[2s] (j<4) and x[2s+1] (j>=4) of the fp32 convention above.  Weight rows
+// are staged in LDS as bf16 with the two middle quads of every 16-block swapped, so a lane reads its 8 weights with one
+// ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+GRL_DEVINL f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+GRL_DEVINL unsigned pack_hi(float a, float b) {  // upper halves of a (low word) and b (high word)
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+GRL_DEVINL float trunc_bf16(float a) { return __uint_as_float(__float_as_uint(a) & 0xFFFF0000u); }
+GRL_DEVINL unsigned pack_rn(float a, float b) {  // round-to-nearest bf16 of a (low) and b (high)
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// fragments x[2s], x[2s+1] (fp32) -> hi / lo bf16 operands of K-step s
+GRL_DEVINL void split_pair(const float4& f0, const float4& f1, bf16x8& hi, bf16x8& lo) {
+  u32x4 h, l;
+  h[0] = pack_hi(f0.x, f0.y); h[1] = pack_hi(f0.z, f0.w); h[2] = pack_hi(f1.x, f1.y); h[3] = pack_hi(f1.z, f1.w);
+  l[0] = pack_rn(f0.x - trunc_bf16(f0.x), f0.y - trunc_bf16(f0.y));
+  l[1] = pack_rn(f0.z - trunc_bf16(f0.z), f0.w - trunc_bf16(f0.w));
+  l[2] = pack_rn(f1.x - trunc_bf16(f1.x), f1.y - trunc_bf16(f1.y));
+  l[3] = pack_rn(f1.z - trunc_bf16(f1.z), f1.w - trunc_bf16(f1.w));
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+template <int K>
+GRL_DEVINL void split_frags(const float4 (&x)[K / 8], bf16x8 (&hi)[K / 16], bf16x8 (&lo)[K / 16]) {
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) split_pair(x[2 * s], x[2 * s + 1], hi[s], lo[s]);
+}
+
+// LDS leading dimension (in bf16 elements) of a [rows][K] split-weight image: +8 elements (16 B) keeps ds_read_b128 conflict-free
+#define GRL_LDB(K) ((K) + 8)
+
+// stage W[rows][K] (fp32, global) as two bf16 images (hi, lo) with the per-16-block quad swap described above
+GRL_DEVINL void stage_split(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int rows, int K, int Ksrc, int ld) {
+  for (int idx = threadIdx.x; idx < rows * K; idx += blockDim.x) {
+    const int r = idx / K, p = idx - r * K;
+    const int q = (p >> 2) & 3;                                   // quad inside the 16-block
+    const int k = (p & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q) + (p & 3);
+    const float w = k < Ksrc ? src[(size_t)r * Ksrc + k] : 0.f;
+    const float wh = trunc_bf16(w);
+    hi[r * ld + p] = (unsigned short)(__float_as_uint(w) >> 16);
+    lo[r * ld + p] = (unsigned short)(pack_rn(w - wh, 0.f) & 0xFFFFu);
+  }
+}
+
+// acc(32 n x 32 r) += W[n0+i][0..K) . X[r][0..K)   with split operands.
+//   whi/wlo = &image[(n0 + (lane&31)) * ld + 8*(lane>>5)]
+template <int K>
+GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, const bf16x8 (&xh)[K / 16], const bf16x8 (&xl)[K / 16],
+                          f32x16& acc) {
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
+    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
+    acc = mfma_bf(wh, xh[s], acc);
+    acc = mfma_bf(wl, xh[s], acc);
+    acc = mfma_bf(wh, xl[s], acc);
+  }
+}

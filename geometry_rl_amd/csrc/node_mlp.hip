@@ -34,6 +34,18 @@ GRL_DEVINL void mlp_stage(MlpSmem& s, const float* W3, const float* b3, const fl
   for (int i = threadIdx.x; i < C; i += blockDim.x) { s.b4s[i] = b4[i]; s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
 }
 
+// split-bf16 weight images for the forward kernel (same bytes as the fp32 image)
+constexpr int LB3 = GRL_LDB(64);   // 72
+constexpr int LB4 = GRL_LDB(256);  // 264
+struct MlpSmemBf {
+  unsigned short W3h[W * LB3], W3l[W * LB3];
+  unsigned short W4h[C * LB4], W4l[C * LB4];
+  float b3s[W];
+  float b4s[C];
+  float gam[C];
+  float bet[C];
+};
+
 GRL_DEVINL float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // loads this lane's 8 fragments of row `row` (64 floats)
@@ -81,13 +93,18 @@ GRL_DEVINL f32x16 bias_acc(const float* bias, int n0, int h) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Both GEMMs run on the bf16 matrix pipe with split operands (grl_common.h): per 32-row tile 2 x 96 bf16 MFMAs of 32 cycles
+// instead of 2 x 256 fp32 MFMAs of 64 cycles.
 __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restrict__ x2, const float* __restrict__ x_dst,
                                                            const float* W3, const float* b3, const float* W4, const float* b4,
                                                            const float* gam, const float* bet, float* __restrict__ out,
                                                            int n_rows, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-  mlp_stage(s, W3, b3, W4, b4, gam, bet);
+  MlpSmemBf& s = *reinterpret_cast<MlpSmemBf*>(smem_raw);
+  stage_split(s.W3h, s.W3l, W3, W, C, C, LB3);
+  stage_split(s.W4h, s.W4l, W4, C, W, W, LB4);
+  for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { s.b4s[i] = b4[i]; s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int n_tiles = (n_rows + 31) >> 5;
@@ -98,19 +115,41 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
     float4 x[8], xh[8], a[8];
     float rstd;
     load_row(x2, rr, h, x);
-    layer_norm_row(s, h, x, xh, a, rstd);
-    // hidden units are produced 32 at a time and folded straight into the two output accumulators
+    {  // LayerNorm (same arithmetic as layer_norm_row, on the bf16 image's gamma/beta)
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) sum += (x[t].x + x[t].y) + (x[t].z + x[t].w);
+      const float mean = pair_sum(sum) * (1.f / C);
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        xh[t] = make_float4(x[t].x - mean, x[t].y - mean, x[t].z - mean, x[t].w - mean);
+        sq += (xh[t].x * xh[t].x + xh[t].y * xh[t].y) + (xh[t].z * xh[t].z + xh[t].w * xh[t].w);
+      }
+      rstd = rsqrtf(pair_sum(sq) * (1.f / C) + LN_EPS);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float4 g = *reinterpret_cast<const float4*>(s.gam + 8 * t + 4 * h);
+        const float4 b = *reinterpret_cast<const float4*>(s.bet + 8 * t + 4 * h);
+        a[t] = make_float4(xh[t].x * rstd * g.x + b.x, xh[t].y * rstd * g.y + b.y, xh[t].z * rstd * g.z + b.z,
+                           xh[t].w * rstd * g.w + b.w);
+      }
+    }
+    bf16x8 ah[4], al[4];
+    split_frags<64>(a, ah, al);
     f32x16 o0 = bias_acc(s.b4s, 0, h), o1 = bias_acc(s.b4s, 32, h);
 #pragma unroll 1
     for (int nt = 0; nt < 8; ++nt) {
       f32x16 acc = bias_acc(s.b3s, 32 * nt, h);
-      mma_wx<64>(s.W3s + (32 * nt + r) * LD3 + 4 * h, a, acc);
+      mma_wx_bf<64>(s.W3h + (32 * nt + r) * LB3 + 8 * h, s.W3l + (32 * nt + r) * LB3 + 8 * h, ah, al, acc);
       float4 hq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         hq[q] = make_float4(gelu_f(acc[4 * q]), gelu_f(acc[4 * q + 1]), gelu_f(acc[4 * q + 2]), gelu_f(acc[4 * q + 3]));
-      mma_wx<32>(s.W4s + r * LD4 + 32 * nt + 4 * h, hq, o0);
-      mma_wx<32>(s.W4s + (32 + r) * LD4 + 32 * nt + 4 * h, hq, o1);
+      bf16x8 hh[2], hl[2];
+      split_frags<32>(hq, hh, hl);
+      mma_wx_bf<32>(s.W4h + r * LB4 + 32 * nt + 8 * h, s.W4l + r * LB4 + 32 * nt + 8 * h, hh, hl, o0);
+      mma_wx_bf<32>(s.W4h + (32 + r) * LB4 + 32 * nt + 8 * h, s.W4l + (32 + r) * LB4 + 32 * nt + 8 * h, hh, hl, o1);
     }
     float4 res[8], y[8];
     load_row(x_dst, rr, h, res);
@@ -326,10 +365,10 @@ int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const
   if (n_rows <= 0) return 0;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmem));
+    hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf));
     attr = true;
   }
-  hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmem), stream, x2, x_dst,
+  hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
                      W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate);
   GRL_CHECK_LAUNCH();
   return 0;

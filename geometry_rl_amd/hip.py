@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
+LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
 SOURCES = ["edge_conv.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
 
 
