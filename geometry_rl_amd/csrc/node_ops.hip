@@ -192,6 +192,26 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   atomicAdd(out + j, acc);
 }
 
+// segmented variant: up to 8 column ranges of the partial rows are folded into 8 different destinations in ONE launch, so a
+// backward kernel's weight gradients go straight into the (flat) parameter-gradient buffer
+struct ReduceSegs {
+  float* dst[8];
+  int start[8];
+  int len[8];
+  int n_seg;
+};
+__global__ __launch_bounds__(256) void reduce_partials_seg_kernel(const float* __restrict__ partial, ReduceSegs segs, int n_rows,
+                                                                  int ld, int rows_per_block) {
+  const int seg = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= segs.n_seg || j >= segs.len[seg]) return;
+  const int w0 = blockIdx.y * rows_per_block, w1 = min(w0 + rows_per_block, n_rows);
+  const float* src = partial + segs.start[seg] + j;
+  float acc = 0.f;
+  for (int w = w0; w < w1; ++w) acc += src[(size_t)w * ld];
+  atomicAdd(segs.dst[seg] + j, acc);
+}
+
 int cap_blocks(long long work, int per_block, int cap) {
   long long b = (work + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -252,6 +272,27 @@ int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hip
   const int rpb = 32;
   dim3 grid((n + 255) / 256, (n_rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, stream, partial, out, n_rows, n, rpb);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst[i][0..len[i]) += sum_rows partial[row][start[i] + j]   for i < n_seg <= 8 (host arrays of length n_seg)
+int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg, float* const* dst, const int* start, const int* len,
+                            hipStream_t stream) {
+  if (n_rows <= 0 || n_seg <= 0) return 0;
+  if (n_seg > 8) return -2;
+  ReduceSegs segs{};
+  int max_len = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    segs.dst[i] = dst[i];
+    segs.start[i] = start[i];
+    segs.len[i] = len[i];
+    if (len[i] > max_len) max_len = len[i];
+  }
+  segs.n_seg = n_seg;
+  const int rpb = 32;
+  dim3 grid((max_len + 255) / 256, (n_rows + rpb - 1) / rpb, n_seg);
+  hipLaunchKernelGGL(reduce_partials_seg_kernel, grid, dim3(256), 0, stream, partial, segs, n_rows, ld, rpb);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -49,6 +49,33 @@ def _reduce(partial: torch.Tensor, out: torch.Tensor):
     hip.call("grl_reduce_partials", partial, out, partial.shape[0], out.numel())
 
 
+def _emit_grads(partial: torch.Tensor, segments):
+    """Fold per-workgroup partial rows into gradients with ONE launch.  ``segments`` = [(start, length, shape, tensor)]:
+    when ``tensor`` is a leaf whose ``.grad`` buffer already exists (PolicyUpdater keeps every parameter's grad as a view of
+    one flat buffer) the sum is accumulated in place and ``None`` is handed to autograd (no AccumulateGrad add kernel);
+    otherwise a fresh gradient tensor is returned."""
+    import ctypes
+    dev = partial.device
+    outs, dsts, starts, lens = [], [], [], []
+    for start, length, shape, t in segments:
+        g = getattr(t, "grad", None) if (t is not None and t.is_leaf) else None
+        if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+            outs.append(None)
+            dsts.append(g)
+        else:
+            fresh = torch.zeros(shape, device=dev, dtype=torch.float32)
+            outs.append(fresh)
+            dsts.append(fresh)
+        starts.append(start)
+        lens.append(length)
+    for i in range(0, len(segments), 8):
+        n = min(8, len(segments) - i)
+        hip.call("grl_reduce_partials_seg", partial, partial.shape[0], partial.shape[1], n,
+                 (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts[i:i + n]]), (ctypes.c_int * n)(*starts[i:i + n]),
+                 (ctypes.c_int * n)(*lens[i:i + n]))
+    return outs
+
+
 class LiftEncode(torch.autograd.Function):
     """x[n,o,:] = [scalars | vectors . grid_o] W_enc^T   (reference hepi.py:136-143)."""
 
@@ -61,6 +88,7 @@ class LiftEncode(torch.autograd.Function):
         hip.call("grl_lift_encode_fwd", scal, vec, grid3, w_enc.contiguous(), x, n, s, v)
         ctx.save_for_backward(scal, vec, grid3)
         ctx.kf = s + v
+        ctx.w_enc = w_enc
         return x
 
     @staticmethod
@@ -71,8 +99,7 @@ class LiftEncode(torch.autograd.Function):
         blocks = hip.query("grl_lift_bwd_blocks", n)
         partial = torch.empty(blocks, 64 * ctx.kf, device=dx.device, dtype=torch.float32)
         hip.call("grl_lift_encode_bwd", scal, vec, grid3, dx.contiguous(), partial, n, s, v)
-        dw = torch.zeros(64, ctx.kf, device=dx.device, dtype=torch.float32)
-        _reduce(partial, dw)
+        (dw,) = _emit_grads(partial, [(0, 64 * ctx.kf, (64, ctx.kf), ctx.w_enc)])
         return None, None, None, dw
 
 
@@ -88,6 +115,7 @@ class EdgeConv(torch.autograd.Function):
                  dim, *args, x1)
         ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
         ctx.edges, ctx.dim = edges, dim
+        ctx.params = (w1, b1, w2, b2, wk)
         return x1
 
     @staticmethod
@@ -102,10 +130,10 @@ class EdgeConv(torch.autograd.Function):
         dxe = torch.empty(e.n_edges, 16, 64, device=dev, dtype=torch.float32)
         hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.eid_s,
                  e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dxe, dx_src, partial)
-        flat = torch.zeros(psize, device=dev, dtype=torch.float32)
-        _reduce(partial, flat)
-        dw1, db1, dw2, db2, dwk = torch.split(flat, [64 * 14, 64, 64 * 64, 64, 64 * 64])
-        return (dx_src, None, None, None, dw1.view(64, 14), db1, dw2.view(64, 64), db2, dwk.view(64, 64), None, None)
+        pw1, pb1, pw2, pb2, pwk = ctx.params
+        dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
+                                                         (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])
+        return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None)
 
 
 class FiberConv(torch.autograd.Function):
@@ -118,6 +146,7 @@ class FiberConv(torch.autograd.Function):
         fk = fk.contiguous()
         hip.call("grl_fiber_conv_fwd", x1, fk, bias.contiguous(), x2, x1.shape[0])
         ctx.save_for_backward(x1, fk)
+        ctx.bias = bias
         return x2
 
     @staticmethod
@@ -129,9 +158,8 @@ class FiberConv(torch.autograd.Function):
         partial = torch.empty(blocks, psize, device=dx2.device, dtype=torch.float32)
         dx1 = torch.empty_like(x1)
         hip.call("grl_fiber_conv_bwd", x1, fk, dx2.contiguous(), dx1, partial, n)
-        flat = torch.zeros(psize, device=dx2.device, dtype=torch.float32)
-        _reduce(partial, flat)
-        return dx1, flat[: 16 * 16 * 64].view(16, 16, 64), flat[16 * 16 * 64:]
+        dfk, dbias = _emit_grads(partial, [(0, 16 * 16 * 64, (16, 16, 64), None), (16 * 16 * 64, 64, (64,), ctx.bias)])
+        return dx1, dfk, dbias
 
 
 class NodeMLP(torch.autograd.Function):
@@ -146,6 +174,7 @@ class NodeMLP(torch.autograd.Function):
         hip.call("grl_node_mlp_fwd", x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0)
         ctx.save_for_backward(x2, *ws)
         ctx.has_prev = prev is not None
+        ctx.params = (w3, b3, w4, b4, gamma, beta)
         return out
 
     @staticmethod
@@ -163,10 +192,11 @@ class NodeMLP(torch.autograd.Function):
         psize = hip.query("grl_node_mlp_partial_size")
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
         hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, xhat, da, hbuf, dz, partial, n_rows)
-        flat = torch.zeros(psize, device=dev, dtype=torch.float32)
-        _reduce(partial, flat)
-        dw3, db3, dw4, db4, dgam, dbet = torch.split(flat, [256 * 64, 256, 64 * 256, 64, 64, 64])
-        return (dx2, dout, dgam, dbet, dw3.view(256, 64), db3, dw4.view(64, 256), db4, dout if ctx.has_prev else None)
+        pw3, pb3, pw4, pb4, pg, pbt = ctx.params
+        dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
+                                                               (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),
+                                                               (33088, 64, (64,), pg), (33152, 64, (64,), pbt)])
+        return (dx2, dout, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None)
 
 
 class Readout(torch.autograd.Function):
@@ -186,6 +216,7 @@ class Readout(torch.autograd.Function):
         hip.call("grl_readout_fwd", lat, grid3, wd_, bd_, ws_, bs_, float(shift), float(min_std), mean, sigma, hidden, n, od, ov)
         ctx.save_for_backward(lat, grid3, wd_, bd_, ws_, bs_)
         ctx.cfg = (float(shift), od, ov)
+        ctx.params = (wd, bd, ws, bs)
         return mean, sigma, hidden
 
     @staticmethod
@@ -202,13 +233,10 @@ class Readout(torch.autograd.Function):
         dsigma = torch.zeros(n, 3 * ov, device=dev) if dsigma is None else dsigma.contiguous()
         dh = dhidden.contiguous() if dhidden is not None else None
         hip.call("grl_readout_bwd", lat, grid3, wd, bd, ws, bs, shift, dmean, dsigma, dh, dlat, partial, n, od, ov)
-        flat = torch.zeros(psize, device=dev, dtype=torch.float32)
-        _reduce(partial, flat)
         J, aper = od + ov, 3 * ov
-        dwd = flat[: 4 * 64].view(4, 64)[:J]
-        dbd = flat[4 * 64: 4 * 64 + 4][:J]
-        dws = flat[4 * 64 + 4: 4 * 64 + 4 + 6 * 64].view(6, 64)[:aper]
-        dbs = flat[4 * 64 + 4 + 6 * 64:][:aper]
+        pwd, pbd, pws, pbs = ctx.params
+        dwd, dbd, dws, dbs = _emit_grads(partial, [(0, J * 64, (J, 64), pwd), (256, J, (J,), pbd), (260, aper * 64, (aper, 64), pws),
+                                                    (260 + 384, aper, (aper,), pbs)])
         return dlat, None, dwd, dbd, dws, dbs, None, None, None, None
 
 
@@ -224,7 +252,8 @@ class DeepSetsValue(torch.autograd.Function):
         B, n, d = x.shape
         dev = x.device
         x = x.contiguous()
-        P = [t.contiguous() for t in (w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)]
+        ctx_params = (w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)
+        P = [t.contiguous() for t in ctx_params]
         w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = P
         world = 1
         if group is not None:
@@ -245,6 +274,7 @@ class DeepSetsValue(torch.autograd.Function):
         hip.call("grl_deepsets_fwd3", u1, stats[2:4], ctypes_double(c2), g2, be2, w4, b4, wv, bv, value, B)
         ctx.save_for_backward(x, h1, z, u1, stats, *P)
         ctx.meta = (B, n, d, c1, c2, group, world)
+        ctx.params = ctx_params
         return value
 
     @staticmethod
@@ -271,17 +301,13 @@ class DeepSetsValue(torch.autograd.Function):
         if world > 1:
             dist.all_reduce(bst[2:4], group=group)
         hip.call("grl_deepsets_bwd1", x, h1, stats[0:2], ctypes_double(c1), q1, bst[2:4], part1, B, n, d)
-        f3 = torch.zeros(p3, device=dev)
-        f2 = torch.zeros(p2, device=dev)
-        f1 = torch.zeros(p1, device=dev)
-        _reduce(part3, f3)
-        _reduce(part2, f2)
-        _reduce(part1, f1)
-        dw4, db4, dwv, dbv, dg2, dbe2 = torch.split(f3, [4096, 64, 64, 1, 64, 64])
-        dw3, db3, dw2, db2, dg1, dbe1 = torch.split(f2, [4096, 64, 4096, 64, 64, 64])
-        dw1, db1 = torch.split(f1, [64 * d, 64])
-        return (None, dw1.view(64, d), db1, dg1, dbe1, dw2.view(64, 64), db2, dw3.view(64, 64), db3, dg2, dbe2,
-                dw4.view(64, 64), db4, dwv.view(1, 64), dbv, None)
+        (pw1, pb1, pg1, pbe1, pw2, pb2, pw3, pb3, pg2, pbe2, pw4, pb4, pwv, pbv) = ctx.params
+        dw4, db4, dwv, dbv, dg2, dbe2 = _emit_grads(part3, [(0, 4096, (64, 64), pw4), (4096, 64, (64,), pb4), (4160, 64, (1, 64), pwv),
+                                                            (4224, 1, (1,), pbv), (4225, 64, (64,), pg2), (4289, 64, (64,), pbe2)])
+        dw3, db3, dw2, db2, dg1, dbe1 = _emit_grads(part2, [(0, 4096, (64, 64), pw3), (4096, 64, (64,), pb3), (4160, 4096, (64, 64), pw2),
+                                                            (8256, 64, (64,), pb2), (8320, 64, (64,), pg1), (8384, 64, (64,), pbe1)])
+        dw1, db1 = _emit_grads(part1, [(0, 64 * d, (64, d), pw1), (64 * d, 64, (64,), pb1)])
+        return (None, dw1, db1, dg1, dbe1, dw2, db2, dw3, db3, dg2, dbe2, dw4, db4, dwv, dbv, None)
 
 
 def ctypes_double(v: float):

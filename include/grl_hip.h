@@ -109,6 +109,9 @@ int grl_deepsets_bwd1(const float* x, const float* h1, const double* stats1, dou
 
 /* ---- training loop: examples/torchrl/train.py:134-146,249-251,308-316; pyg_data/rigid_tasks_data.py:285-287 ------------- */
 int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hipStream_t stream);
+/* dst[i][0..len[i]) += sum_rows partial[row*ld + start[i] + j], i < n_seg <= 8; dst/start/len are HOST arrays */
+int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg, float* const* dst, const int* start, const int* len,
+                            hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream);
