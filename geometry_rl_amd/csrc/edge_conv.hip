@@ -72,7 +72,7 @@ struct ChainW {
   float grid_s[64];
 };
 
-template <bool BWD>
+template <bool BWD, bool STORE_G2 = BWD>
 GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8],
                            float4 (&gp2)[8], float4 (&phi)[2], float* g2_rows = nullptr) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
@@ -116,7 +116,7 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
       if (BWD) gp2[4 * nt + q] = make_float4(px, py, pz, pw);
     }
   }
-  if (BWD) {
+  if (STORE_G2) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g2_rows + 8 * t) = g2[t];
   }
@@ -268,12 +268,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Per pass (2 edges x 16 orientations = 32 rows per wave):
-//   recompute chain; dM = d x1[dst]; dK = dM * x_src; d x_src[src] += dM * K (row-shaped global atomics);
-//   dWk += dK^T g2; dG2 = dK Wk; dZ2 = dG2 * gelu'(z2); dW2 += dZ2^T g1; db2 += colsum dZ2;
-//   dG1 = dZ2 W2; dZ1 = dG1 * gelu'(z1); dW1 += dZ1^T phi; db1 += colsum dZ1.
-// Weight-gradient accumulators live in registers for the whole kernel (one wave per SIMD, 512-VGPR budget) and are
-// written once per wave to a partial slab: partial[(block*4 + wave)][9344] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64].
+// Two launches over the same passes (2 edges x 16 orientations = 32 rows per wave and pass), each recomputing the cheap
+// split-bf16 chain, so that the row-reduction accumulators of one launch fit the register file without spilling
+// (a single launch needed 160 accumulator registers + the chain state: 47 spilled VGPRs, 35 % of the time in s_waitcnt):
+//   PART 0: dM = d x1[dst]; d x_src row = dM * K (stored per edge); dK = dM * x_src; dWk += dK^T g2
+//   PART 1: dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2; dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
+// Accumulators live in registers for the whole launch and leave as one partial row per wave:
+//   partial[(block*4 + wave)][9344] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64].
 constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
 GRL_DEVINL void store_frags_rowmajor(float* buf /*wave-private [32][LDT]*/, int r, int h, const float4 (&f)[8]) {
@@ -281,29 +282,32 @@ GRL_DEVINL void store_frags_rowmajor(float* buf /*wave-private [32][LDT]*/, int 
   for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(buf + r * LDT + 8 * t + 4 * h) = f[t];
 }
 
+template <int PART>
 __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
                                                                 float* __restrict__ dxe /*[E,16,64] per-edge d x_src rows*/,
                                                                 float* __restrict__ partial, int n_edges) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   BwdW& sb = *reinterpret_cast<BwdW*>(smem_raw + sizeof(ChainW) / 4);
-  float* tbuf = smem_raw + (sizeof(ChainW) + sizeof(BwdW)) / 4;          // 4 waves x 2 x [32][LDT]
+  float* tbuf = smem_raw + (sizeof(ChainW) + (PART == 1 ? sizeof(BwdW) : 0)) / 4;  // 4 waves x 2 x [32][LDT]
   load_chain_weights(s, p);
-  stage_split_T(sb.W2Th, sb.W2Tl, p.W2, LDB);
-  stage_split_T(sb.WkTh, sb.WkTl, p.Wk, LDB);
+  if (PART == 1) {
+    stage_split_T(sb.W2Th, sb.W2Tl, p.W2, LDB);
+    stage_split_T(sb.WkTh, sb.WkTl, p.Wk, LDB);
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
-  float* T0 = tbuf + wave * 2 * 32 * LDT;  // gradient-side operand of the row-reduction GEMMs (dK, dZ2, dZ1 in turn)
-  float* T1 = T0 + 32 * LDT;               // activation-side operand (g2 written inside the chain, then g1, then phi)
+  float* T0 = tbuf + wave * 2 * 32 * LDT;  // gradient-side operand of the row-reduction GEMMs
+  float* T1 = T0 + 32 * LDT;               // activation-side operand
 
-  f32x16 dWk[2][2], dW2[2][2], dW1[2];
+  f32x16 accA[2][2], accB[2];              // PART 0: accA = dWk.  PART 1: accA = dW2, accB = dW1
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_) {
-    dW1[a_] = zero16();
+    accB[a_] = zero16();
 #pragma unroll
-    for (int b_ = 0; b_ < 2; ++b_) { dWk[a_][b_] = zero16(); dW2[a_][b_] = zero16(); }
+    for (int b_ = 0; b_ < 2; ++b_) accA[a_][b_] = zero16();
   }
   float db1 = 0.f, db2 = 0.f;  // lane = column (64 columns)
 
@@ -315,19 +319,18 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
     meta_indices(p, 2 * ps + el, n_edges, cur);
     meta_invariants(p, s.grid_s, o, cur);
   }
+#pragma unroll 1
   for (; ps < n_pass; ps += stride) {
     PassMeta nxt;
     const bool more = ps + stride < n_pass;
     if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
     const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
     const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
-    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-    edge_chain<true>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi, T1 + r * LDT + 4 * h);
-    // x_src / d x1 rows are requested only now: one wave per SIMD is register-bound (160 accumulator registers), and holding
-    // 64 more registers across the chain costs more in scratch traffic than the exposed L2 latency
     float4 xv[8], dv[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }
+    for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
+    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
+    edge_chain<PART == 1, PART == 0>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi, T1 + r * LDT + 4 * h);
     if (more) meta_invariants(p, s.grid_s, o, nxt);
 
     float4 dK[8];
@@ -335,82 +338,83 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
     for (int t = 0; t < 8; ++t) {
       if (!cur.valid) dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
       dK[t] = f4_mul(dv[t], xv[t]);
-      kf[t] = f4_mul(dv[t], kf[t]);  // d x_src fragment
     }
-    // ---- d x_src contribution of this lane's (edge, orientation) row: plain stores of the per-edge rows; the per-source sum
-    //      is a separate streaming pass (edge_gather_sum_kernel) -- no atomics, bitwise reproducible
-    if (cur.valid) {
-      float4* de = reinterpret_cast<float4*>(dxe + ((size_t)(2 * ps + el) * O + o) * C) + h;
+    if (PART == 0) {
+      // d x_src contribution of this lane's (edge, orientation) row: plain stores; summed per source node by
+      // edge_gather_sum_kernel -- no atomics, bitwise reproducible
+      if (cur.valid) {
+        float4* de = reinterpret_cast<float4*>(dxe + ((size_t)(2 * ps + el) * O + o) * C) + h;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) de[2 * t] = kf[t];
-    }
-    GRL_SCHED_BARRIER();
-    // ---- Wk: dWk[c][k] += sum_r dK[r][c] g2[r][k]
-    store_frags_rowmajor(T0, r, h, dK);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        mma_tn<32>(T0 + 4 * h * LDT + 32 * ct + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dWk[ct][kt]);
-    GRL_SCHED_BARRIER();
-    // ---- dZ2 = (dK Wk) * gelu'(z2)      (split-bf16: rows of Wk^T)
-    float4 dz2[8];
-    {
-      bf16x8 dh_[4], dl_[4];
-      split_frags<64>(dK, dh_, dl_);
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x16 acc = zero16();
-        mma_wx_bf<64>(sb.WkTh + (32 * kt + r) * LDB + 8 * h, sb.WkTl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
-        float4 f0, f1, f2, f3;
-        acc_to_frag(acc, f0, f1, f2, f3);
-        dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
-        dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
-        dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
-        dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
+        for (int t = 0; t < 8; ++t) de[2 * t] = f4_mul(dv[t], kf[t]);
       }
-    }
-    store_frags_rowmajor(T0, r, h, dz2);
-    store_frags_rowmajor(T1, r, h, g1);
+      // dWk[c][k] += sum_r dK[r][c] g2[r][k]      (g2 rows were written to T1 inside the chain)
+      store_frags_rowmajor(T0, r, h, dK);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, dW2[nt][kt]);
+        for (int kt = 0; kt < 2; ++kt)
+          mma_tn<32>(T0 + 4 * h * LDT + 32 * ct + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, accA[ct][kt]);
+    } else {
+      // ---- dZ2 = (dK Wk) * gelu'(z2)      (split-bf16: rows of Wk^T)
+      float4 dz2[8];
+      {
+        bf16x8 dh_[4], dl_[4];
+        split_frags<64>(dK, dh_, dl_);
 #pragma unroll
-    for (int rr = 0; rr < 32; ++rr) db2 += T0[rr * LDT + lane];
-    GRL_SCHED_BARRIER();
-    // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
-    float4 dz1[8];
-    {
-      bf16x8 dh_[4], dl_[4];
-      split_frags<64>(dz2, dh_, dl_);
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x16 acc = zero16();
-        mma_wx_bf<64>(sb.W2Th + (32 * kt + r) * LDB + 8 * h, sb.W2Tl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
-        float4 f0, f1, f2, f3;
-        acc_to_frag(acc, f0, f1, f2, f3);
-        dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
-        dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
-        dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
-        dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+        for (int kt = 0; kt < 2; ++kt) {
+          f32x16 acc = zero16();
+          mma_wx_bf<64>(sb.WkTh + (32 * kt + r) * LDB + 8 * h, sb.WkTl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
+          float4 f0, f1, f2, f3;
+          acc_to_frag(acc, f0, f1, f2, f3);
+          dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
+          dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
+          dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
+          dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
+        }
       }
+      GRL_SCHED_BARRIER();
+      store_frags_rowmajor(T0, r, h, dz2);
+      store_frags_rowmajor(T1, r, h, g1);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, accA[nt][kt]);
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) db2 += T0[rr * LDT + lane];
+      GRL_SCHED_BARRIER();
+      // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
+      float4 dz1[8];
+      {
+        bf16x8 dh_[4], dl_[4];
+        split_frags<64>(dz2, dh_, dl_);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          f32x16 acc = zero16();
+          mma_wx_bf<64>(sb.W2Th + (32 * kt + r) * LDB + 8 * h, sb.W2Tl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
+          float4 f0, f1, f2, f3;
+          acc_to_frag(acc, f0, f1, f2, f3);
+          dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
+          dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
+          dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
+          dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+        }
+      }
+      GRL_SCHED_BARRIER();
+      store_frags_rowmajor(T0, r, h, dz1);
+      // phi as row-major [32][16] inside T1 (columns 16..31 of the tile are never used downstream)
+      *reinterpret_cast<float4*>(T1 + r * LDT + 4 * h) = phi[0];
+      *reinterpret_cast<float4*>(T1 + r * LDT + 8 + 4 * h) = phi[1];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + r, LDT, accB[nt]);
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) db1 += T0[rr * LDT + lane];
     }
-    GRL_SCHED_BARRIER();
-    store_frags_rowmajor(T0, r, h, dz1);
-    // phi as row-major [32][16] inside T1 (columns 16..31 of the tile are never used downstream)
-    *reinterpret_cast<float4*>(T1 + r * LDT + 4 * h) = phi[0];
-    *reinterpret_cast<float4*>(T1 + r * LDT + 8 + 4 * h) = phi[1];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-      mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + r, LDT, dW1[nt]);
-#pragma unroll
-    for (int rr = 0; rr < 32; ++rr) db1 += T0[rr * LDT + lane];
     cur = nxt;
   }
 
-  // ---- write this wave's weight-gradient partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
+  // ---- write this wave's partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
   float* out = partial + (size_t)(blockIdx.x * 4 + wave) * EDGE_PARTIAL;
   float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64, *oWk = ob2 + 64;
 #pragma unroll
@@ -418,15 +422,14 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
 #pragma unroll
     for (int rho = 0; rho < 16; ++rho) {
       const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * h;
-      if (r < 14) oW1[n * 14 + r] = dW1[nt][rho];
+      if (PART == 1 && r < 14) oW1[n * 14 + r] = accB[nt][rho];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        oW2[n * 64 + 32 * kt + r] = dW2[nt][kt][rho];
-        oWk[n * 64 + 32 * kt + r] = dWk[nt][kt][rho];
+        if (PART == 0) oWk[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
+        else oW2[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
       }
     }
-  ob1[lane] = db1;
-  ob2[lane] = db2;
+  if (PART == 1) { ob1[lane] = db1; ob2[lane] = db2; }
 }
 
 // dx_src[n] = sum over the out-edges of source node n of the per-edge rows dxe[eid]  (CSR by source: rowptr_s, eid_s)
@@ -488,13 +491,17 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
   if (n_edges <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int blocks = grl_edge_bwd_blocks(n_edges);
-  const size_t smem = sizeof(ChainW) + sizeof(BwdW) + sizeof(float) * (4 * 2 * 32 * LDT);
+  const size_t smem0 = sizeof(ChainW) + sizeof(float) * (4 * 2 * 32 * LDT);
+  const size_t smem1 = smem0 + sizeof(BwdW);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)edge_conv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)edge_conv_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem0);
+    hipFuncSetAttribute((const void*)edge_conv_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
     attr = true;
   }
-  hipLaunchKernelGGL(edge_conv_bwd_kernel, dim3(blocks), dim3(256), smem, stream, p, dx1, dxe, partial, n_edges);
+  hipLaunchKernelGGL(edge_conv_bwd_kernel<0>, dim3(blocks), dim3(256), smem0, stream, p, dx1, dxe, partial, n_edges);
+  GRL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(edge_conv_bwd_kernel<1>, dim3(blocks), dim3(256), smem1, stream, p, dx1, dxe, partial, n_edges);
   GRL_CHECK_LAUNCH();
   const int gblocks = (n_src + 3) / 4 < 2048 ? (n_src + 3) / 4 : 2048;
   hipLaunchKernelGGL(edge_gather_sum_kernel, dim3(gblocks), dim3(256), 0, stream, dxe, rowptr_s, eid_s, dx_src, n_src);

@@ -197,3 +197,43 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
     acc = mfma_bf(wh, xl[s], acc);
   }
 }
+
+// ---- register-level transposes on the matrix pipe -------------------------------------------------------------------------
+// X (32 rows x 32 columns) given as split-bf16 A operands (lane = row) times a 0/1 selection matrix gives X back in the
+// ACCUMULATOR layout, i.e. with the column on the lane and the rows in the registers (acc row order == bf16 k-order): exactly the
+// operand layout a product that sums over X's rows needs.  Two MFMAs per 32x32 tile and per hi/lo part, no LDS, exact (x * 1.0).
+//   sel0 / sel1: lane (j = l&31, h = l>>5), element jj = 1.0 iff 8*(jj>>2) + 4h + (jj&3) == j (for j < 16) resp. j - 16 (j >= 16)
+GRL_DEVINL void make_selectors(bf16x8& sel0, bf16x8& sel1) {
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  u32x4 s0, s1;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned v0 = 0, v1 = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int jj = 2 * w + e;
+      const int kappa = 8 * (jj >> 2) + 4 * h + (jj & 3);
+      if (j < 16 && kappa == j) v0 |= 0x3F80u << (16 * e);
+      if (j >= 16 && kappa == j - 16) v1 |= 0x3F80u << (16 * e);
+    }
+    s0[w] = v0;
+    s1[w] = v1;
+  }
+  sel0 = __builtin_bit_cast(bf16x8, s0);
+  sel1 = __builtin_bit_cast(bf16x8, s1);
+}
+// columns 0..15 come from operand c0, columns 16..31 from operand c1 (two consecutive K-step fragments of the row-major tile)
+GRL_DEVINL f32x16 transpose32(const bf16x8& c0, const bf16x8& c1, const bf16x8& sel0, const bf16x8& sel1) {
+  f32x16 t = zero16();
+  t = mfma_bf(c0, sel0, t);
+  t = mfma_bf(c1, sel1, t);
+  return t;
+}
+// accumulator tile holding bf16-exact values -> the two K-step operand fragments (rows 0..15 / 16..31 of the reduction)
+GRL_DEVINL void acc_to_bf(const f32x16& t, bf16x8& k0, bf16x8& k1) {
+  u32x4 a, b;
+  a[0] = pack_hi(t[0], t[1]); a[1] = pack_hi(t[2], t[3]); a[2] = pack_hi(t[4], t[5]); a[3] = pack_hi(t[6], t[7]);
+  b[0] = pack_hi(t[8], t[9]); b[1] = pack_hi(t[10], t[11]); b[2] = pack_hi(t[12], t[13]); b[3] = pack_hi(t[14], t[15]);
+  k0 = __builtin_bit_cast(bf16x8, a);
+  k1 = __builtin_bit_cast(bf16x8, b);
+}

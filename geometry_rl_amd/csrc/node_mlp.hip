@@ -5,9 +5,11 @@
 //
 // Backward is split in two launches:
 //   node_mlp_bwd_data    : per-row chain (recompute z, dH = dOut W4, dZ = dH*gelu', dA = dZ W3, LayerNorm backward) and a
-//                          hand-off of (xhat, dA, H, dZ) rows to HBM,
-//   node_mlp_bwd_weights : plain row-reduction GEMMs  dW3 = dZ^T A, dW4 = dOut^T H  (+ bias / LayerNorm-affine sums)
-//                          into per-workgroup partial slabs.
+//                          hand-off of (dA, dZ) rows to HBM (1.25 KB/row; both kernels run at the HBM roof, so H and xhat are
+//                          NOT handed over but recomputed by the second kernel),
+//   node_mlp_bwd_weights : recomputes LayerNorm and its hidden tile h (split-bf16 MFMA, W3 tile register-stationary), then the
+//                          row-reduction GEMMs  dW3 = dZ^T A, dW4 = dOut^T H  (+ bias / LayerNorm-affine sums) into
+//                          per-workgroup partial slabs.
 #include "grl_common.h"
 
 namespace {
@@ -167,57 +169,125 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ backward, data path
+// All three products per hidden tile run split-bf16: z = W3[nt] a (rows of W3), dH = W4[:,nt]^T dOut (rows of W4^T, second LDS
+// image), dA += W3[nt]^T dZ -- the transposed W3 tile is produced in registers from the same fragments that fed z
+// (transpose32, grl_common.h), so no third weight image is needed.
+struct MlpSmemBwd {
+  unsigned short W3h[W * LB3], W3l[W * LB3];    // [256 n][64 k]
+  unsigned short W4Th[W * LB3], W4Tl[W * LB3];  // [256 n][64 m]  (W4 transposed)
+  float b3s[W];
+  float gam[C];
+  float bet[C];
+};
+
 __global__ __launch_bounds__(512) void node_mlp_bwd_data_kernel(const float* __restrict__ x2, const float* __restrict__ dout,
                                                                 const float* W3, const float* b3, const float* W4,
                                                                 const float* b4, const float* gam, const float* bet,
-                                                                float* __restrict__ dx2, float* __restrict__ xhat_buf,
-                                                                float* __restrict__ da_buf, float* __restrict__ h_buf,
+                                                                float* __restrict__ dx2, float* __restrict__ da_buf,
                                                                 float* __restrict__ dz_buf, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-  mlp_stage(s, W3, b3, W4, b4, gam, bet);
+  MlpSmemBwd& s = *reinterpret_cast<MlpSmemBwd*>(smem_raw);
+  stage_split(s.W3h, s.W3l, W3, W, C, C, LB3);
+  for (int idx = threadIdx.x; idx < W * C; idx += blockDim.x) {  // W4^T image: row n holds W4[m][n] over (permuted) m
+    const int n = idx >> 6, p = idx & 63;
+    const int q = (p >> 2) & 3;
+    const int m = (p & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q) + (p & 3);
+    const float w = W4[m * W + n];
+    s.W4Th[n * LB3 + p] = (unsigned short)(__float_as_uint(w) >> 16);
+    s.W4Tl[n * LB3 + p] = (unsigned short)(pack_rn(w - trunc_bf16(w), 0.f) & 0xFFFFu);
+  }
+  for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  bf16x8 sel0, sel1;
+  make_selectors(sel0, sel1);
   const int n_tiles = (n_rows + 31) >> 5;
   for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
     const int row = tile * 32 + r;
     const bool valid = row < n_rows;
     const size_t rr = valid ? row : 0;
-    float4 x[8], xh[8], a[8], dy[8];
-    float rstd;
-    load_row(x2, rr, h, x);
-    layer_norm_row(s, h, x, xh, a, rstd);
-    load_row(dout, rr, h, dy);
-    if (!valid) {
+    float rstd, mean;
+    bf16x8 ah[4], al[4], dyh[4], dyl[4];
+    {
+      float4 x[8], a[8], dy[8];
+      load_row(x2, rr, h, x);
+      load_row(dout, rr, h, dy);
+      float sum = 0.f;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) dy[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int t = 0; t < 8; ++t) sum += (x[t].x + x[t].y) + (x[t].z + x[t].w);
+      mean = pair_sum(sum) * (1.f / C);
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        x[t] = make_float4(x[t].x - mean, x[t].y - mean, x[t].z - mean, x[t].w - mean);
+        sq += (x[t].x * x[t].x + x[t].y * x[t].y) + (x[t].z * x[t].z + x[t].w * x[t].w);
+      }
+      rstd = rsqrtf(pair_sum(sq) * (1.f / C) + LN_EPS);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float4 g = *reinterpret_cast<const float4*>(s.gam + 8 * t + 4 * h);
+        const float4 b = *reinterpret_cast<const float4*>(s.bet + 8 * t + 4 * h);
+        a[t] = make_float4(x[t].x * rstd * g.x + b.x, x[t].y * rstd * g.y + b.y, x[t].z * rstd * g.z + b.z, x[t].w * rstd * g.w + b.w);
+      }
+      if (!valid) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dy[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      split_frags<64>(a, ah, al);
+      split_frags<64>(dy, dyh, dyl);
     }
     f32x16 da0 = zero16(), da1 = zero16();
-#pragma unroll
+#pragma unroll 1
     for (int nt = 0; nt < 8; ++nt) {
-      f32x16 z = bias_acc(s.b3s, 32 * nt, h);
-      mma_wx<64>(s.W3s + (32 * nt + r) * LD3 + 4 * h, a, z);
-      f32x16 dh = zero16();
-      mma_wTy<64>(s.W4s + 4 * h * LD4 + 32 * nt + r, LD4, dy, dh);
-      float4 hq[4], dz[4];
+      // this hidden tile's W3 rows as A operands (lane = hidden unit)
+      bf16x8 wh[4], wl[4];
+      const unsigned short* w3h = s.W3h + (32 * nt + r) * LB3 + 8 * h;
+      const unsigned short* w3l = s.W3l + (32 * nt + r) * LB3 + 8 * h;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        hq[q] = make_float4(gelu_f(z[4 * q]), gelu_f(z[4 * q + 1]), gelu_f(z[4 * q + 2]), gelu_f(z[4 * q + 3]));
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        wh[sidx] = *reinterpret_cast<const bf16x8*>(w3h + 16 * sidx);
+        wl[sidx] = *reinterpret_cast<const bf16x8*>(w3l + 16 * sidx);
+      }
+      f32x16 z = bias_acc(s.b3s, 32 * nt, h);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        z = mfma_bf(wh[sidx], ah[sidx], z);
+        z = mfma_bf(wl[sidx], ah[sidx], z);
+        z = mfma_bf(wh[sidx], al[sidx], z);
+      }
+      f32x16 dh = zero16();
+      mma_wx_bf<64>(s.W4Th + (32 * nt + r) * LB3 + 8 * h, s.W4Tl + (32 * nt + r) * LB3 + 8 * h, dyh, dyl, dh);
+      float4 dz[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
         dz[q] = make_float4(dh[4 * q] * gelu_grad_f(z[4 * q]), dh[4 * q + 1] * gelu_grad_f(z[4 * q + 1]),
                             dh[4 * q + 2] * gelu_grad_f(z[4 * q + 2]), dh[4 * q + 3] * gelu_grad_f(z[4 * q + 3]));
-      }
       if (valid) {
-        float4* hp = reinterpret_cast<float4*>(h_buf + rr * W + 32 * nt) + h;
         float4* zp = reinterpret_cast<float4*>(dz_buf + rr * W + 32 * nt) + h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { hp[2 * q] = hq[q]; zp[2 * q] = dz[q]; }
+        for (int q = 0; q < 4; ++q) zp[2 * q] = dz[q];
       }
-      mma_wTy<32>(s.W3s + (32 * nt + 4 * h) * LD3 + r, LD3, dz, da0);
-      mma_wTy<32>(s.W3s + (32 * nt + 4 * h) * LD3 + 32 + r, LD3, dz, da1);
+      bf16x8 dzh[2], dzl[2];
+      split_frags<32>(dz, dzh, dzl);
+      // dA[k][r] += sum_n W3[32nt+n][k] dZ[r][n]: transposed W3 tile (lane = k) from the fragments above
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        bf16x8 th0, th1, tl0, tl1;
+        acc_to_bf(transpose32(wh[2 * kt], wh[2 * kt + 1], sel0, sel1), th0, th1);
+        acc_to_bf(transpose32(wl[2 * kt], wl[2 * kt + 1], sel0, sel1), tl0, tl1);
+        f32x16& da = kt == 0 ? da0 : da1;
+        da = mfma_bf(th0, dzh[0], da); da = mfma_bf(tl0, dzh[0], da); da = mfma_bf(th0, dzl[0], da);
+        da = mfma_bf(th1, dzh[1], da); da = mfma_bf(tl1, dzh[1], da); da = mfma_bf(th1, dzl[1], da);
+      }
     }
-    float4 da[8];
+    float4 da[8], xh[8];
     acc_to_frag(da0, da[0], da[1], da[2], da[3]);
     acc_to_frag(da1, da[4], da[5], da[6], da[7]);
+    load_row(x2, rr, h, xh);  // xhat is rebuilt from the (cache-resident) row instead of living in 32 registers across the loop
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      xh[t] = make_float4((xh[t].x - mean) * rstd, (xh[t].y - mean) * rstd, (xh[t].z - mean) * rstd, (xh[t].w - mean) * rstd);
     // LayerNorm backward:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = da * gamma
     float sg = 0.f, sgx = 0.f;
     float4 g[8];
@@ -236,7 +306,6 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_data_kernel(const float* __r
                           rstd * (g[t].z - mg - xh[t].z * mgx), rstd * (g[t].w - mg - xh[t].w * mgx));
     if (valid) {
       store_row(dx2, rr, h, dx);
-      store_row(xhat_buf, rr, h, xh);
       store_row(da_buf, rr, h, da);
     }
   }
@@ -248,16 +317,16 @@ constexpr int MLP_PARTIAL = W * C + W + C * W + C + C + C;
 constexpr int LDH = W + 4;  // 260
 constexpr int LDA = C + 4;  // 68
 
-__global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* __restrict__ xhat_buf,
+__global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* __restrict__ x2,
                                                                    const float* __restrict__ da_buf,
-                                                                   const float* __restrict__ h_buf,
                                                                    const float* __restrict__ dz_buf,
-                                                                   const float* __restrict__ dout, const float* gam,
+                                                                   const float* __restrict__ dout, const float* __restrict__ W3,
+                                                                   const float* __restrict__ b3, const float* gam,
                                                                    const float* bet, float* __restrict__ partial, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  float* DZ = smem_raw;              // [32][260]
-  float* H = DZ + 32 * LDH;          // [32][260]
-  float* A = H + 32 * LDH;           // [32][68]   a = xhat*gamma + beta
+  float* DZ = smem_raw;              // [32][260]  handed over by the data kernel
+  float* H = DZ + 32 * LDH;          // [32][260]  recomputed here: h = gelu(W3 a + b3) (split-bf16 MFMA, W3 tile in registers)
+  float* A = H + 32 * LDH;           // [32][68]   a = LayerNorm(x2) (recomputed here)
   float* DO = A + 32 * LDA;          // [32][68]
   float* DA = DO + 32 * LDA;         // [32][68]
   float* XH = DA + 32 * LDA;         // [32][68]
@@ -265,10 +334,19 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* 
   f32x16 dW3[2], dW4[2];
   dW3[0] = zero16(); dW3[1] = zero16(); dW4[0] = zero16(); dW4[1] = zero16();
   float colsum = 0.f;  // tid<256: db3[tid]; 256..319: db4; 320..383: dgamma; 384..447: dbeta
+  // this wave's hidden tile of W3 (rows 32*wave .. +31) as stationary split-bf16 A operands
+  bf16x8 wh[4], wl[4];
+  {
+    const float* wrow = W3 + (size_t)(32 * wave + r) * C;
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx)
+      split_pair(*reinterpret_cast<const float4*>(wrow + 16 * sidx + 4 * h), *reinterpret_cast<const float4*>(wrow + 16 * sidx + 8 + 4 * h),
+                 wh[sidx], wl[sidx]);
+  }
   const int n_chunks = (n_rows + 31) >> 5;
   // register-staged software pipeline: the next chunk's rows are requested before this chunk's MFMAs and written to LDS
-  // after them, so the HBM latency of the hand-off buffers hides behind the matrix work (one LDS image, two barriers/chunk)
-  float4 pw_dz[4], pw_h[4], p_xh, p_da, p_dy;
+  // after them, so the HBM latency hides behind the matrix work (one LDS image, two barriers/chunk)
+  float4 pw_dz[4], p_x, p_da, p_dy;
   const int nr = tid >> 4, nc4 = tid & 15;
   auto fetch = [&](int ch) {
     const int row0 = ch * 32;
@@ -278,15 +356,14 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* 
       const bool ok = row0 + rr < n_rows;
       const size_t g = (size_t)(ok ? row0 + rr : 0) * W + 4 * c4;
       pw_dz[q] = *reinterpret_cast<const float4*>(dz_buf + g);
-      pw_h[q] = *reinterpret_cast<const float4*>(h_buf + g);
-      if (!ok) { pw_dz[q] = make_float4(0.f, 0.f, 0.f, 0.f); pw_h[q] = pw_dz[q]; }
+      if (!ok) pw_dz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const bool ok = row0 + nr < n_rows;
     const size_t g = (size_t)(ok ? row0 + nr : 0) * C + 4 * nc4;
-    p_xh = *reinterpret_cast<const float4*>(xhat_buf + g);
+    p_x = *reinterpret_cast<const float4*>(x2 + g);
     p_da = *reinterpret_cast<const float4*>(da_buf + g);
     p_dy = *reinterpret_cast<const float4*>(dout + g);
-    if (!ok) { p_xh = make_float4(0.f, 0.f, 0.f, 0.f); p_da = p_xh; p_dy = p_xh; }
+    if (!ok) { p_da = make_float4(0.f, 0.f, 0.f, 0.f); p_dy = p_da; }
   };
   const float4 gm = *reinterpret_cast<const float4*>(gam + 4 * nc4), bt = *reinterpret_cast<const float4*>(bet + 4 * nc4);
   int ch = blockIdx.x;
@@ -298,18 +375,47 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* 
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 512 * q, rr = idx >> 6, c4 = idx & 63;
       *reinterpret_cast<float4*>(DZ + rr * LDH + 4 * c4) = pw_dz[q];
-      *reinterpret_cast<float4*>(H + rr * LDH + 4 * c4) = pw_h[q];
     }
     {
-      float4 a = make_float4(p_xh.x * gm.x + bt.x, p_xh.y * gm.y + bt.y, p_xh.z * gm.z + bt.z, p_xh.w * gm.w + bt.w);
-      if (!ok_row) a = make_float4(0.f, 0.f, 0.f, 0.f);
+      // LayerNorm of this row: its 64 values sit in the 16 consecutive lanes that share nr
+      float sm = (p_x.x + p_x.y) + (p_x.z + p_x.w);
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+      const float mean = sm * (1.f / C);
+      float4 xc = make_float4(p_x.x - mean, p_x.y - mean, p_x.z - mean, p_x.w - mean);
+      float sq = (xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w);
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) sq += __shfl_xor(sq, off, 64);
+      const float rstd = rsqrtf(sq * (1.f / C) + LN_EPS);
+      float4 xh = f4_scale(xc, rstd);
+      float4 a = make_float4(xh.x * gm.x + bt.x, xh.y * gm.y + bt.y, xh.z * gm.z + bt.z, xh.w * gm.w + bt.w);
+      if (!ok_row) { a = make_float4(0.f, 0.f, 0.f, 0.f); xh = a; }
       *reinterpret_cast<float4*>(A + nr * LDA + 4 * nc4) = a;
       *reinterpret_cast<float4*>(DO + nr * LDA + 4 * nc4) = p_dy;
       *reinterpret_cast<float4*>(DA + nr * LDA + 4 * nc4) = p_da;
-      *reinterpret_cast<float4*>(XH + nr * LDA + 4 * nc4) = p_xh;
+      *reinterpret_cast<float4*>(XH + nr * LDA + 4 * nc4) = xh;
     }
     __syncthreads();
     if (ch + (int)gridDim.x < n_chunks) fetch(ch + gridDim.x);
+    // ---- recompute this wave's hidden tile: h[r][32w + n] = gelu(W3[32w+n] . a[r] + b3)
+    {
+      float4 af[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) af[t] = *reinterpret_cast<const float4*>(A + r * LDA + 8 * t + 4 * h);
+      bf16x8 ah[4], al[4];
+      split_frags<64>(af, ah, al);
+      f32x16 z = bias_acc(b3, 32 * wave, h);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        z = mfma_bf(wh[sidx], ah[sidx], z);
+        z = mfma_bf(wl[sidx], ah[sidx], z);
+        z = mfma_bf(wh[sidx], al[sidx], z);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(H + r * LDH + 32 * wave + 8 * q + 4 * h) =
+            make_float4(gelu_f(z[4 * q]), gelu_f(z[4 * q + 1]), gelu_f(z[4 * q + 2]), gelu_f(z[4 * q + 3]));
+    }
     // wave w owns hidden tile nt = w:  dW3[32w..32w+31][0..63] and dW4[0..63][32w..32w+31]
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -374,24 +480,24 @@ int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const
   return 0;
 }
 
-// Scratch: xhat_buf, da_buf [n_rows,64]; h_buf, dz_buf [n_rows,256]; partial [grl_node_mlp_bwd_blocks(n_rows)][partial_size].
+// Scratch: da_buf [n_rows,64], dz_buf [n_rows,256]; partial [grl_node_mlp_bwd_blocks(n_rows)][partial_size].
 // d x_dst is simply dout (residual) and is not produced here.
 int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
-                     const float* gamma, const float* beta, float* dx2, float* xhat_buf, float* da_buf, float* h_buf,
-                     float* dz_buf, float* partial, int n_rows, hipStream_t stream) {
+                     const float* gamma, const float* beta, float* dx2, float* da_buf, float* dz_buf, float* partial, int n_rows,
+                     hipStream_t stream) {
   if (n_rows <= 0) return 0;
   static bool attr = false;
   const size_t smem_w = sizeof(float) * (2 * 32 * LDH + 4 * 32 * LDA);
   if (!attr) {
-    hipFuncSetAttribute((const void*)node_mlp_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmem));
+    hipFuncSetAttribute((const void*)node_mlp_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBwd));
     hipFuncSetAttribute((const void*)node_mlp_bwd_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
     attr = true;
   }
-  hipLaunchKernelGGL(node_mlp_bwd_data_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmem), stream, x2,
-                     dout, W3, b3, W4, b4, gamma, beta, dx2, xhat_buf, da_buf, h_buf, dz_buf, n_rows);
+  hipLaunchKernelGGL(node_mlp_bwd_data_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBwd), stream, x2,
+                     dout, W3, b3, W4, b4, gamma, beta, dx2, da_buf, dz_buf, n_rows);
   GRL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(node_mlp_bwd_weights_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(512), smem_w, stream, xhat_buf,
-                     da_buf, h_buf, dz_buf, dout, gamma, beta, partial, n_rows);
+  hipLaunchKernelGGL(node_mlp_bwd_weights_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(512), smem_w, stream, x2, da_buf,
+                     dz_buf, dout, W3, b3, gamma, beta, partial, n_rows);
   GRL_CHECK_LAUNCH();
   return 0;
 }
