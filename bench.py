@@ -20,13 +20,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic FLOPs per row (row = edge x orientation or node x orientation), DESIGN.md "Roofline"
+# Algorithmic FLOPs per row (row = edge x orientation or node x orientation) of each MFMA kernel, DESIGN.md section 4: the
+# products the kernel has to form from the inputs it is given, un-padded (basis width 14, not the 16 the tile carries).
+_CHAIN = 2 * 64 * (14 + 64 + 64)             # basis MLP 14->64->64 and the 64->64 kernel layer
 FLOPS_PER_ROW = {
-    "grl_edge_conv_fwd": 2 * 64 * (16 + 64 + 64),
-    "grl_edge_conv_bwd": 2 * 64 * (16 + 64 + 64) + 2 * 64 * 64 * 4 + 2 * 64 * 16,
-    "grl_node_mlp_fwd": 4 * 64 * 256,
-    "grl_node_mlp_bwd": 10 * 64 * 256,
+    "edge_conv_fwd_kernel": _CHAIN + 2 * 64,                                       # + message multiply, scatter add
+    "edge_conv_bwd_kernel<0>": _CHAIN + 2 * 64 * 64 + 2 * 64,                      # recompute, dWk, d x_src row, dK
+    "edge_conv_bwd_kernel<1>": _CHAIN + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,  # recompute, dG2, dG1, dW2, dW1
+    "node_mlp_fwd_kernel": 4 * 64 * 256,
+    "node_mlp_bwd_data_kernel": 6 * 64 * 256,                                      # z recompute, dH, dA
+    "node_mlp_bwd_weights_kernel": 6 * 64 * 256,                                   # h recompute, dW3, dW4
 }
+ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel", "grl_node_mlp_fwd": "node_mlp_fwd_kernel"}
+PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md:42 (the path is specified and checked in f32)
+PEAK_BF16X3 = 2500.0 / 3.0     # TFLOP/s of f32-equivalent products when each is three dense bf16 MFMAs (guide: ~2.5 PF dense)
 
 
 def workload(name):
@@ -160,31 +167,43 @@ def main():
         per_step = []
         for i in range(n_prof):
             hip.KERNEL_TIMES = {}
+            hip.KERNEL_ROWS.clear()
+            hip.kernel_prof_enable(True)
             upd.step(pool[i % len(pool)])
-            per_step.append(hip.kernel_time_summary())
+            entry = hip.kernel_time_summary()
+            inner = hip.kernel_prof_summary()   # the kernels inside grl_edge_conv_bwd / grl_node_mlp_bwd, one by one
+            hip.kernel_prof_enable(False)
+            rec = {ENTRY_TO_KERNEL.get(k, k): v for k, v in entry.items() if k not in ("grl_edge_conv_bwd", "grl_node_mlp_bwd")}
+            rec.update(inner)
+            per_step.append(rec)
         hip.KERNEL_TIMES = None
         per_step = per_step[1:]
         n_prof = len(per_step)
-        names = per_step[0].keys()
         med = lambda xs: sorted(xs)[len(xs) // 2]
-        summ = {k: (per_step[0][k][0] * n_prof, med([s[k][1] for s in per_step]) * n_prof) for k in names}
-        dom = max(summ.items(), key=lambda kv: kv[1][1])
-        name, (calls, total) = dom
-        # rows processed by the dominant kernel per launch (from the cached topology of this minibatch size)
-        topo = actor.hyper_data._cache[B]
-        rows = {}
-        for et, es in topo["edges"].items():
-            rows[et] = es.n_edges * 16
-        e_rows = sum(rows.values())
-        n_rows = (topo["n_main"] + B * spec.num_actuators * (2 if spec.num_actuators > 1 else 1)) * 16
-        per_step_rows = e_rows if "edge" in name else n_rows
-        launches_per_step = calls / n_prof
-        flops_per_launch = FLOPS_PER_ROW.get(name, 0) * per_step_rows / max(launches_per_step, 1)
-        avg_ms = total / calls
-        ach = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
-                "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-                "per_kernel_ms_per_step": {k: v[1] / n_prof for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
+        summ = {k: (per_step[0][k][0], med([s_[k][1] for s_ in per_step])) for k in per_step[0]}  # launches/step, ms/step
+        rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_kernel<0>": "grl_edge_conv_bwd",
+                   "edge_conv_bwd_kernel<1>": "grl_edge_conv_bwd", "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
+                   "node_mlp_bwd_data_kernel": "grl_node_mlp_bwd", "node_mlp_bwd_weights_kernel": "grl_node_mlp_bwd"}
+        rows_step = dict(hip.KERNEL_ROWS)      # rows handed to each entry point during the last profiled step
+        kernels = {}
+        for k, fl in FLOPS_PER_ROW.items():
+            if k not in summ:
+                continue
+            launches, ms_step = summ[k]
+            flops_step = fl * rows_step[rows_of[k]]
+            ach = flops_step / (ms_step * 1e-3) / 1e12
+            kernels[k] = {"launches_per_step": launches, "avg_launch_ms": ms_step / launches, "ms_per_step": ms_step,
+                          "rows_per_step": rows_step[rows_of[k]], "gflop_per_launch": flops_step / launches / 1e9, "achieved": ach,
+                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / PEAK_BF16X3}
+        name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        d = kernels[name]
+        roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                "frac": d["frac"], "traffic": None, "avg_launch_ms": d["avg_launch_ms"],
+                "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
+                "peak_note": "f32-exact MFMA peak; the kernel forms each f32 product from three bf16 MFMAs (split-bf16), whose "
+                             f"f32-equivalent peak is {PEAK_BF16X3:.0f} TFLOP/s: frac_of_bf16x3",
+                "frac_of_bf16x3": d["frac_of_bf16x3"], "mfma_kernels": kernels,
+                "per_kernel_ms_per_step": {k: v[1] for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and args.workload == "rigid_hepi":

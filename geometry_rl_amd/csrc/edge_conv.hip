@@ -499,12 +499,18 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
     hipFuncSetAttribute((const void*)edge_conv_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
     attr = true;
   }
+  grl_prof_begin("edge_conv_bwd_kernel<0>", stream);
   hipLaunchKernelGGL(edge_conv_bwd_kernel<0>, dim3(blocks), dim3(256), smem0, stream, p, dx1, dxe, partial, n_edges);
+  grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
+  grl_prof_begin("edge_conv_bwd_kernel<1>", stream);
   hipLaunchKernelGGL(edge_conv_bwd_kernel<1>, dim3(blocks), dim3(256), smem1, stream, p, dx1, dxe, partial, n_edges);
+  grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
   const int gblocks = (n_src + 3) / 4 < 2048 ? (n_src + 3) / 4 : 2048;
+  grl_prof_begin("edge_gather_sum_kernel", stream);
   hipLaunchKernelGGL(edge_gather_sum_kernel, dim3(gblocks), dim3(256), 0, stream, dxe, rowptr_s, eid_s, dx_src, n_src);
+  grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -120,6 +120,10 @@ GRL_DEVINL void stage_matrix(float* dst, const float* __restrict__ src, int rows
   }
 }
 
+// Optional per-kernel HIP-event timing for entry points that launch more than one kernel (grl_prof_* in train_ops.hip).
+void grl_prof_begin(const char* name, hipStream_t stream);
+void grl_prof_end(hipStream_t stream);
+
 #define GRL_CHECK_LAUNCH()                       \
   do {                                           \
     hipError_t e_ = hipGetLastError();           \

@@ -493,11 +493,15 @@ int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const 
     hipFuncSetAttribute((const void*)node_mlp_bwd_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
     attr = true;
   }
+  grl_prof_begin("node_mlp_bwd_data_kernel", stream);
   hipLaunchKernelGGL(node_mlp_bwd_data_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBwd), stream, x2,
                      dout, W3, b3, W4, b4, gamma, beta, dx2, da_buf, dz_buf, n_rows);
+  grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
+  grl_prof_begin("node_mlp_bwd_weights_kernel", stream);
   hipLaunchKernelGGL(node_mlp_bwd_weights_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(512), smem_w, stream, x2, da_buf,
                      dz_buf, dout, W3, b3, gamma, beta, partial, n_rows);
+  grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -122,6 +122,31 @@ __global__ __launch_bounds__(128) void knn_kernel(const float* __restrict__ pos 
 
 }  // namespace
 
+// ---- per-kernel event timing (off by default; bench.py's roofline leg switches it on for a few steps) ---------------------------
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+hipEvent_t g_prof_open = nullptr;
+const char* g_prof_open_name = nullptr;
+}  // namespace
+void grl_prof_begin(const char* name, hipStream_t stream) {
+  if (!g_prof_on) return;
+  hipEventCreate(&g_prof_open);
+  hipEventRecord(g_prof_open, stream);
+  g_prof_open_name = name;
+}
+void grl_prof_end(hipStream_t stream) {
+  if (!g_prof_on || !g_prof_open) return;
+  hipEvent_t e1;
+  hipEventCreate(&e1);
+  hipEventRecord(e1, stream);
+  g_prof.push_back({g_prof_open_name, g_prof_open, e1});
+  g_prof_open = nullptr;
+}
+
 extern "C" {
 
 // step = 1-based Adam step count.  scale_dev: optional device scalar multiplied into the gradient (clip coefficient).
@@ -163,4 +188,23 @@ int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int bat
   return 0;
 }
 
+
+// Switch the per-kernel timing on (clears old records) or off.
+int grl_prof_enable(int on) {
+  for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+int grl_prof_count() { return (int)g_prof.size(); }
+// Record i -> kernel name (NUL-terminated, at most cap bytes) and its duration in ms; waits for the record's end event.
+int grl_prof_get(int i, char* name, int cap, float* ms) {
+  if (i < 0 || i >= (int)g_prof.size() || cap < 1) return 1;
+  hipEventSynchronize(g_prof[i].e1);
+  if (hipEventElapsedTime(ms, g_prof[i].e0, g_prof[i].e1) != hipSuccess) return 2;
+  int k = 0;
+  for (; k < cap - 1 && g_prof[i].name[k]; ++k) name[k] = g_prof[i].name[k];
+  name[k] = 0;
+  return 0;
+}
 }  // extern "C"

@@ -84,9 +84,10 @@ def stream_ptr() -> ctypes.c_void_p:
 # Optional per-entry-point timing with HIP events recorded on the launch stream (bench.py's roofline leg).
 # KERNEL_TIMES maps name -> list of (start_event, end_event); enable with ``hip.KERNEL_TIMES = {}``.
 KERNEL_TIMES = None
+KERNEL_ROWS = {}   # name -> rows (edge x orientation / node x orientation) handed to the entry point while timing is on
 
 
-def call(name: str, *args, stream=None) -> None:
+def call(name: str, *args, stream=None, rows: int = 0) -> None:
     """Launch C-ABI entry point ``name`` on the current stream; raises on a non-zero status."""
     fn = getattr(lib(), name)
     fn.restype = ctypes.c_int
@@ -98,6 +99,7 @@ def call(name: str, *args, stream=None) -> None:
     if timing:
         e1.record()
         KERNEL_TIMES.setdefault(name, []).append((e0, e1))
+        KERNEL_ROWS[name] = KERNEL_ROWS.get(name, 0) + rows
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc}")
 
@@ -106,6 +108,25 @@ def kernel_time_summary():
     """-> {name: (n_calls, total_ms)} from the recorded events (synchronises)."""
     torch.cuda.synchronize()
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (KERNEL_TIMES or {}).items()}
+
+
+def kernel_prof_enable(on: bool) -> None:
+    """In-library HIP-event timing of the kernels inside multi-kernel entry points (grl_prof_*)."""
+    lib().grl_prof_enable(ctypes.c_int(int(on)))
+
+
+def kernel_prof_summary():
+    """-> {kernel name: (n_launches, total_ms)} from the in-library records (synchronises on each record)."""
+    l = lib()
+    out = {}
+    buf = ctypes.create_string_buffer(96)
+    ms = ctypes.c_float(0.0)
+    for i in range(l.grl_prof_count()):
+        if l.grl_prof_get(ctypes.c_int(i), buf, ctypes.c_int(96), ctypes.byref(ms)) != 0:
+            raise RuntimeError("grl_prof_get failed")
+        n, t = out.get(buf.value.decode(), (0, 0.0))
+        out[buf.value.decode()] = (n + 1, t + ms.value)
+    return out
 
 
 def query(name: str, *args) -> int:

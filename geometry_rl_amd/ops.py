@@ -112,7 +112,7 @@ class EdgeConv(torch.autograd.Function):
         x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=torch.float32)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
         hip.call("grl_edge_conv_fwd", x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
-                 dim, *args, x1)
+                 dim, *args, x1, rows=edges.n_edges * 16)
         ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
         ctx.edges, ctx.dim = edges, dim
         ctx.params = (w1, b1, w2, b2, wk)
@@ -129,7 +129,7 @@ class EdgeConv(torch.autograd.Function):
         dx_src = torch.empty_like(x_src)
         dxe = torch.empty(e.n_edges, 16, 64, device=dev, dtype=torch.float32)
         hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.eid_s,
-                 e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dxe, dx_src, partial)
+                 e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dxe, dx_src, partial, rows=e.n_edges * 16)
         pw1, pb1, pw2, pb2, pwk = ctx.params
         dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
                                                          (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])
@@ -171,7 +171,7 @@ class NodeMLP(torch.autograd.Function):
         ws = [a.contiguous() for a in (w3, b3, w4, b4, gamma, beta)]
         n_rows = x2.shape[0] * 16
         out = prev.clone() if prev is not None else torch.empty_like(x2)
-        hip.call("grl_node_mlp_fwd", x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0)
+        hip.call("grl_node_mlp_fwd", x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0, rows=n_rows)
         ctx.save_for_backward(x2, *ws)
         ctx.has_prev = prev is not None
         ctx.params = (w3, b3, w4, b4, gamma, beta)
@@ -189,7 +189,7 @@ class NodeMLP(torch.autograd.Function):
         blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
         psize = hip.query("grl_node_mlp_partial_size")
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
-        hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, da, dz, partial, n_rows)
+        hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, da, dz, partial, n_rows, rows=n_rows)
         pw3, pb3, pw4, pb4, pg, pbt = ctx.params
         dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
                                                                (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),

@@ -119,6 +119,13 @@ int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned 
                  float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream);
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
 
+
+/* ---- measurement aid (no reference counterpart): HIP-event timing of the individual kernels inside multi-kernel entry points
+ * (grl_edge_conv_bwd, grl_node_mlp_bwd), recorded on the launch stream. Off by default. */
+int grl_prof_enable(int on);
+int grl_prof_count(void);
+int grl_prof_get(int i, char* name, int cap, float* ms);
+
 #ifdef __cplusplus
 }
 #endif
