@@ -193,6 +193,9 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 #define GRL_FWD_WAVES 4
 #endif
 constexpr int FWD_WAVES = GRL_FWD_WAVES;
+#ifndef GRL_FWD_MAX_BLOCKS
+#define GRL_FWD_MAX_BLOCKS 256
+#endif
 #ifdef GRL_LB1
 __global__ __launch_bounds__(64 * FWD_WAVES) void edge_conv_fwd_kernel
 #else
@@ -234,11 +237,26 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
         if (more) meta_indices(p, e + 2 + el, e1, nxt);                       // next pass: indices in flight
         const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
         float4 xv[8];
+#ifdef GRL_DBG_WAIT_TOP
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#ifndef GRL_DBG_XV_LATE
 #pragma unroll
         for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];                         // this pass: x_src row in flight
+#endif
         float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
         edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi);
+#ifdef GRL_DBG_XV_LATE
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];
+#endif
+#ifdef GRL_DBG_WAIT_MID
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         if (more) meta_invariants(p, s.grid_s, o, nxt);                       // next pass: positions -> (a, b)
+#ifdef GRL_DBG_WAIT_END
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
         const float wb = (cur.valid && cur.dst != d0) ? 1.f : 0.f;
 #pragma unroll
@@ -469,8 +487,12 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int n_tiles = (n_dst + TD - 1) / TD;
   int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
-  if (blocks > 256) blocks = 256;
+  if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
+#ifdef GRL_DBG_SMEM_PAD
+  const size_t smem = 65536;
+#else
   const size_t smem = sizeof(ChainW);
+#endif
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -192,6 +192,29 @@ GRL_DEVINL void stage_split(unsigned short* hi, unsigned short* lo, const float*
 template <int K>
 GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, const bf16x8 (&xh)[K / 16], const bf16x8 (&xl)[K / 16],
                           f32x16& acc) {
+#ifdef GRL_DBG_SAFE_MFMA
+  bf16x8 wh_[K / 16], wl_[K / 16];
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    wh_[s] = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
+    wl_[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
+  }
+#if GRL_DBG_SAFE_MFMA & 1
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    acc = mfma_bf(wh_[s], xh[s], acc);
+    acc = mfma_bf(wl_[s], xh[s], acc);
+    acc = mfma_bf(wh_[s], xl[s], acc);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#if GRL_DBG_SAFE_MFMA & 2
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc));
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#else
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
     const bf16x8 wh = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
@@ -200,6 +223,10 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
     acc = mfma_bf(wl, xh[s], acc);
     acc = mfma_bf(wh, xl[s], acc);
   }
+#endif
+#ifdef GRL_DBG_NOP_AFTER_MFMA
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc));
+#endif
 }
 
 // ---- register-level transposes on the matrix pipe -------------------------------------------------------------------------
