@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 _CHAIN = 2 * 64 * (14 + 64 + 64)             # basis MLP 14->64->64 and the 64->64 kernel layer
 FLOPS_PER_ROW = {
     "edge_conv_fwd_kernel": _CHAIN + 2 * 64,                                       # + message multiply, scatter add
-    "edge_conv_bwd_kernel<0>": _CHAIN + 2 * 64 * 64 + 2 * 64,                      # recompute, dWk, d x_src row, dK
-    "edge_conv_bwd_kernel<1>": _CHAIN + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,  # recompute, dG2, dG1, dW2, dW1
+    "edge_conv_bwd_x_kernel": _CHAIN + 2 * 64 * 64 + 3 * 64,                       # recompute, dWk, d x_src row (+sum), dK
+    "edge_conv_bwd_w_kernel": (_CHAIN - 2 * 64 * 64) + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,  # z1, z2 recompute, dG2, dG1, dW2, dW1
     "node_mlp_fwd_kernel": 4 * 64 * 256,
     "node_mlp_bwd_data_kernel": 6 * 64 * 256,                                      # z recompute, dH, dA
     "node_mlp_bwd_weights_kernel": 6 * 64 * 256,                                   # h recompute, dW3, dW4
@@ -181,8 +181,8 @@ def main():
         n_prof = len(per_step)
         med = lambda xs: sorted(xs)[len(xs) // 2]
         summ = {k: (per_step[0][k][0], med([s_[k][1] for s_ in per_step])) for k in per_step[0]}  # launches/step, ms/step
-        rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_kernel<0>": "grl_edge_conv_bwd",
-                   "edge_conv_bwd_kernel<1>": "grl_edge_conv_bwd", "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
+        rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_x_kernel": "grl_edge_conv_bwd",
+                   "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
                    "node_mlp_bwd_data_kernel": "grl_node_mlp_bwd", "node_mlp_bwd_weights_kernel": "grl_node_mlp_bwd"}
         rows_step = dict(hip.KERNEL_ROWS)      # rows handed to each entry point during the last profiled step
         kernels = {}

@@ -72,12 +72,21 @@ struct ChainW {
   float grid_s[64];
 };
 
-template <bool BWD, bool STORE_G2 = BWD>
+// Split-bf16 fragments of the chain's activations (rows on the lanes): the B operands of the next layer and, in the backward,
+// the inputs of the register-level transposes for the row-reduction products.
+struct ChainFrags {
+  bf16x8 ph[1], pl[1];    // polynomial features (16 columns, 14 used)
+  bf16x8 g1h[4], g1l[4];  // gelu(z1)
+  bf16x8 g2h[4], g2l[4];  // gelu(z2)
+};
+
+template <bool BWD>
 GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8],
-                           float4 (&gp2)[8], float4 (&phi)[2], float* g2_rows = nullptr) {
+                           float4 (&gp2)[8], ChainFrags& f) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  float4 phi[2];
   poly_frags(a, b, h, phi[0], phi[1]);
-  bf16x8 ph[1], pl[1];
+  bf16x8 (&ph)[1] = f.ph, (&pl)[1] = f.pl;
   split_frags<16>(phi, ph, pl);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -96,7 +105,7 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
       if (BWD) gp1[4 * nt + q] = make_float4(px, py, pz, pw);
     }
   }
-  bf16x8 g1h[4], g1l[4];
+  bf16x8 (&g1h)[4] = f.g1h, (&g1l)[4] = f.g1l;
   split_frags<64>(g1, g1h, g1l);
   GRL_SCHED_BARRIER();
 #pragma unroll
@@ -116,11 +125,7 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
       if (BWD) gp2[4 * nt + q] = make_float4(px, py, pz, pw);
     }
   }
-  if (STORE_G2) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(g2_rows + 8 * t) = g2[t];
-  }
-  bf16x8 g2h[4], g2l[4];
+  bf16x8 (&g2h)[4] = f.g2h, (&g2l)[4] = f.g2l;
   split_frags<64>(g2, g2h, g2l);
   GRL_SCHED_BARRIER();
 #pragma unroll
@@ -171,13 +176,22 @@ struct PassMeta {
 GRL_DEVINL void meta_indices(const EdgeParams& p, int e, int e_end, PassMeta& m) {
   m.valid = e < e_end;
   const int ee = m.valid ? e : e_end - 1;
+#ifdef GRL_DBG_FAKE_META   // timing experiment only: no index / position gathers
+  m.src = ee & 1023;
+  m.dst = (ee * 3) & 1023;
+#else
   m.src = p.e_src[ee];
   m.dst = p.e_dst[ee];
+#endif
 }
 GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o, PassMeta& m) {
+#ifdef GRL_DBG_FAKE_META
+  float rx = 1e-3f * (m.src - m.dst), ry = 2e-3f * m.src, rz = 1e-3f * m.dst;
+#else
   float rx = p.pos_src[3 * m.src] - p.pos_dst[3 * m.dst];
   float ry = p.pos_src[3 * m.src + 1] - p.pos_dst[3 * m.dst + 1];
   float rz = (p.dim == 2) ? 0.f : p.pos_src[3 * m.src + 2] - p.pos_dst[3 * m.dst + 2];
+#endif
   const float gx = grid_s[3 * o], gy = grid_s[3 * o + 1], gz = grid_s[3 * o + 2];
   m.a = rx * gx + ry * gy + rz * gz;                      // hepi.py:115
   rx -= m.a * gx; ry -= m.a * gy; rz -= m.a * gz;
@@ -244,8 +258,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
 #pragma unroll
         for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];                         // this pass: x_src row in flight
 #endif
-        float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-        edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi);
+        float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
+        ChainFrags cf;
+        edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, cf);
 #ifdef GRL_DBG_XV_LATE
 #pragma unroll
         for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];
@@ -286,48 +301,140 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Two launches over the same passes (2 edges x 16 orientations = 32 rows per wave and pass), each recomputing the cheap
-// split-bf16 chain, so that the row-reduction accumulators of one launch fit the register file without spilling
-// (a single launch needed 160 accumulator registers + the chain state: 47 spilled VGPRs, 35 % of the time in s_waitcnt):
-//   PART 0: dM = d x1[dst]; d x_src row = dM * K (stored per edge); dK = dM * x_src; dWk += dK^T g2
-//   PART 1: dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2; dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
-// Accumulators live in registers for the whole launch and leave as one partial row per wave:
+// Two launches, each recomputing the cheap split-bf16 chain, so that the row-reduction accumulators of one launch fit the
+// register file without spilling (a single launch needed 160 accumulator registers + the chain state: 47 spilled VGPRs):
+//   x kernel (edges in SOURCE-sorted order, a wave owns TD = 2 consecutive source nodes, exactly like the forward owns
+//             destination nodes): dM = d x1[dst]; d x_src[src] += dM * K accumulated in registers and stored once per node
+//             (no per-edge scratch, no second pass, no atomics); dK = dM * x_src; dWk += dK^T g2
+//   w kernel (destination-sorted order, flat passes of 2 edges x 16 orientations = 32 rows per wave):
+//             dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2; dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
+// Weight-gradient accumulators live in registers for the whole launch and leave as one partial row per wave:
 //   partial[(block*4 + wave)][9344] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64].
 constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
-GRL_DEVINL void store_frags_rowmajor(float* buf /*wave-private [32][LDT]*/, int r, int h, const float4 (&f)[8]) {
+
+// p is the SOURCE-anchored view of the edge set (rowptr = rowptr_s, e_src / e_dst in source-sorted order, n_anchor = n_src).
+__global__ __launch_bounds__(256, 1) void edge_conv_bwd_x_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
+                                                                 float* __restrict__ dx_src /*[Ns,16,64]*/,
+                                                                 float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
+  load_chain_weights(s, p);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int o = r & 15, el = r >> 4;
+  bf16x8 sel0, sel1;
+  make_selectors(sel0, sel1);
+  f32x16 accW[2][2];                       // dWk
 #pragma unroll
-  for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(buf + r * LDT + 8 * t + 4 * h) = f[t];
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_) accW[a_][b_] = zero16();
+
+  const int n_tiles = (p.n_anchor + TD - 1) / TD;
+#pragma unroll 1
+  for (int tl = blockIdx.x * 4 + wave; tl < n_tiles; tl += gridDim.x * 4) {
+    const int s0 = tl * TD, s1 = min(s0 + TD, p.n_anchor);
+    const int e0 = p.rowptr[s0], e1 = p.rowptr[s1];
+    float4 accA[8], accB[8];               // d x_src rows of the tile's two source nodes
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { accA[t] = make_float4(0.f, 0.f, 0.f, 0.f); accB[t] = accA[t]; }
+    if (e1 > e0) {
+      PassMeta cur;
+      meta_indices(p, e0 + el, e1, cur);
+      meta_invariants(p, s.grid_s, o, cur);
+#pragma unroll 1
+      for (int e = e0; e < e1; e += 2) {
+        PassMeta nxt;
+        const bool more = e + 2 < e1;
+        if (more) meta_indices(p, e + 2 + el, e1, nxt);
+        const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
+        const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
+        float4 xv[8], dv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
+        float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
+        ChainFrags cf;
+        edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, cf);
+        if (more) meta_invariants(p, s.grid_s, o, nxt);
+        const float wa = (cur.valid && cur.src == s0) ? 1.f : 0.f;
+        const float wb = (cur.valid && cur.src != s0) ? 1.f : 0.f;
+        float4 dK[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (!cur.valid) dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 m = f4_mul(dv[t], kf[t]);
+          accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
+          accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
+          dK[t] = f4_mul(dv[t], xv[t]);
+        }
+        // dWk[c][k] += sum_r dK[r][c] g2[r][k]: both operands transposed in registers (grl_common.h), split-bf16 products
+        {
+          bf16x8 kh[4], kl[4];
+          split_frags<64>(dK, kh, kl);
+          GRL_SCHED_BARRIER();
+          const TTile tg0 = transpose_split(cf.g2h[0], cf.g2h[1], cf.g2l[0], cf.g2l[1], sel0, sel1);
+          const TTile tg1 = transpose_split(cf.g2h[2], cf.g2h[3], cf.g2l[2], cf.g2l[3], sel0, sel1);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const TTile tk = transpose_split(kh[2 * ct], kh[2 * ct + 1], kl[2 * ct], kl[2 * ct + 1], sel0, sel1);
+            mma_tn_bf(tk, tg0, accW[ct][0]);
+            mma_tn_bf(tk, tg1, accW[ct][1]);
+          }
+          GRL_SCHED_BARRIER();
+        }
+        cur = nxt;
+      }
+    }
+    // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's (see the forward kernel)
+    const int node = s0 + el;
+    float4* dstp = reinterpret_cast<float4*>(dx_src + ((size_t)node * O + o) * C) + h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float4 a = accA[t], b = accB[t];
+      a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
+      b.x += __shfl_xor(b.x, 16, 64); b.y += __shfl_xor(b.y, 16, 64); b.z += __shfl_xor(b.z, 16, 64); b.w += __shfl_xor(b.w, 16, 64);
+      const bool is_a = el == 0;
+      const float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
+      if (node < s1) dstp[2 * t] = v;
+    }
+  }
+
+  // ---- this wave's dWk partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
+  float* oWk = partial + (size_t)(blockIdx.x * 4 + wave) * EDGE_PARTIAL + 64 * 14 + 64 + 64 * 64 + 64;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int rho = 0; rho < 16; ++rho) {
+      const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * h;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) oWk[n * 64 + 32 * kt + r] = accW[nt][kt][rho];
+    }
 }
 
-template <int PART>
-__global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                float* __restrict__ dxe /*[E,16,64] per-edge d x_src rows*/,
-                                                                float* __restrict__ partial, int n_edges) {
+__global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
+                                                                  float* __restrict__ partial, int n_edges) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   BwdW& sb = *reinterpret_cast<BwdW*>(smem_raw + sizeof(ChainW) / 4);
-  float* tbuf = smem_raw + (sizeof(ChainW) + (PART == 1 ? sizeof(BwdW) : 0)) / 4;  // 4 waves x 2 x [32][LDT]
   load_chain_weights(s, p);
-  if (PART == 1) {
-    stage_split_T(sb.W2Th, sb.W2Tl, p.W2, LDB);
-    stage_split_T(sb.WkTh, sb.WkTl, p.Wk, LDB);
-  }
+  stage_split_T(sb.W2Th, sb.W2Tl, p.W2, LDB);
+  stage_split_T(sb.WkTh, sb.WkTl, p.Wk, LDB);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
-  float* T0 = tbuf + wave * 2 * 32 * LDT;  // gradient-side operand of the row-reduction GEMMs
-  float* T1 = T0 + 32 * LDT;               // activation-side operand
+  bf16x8 sel0, sel1;
+  make_selectors(sel0, sel1);
 
-  f32x16 accA[2][2], accB[2];              // PART 0: accA = dWk.  PART 1: accA = dW2, accB = dW1
+  f32x16 accA[2][2], accB[2];              // accA = dW2, accB = dW1
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_) {
     accB[a_] = zero16();
 #pragma unroll
     for (int b_ = 0; b_ < 2; ++b_) accA[a_][b_] = zero16();
   }
-  float db1 = 0.f, db2 = 0.f;  // lane = column (64 columns)
+  float db1[2] = {0.f, 0.f}, db2[2] = {0.f, 0.f};  // column 32*nt + r, summed over this lane half's rows
 
   const int n_pass = (n_edges + 1) >> 1;
   const int stride = gridDim.x * 4;
@@ -347,8 +454,9 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
     float4 xv[8], dv[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
-    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8], phi[2];
-    edge_chain<PART == 1, PART == 0>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, phi, T1 + r * LDT + 4 * h);
+    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
+    ChainFrags cf;
+    edge_chain<true>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, cf);
     if (more) meta_invariants(p, s.grid_s, o, nxt);
 
     float4 dK[8];
@@ -357,22 +465,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
       if (!cur.valid) dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
       dK[t] = f4_mul(dv[t], xv[t]);
     }
-    if (PART == 0) {
-      // d x_src contribution of this lane's (edge, orientation) row: plain stores; summed per source node by
-      // edge_gather_sum_kernel -- no atomics, bitwise reproducible
-      if (cur.valid) {
-        float4* de = reinterpret_cast<float4*>(dxe + ((size_t)(2 * ps + el) * O + o) * C) + h;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) de[2 * t] = f4_mul(dv[t], kf[t]);
-      }
-      // dWk[c][k] += sum_r dK[r][c] g2[r][k]      (g2 rows were written to T1 inside the chain)
-      store_frags_rowmajor(T0, r, h, dK);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          mma_tn<32>(T0 + 4 * h * LDT + 32 * ct + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, accA[ct][kt]);
-    } else {
+    {
       // ---- dZ2 = (dK Wk) * gelu'(z2)      (split-bf16: rows of Wk^T)
       float4 dz2[8];
       {
@@ -391,82 +484,68 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_kernel(EdgeParams p, con
         }
       }
       GRL_SCHED_BARRIER();
-      store_frags_rowmajor(T0, r, h, dz2);
-      store_frags_rowmajor(T1, r, h, g1);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + 32 * kt + r, LDT, accA[nt][kt]);
-#pragma unroll
-      for (int rr = 0; rr < 32; ++rr) db2 += T0[rr * LDT + lane];
-      GRL_SCHED_BARRIER();
-      // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
-      float4 dz1[8];
+      bf16x8 zh[4], zl[4];
+      split_frags<64>(dz2, zh, zl);
+      // ---- dW2 += dZ2^T g1, db2 += column sums of dZ2      (register-level transposes, split-bf16 products)
       {
-        bf16x8 dh_[4], dl_[4];
-        split_frags<64>(dz2, dh_, dl_);
+        const TTile tg0 = transpose_split(cf.g1h[0], cf.g1h[1], cf.g1l[0], cf.g1l[1], sel0, sel1);
+        const TTile tg1 = transpose_split(cf.g1h[2], cf.g1h[3], cf.g1l[2], cf.g1l[3], sel0, sel1);
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          f32x16 acc = zero16();
-          mma_wx_bf<64>(sb.W2Th + (32 * kt + r) * LDB + 8 * h, sb.W2Tl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
-          float4 f0, f1, f2, f3;
-          acc_to_frag(acc, f0, f1, f2, f3);
-          dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
-          dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
-          dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
-          dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+        for (int nt = 0; nt < 2; ++nt) {
+          const TTile tz = transpose_split(zh[2 * nt], zh[2 * nt + 1], zl[2 * nt], zl[2 * nt + 1], sel0, sel1, &db2[nt]);
+          mma_tn_bf(tz, tg0, accA[nt][0]);
+          mma_tn_bf(tz, tg1, accA[nt][1]);
         }
       }
       GRL_SCHED_BARRIER();
-      store_frags_rowmajor(T0, r, h, dz1);
-      // phi as row-major [32][16] inside T1 (columns 16..31 of the tile are never used downstream)
-      *reinterpret_cast<float4*>(T1 + r * LDT + 4 * h) = phi[0];
-      *reinterpret_cast<float4*>(T1 + r * LDT + 8 + 4 * h) = phi[1];
+      // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
+      float4 dz1[8];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        mma_tn<32>(T0 + 4 * h * LDT + 32 * nt + r, LDT, T1 + 4 * h * LDT + r, LDT, accB[nt]);
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x16 acc = zero16();
+        mma_wx_bf<64>(sb.W2Th + (32 * kt + r) * LDB + 8 * h, sb.W2Tl + (32 * kt + r) * LDB + 8 * h, zh, zl, acc);
+        float4 f0, f1, f2, f3;
+        acc_to_frag(acc, f0, f1, f2, f3);
+        dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
+        dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
+        dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
+        dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
+      }
+      GRL_SCHED_BARRIER();
+      // ---- dW1 += dZ1^T phi, db1 += column sums of dZ1      (phi: one 16-column fragment, columns 16..31 of its tile are zero)
+      {
+        bf16x8 yh[4], yl[4];
+        split_frags<64>(dz1, yh, yl);
+        u32x4 z4 = {0u, 0u, 0u, 0u};
+        const bf16x8 zero8 = __builtin_bit_cast(bf16x8, z4);
+        const TTile tp = transpose_split(cf.ph[0], zero8, cf.pl[0], zero8, sel0, sel1);
 #pragma unroll
-      for (int rr = 0; rr < 32; ++rr) db1 += T0[rr * LDT + lane];
+        for (int nt = 0; nt < 2; ++nt) {
+          const TTile ty = transpose_split(yh[2 * nt], yh[2 * nt + 1], yl[2 * nt], yl[2 * nt + 1], sel0, sel1, &db1[nt]);
+          mma_tn_bf(ty, tp, accB[nt]);
+        }
+      }
+      GRL_SCHED_BARRIER();
     }
     cur = nxt;
   }
 
   // ---- write this wave's partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
   float* out = partial + (size_t)(blockIdx.x * 4 + wave) * EDGE_PARTIAL;
-  float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64, *oWk = ob2 + 64;
+  float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int rho = 0; rho < 16; ++rho) {
       const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * h;
-      if (PART == 1 && r < 14) oW1[n * 14 + r] = accB[nt][rho];
+      if (r < 14) oW1[n * 14 + r] = accB[nt][rho];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        if (PART == 0) oWk[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
-        else oW2[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
-      }
+      for (int kt = 0; kt < 2; ++kt) oW2[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
     }
-  if (PART == 1) { ob1[lane] = db1; ob2[lane] = db2; }
-}
-
-// dx_src[n] = sum over the out-edges of source node n of the per-edge rows dxe[eid]  (CSR by source: rowptr_s, eid_s)
-__global__ __launch_bounds__(256) void edge_gather_sum_kernel(const float* __restrict__ dxe, const int* __restrict__ rowptr_s,
-                                                              const int* __restrict__ eid_s, float* __restrict__ dx_src, int n_src) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int n = blockIdx.x * 4 + wave; n < n_src; n += gridDim.x * 4) {
-    float4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int j0 = rowptr_s[n], j1 = rowptr_s[n + 1];
-    for (int j = j0; j < j1; ++j) {
-      const float4* row = reinterpret_cast<const float4*>(dxe + (size_t)eid_s[j] * O * C) + lane;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = f4_add(acc[q], row[64 * q]);
-    }
-    float4* out = reinterpret_cast<float4*>(dx_src + (size_t)n * O * C) + lane;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) out[64 * q] = acc[q];
+  for (int nt = 0; nt < 2; ++nt) {   // the other 16 rows of every column were summed by lane ^ 32
+    const float v1 = db1[nt] + __shfl_xor(db1[nt], 32, 64), v2 = db2[nt] + __shfl_xor(db2[nt], 32, 64);
+    if (h == 0) { ob1[32 * nt + r] = v1; ob2[32 * nt + r] = v2; }
   }
 }
 
@@ -503,35 +582,34 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
   return 0;
 }
 
-// Same destination-sorted edge arrays as the forward, plus the by-source index (rowptr_s [n_src+1], eid_s [E] = position of
-// each out-edge in the destination-sorted order).  dxe: scratch [n_edges,16,64]; dx_src [n_src,16,64] is fully overwritten.
+// The same edge set in both orders: destination-sorted (rowptr, e_src, e_dst: the forward's arrays) for the weight kernel and
+// source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten.
 // partial must hold grl_edge_bwd_blocks(n_edges)*4 rows of grl_edge_partial_size() floats.
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
-                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* eid_s, int n_src,
+                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                      const float* Wk, const float* dx1, float* dxe, float* dx_src, float* partial, hipStream_t stream) {
-  if (n_edges <= 0) return 0;
-  EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+                      const float* Wk, const float* dx1, float* dx_src, float* partial, hipStream_t stream) {
+  if (n_edges <= 0) {
+    if (n_src > 0) hipMemsetAsync(dx_src, 0, sizeof(float) * (size_t)n_src * O * C, stream);
+    return 0;
+  }
+  EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+  EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
   const int blocks = grl_edge_bwd_blocks(n_edges);
-  const size_t smem0 = sizeof(ChainW) + sizeof(float) * (4 * 2 * 32 * LDT);
-  const size_t smem1 = smem0 + sizeof(BwdW);
+  const size_t smem_x = sizeof(ChainW);
+  const size_t smem_w = smem_x + sizeof(BwdW);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)edge_conv_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem0);
-    hipFuncSetAttribute((const void*)edge_conv_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+    hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x);
+    hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
     attr = true;
   }
-  grl_prof_begin("edge_conv_bwd_kernel<0>", stream);
-  hipLaunchKernelGGL(edge_conv_bwd_kernel<0>, dim3(blocks), dim3(256), smem0, stream, p, dx1, dxe, partial, n_edges);
+  grl_prof_begin("edge_conv_bwd_x_kernel", stream);
+  hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(blocks), dim3(256), smem_x, stream, ps, dx1, dx_src, partial);
   grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
-  grl_prof_begin("edge_conv_bwd_kernel<1>", stream);
-  hipLaunchKernelGGL(edge_conv_bwd_kernel<1>, dim3(blocks), dim3(256), smem1, stream, p, dx1, dxe, partial, n_edges);
-  grl_prof_end(stream);
-  GRL_CHECK_LAUNCH();
-  const int gblocks = (n_src + 3) / 4 < 2048 ? (n_src + 3) / 4 : 2048;
-  grl_prof_begin("edge_gather_sum_kernel", stream);
-  hipLaunchKernelGGL(edge_gather_sum_kernel, dim3(gblocks), dim3(256), 0, stream, dxe, rowptr_s, eid_s, dx_src, n_src);
+  grl_prof_begin("edge_conv_bwd_w_kernel", stream);
+  hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dx1, partial, n_edges);
   grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -192,29 +192,6 @@ GRL_DEVINL void stage_split(unsigned short* hi, unsigned short* lo, const float*
 template <int K>
 GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, const bf16x8 (&xh)[K / 16], const bf16x8 (&xl)[K / 16],
                           f32x16& acc) {
-#ifdef GRL_DBG_SAFE_MFMA
-  bf16x8 wh_[K / 16], wl_[K / 16];
-#pragma unroll
-  for (int s = 0; s < K / 16; ++s) {
-    wh_[s] = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
-    wl_[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
-  }
-#if GRL_DBG_SAFE_MFMA & 1
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int s = 0; s < K / 16; ++s) {
-    acc = mfma_bf(wh_[s], xh[s], acc);
-    acc = mfma_bf(wl_[s], xh[s], acc);
-    acc = mfma_bf(wh_[s], xl[s], acc);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#if GRL_DBG_SAFE_MFMA & 2
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc));
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#else
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
     const bf16x8 wh = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
@@ -223,10 +200,6 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
     acc = mfma_bf(wl, xh[s], acc);
     acc = mfma_bf(wh, xl[s], acc);
   }
-#endif
-#ifdef GRL_DBG_NOP_AFTER_MFMA
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc));
-#endif
 }
 
 // ---- register-level transposes on the matrix pipe -------------------------------------------------------------------------
@@ -267,4 +240,27 @@ GRL_DEVINL void acc_to_bf(const f32x16& t, bf16x8& k0, bf16x8& k1) {
   b[0] = pack_hi(t[8], t[9]); b[1] = pack_hi(t[10], t[11]); b[2] = pack_hi(t[12], t[13]); b[3] = pack_hi(t[14], t[15]);
   k0 = __builtin_bit_cast(bf16x8, a);
   k1 = __builtin_bit_cast(bf16x8, b);
+}
+
+// A 32-column tile of a row-major activation block (rows on the lanes), transposed and split: lane = column, K-steps 0/1 =
+// rows 0..15 / 16..31 (accumulator row order), hi and lo bf16 parts.  Built from the tile's two 16-column fragment pairs.
+struct TTile { bf16x8 h0, h1, l0, l1; };
+GRL_DEVINL TTile transpose_split(const bf16x8& ch0, const bf16x8& ch1, const bf16x8& cl0, const bf16x8& cl1, const bf16x8& sel0,
+                                 const bf16x8& sel1, float* colsum = nullptr) {
+  TTile t;
+  const f32x16 th = transpose32(ch0, ch1, sel0, sel1), tl = transpose32(cl0, cl1, sel0, sel1);
+  if (colsum) {  // sum over this lane's 16 rows of (hi + lo) = the column sum restricted to them; the other 16 rows: lane ^ 32
+    float sacc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sacc += th[q] + tl[q];
+    *colsum += sacc;
+  }
+  acc_to_bf(th, t.h0, t.h1);
+  acc_to_bf(tl, t.l0, t.l1);
+  return t;
+}
+// acc[m][n] += sum over the 32 rows r of P[r][m] Q[r][n]  (both operands transposed-split; split-bf16, 6 MFMAs)
+GRL_DEVINL void mma_tn_bf(const TTile& p, const TTile& q, f32x16& acc) {
+  acc = mfma_bf(p.h0, q.h0, acc); acc = mfma_bf(p.l0, q.h0, acc); acc = mfma_bf(p.h0, q.l0, acc);
+  acc = mfma_bf(p.h1, q.h1, acc); acc = mfma_bf(p.l1, q.h1, acc); acc = mfma_bf(p.h1, q.l1, acc);
 }

@@ -22,8 +22,9 @@ class EdgeSet:
     rowptr_d: torch.Tensor
     src_d: torch.Tensor
     dst_d: torch.Tensor
-    rowptr_s: torch.Tensor  # by-source index for the backward's gather-sum pass
-    eid_s: torch.Tensor     # position (in destination-sorted order) of every out-edge, grouped by source
+    rowptr_s: torch.Tensor  # the same edges as a source-sorted CSR (the backward sums d x_src per source node in registers)
+    src_s: torch.Tensor
+    dst_s: torch.Tensor
 
 
 def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
@@ -39,10 +40,8 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         return rowptr.int().contiguous(), a.int().contiguous(), o.int().contiguous()
 
     rp_d, dst_d, src_d = csr(dst, src, n_dst)
-    eid_s = torch.argsort(src_d.long(), stable=True)
-    rp_s = torch.zeros(n_src + 1, dtype=torch.int64, device=dev)
-    rp_s[1:] = torch.cumsum(torch.bincount(src_d.long(), minlength=n_src), 0)
-    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s.int().contiguous(), eid_s.int().contiguous())
+    rp_s, src_s, dst_s = csr(src, dst, n_src)
+    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s, src_s, dst_s)
 
 
 def _reduce(partial: torch.Tensor, out: torch.Tensor):
@@ -127,9 +126,8 @@ class EdgeConv(torch.autograd.Function):
         psize = hip.query("grl_edge_partial_size")
         partial = torch.empty(blocks * 4, psize, device=dev, dtype=torch.float32)
         dx_src = torch.empty_like(x_src)
-        dxe = torch.empty(e.n_edges, 16, 64, device=dev, dtype=torch.float32)
-        hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.eid_s,
-                 e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dxe, dx_src, partial, rows=e.n_edges * 16)
+        hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.src_s,
+                 e.dst_s, e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dx_src, partial, rows=e.n_edges * 16)
         pw1, pb1, pw2, pb2, pwk = ctx.params
         dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
                                                          (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])

@@ -27,8 +27,9 @@ int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, 
 /* ---- fused edge pipeline: hepi.py:76-82,109-123,145-157 (invariants, PolynomialFeatures, basis MLP),
  *      ponita/conv.py:79-86,115-149 (kernel Linear, message, torch_scatter sum)  ==  ponita/ponita.py:153,161,327-345 ------
  * rowptr/e_src/e_dst = destination-sorted CSR (both directions); x1 [n_dst,16,64] (every row written);
- * backward: rowptr_s [n_src+1] / eid_s [E] = by-source index into the destination-sorted edge order; dxe = scratch [E,16,64];
- *           dx_src [n_src,16,64] fully overwritten (store pass + per-source sum pass, no atomics);
+ * backward: rowptr_s [n_src+1] / src_s [E] / dst_s [E] = the same edges in SOURCE-sorted CSR order (d x_src rows are summed
+ *           in registers per source node, like the forward sums per destination node: no scratch, no atomics);
+ *           dx_src [n_src,16,64] fully overwritten;
  *           partial [grl_edge_bwd_blocks(n_edges)*4][grl_edge_partial_size()] = [dW1 64x14 | db1 64 | dW2 64x64 | db2 64 | dWk 64x64] */
 int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
@@ -36,9 +37,9 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
 int grl_edge_partial_size(void);
 int grl_edge_bwd_blocks(int n_edges);
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
-                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* eid_s, int n_src,
-                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                      const float* Wk, const float* dx1, float* dxe, float* dx_src, float* partial, hipStream_t stream);
+                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
+                      int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
+                      const float* b2, const float* Wk, const float* dx1, float* dx_src, float* partial, hipStream_t stream);
 
 /* ---- depthwise fiber convolution + bias: ponita/conv.py:88-90,108-109 (ponita.py:164-166,183) ----------------------------
  * x2[n,p,c] = 1/16 sum_o x1[n,o,c] fk[o,p,c] + bias[c];  partial [grl_fiber_bwd_blocks][grl_fiber_partial_size] = [dfk | dbias] */
