@@ -99,10 +99,9 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
     mma_wx_bf<16>(w.W1h + (32 * nt + i) * LDB1 + 8 * h, w.W1l + (32 * nt + i) * LDB1 + 8 * h, ph, pl, acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float gx, gy, gz, gw, px, py, pz, pw;
-      gelu_both(acc[4 * q], gx, px); gelu_both(acc[4 * q + 1], gy, py); gelu_both(acc[4 * q + 2], gz, pz); gelu_both(acc[4 * q + 3], gw, pw);
-      g1[4 * nt + q] = make_float4(gx, gy, gz, gw);
-      if (BWD) gp1[4 * nt + q] = make_float4(px, py, pz, pw);
+      const float4 zq = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      if (BWD) gelu_both4(zq, g1[4 * nt + q], gp1[4 * nt + q]);
+      else g1[4 * nt + q] = gelu4(zq);
     }
   }
   bf16x8 (&g1h)[4] = f.g1h, (&g1l)[4] = f.g1l;
@@ -119,10 +118,9 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
     mma_wx_bf<64>(w.W2h + (32 * nt + i) * LDB + 8 * h, w.W2l + (32 * nt + i) * LDB + 8 * h, g1h, g1l, acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float gx, gy, gz, gw, px, py, pz, pw;
-      gelu_both(acc[4 * q], gx, px); gelu_both(acc[4 * q + 1], gy, py); gelu_both(acc[4 * q + 2], gz, pz); gelu_both(acc[4 * q + 3], gw, pw);
-      g2[4 * nt + q] = make_float4(gx, gy, gz, gw);
-      if (BWD) gp2[4 * nt + q] = make_float4(px, py, pz, pw);
+      const float4 zq = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      if (BWD) gelu_both4(zq, g2[4 * nt + q], gp2[4 * nt + q]);
+      else g2[4 * nt + q] = gelu4(zq);
     }
   }
   bf16x8 (&g2h)[4] = f.g2h, (&g2l)[4] = f.g2l;

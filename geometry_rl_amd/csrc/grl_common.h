@@ -79,10 +79,49 @@ GRL_DEVINL void acc_to_frag(const f32x16& a, float4& f0, float4& f1, float4& f2,
   f3 = make_float4(a[12], a[13], a[14], a[15]);
 }
 
-// erf-GELU (torch.nn.GELU() default; reference hepi.py:73, conv.py:67) and its derivative, branch-free:
-//   erf(z) = sign(z) (1 - (a1 t + .. + a5 t^5) exp(-z^2)),  t = 1/(1 + p |z|)     (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
-// with z = x/sqrt(2), so exp(-z^2) = exp(-x^2/2) is also the Gaussian pdf factor the derivative needs: one v_exp_f32 and
-// one v_rcp_f32 per element give both gelu(x) and gelu'(x).  (libm erff costs ~3x the instructions and diverges.)
+// erf-GELU (torch.nn.GELU() default; reference hepi.py:73, conv.py:67) and its derivative, branch-free, two elements at a time so
+// that the multiplies / FMAs become packed VALU instructions (v_pk_mul_f32 / v_pk_fma_f32):
+//   erfc(|z|) = (a1 t + .. + a5 t^5) exp(-z^2),  t = 1/(1 + p |z|)        (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
+// with z = x/sqrt(2): exp(-z^2) = exp(-x^2/2) is also the Gaussian pdf factor the derivative needs, so one v_exp_f32 and one
+// v_rcp_f32 per element give both gelu(x) and gelu'(x).  (libm erff costs ~3x the instructions and diverges.)
+//   gelu(x)  = x/2 + |x|/2 (1 - q),  q = erfc(|z|)          gelu'(x) = 1/2 + sign(x)/2 (1 - q) + x pdf(x)
+typedef float v2f __attribute__((ext_vector_type(2)));
+GRL_DEVINL v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+GRL_DEVINL v2f splat2(float a) { return v2f{a, a}; }
+template <bool WITH_GRAD>
+GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
+  const float kp = 0.3275911f * 0.70710678118654752440f;
+  v2f t, e;
+  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), kp, 1.0f));
+  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), kp, 1.0f));
+  const v2f arg = (x * x) * splat2(-0.72134752044448170368f);   // -x^2/2 * log2(e)
+  e.x = __builtin_amdgcn_exp2f(arg.x);
+  e.y = __builtin_amdgcn_exp2f(arg.y);
+  v2f poly = fma2(t, splat2(1.061405429f), splat2(-1.453152027f));
+  poly = fma2(poly, t, splat2(1.421413741f));
+  poly = fma2(poly, t, splat2(-0.284496736f));
+  poly = fma2(poly, t, splat2(0.254829592f));
+  const v2f q = (poly * t) * e;
+  const v2f hx = x * splat2(0.5f);
+  v2f s;
+  s.x = fabsf(hx.x);
+  s.y = fabsf(hx.y);
+  g = fma2(-s, q, s + hx);
+  if (WITH_GRAD) {
+    v2f cs;
+    cs.x = copysignf(0.5f, x.x);
+    cs.y = copysignf(0.5f, x.y);
+    const v2f cdf = fma2(-cs, q, cs + splat2(0.5f));
+    gp = fma2(x * e, splat2(0.39894228040143267794f), cdf);
+  }
+}
+GRL_DEVINL float4 gelu4(float4 x) {
+  v2f g0, g1, d0, d1;
+  gelu_pair<false>(v2f{x.x, x.y}, g0, d0);
+  gelu_pair<false>(v2f{x.z, x.w}, g1, d1);
+  return make_float4(g0.x, g0.y, g1.x, g1.y);
+}
+// value + derivative: the scalar form schedules better inside the register-heavy backward kernels (measured)
 GRL_DEVINL void gelu_both(float x, float& g, float& gp) {
   const float az = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
@@ -97,10 +136,21 @@ GRL_DEVINL void gelu_both(float x, float& g, float& gp) {
   g = x * cdf;
   gp = fmaf(x * e, 0.39894228040143267794f, cdf);
 }
-GRL_DEVINL float gelu_f(float x) {
-  float g, gp;
-  gelu_both(x, g, gp);
-  return g;
+GRL_DEVINL void gelu_both4(float4 x, float4& g, float4& gp) {
+  gelu_both(x.x, g.x, gp.x);
+  gelu_both(x.y, g.y, gp.y);
+  gelu_both(x.z, g.z, gp.z);
+  gelu_both(x.w, g.w, gp.w);
+}
+GRL_DEVINL float4 gelu_grad4(float4 x) {
+  float4 g, gp;
+  gelu_both4(x, g, gp);
+  return gp;
+}
+GRL_DEVINL float gelu_f(float x) {   // scalar forms (tails, tests)
+  v2f g, gp;
+  gelu_pair<false>(v2f{x, x}, g, gp);
+  return g.x;
 }
 GRL_DEVINL float gelu_grad_f(float x) {
   float g, gp;

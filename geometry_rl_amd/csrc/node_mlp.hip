@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
       float4 hq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        hq[q] = make_float4(gelu_f(acc[4 * q]), gelu_f(acc[4 * q + 1]), gelu_f(acc[4 * q + 2]), gelu_f(acc[4 * q + 3]));
+        hq[q] = gelu4(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
       bf16x8 hh[2], hl[2];
       split_frags<32>(hq, hh, hl);
       mma_wx_bf<32>(s.W4h + r * LB4 + 32 * nt + 8 * h, s.W4l + r * LB4 + 32 * nt + 8 * h, hh, hl, o0);
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_data_kernel(const float* __r
       float4 dz[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        dz[q] = make_float4(dh[4 * q] * gelu_grad_f(z[4 * q]), dh[4 * q + 1] * gelu_grad_f(z[4 * q + 1]),
-                            dh[4 * q + 2] * gelu_grad_f(z[4 * q + 2]), dh[4 * q + 3] * gelu_grad_f(z[4 * q + 3]));
+        dz[q] = f4_mul(make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]),
+                       gelu_grad4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3])));
       if (valid) {
         float4* zp = reinterpret_cast<float4*>(dz_buf + rr * W + 32 * nt) + h;
 #pragma unroll
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* 
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(H + r * LDH + 32 * wave + 8 * q + 4 * h) =
-            make_float4(gelu_f(z[4 * q]), gelu_f(z[4 * q + 1]), gelu_f(z[4 * q + 2]), gelu_f(z[4 * q + 3]));
+            gelu4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]));
     }
     // wave w owns hidden tile nt = w:  dW3[32w..32w+31][0..63] and dW4[0..63][32w..32w+31]
 #pragma unroll
