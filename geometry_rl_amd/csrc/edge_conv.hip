@@ -12,6 +12,7 @@
 // The next pass's indices / positions and this pass's x_src rows are requested before the MFMA chain starts, so the gather
 // latency hides behind it.
 #include "grl_common.h"
+#include <type_traits>
 #ifdef GRL_NO_SCHED_BARRIER
 #define GRL_SCHED_BARRIER()
 #else
@@ -80,9 +81,23 @@ struct ChainFrags {
   bf16x8 g2h[4], g2l[4];  // gelu(z2)
 };
 
-template <bool BWD>
-GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8],
-                           float4 (&gp2)[8], ChainFrags& f) {
+GRL_DEVINL f32x16 bias_frag(const float* bias_s, int n0, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 bb = *reinterpret_cast<const float4*>(bias_s + n0 + 8 * q + 4 * h);
+    acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
+  }
+  return acc;
+}
+
+// One pass of the chain for this lane's row.  BWD keeps the activation derivatives; FENCED selects the two-waves-per-SIMD-safe
+// MFMA grouping (grl_common.h); k_epilogue(nt, acc) receives the two 32-column tiles of the kernel layer K = Wk g2 (pass
+// nullptr_t-like NoK to skip that layer).
+struct NoK {};
+template <bool BWD, bool FENCED, class KEpi>
+GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8], float4 (&gp2)[8],
+                           ChainFrags& f, KEpi&& k_epilogue) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   float4 phi[2];
   poly_frags(a, b, h, phi[0], phi[1]);
@@ -90,18 +105,21 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
   split_frags<16>(phi, ph, pl);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    f32x16 acc;
+    auto act = [&](const f32x16& acc) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bb = *reinterpret_cast<const float4*>(w.b1s + 32 * nt + 8 * q + 4 * h);
-      acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
-    }
-    mma_wx_bf<16>(w.W1h + (32 * nt + i) * LDB1 + 8 * h, w.W1l + (32 * nt + i) * LDB1 + 8 * h, ph, pl, acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 zq = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-      if (BWD) gelu_both4(zq, g1[4 * nt + q], gp1[4 * nt + q]);
-      else g1[4 * nt + q] = gelu4(zq);
+      for (int q = 0; q < 4; ++q) {
+        const float4 zq = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if (BWD) gelu_both4(zq, g1[4 * nt + q], gp1[4 * nt + q]);
+        else g1[4 * nt + q] = gelu4(zq);
+      }
+    };
+    const unsigned short* wh = w.W1h + (32 * nt + i) * LDB1 + 8 * h, *wl = w.W1l + (32 * nt + i) * LDB1 + 8 * h;
+    if (FENCED) {
+      mma_wx_bf_fenced<16>(wh, wl, ph, pl, bias_frag(w.b1s, 32 * nt, h), act);
+    } else {
+      f32x16 acc = bias_frag(w.b1s, 32 * nt, h);
+      mma_wx_bf<16>(wh, wl, ph, pl, acc);
+      act(acc);
     }
   }
   bf16x8 (&g1h)[4] = f.g1h, (&g1l)[4] = f.g1l;
@@ -109,30 +127,40 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&kf)[8], f
   GRL_SCHED_BARRIER();
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    f32x16 acc;
+    auto act = [&](const f32x16& acc) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bb = *reinterpret_cast<const float4*>(w.b2s + 32 * nt + 8 * q + 4 * h);
-      acc[4 * q] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
-    }
-    mma_wx_bf<64>(w.W2h + (32 * nt + i) * LDB + 8 * h, w.W2l + (32 * nt + i) * LDB + 8 * h, g1h, g1l, acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 zq = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-      if (BWD) gelu_both4(zq, g2[4 * nt + q], gp2[4 * nt + q]);
-      else g2[4 * nt + q] = gelu4(zq);
+      for (int q = 0; q < 4; ++q) {
+        const float4 zq = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if (BWD) gelu_both4(zq, g2[4 * nt + q], gp2[4 * nt + q]);
+        else g2[4 * nt + q] = gelu4(zq);
+      }
+    };
+    const unsigned short* wh = w.W2h + (32 * nt + i) * LDB + 8 * h, *wl = w.W2l + (32 * nt + i) * LDB + 8 * h;
+    if (FENCED) {
+      mma_wx_bf_fenced<64>(wh, wl, g1h, g1l, bias_frag(w.b2s, 32 * nt, h), act);
+    } else {
+      f32x16 acc = bias_frag(w.b2s, 32 * nt, h);
+      mma_wx_bf<64>(wh, wl, g1h, g1l, acc);
+      act(acc);
     }
   }
   bf16x8 (&g2h)[4] = f.g2h, (&g2l)[4] = f.g2l;
   split_frags<64>(g2, g2h, g2l);
   GRL_SCHED_BARRIER();
+  if constexpr (!std::is_same<typename std::decay<KEpi>::type, NoK>::value) {
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    f32x16 acc = zero16();
-    mma_wx_bf<64>(w.Wkh + (32 * nt + i) * LDB + 8 * h, w.Wkl + (32 * nt + i) * LDB + 8 * h, g2h, g2l, acc);
-    acc_to_frag(acc, kf[4 * nt], kf[4 * nt + 1], kf[4 * nt + 2], kf[4 * nt + 3]);
+    for (int nt = 0; nt < 2; ++nt) {
+      const unsigned short* wh = w.Wkh + (32 * nt + i) * LDB + 8 * h, *wl = w.Wkl + (32 * nt + i) * LDB + 8 * h;
+      if (FENCED) {
+        mma_wx_bf_fenced<64>(wh, wl, g2h, g2l, zero16(), [&](const f32x16& acc) { k_epilogue(nt, acc); });
+      } else {
+        f32x16 acc = zero16();
+        mma_wx_bf<64>(wh, wl, g2h, g2l, acc);
+        k_epilogue(nt, acc);
+      }
+    }
+    GRL_SCHED_BARRIER();
   }
-  GRL_SCHED_BARRIER();
 }
 
 // backward additionally keeps split-bf16 images of W2^T / Wk^T for dG = dZ W (rows of the transposed matrix = columns of W)
@@ -206,7 +234,7 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 #endif
 constexpr int FWD_WAVES = GRL_FWD_WAVES;
 #ifndef GRL_FWD_MAX_BLOCKS
-#define GRL_FWD_MAX_BLOCKS 256
+#define GRL_FWD_MAX_BLOCKS 512   // two 4-wave workgroups per CU = two waves per SIMD (the chain is fenced for that)
 #endif
 #ifdef GRL_LB1
 __global__ __launch_bounds__(64 * FWD_WAVES) void edge_conv_fwd_kernel
@@ -249,35 +277,23 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
         if (more) meta_indices(p, e + 2 + el, e1, nxt);                       // next pass: indices in flight
         const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
         float4 xv[8];
-#ifdef GRL_DBG_WAIT_TOP
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#ifndef GRL_DBG_XV_LATE
 #pragma unroll
         for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];                         // this pass: x_src row in flight
-#endif
-        float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
+        float4 g1[8], gp1[8], g2[8], gp2[8];
         ChainFrags cf;
-        edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, cf);
-#ifdef GRL_DBG_XV_LATE
-#pragma unroll
-        for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];
-#endif
-#ifdef GRL_DBG_WAIT_MID
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-        if (more) meta_invariants(p, s.grid_s, o, nxt);                       // next pass: positions -> (a, b)
-#ifdef GRL_DBG_WAIT_END
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
         const float wb = (cur.valid && cur.dst != d0) ? 1.f : 0.f;
+        // message = K * x_src, summed into the accumulator of the edge's destination node as each K tile leaves the matrix pipe
+        edge_chain<false, true>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float4 m = f4_mul(kf[t], xv[t]);
-          accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
-          accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
-        }
+          for (int q = 0; q < 4; ++q) {
+            const int t = 4 * nt + q;
+            const float4 m = f4_mul(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), xv[t]);
+            accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
+            accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
+          }
+        });
+        if (more) meta_invariants(p, s.grid_s, o, nxt);                       // next pass: positions -> (a, b)
         cur = nxt;
       }
     }
@@ -353,7 +369,9 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_x_kernel(EdgeParams p, c
         for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
         float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
         ChainFrags cf;
-        edge_chain<false>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, cf);
+        edge_chain<false, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
+          acc_to_frag(acc, kf[4 * nt], kf[4 * nt + 1], kf[4 * nt + 2], kf[4 * nt + 3]);
+        });
         if (more) meta_invariants(p, s.grid_s, o, nxt);
         const float wa = (cur.valid && cur.src == s0) ? 1.f : 0.f;
         const float wb = (cur.valid && cur.src != s0) ? 1.f : 0.f;
@@ -452,9 +470,9 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
     float4 xv[8], dv[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
-    float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
+    float4 g1[8], gp1[8], g2[8], gp2[8];
     ChainFrags cf;
-    edge_chain<true>(s, cur.a, cur.b, kf, g1, gp1, g2, gp2, cf);
+    edge_chain<true, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, NoK{});
     if (more) meta_invariants(p, s.grid_s, o, nxt);
 
     float4 dK[8];

@@ -252,6 +252,32 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
   }
 }
 
+// Fenced form for kernels that run two waves per SIMD.  Measured on gfx950 (tools/det_check_all.py, tools/variant_check.sh):
+// when LDS operand loads are interleaved with the MFMAs of a dependent chain (the form above) and a second wave shares the SIMD,
+// a few 1e-4 of the tiles come out wrong, different ones on every run -- a later load lands in a register that an earlier,
+// still queued MFMA has not read yet (the register allocator reuses dead operand registers; with one wave per SIMD the queue
+// never gets deep enough).  The cure is structural: load EVERY operand fragment of the group first, then issue the MFMAs, then
+// run an epilogue that reads the accumulator (it cannot start before the group has finished), and only then let the next loads go.
+template <int K, class Epi>
+GRL_DEVINL void mma_wx_bf_fenced(const unsigned short* whi, const unsigned short* wlo, const bf16x8 (&xh)[K / 16],
+                                 const bf16x8 (&xl)[K / 16], f32x16 acc, Epi&& epilogue) {
+  bf16x8 wh[K / 16], wl[K / 16];
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    wh[s] = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
+    wl[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    acc = mfma_bf(wh[s], xh[s], acc);
+    acc = mfma_bf(wl[s], xh[s], acc);
+    acc = mfma_bf(wh[s], xl[s], acc);
+  }
+  epilogue(acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- register-level transposes on the matrix pipe -------------------------------------------------------------------------
 // X (32 rows x 32 columns) given as split-bf16 A operands (lane = row) times a 0/1 selection matrix gives X back in the
 // ACCUMULATOR layout, i.e. with the column on the lane and the rows in the registers (acc row order == bf16 k-order): exactly the

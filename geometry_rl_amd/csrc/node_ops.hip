@@ -181,15 +181,41 @@ __global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ slab reduce
-// out[j] (+)= sum_w partial[w][j]
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                              int n_rows, int n, int rows_per_block) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const int w0 = blockIdx.y * rows_per_block, w1 = min(w0 + rows_per_block, n_rows);
-  float acc = 0.f;
-  for (int w = w0; w < w1; ++w) acc += partial[(size_t)w * n + j];
-  atomicAdd(out + j, acc);
+// out[j] += sum_w partial[w][j], bitwise reproducible: a workgroup owns 64 columns; its 8 waves sum interleaved row groups
+// (wave g: rows g, g+8, ..., four independent running sums each, combined in a fixed order) and the 8 wave sums are folded
+// through LDS in wave order.  No atomics, so the result does not depend on scheduling.
+constexpr int RED_WAVES = 8;
+GRL_DEVINL float column_sum(const float* __restrict__ src /*column base*/, size_t ld, int n_rows, int wave) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int w = wave;
+  for (; w + 3 * RED_WAVES < n_rows; w += 4 * RED_WAVES) {
+    a0 += src[(size_t)w * ld];
+    a1 += src[(size_t)(w + RED_WAVES) * ld];
+    a2 += src[(size_t)(w + 2 * RED_WAVES) * ld];
+    a3 += src[(size_t)(w + 3 * RED_WAVES) * ld];
+  }
+  for (; w < n_rows; w += RED_WAVES) a0 += src[(size_t)w * ld];
+  return (a0 + a1) + (a2 + a3);
+}
+GRL_DEVINL void fold_and_add(float v, float* __restrict__ dst, bool active, float (*red)[64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  red[wave][lane] = v;
+  __syncthreads();
+  if (wave == 0 && active) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int g = 1; g < RED_WAVES; ++g) t += red[g][lane];
+    *dst += t;
+  }
+}
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                         int n_rows, int n) {
+  __shared__ float red[RED_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const bool active = j < n;
+  const float v = active ? column_sum(partial + j, (size_t)n, n_rows, wave) : 0.f;
+  fold_and_add(v, out + j, active, red);
 }
 
 // segmented variant: up to 8 column ranges of the partial rows are folded into 8 different destinations in ONE launch, so a
@@ -200,16 +226,16 @@ struct ReduceSegs {
   int len[8];
   int n_seg;
 };
-__global__ __launch_bounds__(256) void reduce_partials_seg_kernel(const float* __restrict__ partial, ReduceSegs segs, int n_rows,
-                                                                  int ld, int rows_per_block) {
-  const int seg = blockIdx.z;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= segs.n_seg || j >= segs.len[seg]) return;
-  const int w0 = blockIdx.y * rows_per_block, w1 = min(w0 + rows_per_block, n_rows);
-  const float* src = partial + segs.start[seg] + j;
-  float acc = 0.f;
-  for (int w = w0; w < w1; ++w) acc += src[(size_t)w * ld];
-  atomicAdd(segs.dst[seg] + j, acc);
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_seg_kernel(const float* __restrict__ partial, ReduceSegs segs,
+                                                                             int n_rows, int ld) {
+  __shared__ float red[RED_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = blockIdx.y;
+  const int j = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= segs.len[seg]) return;   // whole workgroup outside this (shorter) segment
+  const bool active = j < segs.len[seg];
+  const float v = active ? column_sum(partial + segs.start[seg] + j, (size_t)ld, n_rows, wave) : 0.f;
+  fold_and_add(v, segs.dst[seg] + j, active, red);
 }
 
 int cap_blocks(long long work, int per_block, int cap) {
@@ -269,9 +295,7 @@ int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float
 // out[j] += sum over the n_rows partial rows (out must be initialised by the caller)
 int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hipStream_t stream) {
   if (n_rows <= 0 || n <= 0) return 0;
-  const int rpb = 32;
-  dim3 grid((n + 255) / 256, (n_rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, stream, partial, out, n_rows, n, rpb);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(64 * RED_WAVES), 0, stream, partial, out, n_rows, n);
   GRL_CHECK_LAUNCH();
   return 0;
 }
@@ -290,9 +314,8 @@ int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg,
     if (len[i] > max_len) max_len = len[i];
   }
   segs.n_seg = n_seg;
-  const int rpb = 32;
-  dim3 grid((max_len + 255) / 256, (n_rows + rpb - 1) / rpb, n_seg);
-  hipLaunchKernelGGL(reduce_partials_seg_kernel, grid, dim3(256), 0, stream, partial, segs, n_rows, ld, rpb);
+  hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((max_len + 63) / 64, n_seg), dim3(64 * RED_WAVES), 0, stream, partial, segs,
+                     n_rows, ld);
   GRL_CHECK_LAUNCH();
   return 0;
 }
