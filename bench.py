@@ -28,10 +28,10 @@ FLOPS_PER_ROW = {
     "edge_conv_bwd_x_kernel": _CHAIN + 2 * 64 * 64 + 3 * 64,                       # recompute, dWk, d x_src row (+sum), dK
     "edge_conv_bwd_w_kernel": (_CHAIN - 2 * 64 * 64) + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,  # z1, z2 recompute, dG2, dG1, dW2, dW1
     "node_mlp_fwd_kernel": 4 * 64 * 256,
-    "node_mlp_bwd_data_kernel": 6 * 64 * 256,                                      # z recompute, dH, dA
-    "node_mlp_bwd_weights_kernel": 6 * 64 * 256,                                   # h recompute, dW3, dW4
+    "node_mlp_bwd_fused_kernel": 10 * 64 * 256,                                    # z recompute, dH, dA, dW3, dW4
 }
-ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel", "grl_node_mlp_fwd": "node_mlp_fwd_kernel"}
+ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel", "grl_node_mlp_fwd": "node_mlp_fwd_kernel",
+                   "grl_node_mlp_bwd": "node_mlp_bwd_fused_kernel"}
 PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md:42 (the path is specified and checked in f32)
 PEAK_BF16X3 = 2500.0 / 3.0     # TFLOP/s of f32-equivalent products when each is three dense bf16 MFMAs (guide: ~2.5 PF dense)
 
@@ -173,7 +173,7 @@ def main():
             entry = hip.kernel_time_summary()
             inner = hip.kernel_prof_summary()   # the kernels inside grl_edge_conv_bwd / grl_node_mlp_bwd, one by one
             hip.kernel_prof_enable(False)
-            rec = {ENTRY_TO_KERNEL.get(k, k): v for k, v in entry.items() if k not in ("grl_edge_conv_bwd", "grl_node_mlp_bwd")}
+            rec = {ENTRY_TO_KERNEL.get(k, k): v for k, v in entry.items() if k != "grl_edge_conv_bwd"}
             rec.update(inner)
             per_step.append(rec)
         hip.KERNEL_TIMES = None
@@ -183,7 +183,7 @@ def main():
         summ = {k: (per_step[0][k][0], med([s_[k][1] for s_ in per_step])) for k in per_step[0]}  # launches/step, ms/step
         rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_x_kernel": "grl_edge_conv_bwd",
                    "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
-                   "node_mlp_bwd_data_kernel": "grl_node_mlp_bwd", "node_mlp_bwd_weights_kernel": "grl_node_mlp_bwd"}
+                   "node_mlp_bwd_fused_kernel": "grl_node_mlp_bwd"}
         rows_step = dict(hip.KERNEL_ROWS)      # rows handed to each entry point during the last profiled step
         kernels = {}
         for k, fl in FLOPS_PER_ROW.items():

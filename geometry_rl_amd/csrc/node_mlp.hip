@@ -3,39 +3,13 @@
 // Rows are (node, orientation) pairs; each wave owns 32 rows (2 nodes) per step and keeps the whole chain in registers
 // (see grl_common.h): LayerNorm by lane-pair shuffles, W3/W4 staged once per workgroup in LDS as MFMA A operands.
 //
-// Backward is split in two launches:
-//   node_mlp_bwd_data    : per-row chain (recompute z, dH = dOut W4, dZ = dH*gelu', dA = dZ W3, LayerNorm backward) and a
-//                          hand-off of (dA, dZ) rows to HBM (1.25 KB/row; both kernels run at the HBM roof, so H and xhat are
-//                          NOT handed over but recomputed by the second kernel),
-//   node_mlp_bwd_weights : recomputes LayerNorm and its hidden tile h (split-bf16 MFMA, W3 tile register-stationary), then the
-//                          row-reduction GEMMs  dW3 = dZ^T A, dW4 = dOut^T H  (+ bias / LayerNorm-affine sums) into
-//                          per-workgroup partial slabs.
+// Backward: ONE fused launch (node_mlp_bwd_fused_kernel below): dx2 and all six parameter gradients, nothing handed over through HBM.
 #include "grl_common.h"
 
 namespace {
 
 constexpr int C = 64, O = 16, W = 256;
-constexpr int LD3 = GRL_LD(64);   // 68   W3s[256][68]
-constexpr int LD4 = GRL_LD(256);  // 260  W4s[64][260]
 constexpr float LN_EPS = 1e-5f;
-
-struct MlpSmem {
-  float W3s[W * LD3];
-  float W4s[C * LD4];
-  float b3s[W];
-  float b4s[C];
-  float gam[C];
-  float bet[C];
-};
-
-GRL_DEVINL void mlp_stage(MlpSmem& s, const float* W3, const float* b3, const float* W4, const float* b4, const float* gam,
-                          const float* bet) {
-  stage_matrix(s.W3s, W3, W, C, LD3);
-  stage_matrix(s.W4s, W4, C, W, LD4);
-  for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) { s.b4s[i] = b4[i]; s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
-}
-
 // split-bf16 weight images for the forward kernel (same bytes as the fp32 image)
 constexpr int LB3 = GRL_LDB(64);   // 72
 constexpr int LB4 = GRL_LDB(256);  // 264
@@ -60,28 +34,6 @@ GRL_DEVINL void store_row(float* base, size_t row, int h, const float4 (&f)[8]) 
   float4* p = reinterpret_cast<float4*>(base + row * C) + h;
 #pragma unroll
   for (int t = 0; t < 8; ++t) p[2 * t] = f[t];
-}
-
-// LayerNorm over the 64 channels of a row split across the lane pair (l, l^32); returns xhat and the affine output
-GRL_DEVINL void layer_norm_row(const MlpSmem& s, int h, const float4 (&x)[8], float4 (&xh)[8], float4 (&a)[8], float& rstd) {
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) sum += (x[t].x + x[t].y) + (x[t].z + x[t].w);
-  const float mean = pair_sum(sum) * (1.f / C);
-  float sq = 0.f;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    xh[t] = make_float4(x[t].x - mean, x[t].y - mean, x[t].z - mean, x[t].w - mean);
-    sq += (xh[t].x * xh[t].x + xh[t].y * xh[t].y) + (xh[t].z * xh[t].z + xh[t].w * xh[t].w);
-  }
-  rstd = rsqrtf(pair_sum(sq) * (1.f / C) + LN_EPS);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const float4 g = *reinterpret_cast<const float4*>(s.gam + 8 * t + 4 * h);
-    const float4 b = *reinterpret_cast<const float4*>(s.bet + 8 * t + 4 * h);
-    xh[t] = f4_scale(xh[t], rstd);
-    a[t] = make_float4(xh[t].x * g.x + b.x, xh[t].y * g.y + b.y, xh[t].z * g.z + b.z, xh[t].w * g.w + b.w);
-  }
 }
 
 GRL_DEVINL f32x16 bias_acc(const float* bias, int n0, int h) {
@@ -117,7 +69,7 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
     float4 x[8], xh[8], a[8];
     float rstd;
     load_row(x2, rr, h, x);
-    {  // LayerNorm (same arithmetic as layer_norm_row, on the bf16 image's gamma/beta)
+    {  // LayerNorm over the 64 channels of the row, split across the lane pair (l, l^32)
       float sum = 0.f;
 #pragma unroll
       for (int t = 0; t < 8; ++t) sum += (x[t].x + x[t].y) + (x[t].z + x[t].w);
@@ -168,289 +120,296 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------ backward, data path
-// All three products per hidden tile run split-bf16: z = W3[nt] a (rows of W3), dH = W4[:,nt]^T dOut (rows of W4^T, second LDS
-// image), dA += W3[nt]^T dZ -- the transposed W3 tile is produced in registers from the same fragments that fed z
-// (transpose32, grl_common.h), so no third weight image is needed.
-struct MlpSmemBwd {
-  unsigned short W3h[W * LB3], W3l[W * LB3];    // [256 n][64 k]
-  unsigned short W4Th[W * LB3], W4Tl[W * LB3];  // [256 n][64 m]  (W4 transposed)
-  float b3s[W];
-  float gam[C];
-  float bet[C];
-};
-
-__global__ __launch_bounds__(512) void node_mlp_bwd_data_kernel(const float* __restrict__ x2, const float* __restrict__ dout,
-                                                                const float* W3, const float* b3, const float* W4,
-                                                                const float* b4, const float* gam, const float* bet,
-                                                                float* __restrict__ dx2, float* __restrict__ da_buf,
-                                                                float* __restrict__ dz_buf, int n_rows) {
-  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  MlpSmemBwd& s = *reinterpret_cast<MlpSmemBwd*>(smem_raw);
-  stage_split(s.W3h, s.W3l, W3, W, C, C, LB3);
-  for (int idx = threadIdx.x; idx < W * C; idx += blockDim.x) {  // W4^T image: row n holds W4[m][n] over (permuted) m
-    const int n = idx >> 6, p = idx & 63;
-    const int q = (p >> 2) & 3;
-    const int m = (p & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q) + (p & 3);
-    const float w = W4[m * W + n];
-    s.W4Th[n * LB3 + p] = (unsigned short)(__float_as_uint(w) >> 16);
-    s.W4Tl[n * LB3 + p] = (unsigned short)(pack_rn(w - trunc_bf16(w), 0.f) & 0xFFFFu);
-  }
-  for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) { s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  bf16x8 sel0, sel1;
-  make_selectors(sel0, sel1);
-  const int n_tiles = (n_rows + 31) >> 5;
-  for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
-    const int row = tile * 32 + r;
-    const bool valid = row < n_rows;
-    const size_t rr = valid ? row : 0;
-    float rstd, mean;
-    bf16x8 ah[4], al[4], dyh[4], dyl[4];
-    {
-      float4 x[8], a[8], dy[8];
-      load_row(x2, rr, h, x);
-      load_row(dout, rr, h, dy);
-      float sum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) sum += (x[t].x + x[t].y) + (x[t].z + x[t].w);
-      mean = pair_sum(sum) * (1.f / C);
-      float sq = 0.f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        x[t] = make_float4(x[t].x - mean, x[t].y - mean, x[t].z - mean, x[t].w - mean);
-        sq += (x[t].x * x[t].x + x[t].y * x[t].y) + (x[t].z * x[t].z + x[t].w * x[t].w);
-      }
-      rstd = rsqrtf(pair_sum(sq) * (1.f / C) + LN_EPS);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float4 g = *reinterpret_cast<const float4*>(s.gam + 8 * t + 4 * h);
-        const float4 b = *reinterpret_cast<const float4*>(s.bet + 8 * t + 4 * h);
-        a[t] = make_float4(x[t].x * rstd * g.x + b.x, x[t].y * rstd * g.y + b.y, x[t].z * rstd * g.z + b.z, x[t].w * rstd * g.w + b.w);
-      }
-      if (!valid) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) dy[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      split_frags<64>(a, ah, al);
-      split_frags<64>(dy, dyh, dyl);
-    }
-    f32x16 da0 = zero16(), da1 = zero16();
-#pragma unroll 1
-    for (int nt = 0; nt < 8; ++nt) {
-      // this hidden tile's W3 rows as A operands (lane = hidden unit)
-      bf16x8 wh[4], wl[4];
-      const unsigned short* w3h = s.W3h + (32 * nt + r) * LB3 + 8 * h;
-      const unsigned short* w3l = s.W3l + (32 * nt + r) * LB3 + 8 * h;
-#pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        wh[sidx] = *reinterpret_cast<const bf16x8*>(w3h + 16 * sidx);
-        wl[sidx] = *reinterpret_cast<const bf16x8*>(w3l + 16 * sidx);
-      }
-      f32x16 z = bias_acc(s.b3s, 32 * nt, h);
-#pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        z = mfma_bf(wh[sidx], ah[sidx], z);
-        z = mfma_bf(wl[sidx], ah[sidx], z);
-        z = mfma_bf(wh[sidx], al[sidx], z);
-      }
-      f32x16 dh = zero16();
-      mma_wx_bf<64>(s.W4Th + (32 * nt + r) * LB3 + 8 * h, s.W4Tl + (32 * nt + r) * LB3 + 8 * h, dyh, dyl, dh);
-      float4 dz[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        dz[q] = f4_mul(make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]),
-                       gelu_grad4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3])));
-      if (valid) {
-        float4* zp = reinterpret_cast<float4*>(dz_buf + rr * W + 32 * nt) + h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) zp[2 * q] = dz[q];
-      }
-      bf16x8 dzh[2], dzl[2];
-      split_frags<32>(dz, dzh, dzl);
-      // dA[k][r] += sum_n W3[32nt+n][k] dZ[r][n]: transposed W3 tile (lane = k) from the fragments above
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        bf16x8 th0, th1, tl0, tl1;
-        acc_to_bf(transpose32(wh[2 * kt], wh[2 * kt + 1], sel0, sel1), th0, th1);
-        acc_to_bf(transpose32(wl[2 * kt], wl[2 * kt + 1], sel0, sel1), tl0, tl1);
-        f32x16& da = kt == 0 ? da0 : da1;
-        da = mfma_bf(th0, dzh[0], da); da = mfma_bf(tl0, dzh[0], da); da = mfma_bf(th0, dzl[0], da);
-        da = mfma_bf(th1, dzh[1], da); da = mfma_bf(tl1, dzh[1], da); da = mfma_bf(th1, dzl[1], da);
-      }
-    }
-    float4 da[8], xh[8];
-    acc_to_frag(da0, da[0], da[1], da[2], da[3]);
-    acc_to_frag(da1, da[4], da[5], da[6], da[7]);
-    load_row(x2, rr, h, xh);  // xhat is rebuilt from the (cache-resident) row instead of living in 32 registers across the loop
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      xh[t] = make_float4((xh[t].x - mean) * rstd, (xh[t].y - mean) * rstd, (xh[t].z - mean) * rstd, (xh[t].w - mean) * rstd);
-    // LayerNorm backward:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = da * gamma
-    float sg = 0.f, sgx = 0.f;
-    float4 g[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const float4 gm = *reinterpret_cast<const float4*>(s.gam + 8 * t + 4 * h);
-      g[t] = f4_mul(da[t], gm);
-      sg += (g[t].x + g[t].y) + (g[t].z + g[t].w);
-      sgx += (g[t].x * xh[t].x + g[t].y * xh[t].y) + (g[t].z * xh[t].z + g[t].w * xh[t].w);
-    }
-    const float mg = pair_sum(sg) * (1.f / C), mgx = pair_sum(sgx) * (1.f / C);
-    float4 dx[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      dx[t] = make_float4(rstd * (g[t].x - mg - xh[t].x * mgx), rstd * (g[t].y - mg - xh[t].y * mgx),
-                          rstd * (g[t].z - mg - xh[t].z * mgx), rstd * (g[t].w - mg - xh[t].w * mgx));
-    if (valid) {
-      store_row(dx2, rr, h, dx);
-      store_row(da_buf, rr, h, da);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ backward, weights
 // partial slab per workgroup: [dW3 256x64 | db3 256 | dW4 64x256 | db4 64 | dgamma 64 | dbeta 64]
 constexpr int MLP_PARTIAL = W * C + W + C * W + C + C + C;
-constexpr int LDH = W + 4;  // 260
-constexpr int LDA = C + 4;  // 68
 
-__global__ __launch_bounds__(512) void node_mlp_bwd_weights_kernel(const float* __restrict__ x2,
-                                                                   const float* __restrict__ da_buf,
-                                                                   const float* __restrict__ dz_buf,
-                                                                   const float* __restrict__ dout, const float* __restrict__ W3,
-                                                                   const float* __restrict__ b3, const float* gam,
-                                                                   const float* bet, float* __restrict__ partial, int n_rows) {
+// ------------------------------------------------------------------------------------------------ backward, fused
+// ONE launch, nothing handed over through HBM.  A workgroup of 4 waves (one per SIMD, 512 registers each) walks 32-row chunks:
+//   1. all 256 threads: load x2 / dOut (one float4 per thread and row half, prefetched a chunk ahead), LayerNorm by 16-lane
+//      reductions, write a = LN(x2) and dOut as split-bf16 fragment images to LDS; per-thread column sums for db4
+//   2. wave w transposes one of the four shared 32-column tiles (a | dOut) in registers (transpose32) -> LDS
+//   3. wave w owns hidden tiles 2w, 2w+1 (W3 / W4^T fragments register-stationary, hidden unit on the lane):
+//        z^T, dH^T (lane = hidden unit, registers = rows: the layout the row reductions need, no transpose),
+//        dZ = dH * gelu'(z);  dW3 += dZ^T a,  dW4 += dOut^T h  (split-bf16, accumulators live in registers for the launch),
+//        dZ back to row layout (one register transpose) and dA^T += W3^T dZ with the W3 tile transposed in registers;
+//        the wave's partial dA rows go to LDS
+//   4. all threads: sum the four partial dA rows, LayerNorm backward (16-lane reductions), store dx2; per-thread column sums
+//      for dgamma / dbeta.
+// partial slab per workgroup: [dW3 256x64 | db3 256 | dW4 64x256 | db4 64 | dgamma 64 | dbeta 64]  (MLP_PARTIAL)
+constexpr int LDF = GRL_LDB(64);  // 72 bf16: activation fragment images (same layout as the weight images)
+constexpr int LDD = C + 4;        // 68 fp32: partial dA rows
+struct MlpBwdSmem {
+  unsigned short Ah[32 * LDF], Al[32 * LDF];  // a = LN(x2)
+  unsigned short Dh[32 * LDF], Dl[32 * LDF];  // dOut
+  u32x4 TT[4][4][64];                         // [a cols 0-31 | a cols 32-63 | dOut 0-31 | dOut 32-63][h0, h1, l0, l1][lane]
+  float DA[4][32 * LDD];
+  float red[16][3][C];
+  u32x4 W4F[8][4][2][64];                     // W4^T fragments (lane = hidden unit, k = output channel) [tile][K-step][hi, lo][lane]
+};
+
+GRL_DEVINL float row16_sum(float v) {  // sum over the 16 consecutive lanes that share a row
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+GRL_DEVINL void put_split4(unsigned short* hi, unsigned short* lo, const float4& v) {  // 4 consecutive image positions
+  uint2 hv, lv;
+  hv.x = pack_hi(v.x, v.y); hv.y = pack_hi(v.z, v.w);
+  lv.x = pack_rn(v.x - trunc_bf16(v.x), v.y - trunc_bf16(v.y));
+  lv.y = pack_rn(v.z - trunc_bf16(v.z), v.w - trunc_bf16(v.w));
+  *reinterpret_cast<uint2*>(hi) = hv;
+  *reinterpret_cast<uint2*>(lo) = lv;
+}
+GRL_DEVINL TTile load_ttile(const u32x4 (*tt)[64], int lane) {
+  TTile t;
+  t.h0 = __builtin_bit_cast(bf16x8, tt[0][lane]);
+  t.h1 = __builtin_bit_cast(bf16x8, tt[1][lane]);
+  t.l0 = __builtin_bit_cast(bf16x8, tt[2][lane]);
+  t.l1 = __builtin_bit_cast(bf16x8, tt[3][lane]);
+  return t;
+}
+
+__global__ __launch_bounds__(256, 1) void node_mlp_bwd_fused_kernel(const float* __restrict__ x2, const float* __restrict__ dout,
+                                                                    const float* __restrict__ W3, const float* __restrict__ b3,
+                                                                    const float* __restrict__ W4, const float* __restrict__ gam,
+                                                                    const float* __restrict__ bet, float* __restrict__ dx2,
+                                                                    float* __restrict__ partial, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  float* DZ = smem_raw;              // [32][260]  handed over by the data kernel
-  float* H = DZ + 32 * LDH;          // [32][260]  recomputed here: h = gelu(W3 a + b3) (split-bf16 MFMA, W3 tile in registers)
-  float* A = H + 32 * LDH;           // [32][68]   a = LayerNorm(x2) (recomputed here)
-  float* DO = A + 32 * LDA;          // [32][68]
-  float* DA = DO + 32 * LDA;         // [32][68]
-  float* XH = DA + 32 * LDA;         // [32][68]
+  MlpBwdSmem& s = *reinterpret_cast<MlpBwdSmem*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  f32x16 dW3[2], dW4[2];
-  dW3[0] = zero16(); dW3[1] = zero16(); dW4[0] = zero16(); dW4[1] = zero16();
-  float colsum = 0.f;  // tid<256: db3[tid]; 256..319: db4; 320..383: dgamma; 384..447: dbeta
-  // this wave's hidden tile of W3 (rows 32*wave .. +31) as stationary split-bf16 A operands
-  bf16x8 wh[4], wl[4];
-  {
-    const float* wrow = W3 + (size_t)(32 * wave + r) * C;
+  // cooperative stages: thread = (column quad cq, rows row0 and row0 + 16)
+  const int cq = tid & 15, row0 = tid >> 4;
+  const int kq = cq & 3, pq = (kq == 1) ? 2 : (kq == 2) ? 1 : kq;  // quad swap of the fragment images
+  const int ppos = 16 * (cq >> 2) + 4 * pq;
+  const float4 gq = *reinterpret_cast<const float4*>(gam + 4 * cq), bq = *reinterpret_cast<const float4*>(bet + 4 * cq);
+  bf16x8 sel0, sel1;
+  make_selectors(sel0, sel1);
+
+  // operands of this wave's two hidden tiles (lane = hidden unit j), prepared once: W4^T fragments in LDS, W3 fragments in the
+  // workgroup's own (still unused) partial slab, i.e. L2-resident global memory -- 64 registers too many to keep stationary
+  u32x4* w3f = reinterpret_cast<u32x4*>(partial + (size_t)blockIdx.x * MLP_PARTIAL);   // [8 tiles][4 K-steps][hi, lo][64 lanes]
+  float b3v[2];
 #pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx)
+  for (int tix = 0; tix < 2; ++tix) {
+    const int j = 32 * (2 * wave + tix) + r;
+    const float* wrow = W3 + (size_t)j * C;
+    b3v[tix] = b3[j];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      bf16x8 gh, gl;
       split_pair(*reinterpret_cast<const float4*>(wrow + 16 * sidx + 4 * h), *reinterpret_cast<const float4*>(wrow + 16 * sidx + 8 + 4 * h),
-                 wh[sidx], wl[sidx]);
-  }
-  const int n_chunks = (n_rows + 31) >> 5;
-  // register-staged software pipeline: the next chunk's rows are requested before this chunk's MFMAs and written to LDS
-  // after them, so the HBM latency hides behind the matrix work (one LDS image, two barriers/chunk)
-  float4 pw_dz[4], p_x, p_da, p_dy;
-  const int nr = tid >> 4, nc4 = tid & 15;
-  auto fetch = [&](int ch) {
-    const int row0 = ch * 32;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 512 * q, rr = idx >> 6, c4 = idx & 63;
-      const bool ok = row0 + rr < n_rows;
-      const size_t g = (size_t)(ok ? row0 + rr : 0) * W + 4 * c4;
-      pw_dz[q] = *reinterpret_cast<const float4*>(dz_buf + g);
-      if (!ok) pw_dz[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                 gh, gl);
+      w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, gh);   // read back by this lane only
+      w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, gl);
+      const float* c0 = W4 + (size_t)(16 * sidx + 4 * h) * W + j, *c1 = c0 + (size_t)8 * W;
+      bf16x8 fh, fl;
+      split_pair(make_float4(c0[0], c0[W], c0[2 * W], c0[3 * W]), make_float4(c1[0], c1[W], c1[2 * W], c1[3 * W]), fh, fl);
+      s.W4F[2 * wave + tix][sidx][0][lane] = __builtin_bit_cast(u32x4, fh);   // wave-private entries: no barrier needed
+      s.W4F[2 * wave + tix][sidx][1][lane] = __builtin_bit_cast(u32x4, fl);
     }
-    const bool ok = row0 + nr < n_rows;
-    const size_t g = (size_t)(ok ? row0 + nr : 0) * C + 4 * nc4;
-    p_x = *reinterpret_cast<const float4*>(x2 + g);
-    p_da = *reinterpret_cast<const float4*>(da_buf + g);
-    p_dy = *reinterpret_cast<const float4*>(dout + g);
-    if (!ok) { p_da = make_float4(0.f, 0.f, 0.f, 0.f); p_dy = p_da; }
+  }
+  // accumulators of the tile being worked on (cur*) and of the wave's other tile (oth*): the tile loop is NOT unrolled, the two
+  // sets trade places at the end of every iteration (64 moves), so the loop body is compiled once with a bounded live set
+  f32x16 curW3[2], curW4[2], othW3[2], othW4[2];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_) { curW3[a_] = zero16(); curW4[a_] = zero16(); othW3[a_] = zero16(); othW4[a_] = zero16(); }
+  float cur_db3 = 0.f, oth_db3 = 0.f;
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam, db4 = dgam;
+
+  const int n_chunks = (n_rows + 31) >> 5;
+  float4 px[2], pd[2];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = c * 32 + row0 + 16 * i;
+      const bool ok = row < n_rows;
+      const size_t g = (size_t)(ok ? row : 0) * C + 4 * cq;
+      px[i] = *reinterpret_cast<const float4*>(x2 + g);
+      pd[i] = *reinterpret_cast<const float4*>(dout + g);
+      if (!ok) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
-  const float4 gm = *reinterpret_cast<const float4*>(gam + 4 * nc4), bt = *reinterpret_cast<const float4*>(bet + 4 * nc4);
   int ch = blockIdx.x;
   if (ch < n_chunks) fetch(ch);
+#pragma unroll 1
   for (; ch < n_chunks; ch += gridDim.x) {
-    const bool ok_row = ch * 32 + nr < n_rows;
-    __syncthreads();
+    // ------------------------------------------------------------ 1: LayerNorm + fragment images
+    float4 xh[2];
+    float rstd[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 512 * q, rr = idx >> 6, c4 = idx & 63;
-      *reinterpret_cast<float4*>(DZ + rr * LDH + 4 * c4) = pw_dz[q];
+    for (int i = 0; i < 2; ++i) {
+      const float4 x = px[i], d = pd[i];
+      const float mean = row16_sum((x.x + x.y) + (x.z + x.w)) * (1.f / C);
+      const float4 xc = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
+      rstd[i] = rsqrtf(row16_sum((xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w)) * (1.f / C) + LN_EPS);
+      xh[i] = f4_scale(xc, rstd[i]);
+      const float4 a = make_float4(xh[i].x * gq.x + bq.x, xh[i].y * gq.y + bq.y, xh[i].z * gq.z + bq.z, xh[i].w * gq.w + bq.w);
+      const int off = (row0 + 16 * i) * LDF + ppos;
+      put_split4(s.Ah + off, s.Al + off, a);
+      put_split4(s.Dh + off, s.Dl + off, d);
+      db4 = f4_add(db4, d);
     }
+    const int ch_next = ch + gridDim.x;
+    if (ch_next < n_chunks) fetch(ch_next);
+    __syncthreads();
+    // ------------------------------------------------------------ 2: the four shared transposed tiles
     {
-      // LayerNorm of this row: its 64 values sit in the 16 consecutive lanes that share nr
-      float sm = (p_x.x + p_x.y) + (p_x.z + p_x.w);
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
-      const float mean = sm * (1.f / C);
-      float4 xc = make_float4(p_x.x - mean, p_x.y - mean, p_x.z - mean, p_x.w - mean);
-      float sq = (xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w);
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) sq += __shfl_xor(sq, off, 64);
-      const float rstd = rsqrtf(sq * (1.f / C) + LN_EPS);
-      float4 xh = f4_scale(xc, rstd);
-      float4 a = make_float4(xh.x * gm.x + bt.x, xh.y * gm.y + bt.y, xh.z * gm.z + bt.z, xh.w * gm.w + bt.w);
-      if (!ok_row) { a = make_float4(0.f, 0.f, 0.f, 0.f); xh = a; }
-      *reinterpret_cast<float4*>(A + nr * LDA + 4 * nc4) = a;
-      *reinterpret_cast<float4*>(DO + nr * LDA + 4 * nc4) = p_dy;
-      *reinterpret_cast<float4*>(DA + nr * LDA + 4 * nc4) = p_da;
-      *reinterpret_cast<float4*>(XH + nr * LDA + 4 * nc4) = xh;
+      const unsigned short* ih = (wave < 2 ? s.Ah : s.Dh) + r * LDF + 32 * (wave & 1) + 8 * h;
+      const unsigned short* il = (wave < 2 ? s.Al : s.Dl) + r * LDF + 32 * (wave & 1) + 8 * h;
+      const TTile t = transpose_split(*reinterpret_cast<const bf16x8*>(ih), *reinterpret_cast<const bf16x8*>(ih + 16),
+                                      *reinterpret_cast<const bf16x8*>(il), *reinterpret_cast<const bf16x8*>(il + 16), sel0, sel1);
+      s.TT[wave][0][lane] = __builtin_bit_cast(u32x4, t.h0);
+      s.TT[wave][1][lane] = __builtin_bit_cast(u32x4, t.h1);
+      s.TT[wave][2][lane] = __builtin_bit_cast(u32x4, t.l0);
+      s.TT[wave][3][lane] = __builtin_bit_cast(u32x4, t.l1);
     }
     __syncthreads();
-    if (ch + (int)gridDim.x < n_chunks) fetch(ch + gridDim.x);
-    // ---- recompute this wave's hidden tile: h[r][32w + n] = gelu(W3[32w+n] . a[r] + b3)
-    {
-      float4 af[8];
+    // ------------------------------------------------------------ 3: the wave's two hidden tiles
+    f32x16 da0 = zero16(), da1 = zero16();
+#pragma unroll 1
+    for (int tix = 0; tix < 2; ++tix) {
+      f32x16 z, dh = zero16();
+      const float bz = tix == 0 ? b3v[0] : b3v[1];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) af[t] = *reinterpret_cast<const float4*>(A + r * LDA + 8 * t + 4 * h);
-      bf16x8 ah[4], al[4];
-      split_frags<64>(af, ah, al);
-      f32x16 z = bias_acc(b3, 32 * wave, h);
+      for (int q = 0; q < 16; ++q) z[q] = bz;
+      bf16x8 w3h[4], w3l[4];
 #pragma unroll
       for (int sidx = 0; sidx < 4; ++sidx) {
-        z = mfma_bf(wh[sidx], ah[sidx], z);
-        z = mfma_bf(wl[sidx], ah[sidx], z);
-        z = mfma_bf(wh[sidx], al[sidx], z);
+        w3h[sidx] = __builtin_bit_cast(bf16x8, w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 0) * 64 + lane]);
+        w3l[sidx] = __builtin_bit_cast(bf16x8, w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 1) * 64 + lane]);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(H + r * LDH + 32 * wave + 8 * q + 4 * h) =
-            gelu4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]));
-    }
-    // wave w owns hidden tile nt = w:  dW3[32w..32w+31][0..63] and dW4[0..63][32w..32w+31]
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(s.Ah + r * LDF + 16 * sidx + 8 * h);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(s.Al + r * LDF + 16 * sidx + 8 * h);
+        z = mfma_bf(ah, w3h[sidx], z);
+        z = mfma_bf(al, w3h[sidx], z);
+        z = mfma_bf(ah, w3l[sidx], z);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      mma_tn<32>(DZ + 4 * h * LDH + 32 * wave + r, LDH, A + 4 * h * LDA + 32 * kt + r, LDA, dW3[kt]);
-      mma_tn<32>(DO + 4 * h * LDA + 32 * kt + r, LDA, H + 4 * h * LDH + 32 * wave + r, LDH, dW4[kt]);
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const bf16x8 dyh = *reinterpret_cast<const bf16x8*>(s.Dh + r * LDF + 16 * sidx + 8 * h);
+        const bf16x8 dyl = *reinterpret_cast<const bf16x8*>(s.Dl + r * LDF + 16 * sidx + 8 * h);
+        const bf16x8 w4h = __builtin_bit_cast(bf16x8, s.W4F[2 * wave + tix][sidx][0][lane]);
+        const bf16x8 w4l = __builtin_bit_cast(bf16x8, s.W4F[2 * wave + tix][sidx][1][lane]);
+        dh = mfma_bf(dyh, w4h, dh);
+        dh = mfma_bf(dyl, w4h, dh);
+        dh = mfma_bf(dyh, w4l, dh);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float4 hv[4], dz[4];
+      float csum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 gp;
+        gelu_both4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]), hv[q], gp);
+        dz[q] = f4_mul(make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]), gp);
+        csum += (dz[q].x + dz[q].y) + (dz[q].z + dz[q].w);
+      }
+      cur_db3 += csum;
+      __builtin_amdgcn_sched_barrier(0);
+      TTile hT, zT;   // lane = hidden unit, K-steps = rows 0..15 / 16..31 in accumulator order: transposed operands for free
+      split_pair(hv[0], hv[1], hT.h0, hT.l0);
+      split_pair(hv[2], hv[3], hT.h1, hT.l1);
+      split_pair(dz[0], dz[1], zT.h0, zT.l0);
+      split_pair(dz[2], dz[3], zT.h1, zT.l1);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const TTile ta0 = load_ttile(s.TT[0], lane), ta1 = load_ttile(s.TT[1], lane);
+        mma_tn_bf(zT, ta0, curW3[0]);
+        mma_tn_bf(zT, ta1, curW3[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const TTile td0 = load_ttile(s.TT[2], lane), td1 = load_ttile(s.TT[3], lane);
+        mma_tn_bf(td0, hT, curW4[0]);
+        mma_tn_bf(td1, hT, curW4[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // dZ back to row layout (lane = row, k = hidden unit) and dA^T[c][row] += sum_j W3[j][c] dZ[row][j]
+      bf16x8 zrh0, zrh1, zrl0, zrl1;
+      acc_to_bf(transpose32(zT.h0, zT.h1, sel0, sel1), zrh0, zrh1);
+      acc_to_bf(transpose32(zT.l0, zT.l1, sel0, sel1), zrl0, zrl1);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        bf16x8 th0, th1, tl0, tl1;
+        acc_to_bf(transpose32(w3h[2 * ct], w3h[2 * ct + 1], sel0, sel1), th0, th1);
+        acc_to_bf(transpose32(w3l[2 * ct], w3l[2 * ct + 1], sel0, sel1), tl0, tl1);
+        f32x16& da = ct == 0 ? da0 : da1;
+        da = mfma_bf(th0, zrh0, da); da = mfma_bf(tl0, zrh0, da); da = mfma_bf(th0, zrl0, da);
+        da = mfma_bf(th1, zrh1, da); da = mfma_bf(tl1, zrh1, da); da = mfma_bf(th1, zrl1, da);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int a_ = 0; a_ < 2; ++a_) {
+        f32x16 t3 = curW3[a_]; curW3[a_] = othW3[a_]; othW3[a_] = t3;
+        f32x16 t4 = curW4[a_]; curW4[a_] = othW4[a_]; othW4[a_] = t4;
+      }
+      { const float t = cur_db3; cur_db3 = oth_db3; oth_db3 = t; }
     }
-    if (tid < 256) {
-#pragma unroll 8
-      for (int rr = 0; rr < 32; ++rr) colsum += DZ[rr * LDH + tid];
-    } else if (tid < 320) {
-#pragma unroll 8
-      for (int rr = 0; rr < 32; ++rr) colsum += DO[rr * LDA + (tid - 256)];
-    } else if (tid < 384) {
-#pragma unroll 8
-      for (int rr = 0; rr < 32; ++rr) colsum += DA[rr * LDA + (tid - 320)] * XH[rr * LDA + (tid - 320)];
-    } else if (tid < 448) {
-#pragma unroll 8
-      for (int rr = 0; rr < 32; ++rr) colsum += DA[rr * LDA + (tid - 384)];
+    {
+      float4 f[8];
+      acc_to_frag(da0, f[0], f[1], f[2], f[3]);
+      acc_to_frag(da1, f[4], f[5], f[6], f[7]);
+      float* drow = s.DA[wave] + r * LDD + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = f[t];
+    }
+    __syncthreads();
+    // ------------------------------------------------------------ 4: LayerNorm backward
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = row0 + 16 * i, row = ch * 32 + lr;
+      float4 da = *reinterpret_cast<const float4*>(s.DA[0] + lr * LDD + 4 * cq);
+#pragma unroll
+      for (int w_ = 1; w_ < 4; ++w_) da = f4_add(da, *reinterpret_cast<const float4*>(s.DA[w_] + lr * LDD + 4 * cq));
+      const float4 g = f4_mul(da, gq);
+      const float mg = row16_sum((g.x + g.y) + (g.z + g.w)) * (1.f / C);
+      const float mgx = row16_sum((g.x * xh[i].x + g.y * xh[i].y) + (g.z * xh[i].z + g.w * xh[i].w)) * (1.f / C);
+      const float rs = rstd[i];
+      const float4 dx = make_float4(rs * (g.x - mg - xh[i].x * mgx), rs * (g.y - mg - xh[i].y * mgx),
+                                    rs * (g.z - mg - xh[i].z * mgx), rs * (g.w - mg - xh[i].w * mgx));
+      if (row < n_rows) *reinterpret_cast<float4*>(dx2 + (size_t)row * C + 4 * cq) = dx;
+      dgam = make_float4(fmaf(da.x, xh[i].x, dgam.x), fmaf(da.y, xh[i].y, dgam.y), fmaf(da.z, xh[i].z, dgam.z), fmaf(da.w, xh[i].w, dgam.w));
+      dbet = f4_add(dbet, da);
     }
   }
+
+  // ---- partial slab.  accumulator element i of lane (n = r, h) holds row m = 8(i>>2) + 4h + (i&3) of the 32x32 tile
   float* out = partial + (size_t)blockIdx.x * MLP_PARTIAL;
   float* oW3 = out, *ob3 = oW3 + W * C, *oW4 = ob3 + W, *ob4 = oW4 + C * W, *og = ob4 + C, *obt = og + C;
+  // (after an even number of swaps cur* belongs to tile 2*wave, oth* to tile 2*wave + 1)
 #pragma unroll
-  for (int rho = 0; rho < 16; ++rho) {
-    const int n = (rho & 3) + 8 * (rho >> 2) + 4 * h;
+  for (int tix = 0; tix < 2; ++tix) {
+    const int j0 = 32 * (2 * wave + tix);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      oW3[(32 * wave + n) * C + 32 * kt + r] = dW3[kt][rho];        // D[n][k]
-      oW4[(32 * kt + n) * W + 32 * wave + r] = dW4[kt][rho];        // D[m][n']
+    for (int i = 0; i < 16; ++i) {
+      const int m = 8 * (i >> 2) + 4 * h + (i & 3);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        oW3[(size_t)(j0 + m) * C + 32 * t2 + r] = tix == 0 ? curW3[t2][i] : othW3[t2][i];   // rows = hidden unit, lanes = channel
+        oW4[(size_t)(32 * t2 + m) * W + j0 + r] = tix == 0 ? curW4[t2][i] : othW4[t2][i];   // rows = output channel, lanes = hidden unit
+      }
     }
+    const float d = tix == 0 ? cur_db3 : oth_db3;
+    const float v = d + __shfl_xor(d, 32, 64);
+    if (h == 0) ob3[j0 + r] = v;
   }
-  if (tid < 256) ob3[tid] = colsum;
-  else if (tid < 320) ob4[tid - 256] = colsum;
-  else if (tid < 384) og[tid - 320] = colsum;
-  else if (tid < 448) obt[tid - 384] = colsum;
+  __syncthreads();
+  *reinterpret_cast<float4*>(&s.red[row0][0][4 * cq]) = db4;
+  *reinterpret_cast<float4*>(&s.red[row0][1][4 * cq]) = dgam;
+  *reinterpret_cast<float4*>(&s.red[row0][2][4 * cq]) = dbet;
+  __syncthreads();
+  if (tid < 3 * C) {
+    const int which = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int g_ = 0; g_ < 16; ++g_) t += s.red[g_][which][c];
+    (which == 0 ? ob4 : which == 1 ? og : obt)[c] = t;
+  }
 }
 
 int blocks_for(int n_rows, int rows_per_block, int cap) {
@@ -480,28 +439,18 @@ int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const
   return 0;
 }
 
-// Scratch: da_buf [n_rows,64], dz_buf [n_rows,256]; partial [grl_node_mlp_bwd_blocks(n_rows)][partial_size].
-// d x_dst is simply dout (residual) and is not produced here.
+// partial [grl_node_mlp_bwd_blocks(n_rows)][grl_node_mlp_partial_size()].  d x_dst is simply dout (residual), not produced here.
 int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
-                     const float* gamma, const float* beta, float* dx2, float* da_buf, float* dz_buf, float* partial, int n_rows,
-                     hipStream_t stream) {
+                     const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream) {
+  (void)b4;
   if (n_rows <= 0) return 0;
   static bool attr = false;
-  const size_t smem_w = sizeof(float) * (2 * 32 * LDH + 4 * 32 * LDA);
   if (!attr) {
-    hipFuncSetAttribute((const void*)node_mlp_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBwd));
-    hipFuncSetAttribute((const void*)node_mlp_bwd_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
+    hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem));
     attr = true;
   }
-  grl_prof_begin("node_mlp_bwd_data_kernel", stream);
-  hipLaunchKernelGGL(node_mlp_bwd_data_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBwd), stream, x2,
-                     dout, W3, b3, W4, b4, gamma, beta, dx2, da_buf, dz_buf, n_rows);
-  grl_prof_end(stream);
-  GRL_CHECK_LAUNCH();
-  grl_prof_begin("node_mlp_bwd_weights_kernel", stream);
-  hipLaunchKernelGGL(node_mlp_bwd_weights_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(512), smem_w, stream, x2, da_buf,
-                     dz_buf, dout, W3, b3, gamma, beta, partial, n_rows);
-  grl_prof_end(stream);
+  hipLaunchKernelGGL(node_mlp_bwd_fused_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(256), sizeof(MlpBwdSmem), stream, x2,
+                     dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows);
   GRL_CHECK_LAUNCH();
   return 0;
 }

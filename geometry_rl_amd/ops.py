@@ -182,12 +182,10 @@ class NodeMLP(torch.autograd.Function):
         dout = dout.contiguous()
         n_rows = x2.shape[0] * 16
         dx2 = torch.empty_like(x2)
-        da = torch.empty(n_rows, 64, device=dev, dtype=torch.float32)
-        dz = torch.empty(n_rows, 256, device=dev, dtype=torch.float32)
         blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
         psize = hip.query("grl_node_mlp_partial_size")
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
-        hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, da, dz, partial, n_rows, rows=n_rows)
+        hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows, rows=n_rows)
         pw3, pb3, pw4, pb4, pg, pbt = ctx.params
         dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
                                                                (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),

@@ -51,15 +51,14 @@ int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float
 
 /* ---- ConvNeXt node block: ponita/conv.py:64-69,112 (ponita.py:219-230); hetero sum hetero_fiber_conv.py:63-64 -------------
  * out = (accumulate ? out : 0) + x_dst + W4 GELU(W3 LN(x2) + b3) + b4 ; n_rows = n_nodes*16
- * bwd scratch: da_buf [n_rows,64]; dz_buf [n_rows,256];
+ * bwd: one fused launch (dx2 + all six parameter gradients), no scratch;
  * partial [grl_node_mlp_bwd_blocks(n_rows)][grl_node_mlp_partial_size()] = [dW3 | db3 | dW4 | db4 | dgamma | dbeta] */
 int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream);
 int grl_node_mlp_partial_size(void);
 int grl_node_mlp_bwd_blocks(int n_rows);
 int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
-                     const float* gamma, const float* beta, float* dx2, float* da_buf, float* dz_buf, float* partial, int n_rows,
-                     hipStream_t stream);
+                     const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream);
 
 /* ---- read-out + contextual std head: hepi.py:173-190 (ponita_gcn.py:129-146),
  *      algorithms/trust_region_projections/models/policy/gnn_gaussian_policy_diag.py:65-87 ------------------------------------
