@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic minibatches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the recorded hipGraph(s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +123,8 @@ def main():
         pool.append({k: v.to(dev) for k, v in b.items()})
     with torch.no_grad():  # first training call: data-dependent calibration (conv.py:104-105) on rank-local data, then broadcast
         actor.forward_diag(*[pool[0][k] for k in spec.in_features], train=True)
-    upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group,
+                              use_graph=not args.no_graph)
 
     def barrier():
         if world > 1:
@@ -165,6 +167,7 @@ def main():
         # timed events lands on a random kernel) and the per-step totals are reduced with the median over the other steps.
         n_prof = 6
         per_step = []
+        upd.use_graph = False   # per-kernel HIP events need the launches themselves, not a graph replay (same kernels, same stream)
         for i in range(n_prof):
             hip.KERNEL_TIMES = {}
             hip.KERNEL_ROWS.clear()

@@ -24,6 +24,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Same update with the step count read from device memory (bias corrections computed in-kernel), so that the launch can be
+// recorded once into a hipGraph and replayed: *step_dev is advanced by the caller before each replay.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
+                                                      const int* __restrict__ step_dev, const float* __restrict__ scale_dev,
+                                                      float scale_host) {
+  const float t = (float)step_dev[0];
+  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  const float scale = scale_host * (scale_dev ? scale_dev[0] : 1.f);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
 // clip coefficient of torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g||_2 + 1e-6))
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int n, double* __restrict__ out) {
   double s = 0;
@@ -158,6 +178,17 @@ int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
   const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                      bc1, bc2s, scale_dev, scale_host);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// step_dev: device int[1] holding the (1-based) optimizer step of THIS update
+int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
+                      float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                     eps, step_dev, scale_dev, scale_host);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -234,74 +234,111 @@ class Readout(torch.autograd.Function):
         return dlat, None, dwd, dbd, dws, dbs, None, None, None, None
 
 
+class DeepSetsPipeline:
+    """The six kernels of the DeepSets critic (reference deepsets.py:34-53, gnn_vf_net.py:50-86) as explicit stages.  Between
+    fwd1/fwd2, fwd2/fwd3, bwd3/bwd2 and bwd2/bwd1 the whole-tensor LayerNorm sums (``stats`` / ``bst`` halves) have to be summed
+    over the data-parallel ranks by the caller; ``world`` only enters through the element counts."""
+
+    PARAM_ORDER = ("w1", "b1", "g1", "be1", "w2", "b2", "w3", "b3", "g2", "be2", "w4", "b4", "wv", "bv")
+
+    def __init__(self, x, params, world=1):
+        hip.check_f32(x, *params)
+        self.B, self.n, self.d = x.shape
+        B, n, dev = self.B, self.n, x.device
+        self.x = x.contiguous()
+        self.P = [t.contiguous() for t in params]
+        self.stats = torch.zeros(4, device=dev, dtype=torch.float64)  # [sum h1, sum h1^2, sum u1, sum u1^2]
+        self.bst = torch.zeros(4, device=dev, dtype=torch.float64)    # [sum q2, sum q2 xh2, sum q1, sum q1 xh1]
+        self.h1 = torch.empty(B, n, 64, device=dev, dtype=torch.float32)
+        self.z = torch.empty(B, 64, device=dev, dtype=torch.float32)
+        self.u1 = torch.empty(B, 64, device=dev, dtype=torch.float32)
+        self.value = torch.empty(B, device=dev, dtype=torch.float32)
+        self.c1, self.c2 = float(B * world * n * 64), float(B * world * 64)
+
+    def fwd1(self):
+        w1, b1 = self.P[0], self.P[1]
+        hip.call("grl_deepsets_fwd1", self.x, w1, b1, self.h1, self.stats[0:2], self.B, self.n, self.d)
+
+    def fwd2(self):
+        w1, b1, g1, be1, w2, b2, w3, b3 = self.P[:8]
+        hip.call("grl_deepsets_fwd2", self.h1, self.stats[0:2], ctypes_double(self.c1), g1, be1, w2, b2, w3, b3, self.z, self.u1,
+                 self.stats[2:4], self.B, self.n)
+
+    def fwd3(self):
+        g2, be2, w4, b4, wv, bv = self.P[8:]
+        hip.call("grl_deepsets_fwd3", self.u1, self.stats[2:4], ctypes_double(self.c2), g2, be2, w4, b4, wv, bv, self.value, self.B)
+        return self.value
+
+    def bwd3(self, dvalue):
+        dev = self.x.device
+        blocks = hip.query("grl_deepsets_blocks", self.B)
+        self.part3 = torch.empty(blocks, hip.query("grl_deepsets_partial3"), device=dev)
+        self.part2 = torch.empty(blocks, hip.query("grl_deepsets_partial2"), device=dev)
+        self.part1 = torch.empty(blocks, 64 * self.d + 64, device=dev)
+        self.q2 = torch.empty(self.B, 64, device=dev)
+        self.q1 = torch.empty(self.B, self.n, 64, device=dev)
+        g2, be2, w4, b4, wv, bv = self.P[8:]
+        hip.call("grl_deepsets_bwd3", self.u1, self.stats[2:4], ctypes_double(self.c2), g2, be2, w4, b4, wv, dvalue.contiguous(),
+                 self.q2, self.bst[0:2], self.part3, self.B)
+
+    def bwd2(self):
+        w1, b1, g1, be1, w2, b2, w3, b3 = self.P[:8]
+        hip.call("grl_deepsets_bwd2", self.h1, self.stats[0:2], ctypes_double(self.c1), g1, be1, w2, w3, self.z, self.u1,
+                 self.stats[2:4], ctypes_double(self.c2), self.q2, self.bst[0:2], self.q1, self.bst[2:4], self.part2, self.B, self.n)
+
+    def bwd1(self, leaves):
+        """Last stage + folding of the partial slabs.  ``leaves``: the 14 parameter tensors in PARAM_ORDER (gradients are
+        accumulated in place into ``.grad`` where that buffer exists, see _emit_grads).  Returns the 14 gradients (or None)."""
+        d = self.d
+        hip.call("grl_deepsets_bwd1", self.x, self.h1, self.stats[0:2], ctypes_double(self.c1), self.q1, self.bst[2:4], self.part1,
+                 self.B, self.n, d)
+        (pw1, pb1, pg1, pbe1, pw2, pb2, pw3, pb3, pg2, pbe2, pw4, pb4, pwv, pbv) = leaves
+        dw4, db4, dwv, dbv, dg2, dbe2 = _emit_grads(self.part3, [(0, 4096, (64, 64), pw4), (4096, 64, (64,), pb4),
+                                                                 (4160, 64, (1, 64), pwv), (4224, 1, (1,), pbv),
+                                                                 (4225, 64, (64,), pg2), (4289, 64, (64,), pbe2)])
+        dw3, db3, dw2, db2, dg1, dbe1 = _emit_grads(self.part2, [(0, 4096, (64, 64), pw3), (4096, 64, (64,), pb3),
+                                                                 (4160, 4096, (64, 64), pw2), (8256, 64, (64,), pb2),
+                                                                 (8320, 64, (64,), pg1), (8384, 64, (64,), pbe1)])
+        dw1, db1 = _emit_grads(self.part1, [(0, 64 * d, (64, d), pw1), (64 * d, 64, (64,), pb1)])
+        return (dw1, db1, dg1, dbe1, dw2, db2, dw3, db3, dg2, dbe2, dw4, db4, dwv, dbv)
+
+
 class DeepSetsValue(torch.autograd.Function):
-    """DeepSets critic + value head (reference deepsets.py:34-53, gnn_vf_net.py:50-86): x [B, n, d] -> V [B].
+    """DeepSets critic + value head as one autograd node: x [B, n, d] -> V [B] (stages: DeepSetsPipeline).
 
     ``group``: optional torch.distributed process group; the whole-tensor LayerNorm statistics (and their backward
     counterparts) are all-reduced over it so a sharded minibatch reproduces the single-device result."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv, group):
-        hip.check_f32(x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)
-        B, n, d = x.shape
-        dev = x.device
-        x = x.contiguous()
-        ctx_params = (w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)
-        P = [t.contiguous() for t in ctx_params]
-        w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = P
+        leaves = (w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv)
         world = 1
         if group is not None:
             import torch.distributed as dist
             world = dist.get_world_size(group)
-        stats = torch.zeros(4, device=dev, dtype=torch.float64)  # [sum h1, sum h1^2, sum u1, sum u1^2]
-        h1 = torch.empty(B, n, 64, device=dev, dtype=torch.float32)
-        z = torch.empty(B, 64, device=dev, dtype=torch.float32)
-        u1 = torch.empty(B, 64, device=dev, dtype=torch.float32)
-        value = torch.empty(B, device=dev, dtype=torch.float32)
-        c1, c2 = float(B * world * n * 64), float(B * world * 64)
-        hip.call("grl_deepsets_fwd1", x, w1, b1, h1, stats[0:2], B, n, d)
+        pipe = DeepSetsPipeline(x, leaves, world)
+        pipe.fwd1()
         if world > 1:
-            dist.all_reduce(stats[0:2], group=group)
-        hip.call("grl_deepsets_fwd2", h1, stats[0:2], ctypes_double(c1), g1, be1, w2, b2, w3, b3, z, u1, stats[2:4], B, n)
+            dist.all_reduce(pipe.stats[0:2], group=group)
+        pipe.fwd2()
         if world > 1:
-            dist.all_reduce(stats[2:4], group=group)
-        hip.call("grl_deepsets_fwd3", u1, stats[2:4], ctypes_double(c2), g2, be2, w4, b4, wv, bv, value, B)
-        ctx.save_for_backward(x, h1, z, u1, stats, *P)
-        ctx.meta = (B, n, d, c1, c2, group, world)
-        ctx.params = ctx_params
+            dist.all_reduce(pipe.stats[2:4], group=group)
+        value = pipe.fwd3()
+        ctx.pipe, ctx.leaves, ctx.group, ctx.world = pipe, leaves, group, world
         return value
 
     @staticmethod
     def backward(ctx, dvalue):
-        x, h1, z, u1, stats, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = ctx.saved_tensors
-        B, n, d, c1, c2, group, world = ctx.meta
-        dev = x.device
-        blocks = hip.query("grl_deepsets_blocks", B)
-        p3, p2 = hip.query("grl_deepsets_partial3"), hip.query("grl_deepsets_partial2")
-        p1 = 64 * d + 64
-        part3 = torch.empty(blocks, p3, device=dev)
-        part2 = torch.empty(blocks, p2, device=dev)
-        part1 = torch.empty(blocks, p1, device=dev)
-        bst = torch.zeros(4, device=dev, dtype=torch.float64)  # [sum q2, sum q2 xh2, sum q1, sum q1 xh1]
-        q2 = torch.empty(B, 64, device=dev)
-        q1 = torch.empty(B, n, 64, device=dev)
-        hip.call("grl_deepsets_bwd3", u1, stats[2:4], ctypes_double(c2), g2, be2, w4, b4, wv, dvalue.contiguous(), q2, bst[0:2],
-                 part3, B)
+        pipe, group, world = ctx.pipe, ctx.group, ctx.world
+        pipe.bwd3(dvalue)
         if world > 1:
             import torch.distributed as dist
-            dist.all_reduce(bst[0:2], group=group)
-        hip.call("grl_deepsets_bwd2", h1, stats[0:2], ctypes_double(c1), g1, be1, w2, w3, z, u1, stats[2:4], ctypes_double(c2), q2,
-                 bst[0:2], q1, bst[2:4], part2, B, n)
+            dist.all_reduce(pipe.bst[0:2], group=group)
+        pipe.bwd2()
         if world > 1:
-            dist.all_reduce(bst[2:4], group=group)
-        hip.call("grl_deepsets_bwd1", x, h1, stats[0:2], ctypes_double(c1), q1, bst[2:4], part1, B, n, d)
-        (pw1, pb1, pg1, pbe1, pw2, pb2, pw3, pb3, pg2, pbe2, pw4, pb4, pwv, pbv) = ctx.params
-        dw4, db4, dwv, dbv, dg2, dbe2 = _emit_grads(part3, [(0, 4096, (64, 64), pw4), (4096, 64, (64,), pb4), (4160, 64, (1, 64), pwv),
-                                                            (4224, 1, (1,), pbv), (4225, 64, (64,), pg2), (4289, 64, (64,), pbe2)])
-        dw3, db3, dw2, db2, dg1, dbe1 = _emit_grads(part2, [(0, 4096, (64, 64), pw3), (4096, 64, (64,), pb3), (4160, 4096, (64, 64), pw2),
-                                                            (8256, 64, (64,), pb2), (8320, 64, (64,), pg1), (8384, 64, (64,), pbe1)])
-        dw1, db1 = _emit_grads(part1, [(0, 64 * d, (64, d), pw1), (64 * d, 64, (64,), pb1)])
-        return (None, dw1, db1, dg1, dbe1, dw2, db2, dw3, db3, dg2, dbe2, dw4, db4, dwv, dbv, None)
+            dist.all_reduce(pipe.bst[2:4], group=group)
+        grads = pipe.bwd1(ctx.leaves)
+        return (None,) + tuple(grads) + (None,)
 
 
 def ctypes_double(v: float):

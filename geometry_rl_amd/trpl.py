@@ -59,35 +59,61 @@ class _InjectGrad(torch.autograd.Function):
         return (None, None) + tuple(d * g for d in grads) + (None,) * len(grads)
 
 
+def adv_stats_local(m, batch, out):
+    """Rank-local sums (sum, sum of squares; fp64) of the advantage for its batch normalisation (trpl.py:248-252)."""
+    adv = batch["advantage"].reshape(-1).float().contiguous()
+    hip.call("grl_adv_stats", adv, out, adv.numel())
+
+
+def trpl_launch(m, loc, sigma, value, batch, adv_stats):
+    """One launch of the fused kernel on detached inputs: rank-local (sums, maxes) and the gradients of the (1/B_global-scaled)
+    losses with respect to loc, sigma and value."""
+    p = m.projection
+    B = loc.shape[0]
+    sums, maxes, dloc, dsigma, dvalue, _, _ = ops.trpl_fwd_bwd(
+        loc.detach(), sigma.detach(), batch, value.detach() if value is not None else None, mean_bound=p.mean_bound,
+        cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
+        entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, critic_coef=m.critic_coef,
+        clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats)
+    return sums, maxes, dloc, dsigma, dvalue
+
+
+def loss_values(m, sums, maxes):
+    """(actor loss, critic loss, metrics dict) from the globally reduced sums / maxes (trpl.py:280-321)."""
+    n = sums[10]
+    ent_coef = m.entropy_coef if m.entropy_bonus else 0.0
+    s = (sums / n).float()
+    actor = ((sums[0] + sums[1] - ent_coef * sums[2]) / n).float()
+    critic = (sums[3] / n).float()
+    mx = maxes.view(torch.float32)
+    ess = (sums[4] * sums[4] / sums[5] / n).float()  # exp(2 lse(lw) - lse(2 lw)) / B   (trpl.py:294-300,316)
+    metrics = {"loss_trust_region": s[1], "loss_entropy": -ent_coef * s[2], "ESS": ess, "kl": s[6] + s[7], "constraint": s[6] + s[7],
+               "mean_constraint": s[6], "mean_constraint_max": mx[0], "cov_constraint": s[7], "cov_constraint_max": mx[1],
+               "entropy": s[8], "entropy_diff": s[9]}
+    return actor, critic, metrics
+
+
 def _run_trpl(m, loc, sigma, value, batch):
-    """One launch of the fused kernel (+ the advantage statistics launch); everything detached."""
+    """Fused kernel (+ the advantage statistics launch) with the data-parallel reductions; everything detached."""
     with torch.no_grad():
-        adv = batch["advantage"].reshape(-1).float().contiguous()
         B = loc.shape[0]
         stats = None
         if m.normalize_advantage and B * m.world_size > 1:
             stats = torch.zeros(2, device=loc.device, dtype=torch.float64)
-            hip.call("grl_adv_stats", adv, stats, B)
+            adv_stats_local(m, batch, stats)
             if m.group is not None:
                 import torch.distributed as dist
                 dist.all_reduce(stats, group=m.group)
-        p = m.projection
-        sums, maxes, dloc, dsigma, dvalue, _, _ = ops.trpl_fwd_bwd(
-            loc.detach(), sigma.detach(), batch, value.detach() if value is not None else None, mean_bound=p.mean_bound,
-            cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
-            entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, critic_coef=m.critic_coef,
-            clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=stats)
+        sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, batch, stats)
         if m.group is not None:
             import torch.distributed as dist
             dist.all_reduce(sums, group=m.group)
             dist.all_reduce(maxes, op=dist.ReduceOp.MAX, group=m.group)
-        n = sums[10]
-        actor = ((sums[0] + sums[1] - (m.entropy_coef if m.entropy_bonus else 0.0) * sums[2]) / n).float()
-        critic = (sums[3] / n).float()
+        actor, critic, metrics = loss_values(m, sums, maxes)
     actor = _InjectGrad.apply(actor, 2, loc, sigma, dloc, dsigma)
     if value is not None:
         critic = _InjectGrad.apply(critic, 1, value, dvalue.reshape(value.shape))
-    return actor, critic, sums, maxes
+    return actor, critic, metrics
 
 
 class TRPLLoss(nn.Module):
@@ -124,19 +150,10 @@ class TRPLLoss(nn.Module):
         obs = [b[k] for k in self.in_features]
         loc, sigma = self.actor_network.forward_diag(*obs, train=True)
         value = self.critic_network(*obs) if self.critic_coef else None
-        actor, critic, sums, maxes = _run_trpl(self, loc, sigma, value, b)
-        with torch.no_grad():
-            n = sums[10]
-            s = (sums / n).float()
-            ent_coef = self.entropy_coef if self.entropy_bonus else 0.0
-            loss_tr, loss_ent = s[1], -ent_coef * s[2]
-            mx = maxes.view(torch.float32)
-            ess = (sums[4] * sums[4] / sums[5] / n).float()  # exp(2 lse(lw) - lse(2 lw)) / B   (trpl.py:294-300,316)
+        actor, critic, mt = _run_trpl(self, loc, sigma, value, b)
         out = {
-            "loss_objective": actor - (loss_tr + loss_ent),  # value = objective; gradient = d(actor loss)
-            "loss_trust_region": loss_tr, "loss_entropy": loss_ent, "loss_critic": critic, "ESS": ess,
-            "kl": s[6] + s[7], "constraint": s[6] + s[7], "mean_constraint": s[6], "mean_constraint_max": mx[0],
-            "cov_constraint": s[7], "cov_constraint_max": mx[1], "entropy": s[8], "entropy_diff": s[9],
-            "loc": loc, "sigma": sigma, "state_value": value,
+            "loss_objective": actor - (mt["loss_trust_region"] + mt["loss_entropy"]),  # value = objective; gradient = d(actor loss)
+            "loss_critic": critic, "loc": loc, "sigma": sigma, "state_value": value,
         }
+        out.update(mt)
         return out

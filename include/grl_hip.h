@@ -114,6 +114,9 @@ int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg,
                             hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
+/* the same update with the step count in device memory (int[1]): recordable into a hipGraph */
+int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
+                      float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream);
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream);
 int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned char* terminated, const float* values,
                  float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream);

@@ -32,7 +32,7 @@ def _setup(B, group):
     return spec, cfg, actor, critic, loss, {k: v.to(dev) for k, v in batch.items()}
 
 
-def _worker(rank, world, port, B, ret):
+def _worker(rank, world, port, B, ret, use_graph=False, n_steps=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from geometry_rl_amd import agent
@@ -41,8 +41,9 @@ def _worker(rank, world, port, B, ret):
         actor.forward_diag(*[batch[k] for k in spec.in_features], train=True)
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = {k: v[lo:hi].contiguous() for k, v in batch.items()}
-    upd = agent.PolicyUpdater(loss, lr=cfg.lr, group=dist.group.WORLD)
-    out = upd.step(shard)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, group=dist.group.WORLD, use_graph=use_graph)
+    for _ in range(n_steps):
+        out = upd.step(shard)
     ret[rank] = ({k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic", "kl",
                                                      "mean_constraint_max", "ESS")}, upd.flat.detach().cpu())
     dist.destroy_process_group()
@@ -70,3 +71,40 @@ def test_two_ranks_match_single_rank():
         err = (flat - ref_flat).abs().max().item()
         print(f"rank {r}: max |param - single-rank param| = {err:.3e}")
         assert err <= 2e-6
+
+
+def _run_single(B, n_steps, use_graph):
+    from geometry_rl_amd import agent
+    spec, cfg, actor, critic, loss, batch = _setup(B, None)
+    with torch.no_grad():
+        actor.forward_diag(*[batch[k] for k in spec.in_features], train=True)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=use_graph)
+    for _ in range(n_steps):
+        out = upd.step(batch)
+    losses = {k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic", "kl",
+                                                  "mean_constraint_max", "ESS")}
+    return losses, upd.flat.detach().cpu()
+
+
+def test_graph_replay_matches_eager():
+    """The hipGraph-recorded step (replayed 3 times: the Adam step count lives on the device) equals 3 eager steps."""
+    ref_losses, ref_flat = _run_single(16, 3, use_graph=False)
+    losses, flat = _run_single(16, 3, use_graph=True)
+    for k, v in ref_losses.items():
+        assert abs(losses[k] - v) <= 1e-6 * max(1.0, abs(v)), (k, losses[k], v)
+    assert (flat - ref_flat).abs().max().item() <= 1e-7
+
+
+def test_two_ranks_with_graph_segments_match_single_rank():
+    """Data parallel with the step recorded as hipGraph segments between the (eager) collectives, 2 steps."""
+    B, world = 16, 2
+    ref_losses, ref_flat = _run_single(B, 2, use_graph=False)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, 2), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        losses, flat = ret[r]
+        for k, v in ref_losses.items():
+            assert abs(losses[k] - v) <= 1e-5 * max(1.0, abs(v)), (r, k, losses[k], v)
+        assert (flat - ref_flat).abs().max().item() <= 4e-6
