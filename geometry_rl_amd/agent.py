@@ -187,8 +187,8 @@ class PolicyUpdater:
                              hi - lo, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef,
                              1.0)
                 a_loss, c_loss, mt = loss_values(m, st["sums"], st["maxes"])
-                out = {"loss_objective": a_loss - (mt["loss_trust_region"] + mt["loss_entropy"]), "loss_critic": c_loss,
-                       "loc": st["loc"], "sigma": st["sigma"], "state_value": st["value"].unsqueeze(-1)}
+                out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": c_loss, "loc": st["loc"], "sigma": st["sigma"],
+                       "state_value": st["value"].unsqueeze(-1)}
                 out.update(mt)
                 st["out"] = out
 
@@ -240,7 +240,8 @@ class PolicyUpdater:
                 program.append((kind, item))
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=side):
+            # thread_local: background threads of the process (the collectives' watchdog) may keep issuing event queries
+            with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
                 for fn in item:
                     fn()
             pool = g.pool()

@@ -381,6 +381,27 @@ __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict_
   if ((threadIdx.x & 63) == 0) { atomicAdd(stats, s0); atomicAdd(stats + 1, s1); }
 }
 
+__global__ void loss_values_kernel(const double* __restrict__ sums, const unsigned int* __restrict__ maxes, float entropy_coef,
+                                   float* __restrict__ out) {
+  const double n = sums[10];
+  const float tr = (float)(sums[1] / n), ent = -entropy_coef * (float)(sums[2] / n);
+  const float actor = (float)((sums[0] + sums[1] - (double)entropy_coef * sums[2]) / n);
+  out[0] = actor;
+  out[1] = (float)(sums[3] / n);
+  out[2] = tr;
+  out[3] = ent;
+  out[4] = (float)(sums[4] * sums[4] / sums[5] / n);   // exp(2 lse(lw) - lse(2 lw)) / B   (trpl.py:294-300,316)
+  const float mc = (float)(sums[6] / n), cc = (float)(sums[7] / n);
+  out[5] = mc + cc;
+  out[6] = mc;
+  out[7] = __uint_as_float(maxes[0]);
+  out[8] = cc;
+  out[9] = __uint_as_float(maxes[1]);
+  out[10] = (float)(sums[8] / n);
+  out[11] = (float)(sums[9] / n);
+  out[12] = actor - (tr + ent);
+}
+
 }  // namespace
 
 extern "C" {
@@ -430,6 +451,15 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
   hipLaunchKernelGGL(trpl_kernel, dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean, old_var,
                      old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, sums,
                      maxes, batch);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// Reported values from the (globally reduced) sums / maxes of the fused kernel (trpl.py:280-321), one tiny launch instead of a
+// chain of scalar tensor ops:  out = [actor loss, critic loss, loss_trust_region, loss_entropy, ESS, kl, mean_constraint,
+// mean_constraint_max, cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective]
+int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_values_kernel, dim3(1), dim3(1), 0, stream, sums, maxes, entropy_coef, out13);
   GRL_CHECK_LAUNCH();
   return 0;
 }

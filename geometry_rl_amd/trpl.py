@@ -79,18 +79,15 @@ def trpl_launch(m, loc, sigma, value, batch, adv_stats):
 
 
 def loss_values(m, sums, maxes):
-    """(actor loss, critic loss, metrics dict) from the globally reduced sums / maxes (trpl.py:280-321)."""
-    n = sums[10]
+    """(actor loss, critic loss, metrics dict) from the globally reduced sums / maxes (trpl.py:280-321): one launch, the entries
+    are views of its 13-float output."""
     ent_coef = m.entropy_coef if m.entropy_bonus else 0.0
-    s = (sums / n).float()
-    actor = ((sums[0] + sums[1] - ent_coef * sums[2]) / n).float()
-    critic = (sums[3] / n).float()
-    mx = maxes.view(torch.float32)
-    ess = (sums[4] * sums[4] / sums[5] / n).float()  # exp(2 lse(lw) - lse(2 lw)) / B   (trpl.py:294-300,316)
-    metrics = {"loss_trust_region": s[1], "loss_entropy": -ent_coef * s[2], "ESS": ess, "kl": s[6] + s[7], "constraint": s[6] + s[7],
-               "mean_constraint": s[6], "mean_constraint_max": mx[0], "cov_constraint": s[7], "cov_constraint_max": mx[1],
-               "entropy": s[8], "entropy_diff": s[9]}
-    return actor, critic, metrics
+    o = torch.empty(13, device=sums.device, dtype=torch.float32)
+    hip.call("grl_trpl_loss_values", sums, maxes, float(ent_coef), o)
+    metrics = {"loss_trust_region": o[2], "loss_entropy": o[3], "ESS": o[4], "kl": o[5], "constraint": o[5], "mean_constraint": o[6],
+               "mean_constraint_max": o[7], "cov_constraint": o[8], "cov_constraint_max": o[9], "entropy": o[10],
+               "entropy_diff": o[11], "loss_objective_value": o[12]}
+    return o[0], o[1], metrics
 
 
 def _run_trpl(m, loc, sigma, value, batch):
@@ -155,5 +152,5 @@ class TRPLLoss(nn.Module):
             "loss_objective": actor - (mt["loss_trust_region"] + mt["loss_entropy"]),  # value = objective; gradient = d(actor loss)
             "loss_critic": critic, "loc": loc, "sigma": sigma, "state_value": value,
         }
-        out.update(mt)
+        out.update({k: v for k, v in mt.items() if k != "loss_objective_value"})
         return out

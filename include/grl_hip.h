@@ -84,6 +84,10 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
                      const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
                      float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
                      unsigned int* maxes, int batch, hipStream_t stream);
+/* reported loss-dict values (trpl.py:280-321) from the globally reduced sums / maxes:
+ * out13 = [actor loss, critic loss, loss_trust_region, loss_entropy, ESS, kl, mean_constraint, mean_constraint_max,
+ *          cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective] */
+int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream);
 
 /* ---- DeepSets critic: geometry_rl/modules/pyg_models/deepsets.py:34-53, models/value/gnn_vf_net.py:50-86 ---------------------
  * three forward and three backward stages around the whole-tensor LayerNorm statistics (PyG LayerNorm mode="graph") */
