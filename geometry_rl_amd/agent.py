@@ -261,7 +261,16 @@ class PolicyUpdater:
                     self._reduce(kind, item())
             return st["out"]
         if self._program is None:
-            self._compile(batch)
+            try:
+                self._compile(batch)
+            except Exception as e:  # keep training eagerly rather than die on a capture restriction of the runtime at hand
+                import sys
+                print(f"[geometry_rl_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches",
+                      file=sys.stderr)
+                torch.cuda.synchronize()
+                self.use_graph, self._program, self._static = False, None, None
+                self.steps -= 1
+                return self.step(batch)
         for k, v in self._static.items():
             v.copy_(batch[k])
         for kind, item in self._program:

@@ -219,69 +219,96 @@ class HyperData:
         self._cache[key] = topo
         return topo
 
-    def build_data(self, *args, train=True, **kw):
-        """rigid_tasks_data.py / base_data.py:45-55.  Positional obs tensors in ``spec.in_features`` order."""
+    def _slice(self, obs, group, name):
+        """(group tensor, row stride, column offset, vectors per sample) of one named observation inside its group."""
+        base = group.replace("norm_", "")
+        names, dims = self.spec.obs_names[base], self.spec.obs_dims[base]
+        i = names.index(name)
+        x = obs[group]
+        return x, x.shape[1], sum(dims[:i]), dims[i] // 3
+
+    def _feature_terms(self, t, n_t):
+        """[(A, B)] per vector slot of node type t, A / B = (group, name) or None; the value is A - B
+        (rigid_tasks_data.py:150-250, cloth_tasks_data.py:150-240, rope_tasks_data.py:150-235)."""
         spec = self.spec
-        obs = dict(zip(spec.in_features, args))
+        NP, NV = "norm_position_vectors", "norm_velocity_vectors"
+        has_vel = lambda name: name in spec.obs_names["velocity_vectors"]
+        corr = lambda target: ((NP, t), (NP, target)) if self.dist_as_pos else ((NP, target), None)
+        fam = spec.family
+        if fam == "rigid":
+            c = corr("target_geometry") if t == "object_geometry" else (None, None)
+            vel = ((NV, t), None) if has_vel(t) else (None, None)
+            ang = ((NV, f"{t}_angular"), None) if (has_vel(t) and spec.angular_velocity) else (None, None)
+            return [((NP, t), None), c, vel, ang]
+        if fam == "cloth":
+            if t == "particles":
+                c = corr("init_particles")
+            elif t == "hole_boundary":
+                c = corr("target_hook")
+            else:
+                c = (None, None)
+            return [((NP, t), None), c, ((NV, t), None) if has_vel(t) else (None, None)]
+        c = corr("target_geometry") if t == "links" else (None, None)
+        return [((NP, t), None), c, ((NV, t), None) if has_vel(t) else (None, None)]
+
+    def build_data(self, *args, train=True, **kw):
+        """rigid_tasks_data.py / base_data.py:45-55.  Positional obs tensors in ``spec.in_features`` order.  All node features
+        (and the raw positions) are written by ONE launch of ``grl_build_features``."""
+        import ctypes
+        spec = self.spec
+        obs = {k: (v if v.dtype == torch.float32 and v.is_contiguous() else v.float().contiguous())
+               for k, v in zip(spec.in_features, args)}
         B = obs["scalars"].shape[0]
         dev = obs["scalars"].device
         with torch.no_grad():
-            split = self._split(obs)
-            topo = self._topology(split, B, dev)
-            npos, nvel, pos = split["norm_position_vectors"], split["norm_velocity_vectors"], split["position_vectors"]
+            topo = self._cache.get(B)
+            if topo is None:
+                topo = self._topology(self._split(obs), B, dev)
             main, gm = topo["main"], topo["gather_main"]
             full = topo["n_main"] == B * topo["n_per"][main]
-
-            def rows(x, t):  # [B,n,3] -> node rows (compact for the main type)
-                x = x.reshape(-1, 3)
-                return x if (t != main or full) else x[gm]
-
+            n_types, n_vec = len(spec.node_types), spec.n_vec
+            d = n_types + 3 * n_vec
+            n_total = sum(topo["n_per"][t] for t in self.node_type_list)
+            dense = self.concat_input_vector
+            x_dense = torch.empty(B, n_total, d, device=dev, dtype=torch.float32) if dense else None
             graph_pos, scalar_dict, vector_dict = {}, {}, {}
+            words = []
+
+            def term(tn, n_t):
+                if tn is None:
+                    return 0, 0, 0, 0
+                xg, stride, off, n_src = self._slice(obs, *tn)
+                return xg.data_ptr(), stride, off, int(n_src == 1 and n_t > 1)
+
+            row_off = 0
             for t in self.node_type_list:
-                graph_pos[t] = rows(pos[t], t).contiguous()
-                norm_pos = rows(npos[t], t)
-                zeros = torch.zeros_like(norm_pos)
-                fam = spec.family
-                if fam == "rigid":
-                    if t == "object_geometry":
-                        target = rows(npos["target_geometry"], t)
-                        corr = norm_pos - target if self.dist_as_pos else target
+                n_t = topo["n_per"][t]
+                gather = gm.data_ptr() if (t == main and not full) else 0
+                n_nodes = topo["n_main"] if t == main else B * n_t
+                if not dense:
+                    graph_pos[t] = torch.empty(n_nodes, 3, device=dev, dtype=torch.float32)
+                    vector_dict[t] = torch.empty(n_nodes, n_vec, 3, device=dev, dtype=torch.float32)
+                    scalar_dict[t] = topo["one_hot"][t]
+                    pa = term(("position_vectors", t), n_t)
+                    words += [graph_pos[t].data_ptr(), pa[0], 0, gather, 3, 0, 0, 0, n_nodes, n_t, pa[1], pa[2], pa[3], 0, 0, 0, -1, 0]
+                terms = self._feature_terms(t, n_t)
+                assert len(terms) == n_vec
+                for v, (ta, tb) in enumerate(terms):
+                    A, Bt = term(ta, n_t), term(tb, n_t)
+                    if dense:
+                        out, rs, col, rps, ro = x_dense.data_ptr(), d, n_types + 3 * v, n_total, row_off
+                        onehot = spec.node_types.index(t) if v == 0 else -1
                     else:
-                        corr = zeros
-                    if t in nvel:
-                        n_t = npos[t].shape[1]
-                        vel = rows(nvel[t].expand(-1, n_t, -1) if t == main else nvel[t], t)
-                        if spec.angular_velocity:
-                            a = nvel[f"{t}_angular"]
-                            ang = rows(a.expand(-1, n_t, -1) if t == main else a, t)
-                        else:
-                            ang = torch.zeros_like(vel)
-                    else:
-                        vel, ang = zeros, zeros
-                    vecs = [norm_pos, corr, vel, ang]
-                elif fam == "cloth":
-                    if t == "particles":
-                        init = npos["init_particles"].reshape(-1, 3)
-                        corr = norm_pos - init if self.dist_as_pos else init
-                    elif t == "hole_boundary":
-                        target = rows(npos["target_hook"].expand(-1, npos[t].shape[1], -1), t)
-                        corr = norm_pos - target if self.dist_as_pos else target
-                    else:
-                        corr = zeros
-                    vecs = [norm_pos, corr, nvel[t].reshape(-1, 3) if t in nvel else zeros]
-                else:
-                    if t == "links":
-                        target = rows(npos["target_geometry"], t)
-                        corr = norm_pos - target if self.dist_as_pos else target
-                    else:
-                        corr = zeros
-                    vecs = [norm_pos, corr, rows(nvel[t], t) if t in nvel else zeros]
-                scalar_dict[t] = topo["one_hot"][t]
-                vector_dict[t] = torch.stack(vecs, dim=1).contiguous()  # [N_t, n_vec, 3]
-            graph = GraphBatch(B, list(self.node_type_list), {t: graph_pos[t].shape[0] for t in self.node_type_list}, graph_pos,
+                        out, rs, col, rps, ro, onehot = vector_dict[t].data_ptr(), 3 * n_vec, 3 * v, 0, 0, -1
+                    words += [out, A[0], Bt[0], gather, rs, col, rps, ro, n_nodes, n_t, A[1], A[2], A[3], Bt[1], Bt[2], Bt[3], onehot,
+                              n_types]
+                row_off += n_t
+            n_desc = len(words) // 18
+            hip.call("grl_build_features", (ctypes.c_longlong * len(words))(*words), n_desc)
+            self._keepalive = obs  # the launch reads these buffers asynchronously
+            graph = GraphBatch(B, list(self.node_type_list), {t: (topo["n_main"] if t == main else B * topo["n_per"][t])
+                                                              for t in self.node_type_list}, graph_pos,
                                topo["edges"], self._output_mask_key, topo["n_per"], self.drop_padding)
-            if self.concat_input_vector:
-                xs = [torch.cat([scalar_dict[t], vector_dict[t].reshape(vector_dict[t].shape[0], -1)], dim=1).reshape(B, -1, len(
-                    spec.node_types) + 3 * spec.n_vec) for t in self.node_type_list]
-                return graph, torch.cat(xs, dim=1).contiguous()
+            if dense:
+                return graph, x_dense
             return graph, (scalar_dict, vector_dict)

@@ -114,8 +114,12 @@ class HEPi(nn.Module):
     # ------------------------------------------------------------------ helpers
     @property
     def grid3(self) -> torch.Tensor:
-        g = self.ori_grid
-        return F.pad(g, (0, 3 - g.shape[1])).contiguous()
+        """Orientation grid padded to 3 columns (constant: built once, no per-call launches)."""
+        g3 = getattr(self, "_grid3_cache", None)
+        if g3 is None or g3.device != self.ori_grid.device:
+            g = self.ori_grid
+            g3 = self._grid3_cache = F.pad(g, (0, 3 - g.shape[1])).contiguous()
+        return g3
 
     @property
     def calibrated(self) -> bool:
@@ -123,9 +127,12 @@ class HEPi(nn.Module):
 
     def fiber_basis(self) -> torch.Tensor:
         """Phi[o,p,:] = fiber_basis_fn(o_o . o_p)  (hepi.py:119,157): 256 parameter-only rows, plain torch."""
-        g = self.ori_grid
-        inv = (g[None, :, :] * g[:, None, :]).sum(-1, keepdim=True)
-        return self.fiber_basis_fn(inv)
+        poly = getattr(self, "_fiber_poly_cache", None)   # polynomial features of the (constant) grid invariants
+        if poly is None or poly.device != self.ori_grid.device:
+            g = self.ori_grid
+            inv = (g[None, :, :] * g[:, None, :]).sum(-1, keepdim=True)
+            poly = self._fiber_poly_cache = self.fiber_basis_fn[0](inv).detach()
+        return self.fiber_basis_fn[1:](poly)
 
     def _needed_types(self, graph: GraphBatch):
         need = {graph.output_mask_key} if graph.output_mask_key else set(graph.node_types)

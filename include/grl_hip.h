@@ -124,6 +124,11 @@ int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream);
 int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned char* terminated, const float* values,
                  float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream);
+/* node features of the batched graph in ONE launch (pyg_data/rigid_tasks_data.py:150-250, cloth_tasks_data.py, rope_tasks_data.py):
+ * every 3-vector feature = slice A of an observation group [- slice B], gathered per node.  descs: HOST array of n_desc <= 24
+ * records of 18 8-byte words: [out, a, b, gather (device pointers, 0 = absent), out_row_stride, out_col, rows_per_sample,
+ * row_off, n_nodes, n_per, a_stride, a_off, a_bcast, b_stride, b_off, b_bcast, onehot_col, n_types] */
+int grl_build_features(const long long* descs, int n_desc, hipStream_t stream);
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
 
 
