@@ -144,11 +144,13 @@ class PolicyUpdater:
             with torch.no_grad():
                 vf.train(True)
                 _, x = vf.hyper_data.build_data(*st["obs"], train=True)
-                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
+                # one zeroed fp64 workspace per step: critic sums (8) | advantage sums (2) | loss sums (11) | maxes (2 x u32) | clip (2)
+                zw = st["zw"] = torch.zeros(24, device=x.device, dtype=torch.float64)
+                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world, zero_buf=zw[0:8])
                 st["pipe"].fwd1()
                 st["adv"] = None
                 if m.normalize_advantage and x.shape[0] * world > 1:
-                    st["adv"] = torch.zeros(2, device=x.device, dtype=torch.float64)
+                    st["adv"] = zw[8:10]
                     adv_stats_local(m, b, st["adv"])
 
         def s1():
@@ -159,7 +161,9 @@ class PolicyUpdater:
             value = pipe.fwd3()
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
             with torch.no_grad():
-                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, st["b"], st["adv"])
+                zw = st["zw"]
+                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, st["b"], st["adv"], sums=zw[10:21],
+                                                                maxes=zw[21:22].view(torch.int32))
             torch.autograd.backward([loc, sigma], [dloc, dsigma])
             with torch.no_grad():
                 pipe.bwd3(dvalue)
@@ -177,10 +181,10 @@ class PolicyUpdater:
             with torch.no_grad():
                 self.step_dev.add_(1)
                 na, n = self.n_actor, self.flat.numel()
-                for lo, hi in ((0, na), (na, n)):
+                for i_, (lo, hi) in enumerate(((0, na), (na, n))):
                     coef = None
                     if self.clip:  # train.py:308-310
-                        sq = torch.zeros(1, device=self.flat.device, dtype=torch.float64)
+                        sq = st["zw"][22 + i_:23 + i_]
                         coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
                         hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
                     hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
@@ -249,6 +253,24 @@ class PolicyUpdater:
         torch.cuda.current_stream().wait_stream(side)
         self._program = program
 
+    def _refresh_static(self, batch):
+        """Copy the minibatch into the static input buffers the recorded graphs read: one launch for all tensors."""
+        import ctypes
+        jobs = []
+        for k, v in self._static.items():
+            src = batch[k]
+            if src is v:
+                continue
+            if src.dtype != v.dtype or src.shape != v.shape or not src.is_contiguous() or src.device != v.device:
+                v.copy_(src)  # host-resident / strided / other dtype: the ordinary path
+            else:
+                jobs.append((v.data_ptr(), src.data_ptr(), v.numel() * v.element_size()))
+        for i in range(0, len(jobs), 24):
+            part = jobs[i:i + 24]
+            n = len(part)
+            hip.call("grl_copy_many", (ctypes.c_void_p * n)(*[j[0] for j in part]), (ctypes.c_void_p * n)(*[j[1] for j in part]),
+                     (ctypes.c_longlong * n)(*[j[2] for j in part]), n)
+
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         self.loss_module._global_steps = self.steps
         self.steps += 1
@@ -271,8 +293,7 @@ class PolicyUpdater:
                 self.use_graph, self._program, self._static = False, None, None
                 self.steps -= 1
                 return self.step(batch)
-        for k, v in self._static.items():
-            v.copy_(batch[k])
+        self._refresh_static(batch)
         for kind, item in self._program:
             if kind == "graph":
                 item.replay()

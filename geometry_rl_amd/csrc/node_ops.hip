@@ -197,7 +197,7 @@ GRL_DEVINL float column_sum(const float* __restrict__ src /*column base*/, size_
   for (; w < n_rows; w += RED_WAVES) a0 += src[(size_t)w * ld];
   return (a0 + a1) + (a2 + a3);
 }
-GRL_DEVINL void fold_and_add(float v, float* __restrict__ dst, bool active, float (*red)[64]) {
+GRL_DEVINL void fold_and_add(float v, float* __restrict__ dst, bool active, float (*red)[64], bool overwrite = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   red[wave][lane] = v;
   __syncthreads();
@@ -205,7 +205,7 @@ GRL_DEVINL void fold_and_add(float v, float* __restrict__ dst, bool active, floa
     float t = red[0][lane];
 #pragma unroll
     for (int g = 1; g < RED_WAVES; ++g) t += red[g][lane];
-    *dst += t;
+    *dst = overwrite ? t : *dst + t;
   }
 }
 __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
@@ -225,6 +225,7 @@ struct ReduceSegs {
   int start[8];
   int len[8];
   int n_seg;
+  int overwrite_mask;   // bit i set: dst[i] = sum (destination not read, need not be initialised) instead of dst[i] += sum
 };
 __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_seg_kernel(const float* __restrict__ partial, ReduceSegs segs,
                                                                              int n_rows, int ld) {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_seg_kernel(con
   if (blockIdx.x * 64 >= segs.len[seg]) return;   // whole workgroup outside this (shorter) segment
   const bool active = j < segs.len[seg];
   const float v = active ? column_sum(partial + segs.start[seg] + j, (size_t)ld, n_rows, wave) : 0.f;
-  fold_and_add(v, segs.dst[seg] + j, active, red);
+  fold_and_add(v, segs.dst[seg] + j, active, red, (segs.overwrite_mask >> seg) & 1);
 }
 
 int cap_blocks(long long work, int per_block, int cap) {
@@ -302,7 +303,7 @@ int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hip
 
 // dst[i][0..len[i]) += sum_rows partial[row][start[i] + j]   for i < n_seg <= 8 (host arrays of length n_seg)
 int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg, float* const* dst, const int* start, const int* len,
-                            hipStream_t stream) {
+                            int overwrite_mask, hipStream_t stream) {
   if (n_rows <= 0 || n_seg <= 0) return 0;
   if (n_seg > 8) return -2;
   ReduceSegs segs{};
@@ -314,6 +315,7 @@ int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg,
     if (len[i] > max_len) max_len = len[i];
   }
   segs.n_seg = n_seg;
+  segs.overwrite_mask = overwrite_mask;
   hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((max_len + 63) / 64, n_seg), dim3(64 * RED_WAVES), 0, stream, partial, segs,
                      n_rows, ld);
   GRL_CHECK_LAUNCH();

@@ -181,6 +181,26 @@ __global__ __launch_bounds__(256) void build_features_kernel(FeatDescs all) {
   }
 }
 
+// ---- several small device-to-device copies in one launch (refreshing the static input buffers of a recorded step) -------------
+constexpr int COPY_MAX = 24;
+struct CopyJobs {
+  void* dst[COPY_MAX];
+  const void* src[COPY_MAX];
+  long long bytes[COPY_MAX];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs jobs) {
+  const int j = blockIdx.y;
+  const long long n = jobs.bytes[j];
+  const long long n16 = ((reinterpret_cast<size_t>(jobs.dst[j]) | reinterpret_cast<size_t>(jobs.src[j])) & 15) == 0 ? n >> 4 : 0;
+  const uint4* s16 = reinterpret_cast<const uint4*>(jobs.src[j]);
+  uint4* d16 = reinterpret_cast<uint4*>(jobs.dst[j]);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) d16[i] = s16[i];
+  const unsigned char* s1 = reinterpret_cast<const unsigned char*>(jobs.src[j]);
+  unsigned char* d1 = reinterpret_cast<unsigned char*>(jobs.dst[j]);
+  for (long long i = (n16 << 4) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    d1[i] = s1[i];
+}
+
 // ---- per-kernel event timing (off by default; bench.py's roofline leg switches it on for a few steps) ---------------------------
 #include <string>
 #include <vector>
@@ -275,6 +295,26 @@ int grl_build_features(const long long* descs, int n_desc, hipStream_t stream) {
   }
   const int bx = (max_nodes + 255) / 256 < 256 ? (max_nodes + 255) / 256 : 256;
   hipLaunchKernelGGL(build_features_kernel, dim3(bx, n_desc), dim3(256), 0, stream, all);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst / src: HOST arrays of n <= 24 device pointers, bytes: HOST array of sizes
+int grl_copy_many(void* const* dst, const void* const* src, const long long* bytes, int n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n > COPY_MAX) return -2;
+  CopyJobs jobs{};
+  long long mx = 0;
+  for (int i = 0; i < n; ++i) {
+    jobs.dst[i] = dst[i];
+    jobs.src[i] = src[i];
+    jobs.bytes[i] = bytes[i];
+    if (bytes[i] > mx) mx = bytes[i];
+  }
+  long long bx = (mx / 16 + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 128) bx = 128;
+  hipLaunchKernelGGL(copy_many_kernel, dim3((int)bx, n), dim3(256), 0, stream, jobs);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -55,23 +55,26 @@ def _emit_grads(partial: torch.Tensor, segments):
     otherwise a fresh gradient tensor is returned."""
     import ctypes
     dev = partial.device
-    outs, dsts, starts, lens = [], [], [], []
+    outs, dsts, starts, lens, fresh_flags = [], [], [], [], []
     for start, length, shape, t in segments:
         g = getattr(t, "grad", None) if (t is not None and t.is_leaf) else None
         if g is not None and g.is_contiguous() and g.dtype == torch.float32:
             outs.append(None)
             dsts.append(g)
+            fresh_flags.append(0)
         else:
-            fresh = torch.zeros(shape, device=dev, dtype=torch.float32)
+            fresh = torch.empty(shape, device=dev, dtype=torch.float32)  # written (not accumulated) by the reduction
             outs.append(fresh)
             dsts.append(fresh)
+            fresh_flags.append(1)
         starts.append(start)
         lens.append(length)
     for i in range(0, len(segments), 8):
         n = min(8, len(segments) - i)
+        mask = sum(f << k for k, f in enumerate(fresh_flags[i:i + n]))
         hip.call("grl_reduce_partials_seg", partial, partial.shape[0], partial.shape[1], n,
                  (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts[i:i + n]]), (ctypes.c_int * n)(*starts[i:i + n]),
-                 (ctypes.c_int * n)(*lens[i:i + n]))
+                 (ctypes.c_int * n)(*lens[i:i + n]), mask)
     return outs
 
 
@@ -241,14 +244,17 @@ class DeepSetsPipeline:
 
     PARAM_ORDER = ("w1", "b1", "g1", "be1", "w2", "b2", "w3", "b3", "g2", "be2", "w4", "b4", "wv", "bv")
 
-    def __init__(self, x, params, world=1):
+    def __init__(self, x, params, world=1, zero_buf=None):
+        """``zero_buf``: optional zeroed fp64[8] (stats | bst) from the caller's per-step workspace (saves two fill launches)."""
         hip.check_f32(x, *params)
         self.B, self.n, self.d = x.shape
         B, n, dev = self.B, self.n, x.device
         self.x = x.contiguous()
         self.P = [t.contiguous() for t in params]
-        self.stats = torch.zeros(4, device=dev, dtype=torch.float64)  # [sum h1, sum h1^2, sum u1, sum u1^2]
-        self.bst = torch.zeros(4, device=dev, dtype=torch.float64)    # [sum q2, sum q2 xh2, sum q1, sum q1 xh1]
+        if zero_buf is None:
+            zero_buf = torch.zeros(8, device=dev, dtype=torch.float64)
+        self.stats = zero_buf[0:4]  # [sum h1, sum h1^2, sum u1, sum u1^2]
+        self.bst = zero_buf[4:8]    # [sum q2, sum q2 xh2, sum q1, sum q1 xh1]
         self.h1 = torch.empty(B, n, 64, device=dev, dtype=torch.float32)
         self.z = torch.empty(B, 64, device=dev, dtype=torch.float32)
         self.u1 = torch.empty(B, 64, device=dev, dtype=torch.float32)
@@ -351,7 +357,7 @@ TRPL_SUM_KEYS = ("loss_objective", "loss_trust_region", "entropy_dist", "loss_cr
 
 
 def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
-                 global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False):
+                 global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False, sums=None, maxes=None):
     """Launches the fused TRPL kernel.  Returns (sums fp64[11], maxes u32[2], dloc, dsigma, dvalue, proj_mean, proj_var)."""
     import ctypes
     hip.check_f32(loc, sigma)
@@ -359,8 +365,9 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
     dev = loc.device
     cfg = (ctypes.c_double * 8)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
                                 clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch))
-    sums = torch.zeros(11, device=dev, dtype=torch.float64)
-    maxes = torch.zeros(2, device=dev, dtype=torch.int32)
+    if sums is None:   # otherwise: zeroed views of the caller's per-step workspace
+        sums = torch.zeros(11, device=dev, dtype=torch.float64)
+        maxes = torch.zeros(2, device=dev, dtype=torch.int32)
     dloc, dsigma = torch.empty_like(loc), torch.empty_like(sigma)
     dvalue = torch.empty(B, device=dev, dtype=torch.float32) if value is not None else None
     pm = torch.empty_like(loc) if want_projection else None

@@ -65,7 +65,7 @@ def adv_stats_local(m, batch, out):
     hip.call("grl_adv_stats", adv, out, adv.numel())
 
 
-def trpl_launch(m, loc, sigma, value, batch, adv_stats):
+def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None):
     """One launch of the fused kernel on detached inputs: rank-local (sums, maxes) and the gradients of the (1/B_global-scaled)
     losses with respect to loc, sigma and value."""
     p = m.projection
@@ -74,7 +74,8 @@ def trpl_launch(m, loc, sigma, value, batch, adv_stats):
         loc.detach(), sigma.detach(), batch, value.detach() if value is not None else None, mean_bound=p.mean_bound,
         cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
         entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, critic_coef=m.critic_coef,
-        clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats)
+        clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats,
+        sums=sums, maxes=maxes)
     return sums, maxes, dloc, dsigma, dvalue
 
 

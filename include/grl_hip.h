@@ -115,7 +115,7 @@ int grl_deepsets_bwd1(const float* x, const float* h1, const double* stats1, dou
 int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hipStream_t stream);
 /* dst[i][0..len[i]) += sum_rows partial[row*ld + start[i] + j], i < n_seg <= 8; dst/start/len are HOST arrays */
 int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg, float* const* dst, const int* start, const int* len,
-                            hipStream_t stream);
+                            int overwrite_mask /* bit i: dst[i] = sum instead of += */, hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
 /* the same update with the step count in device memory (int[1]): recordable into a hipGraph */
@@ -129,6 +129,8 @@ int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned 
  * records of 18 8-byte words: [out, a, b, gather (device pointers, 0 = absent), out_row_stride, out_col, rows_per_sample,
  * row_off, n_nodes, n_per, a_stride, a_off, a_bcast, b_stride, b_off, b_bcast, onehot_col, n_types] */
 int grl_build_features(const long long* descs, int n_desc, hipStream_t stream);
+/* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */
+int grl_copy_many(void* const* dst, const void* const* src, const long long* bytes, int n, hipStream_t stream);
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
 
 
