@@ -37,21 +37,27 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(const float* __restrict
   for (int a = 0; a < APER_MAX; ++a) ws[a] = a < aper ? Ws[a * C + c] : 0.f;
   for (int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
     const float* l = lat + (size_t)n * O * C + c;
-    float hsum = 0.f;
-    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f};      // sum_o y[o][j]          (j < od)
-    float vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f}, vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
+    // y[o][j] = lat[o] . wd[j] + bd[j] is linear in lat, so the sums over the orientations are taken per lane FIRST and each
+    // output needs ONE wave reduction (14 per node instead of 70):
+    //   sum_o y[o][j] = (sum_o lat[o]) . wd[j] + 16 bd[j],   sum_o y[o][j] g_o = (sum_o lat[o] g_o) . wd[j] + bd[j] sum_o g_o
+    float hsum = 0.f, lgx = 0.f, lgy = 0.f, lgz = 0.f, sgx = 0.f, sgy = 0.f, sgz = 0.f;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
       const float v = l[o * C];
-      hsum += v;
       const float gx = grid[3 * o], gy = grid[3 * o + 1], gz = grid[3 * o + 2];
+      hsum += v;
+      lgx += v * gx; lgy += v * gy; lgz += v * gz;
+      sgx += gx; sgy += gy; sgz += gz;
+    }
+    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f};      // sum_o y[o][j]          (j < od)
+    float vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f}, vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < JMAX; ++j) {
-        if (j < J) {
-          const float y = wave_sum(v * wd[j]) + bd[j];
-          if (j < od) sc[j] += y;
-          else { vx[j - od] += y * gx; vy[j - od] += y * gy; vz[j - od] += y * gz; }
-        }
+    for (int j = 0; j < JMAX; ++j) {
+      if (j < od) sc[j] = wave_sum(hsum * wd[j]) + O * bd[j];
+      else if (j < J) {
+        vx[j - od] = wave_sum(lgx * wd[j]) + bd[j] * sgx;
+        vy[j - od] = wave_sum(lgy * wd[j]) + bd[j] * sgy;
+        vz[j - od] = wave_sum(lgz * wd[j]) + bd[j] * sgz;
       }
     }
     const float hid = hsum * (1.f / O);
@@ -91,21 +97,24 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(const float* __restrict
   for (int a = 0; a < APER_MAX; ++a) { ws[a] = a < aper ? Ws[a * C + c] : 0.f; dws[a] = 0.f; dbs[a] = 0.f; }
   for (int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
     const float* l = lat + (size_t)n * O * C + c;
-    float lv[O], hsum = 0.f;
-    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f}, vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f},
-          vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
+    float lv[O], hsum = 0.f, lgx = 0.f, lgy = 0.f, lgz = 0.f, sgx = 0.f, sgy = 0.f, sgz = 0.f;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
       lv[o] = l[o * C];
-      hsum += lv[o];
       const float gx = grid[3 * o], gy = grid[3 * o + 1], gz = grid[3 * o + 2];
+      hsum += lv[o];
+      lgx += lv[o] * gx; lgy += lv[o] * gy; lgz += lv[o] * gz;
+      sgx += gx; sgy += gy; sgz += gz;
+    }
+    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f}, vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f},
+          vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < JMAX; ++j) {
-        if (j < J) {
-          const float y = wave_sum(lv[o] * wd[j]) + bd[j];
-          if (j < od) sc[j] += y;
-          else { vx[j - od] += y * gx; vy[j - od] += y * gy; vz[j - od] += y * gz; }
-        }
+    for (int j = 0; j < JMAX; ++j) {   // one wave reduction per output (see the forward kernel)
+      if (j < od) sc[j] = wave_sum(hsum * wd[j]) + O * bd[j];
+      else if (j < J) {
+        vx[j - od] = wave_sum(lgx * wd[j]) + bd[j] * sgx;
+        vy[j - od] = wave_sum(lgy * wd[j]) + bd[j] * sgy;
+        vz[j - od] = wave_sum(lgz * wd[j]) + bd[j] * sgz;
       }
     }
     const float hid = hsum * (1.f / O);

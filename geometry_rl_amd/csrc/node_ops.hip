@@ -15,15 +15,20 @@ constexpr int KF_MAX = 8;  // scalars + vectors per node (7 in every reference c
 __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const float* __restrict__ Wenc,
                                                               float* __restrict__ x, int N, int S, int V) {
-  __shared__ float Ws[C * KF_MAX];
   __shared__ float gs[O * 3];
   const int KF = S + V;
-  for (int i = threadIdx.x; i < C * KF; i += blockDim.x) Ws[i] = Wenc[i];
   for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
   __syncthreads();
+  // the grid stride is a multiple of 16, so a thread keeps its channel quad for the whole launch: its 4 x KF weights live in
+  // registers (the LDS image they used to be read from had 1.5 bank conflicts per access, profiles/r01_pmc_*)
+  const int c4 = threadIdx.x & 15;
+  float w[4][KF_MAX];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < KF_MAX; ++k) w[j][k] = k < KF ? Wenc[(4 * c4 + j) * KF + k] : 0.f;
   const size_t total = (size_t)N * O * (C / 4);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = idx & 15;
     const size_t row = idx >> 4;
     const int o = row & 15;
     const size_t n = row >> 4;
@@ -39,11 +44,10 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
     float out[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float* w = Ws + (4 * c4 + j) * KF;
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < KF_MAX; ++k)
-        if (k < KF) acc += feat[k] * w[k];
+        if (k < KF) acc += feat[k] * w[j][k];
       out[j] = acc;
     }
     reinterpret_cast<float4*>(x)[idx] = make_float4(out[0], out[1], out[2], out[3]);
