@@ -9,6 +9,9 @@ namespace {
 
 constexpr int C = 64, O = 16;
 constexpr int KF_MAX = 8;  // scalars + vectors per node (7 in every reference config)
+struct FiberWfs { const float* w[4]; int n; };
+struct FiberFks { float* p[4]; };
+struct FiberDfks { const float* p[4]; };
 
 // ------------------------------------------------------------------------------------------------ lift + encode
 // x[n,o,c] = sum_s scal[n,s] W[c,s] + sum_v (vec[n,v,:] . grid[o,:]) W[c,S+v]
@@ -184,6 +187,123 @@ __global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const float* __rest
   if (q == 0) out[O * O * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
 }
 
+// ------------------------------------------------------------------------------------------------ fiber kernel basis
+// Phi = GELU(W2 GELU(W1 poly + b1) + b2) over the 256 (orientation, orientation) pairs (reference hepi.py:109-123,157;
+// ponita.py:246-268: fiber_basis_fn on the degree-3 polynomial of o_i . o_j) and the fiber kernels fk_i = Phi Wf_i^T of up to
+// FB_MAXC convolutions (conv.py:62,88): parameter-only, 256 rows -- one launch each way instead of ~30 rocBLAS / elementwise
+// launches.  A workgroup owns 4 rows, thread = (row, column); weight rows are staged in LDS ([64][65], conflict-free by row and
+// by column).  The backward leaves one partial row per workgroup: [dWf_0 .. dWf_{n-1} (4096 each) | dW2 4096 | db2 64 | dW1 192 | db1 64].
+constexpr int FB_ROWS = 256, FB_RPB = 4, FB_MAXC = 4, FB_P = 3;
+GRL_DEVINL void fb_stage(float* dst /*[64][65]*/, const float* __restrict__ src /*[64][64]*/) {
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) dst[(i >> 6) * 65 + (i & 63)] = src[i];
+}
+__global__ __launch_bounds__(256) void fiber_basis_fwd_kernel(const float* __restrict__ poly, const float* __restrict__ W1,
+                                                              const float* __restrict__ b1, const float* __restrict__ W2,
+                                                              const float* __restrict__ b2, FiberWfs wf, float* __restrict__ saved,
+                                                              FiberFks fk) {
+  extern __shared__ float fb_smem[];
+  float* W2s = fb_smem;                    // [64][65]
+  float* Wfs = W2s + 64 * 65;              // [n_conv][64][65]
+  float* hs = Wfs + wf.n * 64 * 65;        // [2][FB_RPB][64]  h1 | h2
+  fb_stage(W2s, W2);
+  for (int i = 0; i < wf.n; ++i) fb_stage(Wfs + i * 64 * 65, wf.w[i]);
+  const int rl = threadIdx.x >> 6, c = threadIdx.x & 63, r = blockIdx.x * FB_RPB + rl;
+  float z1 = b1[c];
+#pragma unroll
+  for (int k = 0; k < FB_P; ++k) z1 += W1[c * FB_P + k] * poly[r * FB_P + k];
+  const float h1 = gelu_f(z1);
+  hs[rl * 64 + c] = h1;
+  __syncthreads();
+  float z2 = b2[c];
+#pragma unroll 16
+  for (int k = 0; k < 64; ++k) z2 += W2s[c * 65 + k] * hs[rl * 64 + k];
+  const float h2 = gelu_f(z2);
+  hs[(FB_RPB + rl) * 64 + c] = h2;
+  // saved for the backward: [z1 | h1 | z2 | h2] each [256][64]
+  saved[(0 * FB_ROWS + r) * 64 + c] = z1;
+  saved[(1 * FB_ROWS + r) * 64 + c] = h1;
+  saved[(2 * FB_ROWS + r) * 64 + c] = z2;
+  saved[(3 * FB_ROWS + r) * 64 + c] = h2;
+  __syncthreads();
+  for (int i = 0; i < wf.n; ++i) {
+    const float* w = Wfs + i * 64 * 65 + c * 65;
+    float acc = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) acc += w[k] * hs[(FB_RPB + rl) * 64 + k];
+    fk.p[i][r * 64 + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __restrict__ poly, const float* __restrict__ W2,
+                                                              FiberWfs wf, const float* __restrict__ saved, FiberDfks dfk,
+                                                              float* __restrict__ partial, int partial_ld) {
+  extern __shared__ float fb_smem[];
+  float* W2s = fb_smem;                          // [64][65]
+  float* Wfs = W2s + 64 * 65;                    // [n][64][65]
+  float* dfs = Wfs + wf.n * 64 * 65;             // [n][FB_RPB][64]   dfk rows
+  float* h2s = dfs + wf.n * FB_RPB * 64;         // [FB_RPB][64]
+  float* h1s = h2s + FB_RPB * 64;
+  float* dz2s = h1s + FB_RPB * 64;
+  float* dz1s = dz2s + FB_RPB * 64;
+  fb_stage(W2s, W2);
+  for (int i = 0; i < wf.n; ++i) fb_stage(Wfs + i * 64 * 65, wf.w[i]);
+  const int rl = threadIdx.x >> 6, c = threadIdx.x & 63, r = blockIdx.x * FB_RPB + rl;
+  for (int i = 0; i < wf.n; ++i) dfs[(i * FB_RPB + rl) * 64 + c] = dfk.p[i] ? dfk.p[i][r * 64 + c] : 0.f;
+  const float z1 = saved[(0 * FB_ROWS + r) * 64 + c], h1 = saved[(1 * FB_ROWS + r) * 64 + c];
+  const float z2 = saved[(2 * FB_ROWS + r) * 64 + c], h2 = saved[(3 * FB_ROWS + r) * 64 + c];
+  h2s[rl * 64 + c] = h2;
+  h1s[rl * 64 + c] = h1;
+  __syncthreads();
+  // dPhi[r][k = c] = sum_i sum_c' dfk_i[r][c'] Wf_i[c'][k]
+  float dphi = 0.f;
+  for (int i = 0; i < wf.n; ++i) {
+    const float* w = Wfs + i * 64 * 65 + c;
+    const float* d = dfs + (i * FB_RPB + rl) * 64;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) dphi += d[k] * w[k * 65];
+  }
+  const float dz2 = dphi * gelu_grad_f(z2);
+  dz2s[rl * 64 + c] = dz2;
+  __syncthreads();
+  float dh1 = 0.f;
+#pragma unroll 16
+  for (int k = 0; k < 64; ++k) dh1 += dz2s[rl * 64 + k] * W2s[k * 65 + c];
+  const float dz1 = dh1 * gelu_grad_f(z1);
+  dz1s[rl * 64 + c] = dz1;
+  __syncthreads();
+  // ---- this workgroup's partial row (sums over its FB_RPB rows)
+  float* out = partial + (size_t)blockIdx.x * partial_ld;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int cc = e >> 6, k = e & 63;
+    for (int i = 0; i < wf.n; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < FB_RPB; ++q) t += dfs[(i * FB_RPB + q) * 64 + cc] * h2s[q * 64 + k];
+      out[i * 4096 + e] = t;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < FB_RPB; ++q) t += dz2s[q * 64 + cc] * h1s[q * 64 + k];
+    out[wf.n * 4096 + e] = t;
+  }
+  float* ob2 = out + (wf.n + 1) * 4096, *oW1 = ob2 + 64, *ob1 = oW1 + 64 * FB_P;
+  if (threadIdx.x < 64) {
+    float t2 = 0.f, t1 = 0.f, tw[FB_P] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < FB_RPB; ++q) {
+      const int rr = blockIdx.x * FB_RPB + q;
+      t2 += dz2s[q * 64 + c];
+      t1 += dz1s[q * 64 + c];
+#pragma unroll
+      for (int k = 0; k < FB_P; ++k) tw[k] += dz1s[q * 64 + c] * poly[rr * FB_P + k];
+    }
+    ob2[c] = t2;
+    ob1[c] = t1;
+#pragma unroll
+    for (int k = 0; k < FB_P; ++k) oW1[c * FB_P + k] = tw[k];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ slab reduce
 // out[j] += sum_w partial[w][j], bitwise reproducible: a workgroup owns 64 columns; its 8 waves sum interleaved row groups
 // (wave g: rows g, g+8, ..., four independent running sums each, combined in a fixed order) and the 8 wave sums are folded
@@ -293,6 +413,43 @@ int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float
   if (n_nodes <= 0) return 0;
   hipLaunchKernelGGL(fiber_conv_bwd_kernel, dim3(grl_fiber_bwd_blocks(n_nodes)), dim3(256), 0, stream, x1, fk, dx2, dx1,
                      partial, n_nodes);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// poly [256,3]; W1 [64,3]; W2 [64,64]; wf: HOST array of n_conv <= 4 device pointers to fiber_kernel weights [64 channels, 64];
+// fk: HOST array of n_conv device pointers to outputs [256,64]; saved: scratch [4,256,64] kept for the backward
+int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, const float* W2, const float* b2, const float* const* wf,
+                        int n_conv, float* saved, float* const* fk, hipStream_t stream) {
+  if (n_conv < 1 || n_conv > FB_MAXC) return -2;
+  FiberWfs w{};
+  FiberFks f{};
+  w.n = n_conv;
+  for (int i = 0; i < n_conv; ++i) { w.w[i] = wf[i]; f.p[i] = fk[i]; }
+  const size_t smem = sizeof(float) * (64 * 65 * (1 + n_conv) + 2 * FB_RPB * 64);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)fiber_basis_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void*)fiber_basis_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(fiber_basis_fwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), smem, stream, poly, W1, b1, W2, b2, w, saved, f);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+int grl_fiber_basis_partial_size(int n_conv) { return (n_conv + 1) * 4096 + 64 + 64 * FB_P + 64; }
+int grl_fiber_basis_blocks() { return FB_ROWS / FB_RPB; }
+// dfk: HOST array of n_conv device pointers [256,64] (NULL = no gradient); partial [grl_fiber_basis_blocks()][partial_size(n_conv)]
+int grl_fiber_basis_bwd(const float* poly, const float* W2, const float* const* wf, int n_conv, const float* saved,
+                        const float* const* dfk, float* partial, hipStream_t stream) {
+  if (n_conv < 1 || n_conv > FB_MAXC) return -2;
+  FiberWfs w{};
+  FiberDfks d{};
+  w.n = n_conv;
+  for (int i = 0; i < n_conv; ++i) { w.w[i] = wf[i]; d.p[i] = dfk[i]; }
+  const size_t smem = sizeof(float) * (64 * 65 * (1 + n_conv) + n_conv * FB_RPB * 64 + 4 * FB_RPB * 64);
+  hipLaunchKernelGGL(fiber_basis_bwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), smem, stream, poly, W2, w, saved, d, partial,
+                     grl_fiber_basis_partial_size(n_conv));
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -125,14 +125,23 @@ class HEPi(nn.Module):
     def calibrated(self) -> bool:
         return all(bool(c.callibrated) for r in self.processor for _, c in r.items())
 
-    def fiber_basis(self) -> torch.Tensor:
-        """Phi[o,p,:] = fiber_basis_fn(o_o . o_p)  (hepi.py:119,157): 256 parameter-only rows, plain torch."""
-        poly = getattr(self, "_fiber_poly_cache", None)   # polynomial features of the (constant) grid invariants
+    def fiber_poly(self) -> torch.Tensor:
+        """Polynomial features of the (constant) grid invariants o_o . o_p  (hepi.py:119): [16,16,3], built once."""
+        poly = getattr(self, "_fiber_poly_cache", None)
         if poly is None or poly.device != self.ori_grid.device:
             g = self.ori_grid
             inv = (g[None, :, :] * g[:, None, :]).sum(-1, keepdim=True)
-            poly = self._fiber_poly_cache = self.fiber_basis_fn[0](inv).detach()
-        return self.fiber_basis_fn[1:](poly)
+            poly = self._fiber_poly_cache = self.fiber_basis_fn[0](inv).detach().contiguous()
+        return poly
+
+    def fiber_basis(self) -> torch.Tensor:
+        """Phi[o,p,:] = fiber_basis_fn(o_o . o_p)  (hepi.py:119,157) in plain torch (inspection / tests)."""
+        return self.fiber_basis_fn[1:](self.fiber_poly())
+
+    def _fiber_kernels(self, graph: GraphBatch):
+        """fk = Phi Wf^T of every convolution this pass will run, from one fused launch (ops.FiberKernels)."""
+        convs = [conv for rnd in self.processor for et, conv in rnd.items() if et in graph.edges]
+        return ops.fiber_kernels(self.fiber_poly(), self.fiber_basis_fn, convs)
 
     def _needed_types(self, graph: GraphBatch):
         need = {graph.output_mask_key} if graph.output_mask_key else set(graph.node_types)
@@ -142,13 +151,13 @@ class HEPi(nn.Module):
                     need.update((s, d))
         return [t for t in graph.node_types if t in need]
 
-    def _conv(self, conv, x_src, x_dst, graph, et, grid3, phi, prev):
+    def _conv(self, conv, x_src, x_dst, graph, et, grid3, fks, prev):
         es = graph.edges[et]
         s, _, d = et
         b = self.basis_fn
         x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
                                 conv.kernel.weight, es, self.dim)
-        fk = F.linear(phi, conv.fiber_kernel.weight)
+        fk = fks[id(conv)]
         x2 = ops.FiberConv.apply(x1, fk, conv.bias)
         m = conv.node_mlp
         return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev), x1, fk
@@ -160,14 +169,14 @@ class HEPi(nn.Module):
         grid3 = self.grid3
         x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight)
              for t in self._needed_types(graph)}
-        phi = self.fiber_basis()
+        fks = self._fiber_kernels(graph)
         for rnd in self.processor:
             outs = {}
             for et, conv in rnd.items():
                 if et not in graph.edges:  # empty edge set: skipped like hetero_fiber_conv.py:48-49
                     continue
                 s, _, d = et
-                outs[d], _, _ = self._conv(conv, x[s], x[d], graph, et, grid3, phi, outs.get(d))
+                outs[d], _, _ = self._conv(conv, x[s], x[d], graph, et, grid3, fks, outs.get(d))
             x.update(outs)
         return x[graph.output_mask_key]
 
@@ -188,14 +197,14 @@ class HEPi(nn.Module):
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
         x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight) for t in graph_full.node_types}
-        phi = self.fiber_basis()
+        fks = self._fiber_kernels(graph_full)
         for rnd in self.processor:
             outs = {}
             for et, conv in rnd.items():
                 if et not in graph_full.edges:
                     continue
                 s, _, d = et
-                out, x1, fk = self._conv(conv, x[s], x[d], graph_full, et, grid3, phi, outs.get(d))
+                out, x1, fk = self._conv(conv, x[s], x[d], graph_full, et, grid3, fks, outs.get(d))
                 if not bool(conv.callibrated):
                     x2 = ops.FiberConv.apply(x1, fk, torch.zeros_like(conv.bias))
                     s_in, s_1, s_2 = x[d].std(), x1.std(), x2.std()

@@ -163,6 +163,58 @@ class FiberConv(torch.autograd.Function):
         return dx1, dfk, dbias
 
 
+class FiberKernels(torch.autograd.Function):
+    """fk_i = fiber_basis_fn(poly) @ Wf_i^T for all convolutions of a forward pass (reference hepi.py:109-123,157 / ponita.py:246-268,
+    conv.py:62): parameter-only work on 256 rows, one launch forward, one launch + one reduction backward."""
+
+    @staticmethod
+    def forward(ctx, poly, w1, b1, w2, b2, *wfs):
+        import ctypes
+        hip.check_f32(poly, w1, b1, w2, b2, *wfs)
+        n = len(wfs)
+        dev = poly.device
+        poly2 = poly.reshape(256, 3).contiguous()
+        P = [t.contiguous() for t in (w1, b1, w2, b2)]
+        W = [t.contiguous() for t in wfs]
+        saved = torch.empty(4, 256, 64, device=dev, dtype=torch.float32)
+        fks = [torch.empty(16, 16, 64, device=dev, dtype=torch.float32) for _ in range(n)]
+        hip.call("grl_fiber_basis_fwd", poly2, *P, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
+                 (ctypes.c_void_p * n)(*[t.data_ptr() for t in fks]))
+        ctx.save_for_backward(poly2, P[2], saved, *W)
+        ctx.params = (w1, b1, w2, b2) + tuple(wfs)
+        return tuple(fks)
+
+    @staticmethod
+    def backward(ctx, *dfks):
+        import ctypes
+        poly2, w2, saved, *W = ctx.saved_tensors
+        n = len(W)
+        dev = poly2.device
+        d = [g.contiguous() if g is not None else None for g in dfks]
+        partial = torch.empty(hip.query("grl_fiber_basis_blocks"), hip.query("grl_fiber_basis_partial_size", n), device=dev,
+                              dtype=torch.float32)
+        hip.call("grl_fiber_basis_bwd", poly2, w2, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
+                 (ctypes.c_void_p * n)(*[(g.data_ptr() if g is not None else 0) for g in d]), partial)
+        pw1, pb1, pw2, pb2, *pwf = ctx.params
+        o = n * 4096
+        segs = [(i * 4096, 4096, (64, 64), pwf[i]) for i in range(n)]
+        segs += [(o, 4096, (64, 64), pw2), (o + 4096, 64, (64,), pb2), (o + 4160, 192, (64, 3), pw1), (o + 4352, 64, (64,), pb1)]
+        g = _emit_grads(partial, segs)
+        return (None, g[n + 2], g[n + 3], g[n], g[n + 1]) + tuple(g[:n])
+
+
+def fiber_kernels(poly, basis_fn, convs):
+    """{conv: fk} for the given FiberBundleConv-like modules (``.fiber_kernel.weight``); ``basis_fn`` = the reference's
+    fiber_basis_fn Sequential (index 1 and 3 are the Linear layers), ``poly`` its (constant) polynomial input features."""
+    out = {}
+    for i in range(0, len(convs), 4):
+        part = convs[i:i + 4]
+        fks = FiberKernels.apply(poly, basis_fn[1].weight, basis_fn[1].bias, basis_fn[3].weight, basis_fn[3].bias,
+                                 *[c.fiber_kernel.weight for c in part])
+        out.update({id(c): fk for c, fk in zip(part, fks)})
+    return out
+
+
 class NodeMLP(torch.autograd.Function):
     """out = [prev +] x_dst + W4 GELU(W3 LN(x2) + b3) + b4   (reference conv.py:64-69,112; hetero_fiber_conv.py:63-64)."""
 

@@ -85,11 +85,16 @@ class PonitaGCN(nn.Module):
     def calibrated(self) -> bool:
         return all(bool(l.conv.callibrated) for l in self.ponita.interaction_layers)
 
-    def _fiber_basis(self):
+    def _fiber_kernels(self):
+        """fk = Phi Wf^T of every interaction layer from one fused launch (ops.FiberKernels); ponita.py:246-268."""
+        poly = getattr(self, "_fiber_poly_cache", None)
         g = self.ponita.ori_grid
-        return self.ponita.fiber_basis_fn((g[None, :, :] * g[:, None, :]).sum(-1, keepdim=True))
+        if poly is None or poly.device != g.device:
+            inv = (g[None, :, :] * g[:, None, :]).sum(-1, keepdim=True)
+            poly = self._fiber_poly_cache = self.ponita.fiber_basis_fn[0](inv).detach().contiguous()
+        return ops.fiber_kernels(poly, self.ponita.fiber_basis_fn, [l.conv for l in self.ponita.interaction_layers])
 
-    def _layer(self, layer, x, graph: GraphBatch, grid3, phi, collect=None):
+    def _layer(self, layer, x, graph: GraphBatch, grid3, fks, collect=None):
         b = self.ponita.basis_fn
         x1 = {}
         for et, es in graph.edges.items():  # spatial conv summed over all (merged) edge types: ponita.py:153,161
@@ -97,7 +102,7 @@ class PonitaGCN(nn.Module):
             part = ops.EdgeConv.apply(x[s], graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
                                       layer.conv.kernel.weight, es, self.dim)
             x1[d] = part if d not in x1 else x1[d] + part
-        fk = F.linear(phi, layer.conv.fiber_kernel.weight)
+        fk = fks[id(layer.conv)]
         out = {}
         for t, xt in x.items():
             x1t = x1.get(t)
@@ -114,9 +119,9 @@ class PonitaGCN(nn.Module):
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
         x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight) for t in graph.node_types}
-        phi = self._fiber_basis()
+        fks = self._fiber_kernels()
         for layer in self.ponita.interaction_layers:
-            x = self._layer(layer, x, graph, grid3, phi)
+            x = self._layer(layer, x, graph, grid3, fks)
         return x[graph.output_mask_key]
 
     def one_step(self, graph: GraphBatch, u_dict, **ignored):
@@ -133,11 +138,11 @@ class PonitaGCN(nn.Module):
         grid3 = self.grid3
         x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight)
              for t in graph_full.node_types}
-        phi = self._fiber_basis()
+        fks = self._fiber_kernels()
         cat = lambda d: torch.cat([d[t].reshape(-1) for t in graph_full.node_types])
         for layer in self.ponita.interaction_layers:
             col = {}
-            out = self._layer(layer, x, graph_full, grid3, phi, collect=col)
+            out = self._layer(layer, x, graph_full, grid3, fks, collect=col)
             if not bool(layer.conv.callibrated):
                 x1 = {t: col[t][0] for t in col}
                 x2 = {t: ops.FiberConv.apply(col[t][0], col[t][1], torch.zeros_like(layer.conv.bias)) for t in col}

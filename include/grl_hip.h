@@ -41,6 +41,17 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
                       int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
                       const float* b2, const float* Wk, const float* dx1, float* dx_src, float* partial, hipStream_t stream);
 
+/* ---- fiber kernel basis (parameter-only, 256 rows): hepi.py:109-123,157 / ponita.py:246-268 + conv.py:62 ------------------------
+ * Phi = GELU(W2 GELU(W1 poly + b1) + b2), fk_i = Phi Wf_i^T for n_conv <= 4 convolutions, one launch each way.
+ * wf / fk / dfk: HOST arrays of device pointers; saved: scratch [4,256,64] kept for the backward;
+ * partial [grl_fiber_basis_blocks()][grl_fiber_basis_partial_size(n_conv)] = [dWf_0..dWf_{n-1} (4096 each) | dW2 4096 | db2 64 | dW1 192 | db1 64] */
+int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, const float* W2, const float* b2, const float* const* wf,
+                        int n_conv, float* saved, float* const* fk, hipStream_t stream);
+int grl_fiber_basis_partial_size(int n_conv);
+int grl_fiber_basis_blocks(void);
+int grl_fiber_basis_bwd(const float* poly, const float* W2, const float* const* wf, int n_conv, const float* saved,
+                        const float* const* dfk, float* partial, hipStream_t stream);
+
 /* ---- depthwise fiber convolution + bias: ponita/conv.py:88-90,108-109 (ponita.py:164-166,183) ----------------------------
  * x2[n,p,c] = 1/16 sum_o x1[n,o,c] fk[o,p,c] + bias[c];  partial [grl_fiber_bwd_blocks][grl_fiber_partial_size] = [dfk | dbias] */
 int grl_fiber_conv_fwd(const float* x1, const float* fk, const float* bias, float* x2, int n_nodes, hipStream_t stream);
