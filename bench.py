@@ -100,10 +100,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     group = None
+    if os.environ.get("GRL_BENCH_ONE_GPU"):   # functional test of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("GRL_BENCH_ONE_GPU"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         group = dist.group.WORLD
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -162,6 +167,10 @@ def main():
         gae_ms = 1e3 * (time.perf_counter() - t1) / 5
 
     roof = None
+    if rank != 0 and not args.no_roofline:   # the profiled steps are collective when data parallel: every rank runs them
+        upd.use_graph = False
+        for i in range(6):
+            upd.step(pool[i % len(pool)])
     if rank == 0 and not args.no_roofline:
         # HIP events around every C-ABI launch, on the launch stream; one profiled step is discarded (first-use cost of
         # timed events lands on a random kernel) and the per-step totals are reduced with the median over the other steps.
