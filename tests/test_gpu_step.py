@@ -28,6 +28,24 @@ def make_case(name, B):
         o_spec, spec = ogr.rigid_spec(), graph.rigid_spec()
         kw = dict(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
         obs = syn.make_rigid_obs(B, seed=3)
+    elif name in ("rigid_tiny", "rigid_one"):
+        # edge cases of the ragged graph: samples with 1, 2 and 3 valid object points (fewer than the k = 3 neighbours kNN asks
+        # for: missing neighbours give no edge; a 1-point sample has no internal edge at all), next to a full 32-point sample;
+        # "rigid_one": a single frame (the advantage is not normalised for a batch of one, trpl.py:248)
+        o_spec, spec = ogr.rigid_spec(), graph.rigid_spec()
+        kw = dict(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
+        obs = syn.make_rigid_obs(B, seed=9)
+        P = 32
+        counts = torch.tensor([1, 2, 3, 32, 5, 4])[torch.arange(B) % 6] if name == "rigid_tiny" else torch.tensor([7])
+        valid = (torch.arange(P)[None, :] < counts[:, None]).float()[..., None]
+        pos = obs["position_vectors"].clone()
+        G = 1
+        gen = torch.Generator().manual_seed(99)
+        for blk in range(2):  # object points, target points: fresh distinct positions (coincident points = kNN ties), then padding
+            sl = slice(3 * G + blk * 3 * P, 3 * G + (blk + 1) * 3 * P)
+            pos[:, sl] = ((torch.rand(B, P, 3, generator=gen) * 2 - 1) * valid).reshape(B, -1)
+        obs["position_vectors"] = pos
+        obs["infos"][:, 0] = counts.float()
     elif name == "rigid_g2":
         o_spec = ogr.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
         spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
@@ -59,7 +77,8 @@ def load_params(module, params, dev):
     module.load_state_dict({k: v.to(dev) for k, v in params.items()}, strict=False)
 
 
-@pytest.mark.parametrize("name,B", [("rigid_g1", 24), ("rigid_g2", 16), ("cloth", 8), ("rope", 8), ("empn_g2", 12)])
+@pytest.mark.parametrize("name,B", [("rigid_g1", 24), ("rigid_g2", 16), ("cloth", 8), ("rope", 8), ("empn_g2", 12),
+                                    ("rigid_tiny", 6), ("rigid_one", 1)])
 def test_policy_update_step(name, B):
     from geometry_rl_amd import agent
     dev = torch.device("cuda:0")
