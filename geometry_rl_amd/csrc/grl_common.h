@@ -123,16 +123,15 @@ GRL_DEVINL float4 gelu4(float4 x) {
 }
 // value + derivative: the scalar form schedules better inside the register-heavy backward kernels (measured)
 GRL_DEVINL void gelu_both(float x, float& g, float& gp) {
-  const float az = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-  const float e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float e = __builtin_amdgcn_exp2f((x * -0.72134752044448170368f) * x);   // exp(-x^2/2)
   float poly = fmaf(t, 1.061405429f, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float erf_abs = fmaf(-poly, e, 1.0f);
-  const float cdf = fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
+  const float q = (poly * t) * e;                       // erfc(|x| / sqrt 2)
+  const float cs = copysignf(0.5f, x);
+  const float cdf = fmaf(-cs, q, cs + 0.5f);            // 1/2 + sign(x)/2 (1 - q)
   g = x * cdf;
   gp = fmaf(x * e, 0.39894228040143267794f, cdf);
 }
