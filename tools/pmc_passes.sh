@@ -7,4 +7,4 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY 
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/pmcB -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcB.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmcC -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcC.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmcD -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcD.log 2>&1
-tail -2 $R/gpurun_out/pmc?.log
+echo done

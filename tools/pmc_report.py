@@ -1,0 +1,22 @@
+"""Per-kernel summary of the PMC passes written by tools/pmc_passes.sh (gpurun_out/pmc{A,B,C,D})."""
+import csv, glob, collections, sys
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+def load(d):
+    f = glob.glob(f"{root}/{d}/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:40]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); n[k] += 1
+    return acc, n
+A, nA = load("pmcA"); B, nB = load("pmcB"); C, nC = load("pmcC"); D, nD = load("pmcD")
+print("kernel | launches | wave-cycle shares: active / wait(waitcnt,barrier) / issue-stall | VALU active | MFMA busy/(4 wave cyc) | VALU per MFMA | LDS insts | LDS conflict | fetch MB (x2 corr.) | write MB")
+for k in A:
+    if not any(s in k for s in ("edge_conv", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
+        continue
+    a, b, n = A[k], B[k], nA[k]
+    wc = a["SQ_WAVE_CYCLES"] or 1
+    print(f"{k:40s} {n:3d}  act {a['SQ_ACTIVE_INST_ANY']/wc:.2f} wait {a['SQ_WAIT_ANY']/wc:.2f} stall {a['SQ_WAIT_INST_ANY']/wc:.2f} | valu {a['SQ_ACTIVE_INST_VALU']/wc:.2f} | mfma {a['SQ_VALU_MFMA_BUSY_CYCLES']/(4*wc):.2f} | "
+          f"valu/mfma {b['SQ_INSTS_VALU']/max(b['SQ_INSTS_MFMA'],1):6.1f} | lds {b['SQ_INSTS_LDS']/n:.3g} conf {b['SQ_LDS_BANK_CONFLICT']/max(b['SQ_ACTIVE_INST_LDS'],1):.2f} | "
+          f"rd {2*C[k]['FETCH_SIZE']*1024/max(nC[k],1)/1e6:8.1f} wr {D[k]['WRITE_SIZE']*1024/max(nD[k],1)/1e6:8.1f}")
