@@ -124,28 +124,24 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
 constexpr int MLP_PARTIAL = W * C + W + C * W + C + C + C;
 
 // ------------------------------------------------------------------------------------------------ backward, fused
-// ONE launch, nothing handed over through HBM.  A workgroup of 4 waves (one per SIMD, 512 registers each) walks 32-row chunks:
-//   1. all 256 threads: load x2 / dOut (one float4 per thread and row half, prefetched a chunk ahead), LayerNorm by 16-lane
-//      reductions, write a = LN(x2) and dOut as split-bf16 fragment images to LDS; per-thread column sums for db4
-//   2. wave w transposes one of the four shared 32-column tiles (a | dOut) in registers (transpose32) -> LDS
-//   3. wave w owns hidden tiles 2w, 2w+1 (W3 / W4^T fragments register-stationary, hidden unit on the lane):
-//        z^T, dH^T (lane = hidden unit, registers = rows: the layout the row reductions need, no transpose),
-//        dZ = dH * gelu'(z);  dW3 += dZ^T a,  dW4 += dOut^T h  (split-bf16, accumulators live in registers for the launch),
-//        dZ back to row layout (one register transpose) and dA^T += W3^T dZ with the W3 tile transposed in registers;
-//        the wave's partial dA rows go to LDS
-//   4. all threads: sum the four partial dA rows, LayerNorm backward (16-lane reductions), store dx2; per-thread column sums
-//      for dgamma / dbeta.
+// ONE launch, nothing handed over through HBM.  A workgroup of 8 waves (two per SIMD, <= 256 registers, no spills) walks 32-row
+// chunks; wave w owns hidden tile w (32 of the 256 hidden units):
+//   1. all 512 threads: load x2 / dOut (one float4 per thread, prefetched a chunk ahead), LayerNorm by 16-lane reductions, write
+//      a = LN(x2) and dOut as split-bf16 fragment images to LDS; per-thread column sums for db4
+//   2. waves 0-3 transpose the four shared 32-column tiles (a | dOut) in registers (transpose32) -> LDS
+//   3. every wave, its hidden tile: z^T, dH^T with the hidden unit on the lane (activation on the A side: the layout the row
+//      reductions need, no transpose); dZ = dH * gelu'(z); dW3 += dZ^T a, dW4 += dOut^T h (split-bf16, accumulators in registers
+//      for the whole launch); dZ back to row layout (one register transpose) and dA^T += W3^T dZ with the W3 tile transposed in
+//      registers; partial dA rows to LDS in two rounds (waves 0-3 write, waves 4-7 add)
+//   4. all threads: sum the four partial dA rows, LayerNorm backward (16-lane reductions), store dx2; per-thread column sums for
+//      dgamma / dbeta.
+// W4^T fragments live in LDS, W3 fragments in the workgroup's own (still unused) partial slab, i.e. L2-resident global memory.
+// Two waves share every SIMD, so each MFMA group is fenced (grl_common.h, mma_wx_bf_fenced): all operand loads first, then the
+// MFMAs, then a VALU read of the accumulator before the next loads may go; the two K-halves of z and dH are separate groups to
+// halve the operand registers live at a time.
 // partial slab per workgroup: [dW3 256x64 | db3 256 | dW4 64x256 | db4 64 | dgamma 64 | dbeta 64]  (MLP_PARTIAL)
 constexpr int LDF = GRL_LDB(64);  // 72 bf16: activation fragment images (same layout as the weight images)
 constexpr int LDD = C + 4;        // 68 fp32: partial dA rows
-struct MlpBwdSmem {
-  unsigned short Ah[32 * LDF], Al[32 * LDF];  // a = LN(x2)
-  unsigned short Dh[32 * LDF], Dl[32 * LDF];  // dOut
-  u32x4 TT[4][4][64];                         // [a cols 0-31 | a cols 32-63 | dOut 0-31 | dOut 32-63][h0, h1, l0, l1][lane]
-  float DA[4][32 * LDD];
-  float red[16][3][C];
-  u32x4 W4F[8][4][2][64];                     // W4^T fragments (lane = hidden unit, k = output channel) [tile][K-step][hi, lo][lane]
-};
 
 GRL_DEVINL float row16_sum(float v) {  // sum over the 16 consecutive lanes that share a row
   v += __shfl_xor(v, 1, 64);
@@ -171,82 +167,84 @@ GRL_DEVINL TTile load_ttile(const u32x4 (*tt)[64], int lane) {
   return t;
 }
 
-__global__ __launch_bounds__(256, 1) void node_mlp_bwd_fused_kernel(const float* __restrict__ x2, const float* __restrict__ dout,
-                                                                    const float* __restrict__ W3, const float* __restrict__ b3,
-                                                                    const float* __restrict__ W4, const float* __restrict__ gam,
-                                                                    const float* __restrict__ bet, float* __restrict__ dx2,
-                                                                    float* __restrict__ partial, int n_rows) {
+struct MlpBwdSmem {
+  unsigned short Ah[32 * LDF], Al[32 * LDF];
+  unsigned short Dh[32 * LDF], Dl[32 * LDF];
+  u32x4 TT[4][4][64];
+  float DA[4][32 * LDD];      // dA partial rows: waves 0-3 write, waves 4-7 add (second round); reused for the final column sums
+  u32x4 W4F[8][4][2][64];
+};
+GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
+  // a compiler-visible VALU read of the accumulator: it cannot issue before the MFMA group that produced acc has finished
+  sink += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, acc[0]), 0xE4, 0xF, 0xF, false));
+}
+
+__global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __restrict__ x2, const float* __restrict__ dout,
+                                                                  const float* __restrict__ W3, const float* __restrict__ b3,
+                                                                  const float* __restrict__ W4, const float* __restrict__ gam,
+                                                                  const float* __restrict__ bet, float* __restrict__ dx2,
+                                                                  float* __restrict__ partial, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   MlpBwdSmem& s = *reinterpret_cast<MlpBwdSmem*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  // cooperative stages: thread = (column quad cq, rows row0 and row0 + 16)
-  const int cq = tid & 15, row0 = tid >> 4;
-  const int kq = cq & 3, pq = (kq == 1) ? 2 : (kq == 2) ? 1 : kq;  // quad swap of the fragment images
+  const int cq = tid & 15, lrow = tid >> 4;   // cooperative stages: thread = (row of the chunk, column quad)
+  const int kq = cq & 3, pq = (kq == 1) ? 2 : (kq == 2) ? 1 : kq;
   const int ppos = 16 * (cq >> 2) + 4 * pq;
   const float4 gq = *reinterpret_cast<const float4*>(gam + 4 * cq), bq = *reinterpret_cast<const float4*>(bet + 4 * cq);
   bf16x8 sel0, sel1;
   make_selectors(sel0, sel1);
+  float sink = 0.f;
 
-  // operands of this wave's two hidden tiles (lane = hidden unit j), prepared once: W4^T fragments in LDS, W3 fragments in the
-  // workgroup's own (still unused) partial slab, i.e. L2-resident global memory -- 64 registers too many to keep stationary
-  u32x4* w3f = reinterpret_cast<u32x4*>(partial + (size_t)blockIdx.x * MLP_PARTIAL);   // [8 tiles][4 K-steps][hi, lo][64 lanes]
-  float b3v[2];
-#pragma unroll
-  for (int tix = 0; tix < 2; ++tix) {
-    const int j = 32 * (2 * wave + tix) + r;
+  // this wave's hidden tile (lane = hidden unit j): W4^T fragments -> LDS, W3 fragments -> the workgroup's partial slab (L2)
+  u32x4* w3f = reinterpret_cast<u32x4*>(partial + (size_t)blockIdx.x * MLP_PARTIAL) + (size_t)wave * 4 * 2 * 64;
+  const int j = 32 * wave + r;
+  const float b3v = b3[j];
+  {
     const float* wrow = W3 + (size_t)j * C;
-    b3v[tix] = b3[j];
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
       bf16x8 gh, gl;
       split_pair(*reinterpret_cast<const float4*>(wrow + 16 * sidx + 4 * h), *reinterpret_cast<const float4*>(wrow + 16 * sidx + 8 + 4 * h),
                  gh, gl);
-      w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, gh);   // read back by this lane only
-      w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, gl);
+      w3f[(sidx * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, gh);
+      w3f[(sidx * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, gl);
       const float* c0 = W4 + (size_t)(16 * sidx + 4 * h) * W + j, *c1 = c0 + (size_t)8 * W;
       bf16x8 fh, fl;
       split_pair(make_float4(c0[0], c0[W], c0[2 * W], c0[3 * W]), make_float4(c1[0], c1[W], c1[2 * W], c1[3 * W]), fh, fl);
-      s.W4F[2 * wave + tix][sidx][0][lane] = __builtin_bit_cast(u32x4, fh);   // wave-private entries: no barrier needed
-      s.W4F[2 * wave + tix][sidx][1][lane] = __builtin_bit_cast(u32x4, fl);
+      s.W4F[wave][sidx][0][lane] = __builtin_bit_cast(u32x4, fh);
+      s.W4F[wave][sidx][1][lane] = __builtin_bit_cast(u32x4, fl);
     }
   }
-  // accumulators of the tile being worked on (cur*) and of the wave's other tile (oth*): the tile loop is NOT unrolled, the two
-  // sets trade places at the end of every iteration (64 moves), so the loop body is compiled once with a bounded live set
-  f32x16 curW3[2], curW4[2], othW3[2], othW4[2];
-#pragma unroll
-  for (int a_ = 0; a_ < 2; ++a_) { curW3[a_] = zero16(); curW4[a_] = zero16(); othW3[a_] = zero16(); othW4[a_] = zero16(); }
-  float cur_db3 = 0.f, oth_db3 = 0.f;
+  f32x16 aW3[2], aW4[2];
+  aW3[0] = zero16(); aW3[1] = zero16(); aW4[0] = zero16(); aW4[1] = zero16();
+  float adb3 = 0.f;
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = dgam, db4 = dgam;
 
   const int n_chunks = (n_rows + 31) >> 5;
-  float4 px[2], pd[2];
+  float4 px, pd;
   auto fetch = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = c * 32 + row0 + 16 * i;
-      const bool ok = row < n_rows;
-      const size_t g = (size_t)(ok ? row : 0) * C + 4 * cq;
-      px[i] = *reinterpret_cast<const float4*>(x2 + g);
-      pd[i] = *reinterpret_cast<const float4*>(dout + g);
-      if (!ok) pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const int row = c * 32 + lrow;
+    const bool ok = row < n_rows;
+    const size_t g = (size_t)(ok ? row : 0) * C + 4 * cq;
+    px = *reinterpret_cast<const float4*>(x2 + g);
+    pd = *reinterpret_cast<const float4*>(dout + g);
+    if (!ok) pd = make_float4(0.f, 0.f, 0.f, 0.f);
   };
   int ch = blockIdx.x;
   if (ch < n_chunks) fetch(ch);
 #pragma unroll 1
   for (; ch < n_chunks; ch += gridDim.x) {
     // ------------------------------------------------------------ 1: LayerNorm + fragment images
-    float4 xh[2];
-    float rstd[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float4 x = px[i], d = pd[i];
+    float4 xh;
+    float rstd;
+    {
+      const float4 x = px, d = pd;
       const float mean = row16_sum((x.x + x.y) + (x.z + x.w)) * (1.f / C);
       const float4 xc = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
-      rstd[i] = rsqrtf(row16_sum((xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w)) * (1.f / C) + LN_EPS);
-      xh[i] = f4_scale(xc, rstd[i]);
-      const float4 a = make_float4(xh[i].x * gq.x + bq.x, xh[i].y * gq.y + bq.y, xh[i].z * gq.z + bq.z, xh[i].w * gq.w + bq.w);
-      const int off = (row0 + 16 * i) * LDF + ppos;
+      rstd = rsqrtf(row16_sum((xc.x * xc.x + xc.y * xc.y) + (xc.z * xc.z + xc.w * xc.w)) * (1.f / C) + LN_EPS);
+      xh = f4_scale(xc, rstd);
+      const float4 a = make_float4(xh.x * gq.x + bq.x, xh.y * gq.y + bq.y, xh.z * gq.z + bq.z, xh.w * gq.w + bq.w);
+      const int off = lrow * LDF + ppos;
       put_split4(s.Ah + off, s.Al + off, a);
       put_split4(s.Dh + off, s.Dl + off, d);
       db4 = f4_add(db4, d);
@@ -254,162 +252,188 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd_fused_kernel(const float*
     const int ch_next = ch + gridDim.x;
     if (ch_next < n_chunks) fetch(ch_next);
     __syncthreads();
-    // ------------------------------------------------------------ 2: the four shared transposed tiles
-    {
+    // ------------------------------------------------------------ 2: the four shared transposed tiles (waves 0-3)
+    if (wave < 4) {
       const unsigned short* ih = (wave < 2 ? s.Ah : s.Dh) + r * LDF + 32 * (wave & 1) + 8 * h;
       const unsigned short* il = (wave < 2 ? s.Al : s.Dl) + r * LDF + 32 * (wave & 1) + 8 * h;
-      const TTile t = transpose_split(*reinterpret_cast<const bf16x8*>(ih), *reinterpret_cast<const bf16x8*>(ih + 16),
-                                      *reinterpret_cast<const bf16x8*>(il), *reinterpret_cast<const bf16x8*>(il + 16), sel0, sel1);
+      const bf16x8 c0h = *reinterpret_cast<const bf16x8*>(ih), c1h = *reinterpret_cast<const bf16x8*>(ih + 16);
+      const bf16x8 c0l = *reinterpret_cast<const bf16x8*>(il), c1l = *reinterpret_cast<const bf16x8*>(il + 16);
+      __builtin_amdgcn_sched_barrier(0);
+      const TTile t = transpose_split(c0h, c1h, c0l, c1l, sel0, sel1);   // reads its accumulators (packs): fenced by construction
       s.TT[wave][0][lane] = __builtin_bit_cast(u32x4, t.h0);
       s.TT[wave][1][lane] = __builtin_bit_cast(u32x4, t.h1);
       s.TT[wave][2][lane] = __builtin_bit_cast(u32x4, t.l0);
       s.TT[wave][3][lane] = __builtin_bit_cast(u32x4, t.l1);
     }
     __syncthreads();
-    // ------------------------------------------------------------ 3: the wave's two hidden tiles
-    f32x16 da0 = zero16(), da1 = zero16();
-#pragma unroll 1
-    for (int tix = 0; tix < 2; ++tix) {
-      f32x16 z, dh = zero16();
-      const float bz = tix == 0 ? b3v[0] : b3v[1];
+    // ------------------------------------------------------------ 3: this wave's hidden tile
+    f32x16 z, dh = zero16();
 #pragma unroll
-      for (int q = 0; q < 16; ++q) z[q] = bz;
-      bf16x8 w3h[4], w3l[4];
+    for (int q = 0; q < 16; ++q) z[q] = b3v;
+    // two K-halves per product, each its own fenced group: half the operand registers live at a time
 #pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        w3h[sidx] = __builtin_bit_cast(bf16x8, w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 0) * 64 + lane]);
-        w3l[sidx] = __builtin_bit_cast(bf16x8, w3f[(((2 * wave + tix) * 4 + sidx) * 2 + 1) * 64 + lane]);
-      }
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 ah[2], al[2], w3h[2], w3l[2];   // W3 fragments of this wave's tile: from its slab in L2 (re-read in the dA phase)
 #pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(s.Ah + r * LDF + 16 * sidx + 8 * h);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(s.Al + r * LDF + 16 * sidx + 8 * h);
-        z = mfma_bf(ah, w3h[sidx], z);
-        z = mfma_bf(al, w3h[sidx], z);
-        z = mfma_bf(ah, w3l[sidx], z);
+      for (int u = 0; u < 2; ++u) {
+        const int sidx = 2 * half + u;
+        w3h[u] = __builtin_bit_cast(bf16x8, w3f[(sidx * 2 + 0) * 64 + lane]);
+        w3l[u] = __builtin_bit_cast(bf16x8, w3f[(sidx * 2 + 1) * 64 + lane]);
+        ah[u] = *reinterpret_cast<const bf16x8*>(s.Ah + r * LDF + 16 * sidx + 8 * h);
+        al[u] = *reinterpret_cast<const bf16x8*>(s.Al + r * LDF + 16 * sidx + 8 * h);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        const bf16x8 dyh = *reinterpret_cast<const bf16x8*>(s.Dh + r * LDF + 16 * sidx + 8 * h);
-        const bf16x8 dyl = *reinterpret_cast<const bf16x8*>(s.Dl + r * LDF + 16 * sidx + 8 * h);
-        const bf16x8 w4h = __builtin_bit_cast(bf16x8, s.W4F[2 * wave + tix][sidx][0][lane]);
-        const bf16x8 w4l = __builtin_bit_cast(bf16x8, s.W4F[2 * wave + tix][sidx][1][lane]);
-        dh = mfma_bf(dyh, w4h, dh);
-        dh = mfma_bf(dyl, w4h, dh);
-        dh = mfma_bf(dyh, w4l, dh);
+      for (int u = 0; u < 2; ++u) {
+        z = mfma_bf(ah[u], w3h[u], z);
+        z = mfma_bf(al[u], w3h[u], z);
+        z = mfma_bf(ah[u], w3l[u], z);
       }
+      mfma_fence(z, sink);
       __builtin_amdgcn_sched_barrier(0);
-      float4 hv[4], dz[4];
-      float csum = 0.f;
+    }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 gp;
-        gelu_both4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]), hv[q], gp);
-        dz[q] = f4_mul(make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]), gp);
-        csum += (dz[q].x + dz[q].y) + (dz[q].z + dz[q].w);
-      }
-      cur_db3 += csum;
-      __builtin_amdgcn_sched_barrier(0);
-      TTile hT, zT;   // lane = hidden unit, K-steps = rows 0..15 / 16..31 in accumulator order: transposed operands for free
-      split_pair(hv[0], hv[1], hT.h0, hT.l0);
-      split_pair(hv[2], hv[3], hT.h1, hT.l1);
-      split_pair(dz[0], dz[1], zT.h0, zT.l0);
-      split_pair(dz[2], dz[3], zT.h1, zT.l1);
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const TTile ta0 = load_ttile(s.TT[0], lane), ta1 = load_ttile(s.TT[1], lane);
-        mma_tn_bf(zT, ta0, curW3[0]);
-        mma_tn_bf(zT, ta1, curW3[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const TTile td0 = load_ttile(s.TT[2], lane), td1 = load_ttile(s.TT[3], lane);
-        mma_tn_bf(td0, hT, curW4[0]);
-        mma_tn_bf(td1, hT, curW4[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // dZ back to row layout (lane = row, k = hidden unit) and dA^T[c][row] += sum_j W3[j][c] dZ[row][j]
-      bf16x8 zrh0, zrh1, zrl0, zrl1;
-      acc_to_bf(transpose32(zT.h0, zT.h1, sel0, sel1), zrh0, zrh1);
-      acc_to_bf(transpose32(zT.l0, zT.l1, sel0, sel1), zrl0, zrl1);
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 dyh[2], dyl[2], w4h[2], w4l[2];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        bf16x8 th0, th1, tl0, tl1;
-        acc_to_bf(transpose32(w3h[2 * ct], w3h[2 * ct + 1], sel0, sel1), th0, th1);
-        acc_to_bf(transpose32(w3l[2 * ct], w3l[2 * ct + 1], sel0, sel1), tl0, tl1);
-        f32x16& da = ct == 0 ? da0 : da1;
-        da = mfma_bf(th0, zrh0, da); da = mfma_bf(tl0, zrh0, da); da = mfma_bf(th0, zrl0, da);
-        da = mfma_bf(th1, zrh1, da); da = mfma_bf(tl1, zrh1, da); da = mfma_bf(th1, zrl1, da);
+      for (int u = 0; u < 2; ++u) {
+        const int sidx = 2 * half + u;
+        dyh[u] = *reinterpret_cast<const bf16x8*>(s.Dh + r * LDF + 16 * sidx + 8 * h);
+        dyl[u] = *reinterpret_cast<const bf16x8*>(s.Dl + r * LDF + 16 * sidx + 8 * h);
+        w4h[u] = __builtin_bit_cast(bf16x8, s.W4F[wave][sidx][0][lane]);
+        w4l[u] = __builtin_bit_cast(bf16x8, s.W4F[wave][sidx][1][lane]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        dh = mfma_bf(dyh[u], w4h[u], dh);
+        dh = mfma_bf(dyl[u], w4h[u], dh);
+        dh = mfma_bf(dyh[u], w4l[u], dh);
+      }
+      if (half == 0) {
+        mfma_fence(dh, sink);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    float4 hv[4], dz[4];
+    float csum = 0.f;
 #pragma unroll
-      for (int a_ = 0; a_ < 2; ++a_) {
-        f32x16 t3 = curW3[a_]; curW3[a_] = othW3[a_]; othW3[a_] = t3;
-        f32x16 t4 = curW4[a_]; curW4[a_] = othW4[a_]; othW4[a_] = t4;
-      }
-      { const float t = cur_db3; cur_db3 = oth_db3; oth_db3 = t; }
+    for (int q = 0; q < 4; ++q) {   // reads z and dh: fences both groups
+      float4 gp;
+      gelu_both4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]), hv[q], gp);
+      dz[q] = f4_mul(make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]), gp);
+      csum += (dz[q].x + dz[q].y) + (dz[q].z + dz[q].w);
+    }
+    adb3 += csum;
+    TTile hT, zT;
+    split_pair(hv[0], hv[1], hT.h0, hT.l0);
+    split_pair(hv[2], hv[3], hT.h1, hT.l1);
+    split_pair(dz[0], dz[1], zT.h0, zT.l0);
+    split_pair(dz[2], dz[3], zT.h1, zT.l1);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const TTile ta0 = load_ttile(s.TT[0], lane), ta1 = load_ttile(s.TT[1], lane);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tn_bf(zT, ta0, aW3[0]);
+      mma_tn_bf(zT, ta1, aW3[1]);
+      mfma_fence(aW3[1], sink);
+      __builtin_amdgcn_sched_barrier(0);
     }
     {
-      float4 f[8];
-      acc_to_frag(da0, f[0], f[1], f[2], f[3]);
-      acc_to_frag(da1, f[4], f[5], f[6], f[7]);
-      float* drow = s.DA[wave] + r * LDD + 4 * h;
+      const TTile td0 = load_ttile(s.TT[2], lane), td1 = load_ttile(s.TT[3], lane);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tn_bf(td0, hT, aW4[0]);
+      mma_tn_bf(td1, hT, aW4[1]);
+      mfma_fence(aW4[1], sink);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // dZ back to row layout, then dA^T per 32-column tile: partial rows to LDS (waves 0-3 write, waves 4-7 add)
+    bf16x8 zrh0, zrh1, zrl0, zrl1;
+    acc_to_bf(transpose32(zT.h0, zT.h1, sel0, sel1), zrh0, zrh1);
+    acc_to_bf(transpose32(zT.l0, zT.l1, sel0, sel1), zrl0, zrl1);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 daf[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = f[t];
+    for (int ct = 0; ct < 2; ++ct) {
+      bf16x8 th0, th1, tl0, tl1;
+      {
+        const bf16x8 ch0 = __builtin_bit_cast(bf16x8, w3f[((2 * ct) * 2 + 0) * 64 + lane]);
+        const bf16x8 ch1 = __builtin_bit_cast(bf16x8, w3f[((2 * ct + 1) * 2 + 0) * 64 + lane]);
+        const bf16x8 cl0 = __builtin_bit_cast(bf16x8, w3f[((2 * ct) * 2 + 1) * 64 + lane]);
+        const bf16x8 cl1 = __builtin_bit_cast(bf16x8, w3f[((2 * ct + 1) * 2 + 1) * 64 + lane]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc_to_bf(transpose32(ch0, ch1, sel0, sel1), th0, th1);
+        acc_to_bf(transpose32(cl0, cl1, sel0, sel1), tl0, tl1);
+      }
+      f32x16 da = zero16();
+      da = mfma_bf(th0, zrh0, da); da = mfma_bf(tl0, zrh0, da); da = mfma_bf(th0, zrl0, da);
+      da = mfma_bf(th1, zrh1, da); da = mfma_bf(tl1, zrh1, da); da = mfma_bf(th1, zrl1, da);
+      acc_to_frag(da, daf[4 * ct], daf[4 * ct + 1], daf[4 * ct + 2], daf[4 * ct + 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* drow = s.DA[wave & 3] + r * LDD + 4 * h;
+    if (wave < 4) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = daf[t];
+    }
+    __syncthreads();
+    if (wave >= 4) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float4* p = reinterpret_cast<float4*>(drow + 8 * t);
+        *p = f4_add(*p, daf[t]);
+      }
     }
     __syncthreads();
     // ------------------------------------------------------------ 4: LayerNorm backward
+    {
+      const int row = ch * 32 + lrow;
+      float4 da = *reinterpret_cast<const float4*>(s.DA[0] + lrow * LDD + 4 * cq);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int lr = row0 + 16 * i, row = ch * 32 + lr;
-      float4 da = *reinterpret_cast<const float4*>(s.DA[0] + lr * LDD + 4 * cq);
-#pragma unroll
-      for (int w_ = 1; w_ < 4; ++w_) da = f4_add(da, *reinterpret_cast<const float4*>(s.DA[w_] + lr * LDD + 4 * cq));
+      for (int w_ = 1; w_ < 4; ++w_) da = f4_add(da, *reinterpret_cast<const float4*>(s.DA[w_] + lrow * LDD + 4 * cq));
       const float4 g = f4_mul(da, gq);
       const float mg = row16_sum((g.x + g.y) + (g.z + g.w)) * (1.f / C);
-      const float mgx = row16_sum((g.x * xh[i].x + g.y * xh[i].y) + (g.z * xh[i].z + g.w * xh[i].w)) * (1.f / C);
-      const float rs = rstd[i];
-      const float4 dx = make_float4(rs * (g.x - mg - xh[i].x * mgx), rs * (g.y - mg - xh[i].y * mgx),
-                                    rs * (g.z - mg - xh[i].z * mgx), rs * (g.w - mg - xh[i].w * mgx));
+      const float mgx = row16_sum((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w)) * (1.f / C);
+      const float4 dx = make_float4(rstd * (g.x - mg - xh.x * mgx), rstd * (g.y - mg - xh.y * mgx), rstd * (g.z - mg - xh.z * mgx),
+                                    rstd * (g.w - mg - xh.w * mgx));
       if (row < n_rows) *reinterpret_cast<float4*>(dx2 + (size_t)row * C + 4 * cq) = dx;
-      dgam = make_float4(fmaf(da.x, xh[i].x, dgam.x), fmaf(da.y, xh[i].y, dgam.y), fmaf(da.z, xh[i].z, dgam.z), fmaf(da.w, xh[i].w, dgam.w));
+      dgam = make_float4(fmaf(da.x, xh.x, dgam.x), fmaf(da.y, xh.y, dgam.y), fmaf(da.z, xh.z, dgam.z), fmaf(da.w, xh.w, dgam.w));
       dbet = f4_add(dbet, da);
     }
+    // (stage 1 of the next chunk only writes the A / D images, last read before the two barriers above)
   }
 
   // ---- partial slab.  accumulator element i of lane (n = r, h) holds row m = 8(i>>2) + 4h + (i&3) of the 32x32 tile
+  __syncthreads();   // every wave is done with its W3 fragments (same slab)
   float* out = partial + (size_t)blockIdx.x * MLP_PARTIAL;
   float* oW3 = out, *ob3 = oW3 + W * C, *oW4 = ob3 + W, *ob4 = oW4 + C * W, *og = ob4 + C, *obt = og + C;
-  // (after an even number of swaps cur* belongs to tile 2*wave, oth* to tile 2*wave + 1)
+  const int j0 = 32 * wave;
 #pragma unroll
-  for (int tix = 0; tix < 2; ++tix) {
-    const int j0 = 32 * (2 * wave + tix);
+  for (int i = 0; i < 16; ++i) {
+    const int m = 8 * (i >> 2) + 4 * h + (i & 3);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = 8 * (i >> 2) + 4 * h + (i & 3);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        oW3[(size_t)(j0 + m) * C + 32 * t2 + r] = tix == 0 ? curW3[t2][i] : othW3[t2][i];   // rows = hidden unit, lanes = channel
-        oW4[(size_t)(32 * t2 + m) * W + j0 + r] = tix == 0 ? curW4[t2][i] : othW4[t2][i];   // rows = output channel, lanes = hidden unit
-      }
+    for (int t2 = 0; t2 < 2; ++t2) {
+      oW3[(size_t)(j0 + m) * C + 32 * t2 + r] = aW3[t2][i];
+      oW4[(size_t)(32 * t2 + m) * W + j0 + r] = aW4[t2][i];
     }
-    const float d = tix == 0 ? cur_db3 : oth_db3;
-    const float v = d + __shfl_xor(d, 32, 64);
+  }
+  {
+    const float v = adb3 + __shfl_xor(adb3, 32, 64);
     if (h == 0) ob3[j0 + r] = v;
   }
-  __syncthreads();
-  *reinterpret_cast<float4*>(&s.red[row0][0][4 * cq]) = db4;
-  *reinterpret_cast<float4*>(&s.red[row0][1][4 * cq]) = dgam;
-  *reinterpret_cast<float4*>(&s.red[row0][2][4 * cq]) = dbet;
+  float* red = &s.DA[0][0];   // [32 rows][3][64]
+  *reinterpret_cast<float4*>(red + (lrow * 3 + 0) * C + 4 * cq) = db4;
+  *reinterpret_cast<float4*>(red + (lrow * 3 + 1) * C + 4 * cq) = dgam;
+  *reinterpret_cast<float4*>(red + (lrow * 3 + 2) * C + 4 * cq) = dbet;
   __syncthreads();
   if (tid < 3 * C) {
     const int which = tid >> 6, c = tid & 63;
     float t = 0.f;
 #pragma unroll
-    for (int g_ = 0; g_ < 16; ++g_) t += s.red[g_][which][c];
+    for (int g_ = 0; g_ < 32; ++g_) t += red[(g_ * 3 + which) * C + c];
     (which == 0 ? ob4 : which == 1 ? og : obt)[c] = t;
   }
+  if (sink == 123456.789f) out[0] = sink;   // keeps the fences alive; never true
 }
 
 int blocks_for(int n_rows, int rows_per_block, int cap) {
@@ -449,7 +473,7 @@ int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const 
     hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem));
     attr = true;
   }
-  hipLaunchKernelGGL(node_mlp_bwd_fused_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(256), sizeof(MlpBwdSmem), stream, x2,
+  hipLaunchKernelGGL(node_mlp_bwd_fused_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(512), sizeof(MlpBwdSmem), stream, x2,
                      dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows);
   GRL_CHECK_LAUNCH();
   return 0;
