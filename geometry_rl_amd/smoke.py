@@ -17,9 +17,16 @@ def run():
     batch = dict(syn.make_rigid_obs(B, seed=2))
     batch.update(syn.make_ppo_fields(B, 6, seed=2))
     dbatch = {k: v.to(dev) for k, v in batch.items()}
-    with torch.no_grad():
+    with torch.no_grad():  # first training call = data-dependent calibration of the conv kernels (conv.py:104-105)
         oracle.actor_forward({k: batch[k] for k in o_spec.in_features}, calibrate=True)
         actor.forward_diag(*[dbatch[k] for k in spec.in_features], train=True)
+    for k, v in oracle.actor.items():  # std ratios of split-bf16 activations: 1e-4 (same bar as tests/test_gpu_step.py)
+        if "kernel.weight" in k:
+            err = (actor.state_dict()[k].cpu() - v).abs().max().item()
+            assert err <= 1e-4 * max(1.0, v.abs().max().item()), ("calibration", k, err)
+    # continue from identical (oracle-calibrated) weights so that the update below is compared on its own
+    actor.load_state_dict({k: v.detach().to(dev) for k, v in oracle.actor.items()}, strict=False)
+    actor._calib_checked = True
     upd = agent.PolicyUpdater(loss)
     out = upd.step(dbatch)
     ref, _ = oracle.update(batch)
