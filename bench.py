@@ -53,6 +53,11 @@ def workload(name):
         cfg = agent.AgentConfig(dim=2, clip_grad_norm=True)
         make = lambda B, seed, off: syn.make_rope_obs(B, seed=seed)
         cfg_name = "rope_shaping_hepi_trpl"
+    elif name == "rigid2_empn":
+        spec = graph.rigid_spec(G=2)
+        cfg = agent.AgentConfig(model="empn")  # configs/rigid_insertion_two_agents_multi_empn_trpl_cfg.yaml
+        make = lambda B, seed, off: syn.make_rigid_obs(B, G=2, seed=seed, env_offset=off)
+        cfg_name = "rigid_insertion_two_agents_multi_empn_trpl"
     else:
         raise ValueError(name)
     return spec, cfg, make, cfg_name
