@@ -214,8 +214,21 @@ def main():
                           "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / PEAK_BF16X3}
         name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         d = kernels[name]
+        # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the committed
+        # summary of the separate `rocprofv3 --pmc` passes (tools/pmc_passes.sh -> profiles/r01_pmc_summary_*.json), same workload
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_pmc_summary_*.json")))[-1]
+            pk = json.load(open(f))["kernels"].get(name)
+            if pk:
+                traffic = pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"]
+                traffic_src = os.path.basename(f)
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                "frac": d["frac"], "traffic": None, "avg_launch_ms": d["avg_launch_ms"],
+                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
                 "peak_note": "f32-exact MFMA peak; the kernel forms each f32 product from three bf16 MFMAs (split-bf16), whose "
                              f"f32-equivalent peak is {PEAK_BF16X3:.0f} TFLOP/s: frac_of_bf16x3",
