@@ -13,11 +13,7 @@
 // latency hides behind it.
 #include "grl_common.h"
 #include <type_traits>
-#ifdef GRL_NO_SCHED_BARRIER
-#define GRL_SCHED_BARRIER()
-#else
 #define GRL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 namespace {
 
@@ -202,22 +198,13 @@ struct PassMeta {
 GRL_DEVINL void meta_indices(const EdgeParams& p, int e, int e_end, PassMeta& m) {
   m.valid = e < e_end;
   const int ee = m.valid ? e : e_end - 1;
-#ifdef GRL_DBG_FAKE_META   // timing experiment only: no index / position gathers
-  m.src = ee & 1023;
-  m.dst = (ee * 3) & 1023;
-#else
   m.src = p.e_src[ee];
   m.dst = p.e_dst[ee];
-#endif
 }
 GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o, PassMeta& m) {
-#ifdef GRL_DBG_FAKE_META
-  float rx = 1e-3f * (m.src - m.dst), ry = 2e-3f * m.src, rz = 1e-3f * m.dst;
-#else
   float rx = p.pos_src[3 * m.src] - p.pos_dst[3 * m.dst];
   float ry = p.pos_src[3 * m.src + 1] - p.pos_dst[3 * m.dst + 1];
   float rz = (p.dim == 2) ? 0.f : p.pos_src[3 * m.src + 2] - p.pos_dst[3 * m.dst + 2];
-#endif
   const float gx = grid_s[3 * o], gy = grid_s[3 * o + 1], gz = grid_s[3 * o + 2];
   m.a = rx * gx + ry * gy + rz * gz;                      // hepi.py:115
   rx -= m.a * gx; ry -= m.a * gy; rz -= m.a * gz;
@@ -236,31 +223,16 @@ constexpr int FWD_WAVES = GRL_FWD_WAVES;
 #ifndef GRL_FWD_MAX_BLOCKS
 #define GRL_FWD_MAX_BLOCKS 512   // two 4-wave workgroups per CU = two waves per SIMD (the chain is fenced for that)
 #endif
-#ifdef GRL_LB1
-__global__ __launch_bounds__(64 * FWD_WAVES) void edge_conv_fwd_kernel
-#else
 __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
-#endif
 (EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   load_chain_weights(s, p);
   __syncthreads();
-  // the two waves of a SIMD (w, w+4) run the same program; starting the second one half a pass late keeps one of them in
-  // its MFMA phase while the other is in its VALU phase (MI355X_MICROARCH.md, "Two waves per SIMD", item 9)
-#ifndef GRL_NO_STAGGER
-  if (wave >= 4) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(32); }
-#endif
-
   const int o = r & 15, el = r >> 4;
   const int n_tiles = (p.n_anchor + TD - 1) / TD;
-#ifdef GRL_DBG_HALF_IDLE
-  if (wave >= 4) return;
-  for (int tl = blockIdx.x * 4 + wave; tl < n_tiles; tl += gridDim.x * 4) {
-#else
   for (int tl = blockIdx.x * FWD_WAVES + wave; tl < n_tiles; tl += gridDim.x * FWD_WAVES) {
-#endif
     const int d0 = tl * TD, d1 = min(d0 + TD, p.n_anchor);
     const int e0 = p.rowptr[d0], e1 = p.rowptr[d1];
     float4 accA[8], accB[8];
@@ -583,11 +555,7 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
   const int n_tiles = (n_dst + TD - 1) / TD;
   int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
   if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
-#ifdef GRL_DBG_SMEM_PAD
-  const size_t smem = 65536;
-#else
   const size_t smem = sizeof(ChainW);
-#endif
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
