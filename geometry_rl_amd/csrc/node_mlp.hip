@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       s.TT[wave][2][lane] = __builtin_bit_cast(u32x4, t.l0);
       s.TT[wave][3][lane] = __builtin_bit_cast(u32x4, t.l1);
     }
-    __syncthreads();
+    // (no barrier yet: z, dH and the activation below only read the fragment images; the transposed tiles are first needed by dW3)
     // ------------------------------------------------------------ 3: this wave's hidden tile
     f32x16 z, dh = zero16();
 #pragma unroll
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     split_pair(dz[0], dz[1], zT.h0, zT.l0);
     split_pair(dz[2], dz[3], zT.h1, zT.l1);
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // transposed shared tiles (stage 2) complete
     {
       const TTile ta0 = load_ttile(s.TT[0], lane), ta1 = load_ttile(s.TT[1], lane);
       __builtin_amdgcn_sched_barrier(0);
