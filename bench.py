@@ -25,8 +25,9 @@ sys.path.insert(0, ROOT)
 _CHAIN = 2 * 64 * (14 + 64 + 64)             # basis MLP 14->64->64 and the 64->64 kernel layer
 FLOPS_PER_ROW = {
     "edge_conv_fwd_kernel": _CHAIN + 2 * 64,                                       # + message multiply, scatter add
-    "edge_conv_bwd_x_kernel": _CHAIN + 2 * 64 * 64 + 3 * 64,                       # recompute, dWk, d x_src row (+sum), dK
-    "edge_conv_bwd_w_kernel": (_CHAIN - 2 * 64 * 64) + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,  # z1, z2 recompute, dG2, dG1, dW2, dW1
+    "edge_conv_bwd_x_kernel": _CHAIN + 2 * 64,                                      # recompute, d x_src row (+ sum)
+    "edge_conv_bwd_w_kernel": (_CHAIN - 2 * 64 * 64) + 2 * 64 + 2 * 64 * 64 + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,
+    # ^ z1, z2 recompute, dK, dWk, dG2, dG1, dW2, dW1
     "node_mlp_fwd_kernel": 4 * 64 * 256,
     "node_mlp_bwd_fused_kernel": 10 * 64 * 256,                                    # z recompute, dH, dA, dW3, dW4
 }

@@ -287,35 +287,28 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Two launches, each recomputing the cheap split-bf16 chain, so that the row-reduction accumulators of one launch fit the
-// register file without spilling (a single launch needed 160 accumulator registers + the chain state: 47 spilled VGPRs):
+// Two launches, each recomputing the cheap split-bf16 chain, so that the register file holds one launch's accumulators without
+// spilling (everything in one kernel: 224 accumulator registers + the chain state, 170-220 spilled VGPRs, 30 % slower):
 //   x kernel (edges in SOURCE-sorted order, a wave owns TD = 2 consecutive source nodes, exactly like the forward owns
-//             destination nodes): dM = d x1[dst]; d x_src[src] += dM * K accumulated in registers and stored once per node
-//             (no per-edge scratch, no second pass, no atomics); dK = dM * x_src; dWk += dK^T g2
-//   w kernel (destination-sorted order, flat passes of 2 edges x 16 orientations = 32 rows per wave):
-//             dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2; dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
+//             destination nodes; two waves per SIMD, fenced MFMA groups): dM = d x1[dst]; d x_src[src] += dM * K accumulated in
+//             registers and stored once per node (no per-edge scratch, no second pass, no atomics)
+//   w kernel (destination-sorted order, flat passes of 2 edges x 16 orientations = 32 rows per wave; one wave per SIMD):
+//             dK = dM * x_src; dWk += dK^T g2; dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2;
+//             dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
 // Weight-gradient accumulators live in registers for the whole launch and leave as one partial row per wave:
 //   partial[(block*4 + wave)][9344] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64].
 constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
 
 // p is the SOURCE-anchored view of the edge set (rowptr = rowptr_s, e_src / e_dst in source-sorted order, n_anchor = n_src).
-__global__ __launch_bounds__(256, 1) void edge_conv_bwd_x_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                 float* __restrict__ dx_src /*[Ns,16,64]*/,
-                                                                 float* __restrict__ partial) {
+__global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
+                                                                 float* __restrict__ dx_src /*[Ns,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   load_chain_weights(s, p);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
-  bf16x8 sel0, sel1;
-  make_selectors(sel0, sel1);
-  f32x16 accW[2][2];                       // dWk
-#pragma unroll
-  for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-    for (int b_ = 0; b_ < 2; ++b_) accW[a_][b_] = zero16();
 
   const int n_tiles = (p.n_anchor + TD - 1) / TD;
 #pragma unroll 1
@@ -334,43 +327,26 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_x_kernel(EdgeParams p, c
         PassMeta nxt;
         const bool more = e + 2 < e1;
         if (more) meta_indices(p, e + 2 + el, e1, nxt);
-        const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
         const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
-        float4 xv[8], dv[8];
+        float4 dv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
-        float4 kf[8], g1[8], gp1[8], g2[8], gp2[8];
+        for (int t = 0; t < 8; ++t) dv[t] = dm[2 * t];   // in flight behind the chain
+        float4 g1[8], gp1[8], g2[8], gp2[8];
         ChainFrags cf;
-        edge_chain<false, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
-          acc_to_frag(acc, kf[4 * nt], kf[4 * nt + 1], kf[4 * nt + 2], kf[4 * nt + 3]);
-        });
-        if (more) meta_invariants(p, s.grid_s, o, nxt);
         const float wa = (cur.valid && cur.src == s0) ? 1.f : 0.f;
         const float wb = (cur.valid && cur.src != s0) ? 1.f : 0.f;
-        float4 dK[8];
+        // d x_src row = dM * K, summed into the accumulator of the edge's source node as each K tile leaves the matrix pipe
+        // (two waves share a SIMD: fenced MFMA groups, exactly like the forward kernel)
+        edge_chain<false, true>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (!cur.valid) dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 m = f4_mul(dv[t], kf[t]);
-          accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
-          accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
-          dK[t] = f4_mul(dv[t], xv[t]);
-        }
-        // dWk[c][k] += sum_r dK[r][c] g2[r][k]: both operands transposed in registers (grl_common.h), split-bf16 products
-        {
-          bf16x8 kh[4], kl[4];
-          split_frags<64>(dK, kh, kl);
-          GRL_SCHED_BARRIER();
-          const TTile tg0 = transpose_split(cf.g2h[0], cf.g2h[1], cf.g2l[0], cf.g2l[1], sel0, sel1);
-          const TTile tg1 = transpose_split(cf.g2h[2], cf.g2h[3], cf.g2l[2], cf.g2l[3], sel0, sel1);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const TTile tk = transpose_split(kh[2 * ct], kh[2 * ct + 1], kl[2 * ct], kl[2 * ct + 1], sel0, sel1);
-            mma_tn_bf(tk, tg0, accW[ct][0]);
-            mma_tn_bf(tk, tg1, accW[ct][1]);
+          for (int q = 0; q < 4; ++q) {
+            const int t = 4 * nt + q;
+            const float4 m = f4_mul(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), dv[t]);
+            accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
+            accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
           }
-          GRL_SCHED_BARRIER();
-        }
+        });
+        if (more) meta_invariants(p, s.grid_s, o, nxt);
         cur = nxt;
       }
     }
@@ -388,16 +364,6 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_x_kernel(EdgeParams p, c
     }
   }
 
-  // ---- this wave's dWk partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
-  float* oWk = partial + (size_t)(blockIdx.x * 4 + wave) * EDGE_PARTIAL + 64 * 14 + 64 + 64 * 64 + 64;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int rho = 0; rho < 16; ++rho) {
-      const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * h;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) oWk[n * 64 + 32 * kt + r] = accW[nt][kt][rho];
-    }
 }
 
 __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
@@ -415,12 +381,12 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
   bf16x8 sel0, sel1;
   make_selectors(sel0, sel1);
 
-  f32x16 accA[2][2], accB[2];              // accA = dW2, accB = dW1
+  f32x16 accA[2][2], accB[2], accK[2][2];  // accA = dW2, accB = dW1, accK = dWk
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_) {
     accB[a_] = zero16();
 #pragma unroll
-    for (int b_ = 0; b_ < 2; ++b_) accA[a_][b_] = zero16();
+    for (int b_ = 0; b_ < 2; ++b_) { accA[a_][b_] = zero16(); accK[a_][b_] = zero16(); }
   }
   float db1[2] = {0.f, 0.f}, db2[2] = {0.f, 0.f};  // column 32*nt + r, summed over this lane half's rows
 
@@ -459,6 +425,18 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
       {
         bf16x8 dh_[4], dl_[4];
         split_frags<64>(dK, dh_, dl_);
+        // ---- dWk[c][k] += sum_r dK[r][c] g2[r][k]   (g2 fragments straight from the chain; consumed first so they die early)
+        {
+          const TTile tg0 = transpose_split(cf.g2h[0], cf.g2h[1], cf.g2l[0], cf.g2l[1], sel0, sel1);
+          const TTile tg1 = transpose_split(cf.g2h[2], cf.g2h[3], cf.g2l[2], cf.g2l[3], sel0, sel1);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const TTile tk = transpose_split(dh_[2 * ct], dh_[2 * ct + 1], dl_[2 * ct], dl_[2 * ct + 1], sel0, sel1);
+            mma_tn_bf(tk, tg0, accK[ct][0]);
+            mma_tn_bf(tk, tg1, accK[ct][1]);
+          }
+        }
+        GRL_SCHED_BARRIER();
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           f32x16 acc = zero16();
@@ -520,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
 
   // ---- write this wave's partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
   float* out = partial + (size_t)(blockIdx.x * 4 + wave) * EDGE_PARTIAL;
-  float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64;
+  float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64, *oWk = ob2 + 64;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -528,7 +506,10 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
       const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * h;
       if (r < 14) oW1[n * 14 + r] = accB[nt][rho];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) oW2[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
+      for (int kt = 0; kt < 2; ++kt) {
+        oW2[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
+        oWk[n * 64 + 32 * kt + r] = accK[nt][kt][rho];
+      }
     }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {   // the other 16 rows of every column were summed by lane ^ 32
@@ -589,7 +570,12 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
     attr = true;
   }
   grl_prof_begin("edge_conv_bwd_x_kernel", stream);
-  hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(blocks), dim3(256), smem_x, stream, ps, dx1, dx_src, partial);
+  {
+    const int n_tiles_s = (n_src + TD - 1) / TD;
+    int xblocks = (n_tiles_s + 3) / 4;
+    if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;   // two 4-wave workgroups per CU, like the forward
+    hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dx1, dx_src);
+  }
   grl_prof_end(stream);
   GRL_CHECK_LAUNCH();
   grl_prof_begin("edge_conv_bwd_w_kernel", stream);
