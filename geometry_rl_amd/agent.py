@@ -157,6 +157,7 @@ class PolicyUpdater:
             st["pipe"].fwd2()
 
         def s2():  # value head, actor forward, fused TRPL kernel, actor backward, last critic stage backward
+            ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch in s4
             pipe = st["pipe"]
             value = pipe.fwd3()
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
@@ -176,6 +177,8 @@ class PolicyUpdater:
             with torch.no_grad():
                 grads = st["pipe"].bwd1(leaves)
             assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
+            ops.flush_deferred_grads()
+            ops.DEFERRED = None
 
         def s5():  # optimizers + reported values (train.py:308-316, trpl.py:280-321)
             with torch.no_grad():

@@ -363,6 +363,29 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_seg_kernel(con
   fold_and_add(v, segs.dst[seg] + j, active, red, (segs.overwrite_mask >> seg) & 1);
 }
 
+// every leaf-gradient fold of a backward pass in ONE launch: up to RED_MULTI_MAX source slabs, grouped by destination (several
+// slabs may feed the same gradient, e.g. the basis MLP shared by all edge convolutions: one workgroup sums them in order)
+constexpr int RED_MULTI_MAX = 64;
+struct ReduceMulti {
+  const float* partial[RED_MULTI_MAX];                                 // sources, grouped by destination
+  int n_rows[RED_MULTI_MAX], ld[RED_MULTI_MAX], start[RED_MULTI_MAX];
+  float* dst[RED_MULTI_MAX];                                           // destinations
+  int len[RED_MULTI_MAX], first[RED_MULTI_MAX], count[RED_MULTI_MAX];
+};
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(ReduceMulti m) {
+  __shared__ float red[RED_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = blockIdx.y;
+  if (blockIdx.x * 64 >= m.len[d]) return;
+  const int j = blockIdx.x * 64 + lane;
+  const bool active = j < m.len[d];
+  float v = 0.f;
+  if (active)
+    for (int q = m.first[d]; q < m.first[d] + m.count[d]; ++q)
+      v += column_sum(m.partial[q] + m.start[q] + j, (size_t)m.ld[q], m.n_rows[q], wave);
+  fold_and_add(v, m.dst[d] + j, active, red);
+}
+
 int cap_blocks(long long work, int per_block, int cap) {
   long long b = (work + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -479,6 +502,36 @@ int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg,
   segs.overwrite_mask = overwrite_mask;
   hipLaunchKernelGGL(reduce_partials_seg_kernel, dim3((max_len + 63) / 64, n_seg), dim3(64 * RED_WAVES), 0, stream, partial, segs,
                      n_rows, ld);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// n_seg <= 64 folds in one launch: dst[i][0..len[i]) += sum over n_rows[i] rows of partial[i][row*ld[i] + start[i] + j]
+// (all arrays are HOST arrays of length n_seg).  Segments with the same destination are summed by the same workgroup, in order.
+int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                              const int* len, float* const* dst, hipStream_t stream) {
+  if (n_seg <= 0) return 0;
+  if (n_seg > RED_MULTI_MAX) return -2;
+  ReduceMulti m{};
+  int n_dst = 0, n_src = 0, max_len = 0;
+  bool used[RED_MULTI_MAX] = {false};
+  for (int i = 0; i < n_seg; ++i) {
+    if (used[i]) continue;
+    m.dst[n_dst] = dst[i];
+    m.len[n_dst] = len[i];
+    m.first[n_dst] = n_src;
+    for (int k = i; k < n_seg; ++k) {
+      if (used[k] || dst[k] != dst[i]) continue;
+      if (len[k] != len[i]) return -3;
+      used[k] = true;
+      m.partial[n_src] = partial[k]; m.n_rows[n_src] = n_rows[k]; m.ld[n_src] = ld[k]; m.start[n_src] = start[k];
+      ++n_src;
+    }
+    m.count[n_dst] = n_src - m.first[n_dst];
+    if (len[i] > max_len) max_len = len[i];
+    ++n_dst;
+  }
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((max_len + 63) / 64, n_dst), dim3(64 * RED_WAVES), 0, stream, m);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -48,6 +48,26 @@ def _reduce(partial: torch.Tensor, out: torch.Tensor):
     hip.call("grl_reduce_partials", partial, out, partial.shape[0], out.numel())
 
 
+# Deferred folding: while a list is installed here (PolicyUpdater does, around the backward), folds whose destinations are all
+# existing leaf ``.grad`` buffers are queued and executed by ONE launch (flush_deferred_grads) instead of one launch each.
+DEFERRED = None
+
+
+def flush_deferred_grads():
+    import ctypes
+    global DEFERRED
+    jobs = DEFERRED or []
+    if DEFERRED is not None:
+        DEFERRED = []
+    for i in range(0, len(jobs), 64):
+        part = jobs[i:i + 64]
+        n = len(part)
+        hip.call("grl_reduce_partials_multi", n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part]),
+                 (ctypes.c_int * n)(*[j[0].shape[0] for j in part]), (ctypes.c_int * n)(*[j[0].shape[1] for j in part]),
+                 (ctypes.c_int * n)(*[j[1] for j in part]), (ctypes.c_int * n)(*[j[2] for j in part]),
+                 (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]))
+
+
 def _emit_grads(partial: torch.Tensor, segments):
     """Fold per-workgroup partial rows into gradients with ONE launch.  ``segments`` = [(start, length, shape, tensor)]:
     when ``tensor`` is a leaf whose ``.grad`` buffer already exists (PolicyUpdater keeps every parameter's grad as a view of
@@ -69,6 +89,9 @@ def _emit_grads(partial: torch.Tensor, segments):
             fresh_flags.append(1)
         starts.append(start)
         lens.append(length)
+    if DEFERRED is not None and not any(fresh_flags):
+        DEFERRED.extend((partial, st, ln, d) for st, ln, d in zip(starts, lens, dsts))   # keeps `partial` alive until the flush
+        return outs
     for i in range(0, len(segments), 8):
         n = min(8, len(segments) - i)
         mask = sum(f << k for k, f in enumerate(fresh_flags[i:i + n]))

@@ -127,6 +127,9 @@ int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hip
 /* dst[i][0..len[i]) += sum_rows partial[row*ld + start[i] + j], i < n_seg <= 8; dst/start/len are HOST arrays */
 int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg, float* const* dst, const int* start, const int* len,
                             int overwrite_mask /* bit i: dst[i] = sum instead of += */, hipStream_t stream);
+/* n_seg <= 64 independent folds in ONE launch (all arrays HOST arrays of length n_seg): every leaf gradient of a backward pass */
+int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                              const int* len, float* const* dst, hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
 /* the same update with the step count in device memory (int[1]): recordable into a hipGraph */
