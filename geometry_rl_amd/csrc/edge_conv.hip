@@ -302,7 +302,8 @@ constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
 // p is the SOURCE-anchored view of the edge set (rowptr = rowptr_s, e_src / e_dst in source-sorted order, n_anchor = n_src).
 __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                 float* __restrict__ dx_src /*[Ns,16,64]*/) {
+                                                                 float* __restrict__ dx_src /*[Ns,16,64]*/,
+                                                                 const float* __restrict__ dres /*[Ns,16,64] or null*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   load_chain_weights(s, p);
@@ -359,8 +360,11 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
       a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
       b.x += __shfl_xor(b.x, 16, 64); b.y += __shfl_xor(b.y, 16, 64); b.z += __shfl_xor(b.z, 16, 64); b.w += __shfl_xor(b.w, 16, 64);
       const bool is_a = el == 0;
-      const float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
-      if (node < s1) dstp[2 * t] = v;
+      float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
+      if (node < s1) {
+        if (dres) v = f4_add(v, (reinterpret_cast<const float4*>(dres + ((size_t)node * O + o) * C) + h)[2 * t]);  // + residual branch
+        dstp[2 * t] = v;
+      }
     }
   }
 
@@ -548,14 +552,18 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
 }
 
 // The same edge set in both orders: destination-sorted (rowptr, e_src, e_dst: the forward's arrays) for the weight kernel and
-// source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten.
+// source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten:
+// dx_src = (dres ? dres : 0) + sum over out-edges; dres [n_src,16,64] = gradient of another use of x_src (the residual branch), or NULL.
 // partial must hold grl_edge_bwd_blocks(n_edges)*4 rows of grl_edge_partial_size() floats.
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                      const float* Wk, const float* dx1, float* dx_src, float* partial, hipStream_t stream) {
+                      const float* Wk, const float* dx1, const float* dres, float* dx_src, float* partial, hipStream_t stream) {
   if (n_edges <= 0) {
-    if (n_src > 0) hipMemsetAsync(dx_src, 0, sizeof(float) * (size_t)n_src * O * C, stream);
+    if (n_src > 0) {
+      if (dres) hipMemcpyAsync(dx_src, dres, sizeof(float) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
+      else hipMemsetAsync(dx_src, 0, sizeof(float) * (size_t)n_src * O * C, stream);
+    }
     return 0;
   }
   EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
@@ -574,7 +582,7 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
     const int n_tiles_s = (n_src + TD - 1) / TD;
     int xblocks = (n_tiles_s + 3) / 4;
     if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;   // two 4-wave workgroups per CU, like the forward
-    hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dx1, dx_src);
+    hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dx1, dx_src, dres);
   }
   grl_prof_end(stream);
   GRL_CHECK_LAUNCH();

@@ -155,12 +155,14 @@ class HEPi(nn.Module):
         es = graph.edges[et]
         s, _, d = et
         b = self.basis_fn
+        # x feeds the convolution AND the residual of its own node block: the two gradients are summed inside the d x_src kernel
+        res = {} if (x_src is x_dst and prev is None and torch.is_grad_enabled() and x_src.requires_grad) else None
         x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
-                                conv.kernel.weight, es, self.dim)
+                                conv.kernel.weight, es, self.dim, res)
         fk = fks[id(conv)]
         x2 = ops.FiberConv.apply(x1, fk, conv.bias)
         m = conv.node_mlp
-        return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev), x1, fk
+        return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res), x1, fk
 
     # ------------------------------------------------------------------ forward
     def latent_step(self, graph: GraphBatch, u_dict) -> torch.Tensor:

@@ -39,7 +39,8 @@ int grl_edge_bwd_blocks(int n_edges);
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
                       int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
-                      const float* b2, const float* Wk, const float* dx1, float* dx_src, float* partial, hipStream_t stream);
+                      const float* b2, const float* Wk, const float* dx1, const float* dres /* optional [n_src,16,64] added to dx_src */,
+                      float* dx_src, float* partial, hipStream_t stream);
 
 /* ---- fiber kernel basis (parameter-only, 256 rows): hepi.py:109-123,157 / ponita.py:246-268 + conv.py:62 ------------------------
  * Phi = GELU(W2 GELU(W1 poly + b1) + b2), fk_i = Phi Wf_i^T for n_conv <= 4 convolutions, one launch each way.
