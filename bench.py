@@ -229,13 +229,40 @@ def main():
                 traffic_src = os.path.basename(f)
         except Exception:
             pass
+        # whole-step figures from SURVEY.md section 8(d): algorithmic FLOPs (3 x forward) and bytes of a perfectly fused step
+        step_fig = None
+        try:
+            topo_b = actor.hyper_data._cache[B]
+            O_, C_, W_ = 16, 64, 256
+            F_ = O_ * C_ * 4
+            n_of = lambda t: topo_b["n_main"] if t == topo_b["main"] else B * topo_b["n_per"][t]
+            convs = [(et, topo_b["edges"][et].n_src, topo_b["edges"][et].n_dst, topo_b["edges"][et].n_edges)
+                     for rnd in actor.gnn.processor for et, _c in rnd.items() if et in topo_b["edges"]] if hasattr(actor.gnn, "processor") else []
+            types_used = {t for et, _, _, _ in convs for t in (et[0], et[2])}
+            n_nodes = sum(n_of(t) for t in types_used)
+            c_in = len(spec.node_types) + spec.n_vec
+            fwd = n_nodes * O_ * c_in * C_ * 2
+            fwd += sum(E * O_ * 2 * (14 * C_ + C_ * C_) + O_ * O_ * 2 * (3 * C_ + C_ * C_) for _, _, _, E in convs)
+            fwd += sum(E * O_ * C_ * C_ * 2 + 2 * E * O_ * C_ + O_ * O_ * C_ * C_ * 2 + nd * O_ * O_ * C_ * 2 + nd * O_ * 4 * C_ * W_
+                       + 8 * nd * O_ * C_ for _, _, nd, E in convs)
+            fwd += B * spec.num_actuators * O_ * C_ * (cfg.output_dim + cfg.output_dim_vec) * 2
+            n_params = upd.flat.numel()
+            obs_bytes = sum(v.numel() * 4 for k, v in pool[0].items() if k in spec.in_features)
+            byt = sum(((ns + 2 * nd) + (2 * ns + 3 * nd)) * F_ for _, ns, nd, _ in convs) + 2 * n_nodes * F_ \
+                + sum(2 * 16 * E for _, _, _, E in convs) + 2 * obs_bytes + B * (4 * A + A * A + 7) * 4 + 10 * 4 * n_params
+            t_step = ms * 1e-3
+            step_fig = {"alg_tflop": 3 * fwd / 1e12, "alg_gbyte": byt / 1e9,
+                        "mfma_f32_frac": 3 * fwd / t_step / 1e12 / PEAK_F32_MFMA, "hbm_frac": byt / t_step / 8.0e12,
+                        "note": "formulas of SURVEY.md 8(d) with the realised node / edge counts of this minibatch; time = the timed region"}
+        except Exception as e:  # never let bookkeeping break the benchmark line
+            step_fig = {"error": repr(e)}
         roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
                 "peak_note": "f32-exact MFMA peak; the kernel forms each f32 product from three bf16 MFMAs (split-bf16), whose "
                              f"f32-equivalent peak is {PEAK_BF16X3:.0f} TFLOP/s: frac_of_bf16x3",
-                "frac_of_bf16x3": d["frac_of_bf16x3"], "mfma_kernels": kernels,
+                "frac_of_bf16x3": d["frac_of_bf16x3"], "whole_step": step_fig, "mfma_kernels": kernels,
                 "per_kernel_ms_per_step": {k: v[1] for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
 
     cpu = None
