@@ -96,7 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="rigid_hepi")
     ap.add_argument("--minibatch", type=int, default=4096, help="global frames per policy update (= num_envs)")
-    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic minibatches cycled through")
+    ap.add_argument("--pool", type=int, default=8, help="time steps of the synthetic device-resident rollout the minibatches are "
+                    "sampled from (without replacement, one frame per env: train.py:128,258); the full 128-step rollout is 1.6 GB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the recorded hipGraph(s)")
@@ -136,6 +137,28 @@ def main():
         actor.forward_diag(*[pool[0][k] for k in spec.in_features], train=True)
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group,
                               use_graph=not args.no_graph)
+    # device-resident rollout [B envs, pool steps, ...] + the reference's once-per-rollout work (critic over T+1 frames, shifted GAE)
+    from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
+    T_roll = len(pool)
+    data = {k: torch.stack([f[k] for f in pool], dim=1) for k in pool[0]}
+    g_in = syn.make_gae_inputs(B, T_roll, seed=rank)
+    data.update(reward=g_in["reward"].reshape(B, T_roll, 1).to(dev), done=g_in["done"].reshape(B, T_roll, 1).to(dev),
+                terminated=g_in["terminated"].reshape(B, T_roll, 1).to(dev))
+    buf = RolloutBuffer(data)
+    drv = RolloutDriver(upd, spec, ppo_epochs=5, seed=rank)
+    next_last = {k: pool[0][k].unsqueeze(1) for k in spec.in_features}
+    torch.cuda.synchronize()
+    t_adv = time.perf_counter()
+    drv.compute_advantages(buf, next_last)
+    torch.cuda.synchronize()
+    adv_ms = 1e3 * (time.perf_counter() - t_adv)
+
+    def sampler():   # sampling without replacement, reshuffled every epoch
+        while True:
+            idx = drv.epoch_indices(B, T_roll, dev)
+            for j in range(T_roll):
+                yield idx[j]
+    mb = sampler()
 
     def barrier():
         if world > 1:
@@ -144,13 +167,13 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(3):  # set-up steps (not warmup): the first runs eagerly and builds the cached topology, the second records the
-        upd.step(pool[i % len(pool)])  # hipGraph(s), the third is the first replay
+        upd.step_from(buf, next(mb))  # hipGraph(s), the third is the first replay
     for i in range(args.warmup):
-        upd.step(pool[i % len(pool)])
+        upd.step_from(buf, next(mb))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = upd.step(pool[i % len(pool)])
+        out = upd.step_from(buf, next(mb))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -178,7 +201,7 @@ def main():
     if rank != 0 and not args.no_roofline:   # the profiled steps are collective when data parallel: every rank runs them
         upd.use_graph = False
         for i in range(6):
-            upd.step(pool[i % len(pool)])
+            upd.step_from(buf, next(mb))
     if rank == 0 and not args.no_roofline:
         # HIP events around every C-ABI launch, on the launch stream; one profiled step is discarded (first-use cost of
         # timed events lands on a random kernel) and the per-step totals are reduced with the median over the other steps.
@@ -189,7 +212,7 @@ def main():
             hip.KERNEL_TIMES = {}
             hip.KERNEL_ROWS.clear()
             hip.kernel_prof_enable(True)
-            upd.step(pool[i % len(pool)])
+            upd.step_from(buf, next(mb))
             entry = hip.kernel_time_summary()
             inner = hip.kernel_prof_summary()   # the kernels inside grl_edge_conv_bwd / grl_node_mlp_bwd, one by one
             hip.kernel_prof_enable(False)
@@ -277,7 +300,9 @@ def main():
             "config": {"workload": f"{cfg_name}, 4096 synthetic envs x 128 steps, minibatch {args.minibatch} frames "
                                    f"({B} per GPU), 640 updates per rollout", "global_minibatch": args.minibatch,
                        "parallelism": f"dp{world}"},
-            "gae_ms_per_rollout_scan": gae_ms,
+            "gae_ms_per_rollout_scan": gae_ms, "advantage_pass_ms": adv_ms,
+            "minibatches": f"sampled without replacement from a device-resident {B} x {T_roll}-frame rollout per GPU (one frame per env), "
+                           "gathered into the static inputs of the recorded step by one launch",
             "loss": {k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")},
             "roofline": roof, "cpu_baseline": cpu,
         }

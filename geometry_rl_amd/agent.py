@@ -274,6 +274,25 @@ class PolicyUpdater:
             hip.call("grl_copy_many", (ctypes.c_void_p * n)(*[j[0] for j in part]), (ctypes.c_void_p * n)(*[j[1] for j in part]),
                      (ctypes.c_longlong * n)(*[j[2] for j in part]), n)
 
+    def step_from(self, buf, idx: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One update on the minibatch made of rows ``idx`` (device int64 [B]) of a device-resident ``rollout.RolloutBuffer``.
+        With recorded graphs the rows are gathered by ONE launch straight into the static input buffers."""
+        import ctypes
+        keys = list(self.loss_module.in_features) + ["action", "loc", "var" if "var" in buf.data else "covariance_matrix",
+                                                     "sample_log_prob", "state_value", "advantage", "value_target"]
+        if not self.use_graph or self._program is None or self.steps < 2:
+            return self.step(buf.rows(idx, keys))
+        jobs = []
+        for k in keys:
+            dst, src = self._static[k], buf.flat(k)
+            if dst.dtype != src.dtype or dst[0].numel() != src.shape[1]:
+                return self.step(buf.rows(idx, keys))
+            jobs.append((dst.data_ptr(), src.data_ptr(), src.shape[1] * src.element_size()))
+        n = len(jobs)
+        hip.call("grl_gather_rows_many", (ctypes.c_void_p * n)(*[j[0] for j in jobs]), (ctypes.c_void_p * n)(*[j[1] for j in jobs]),
+                 (ctypes.c_longlong * n)(*[j[2] for j in jobs]), n, idx, int(idx.numel()))
+        return self.step(self._static)
+
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         self.loss_module._global_steps = self.steps
         self.steps += 1

@@ -201,6 +201,23 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs jobs) {
     d1[i] = s1[i];
 }
 
+// ---- minibatch assembly from a device-resident rollout: rows idx[0..n_rows) of several [R, width] tensors in one launch ---------
+// (replaces the reference's CPU replay storage + sampler + per-minibatch H2D copy, examples/torchrl/train.py:120,128,258-261)
+struct GatherJobs {
+  unsigned int* dst[COPY_MAX];
+  const unsigned int* src[COPY_MAX];
+  int words[COPY_MAX];   // 4-byte words per row
+};
+__global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherJobs jobs, const long long* __restrict__ idx, int n_rows) {
+  const int k = blockIdx.y;
+  const int wpr = jobs.words[k];
+  const long long total = (long long)n_rows * wpr;
+  for (long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(w / wpr), c = (int)(w - (long long)r * wpr);
+    jobs.dst[k][w] = jobs.src[k][idx[r] * wpr + c];
+  }
+}
+
 // ---- per-kernel event timing (off by default; bench.py's roofline leg switches it on for a few steps) ---------------------------
 #include <string>
 #include <vector>
@@ -315,6 +332,28 @@ int grl_copy_many(void* const* dst, const void* const* src, const long long* byt
   if (bx < 1) bx = 1;
   if (bx > 128) bx = 128;
   hipLaunchKernelGGL(copy_many_kernel, dim3((int)bx, n), dim3(256), 0, stream, jobs);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst[k][i, :] = src[k][idx[i], :] for k < n <= 24 tensors with rows of row_bytes[k] bytes (multiples of 4); idx: DEVICE int64[n_rows]
+int grl_gather_rows_many(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
+                         hipStream_t stream) {
+  if (n <= 0 || n_rows <= 0) return 0;
+  if (n > COPY_MAX) return -2;
+  GatherJobs jobs{};
+  long long mx = 0;
+  for (int i = 0; i < n; ++i) {
+    if (row_bytes[i] % 4) return -3;
+    jobs.dst[i] = reinterpret_cast<unsigned int*>(dst[i]);
+    jobs.src[i] = reinterpret_cast<const unsigned int*>(src[i]);
+    jobs.words[i] = (int)(row_bytes[i] / 4);
+    if (row_bytes[i] / 4 * n_rows > mx) mx = row_bytes[i] / 4 * n_rows;
+  }
+  long long bx = (mx + 1023) / 1024;
+  if (bx < 1) bx = 1;
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(gather_rows_many_kernel, dim3((int)bx, n), dim3(256), 0, stream, jobs, idx, n_rows);
   GRL_CHECK_LAUNCH();
   return 0;
 }

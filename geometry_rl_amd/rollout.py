@@ -1,0 +1,95 @@
+"""The once-per-rollout part of the training loop around the policy update (examples/torchrl/train.py:249-316):
+
+    values over the [N, T+1] frames  ->  shifted GAE  ->  ppo_epochs x (N*T / mini_batch) minibatch updates, each minibatch
+    drawn WITHOUT replacement.
+
+The reference keeps the rollout in a CPU ``LazyTensorStorage`` and moves every minibatch to the device (train.py:120,128,261);
+here the rollout stays resident in HBM (4096 x 128 rigid frames are 1.6 GB) and a minibatch is assembled by ONE gather launch
+(``grl_gather_rows_many``) straight into the static input buffers of the recorded update step.
+
+Minibatches are env-aligned: minibatch j takes, for every environment n, the frame (n, perm_n[j]) of a per-environment random
+permutation of the T time steps -- every frame is used exactly once per epoch (sampling without replacement, mini_batch_size =
+num_envs as in configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:44,138) and position n of every minibatch belongs to environment
+n, which is what the graph topology cached per batch size assumes (rigid_tasks_data.py:254-255)."""
+from typing import Dict, Iterator, Optional
+
+import torch
+
+from . import agent as _agent
+
+PPO_KEYS = ("action", "loc", "var", "sample_log_prob", "state_value", "advantage", "value_target")
+
+
+class RolloutBuffer:
+    """Device-resident rollout: every tensor is [N, T, ...]; ``flat(k)`` views it as rows [N*T, width]."""
+
+    def __init__(self, data: Dict[str, torch.Tensor]):
+        some = next(iter(data.values()))
+        self.N, self.T = some.shape[0], some.shape[1]
+        self.data = {k: v.contiguous() for k, v in data.items()}
+        for k, v in self.data.items():
+            if v.shape[:2] != (self.N, self.T):
+                raise ValueError(f"{k}: expected leading dims [{self.N}, {self.T}], got {tuple(v.shape)}")
+
+    def flat(self, k: str) -> torch.Tensor:
+        v = self.data[k]
+        return v.reshape(self.N * self.T, -1)
+
+    def rows(self, idx: torch.Tensor, keys) -> Dict[str, torch.Tensor]:
+        """Plain (allocating) minibatch: rows ``idx`` of the given keys."""
+        return {k: self.flat(k).index_select(0, idx) for k in keys}
+
+
+class RolloutDriver:
+    def __init__(self, updater: "_agent.PolicyUpdater", spec, gamma: float = 0.99, lmbda: float = 0.95, ppo_epochs: int = 5,
+                 seed: int = 0):
+        self.updater, self.spec = updater, spec
+        self.gamma, self.lmbda, self.ppo_epochs = gamma, lmbda, ppo_epochs
+        self.gen = None
+        self.seed = seed
+
+    # ---- train.py:134-140,249-251: critic over the T+1 frames of every environment, then the shifted GAE scan
+    @torch.no_grad()
+    def compute_advantages(self, buf: RolloutBuffer, next_last: Dict[str, torch.Tensor], chunk: int = 16) -> None:
+        """``next_last``: observation groups of the frame after the last one, [N, 1, width].  Writes ``state_value``,
+        ``advantage`` and ``value_target`` [N, T, 1] into the buffer."""
+        critic = self.updater.loss_module.critic_network
+        N, T = buf.N, buf.T
+        vals = torch.empty(N, T + 1, device=buf.data["reward"].device, dtype=torch.float32)
+        for t0 in range(0, T + 1, chunk):   # time-chunked so the critic's Python loop over T stays short per call
+            t1 = min(t0 + chunk, T + 1)
+            obs = []
+            for k in self.spec.in_features:
+                x = buf.data[k]
+                x = torch.cat([x, next_last[k]], dim=1) if t1 > T else x
+                obs.append(x[:, t0:t1].contiguous())
+            vals[:, t0:t1] = critic(*obs, train=False).reshape(N, t1 - t0)
+        adv, tgt = _agent.gae(buf.data["reward"].reshape(N, T), buf.data["done"].reshape(N, T), buf.data["terminated"].reshape(N, T),
+                              vals, self.gamma, self.lmbda)
+        buf.data["state_value"] = vals[:, :T].reshape(N, T, 1).contiguous()
+        buf.data["advantage"] = adv.reshape(N, T, 1)
+        buf.data["value_target"] = tgt.reshape(N, T, 1)
+
+    # ---- sampler without replacement (train.py:128,258)
+    def epoch_indices(self, N: int, T: int, device) -> torch.Tensor:
+        """[T, N] int64 row indices into the flattened [N*T] rollout: row j = minibatch j."""
+        if self.gen is None:
+            self.gen = torch.Generator(device=device)
+            self.gen.manual_seed(self.seed)
+        perm = torch.argsort(torch.rand(N, T, device=device, generator=self.gen), dim=1)       # per-environment permutation of time
+        return (torch.arange(N, device=device)[:, None] * T + perm).t().contiguous()
+
+    def minibatches(self, buf: RolloutBuffer) -> Iterator[torch.Tensor]:
+        for _ in range(self.ppo_epochs):
+            idx = self.epoch_indices(buf.N, buf.T, next(iter(buf.data.values())).device)
+            for j in range(buf.T):
+                yield idx[j]
+
+    def run(self, buf: RolloutBuffer, next_last: Optional[Dict[str, torch.Tensor]] = None):
+        """One rollout pass: [GAE] + ppo_epochs * T policy updates.  Returns the loss dict of the last update."""
+        if next_last is not None:
+            self.compute_advantages(buf, next_last)
+        out = None
+        for idx in self.minibatches(buf):
+            out = self.updater.step_from(buf, idx)
+        return out

@@ -146,6 +146,10 @@ int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned 
 int grl_build_features(const long long* descs, int n_desc, hipStream_t stream);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */
 int grl_copy_many(void* const* dst, const void* const* src, const long long* bytes, int n, hipStream_t stream);
+/* minibatch assembly from a device-resident rollout (train.py:120,128,258-261): dst[k][i,:] = src[k][idx[i],:] for k < n <= 24
+ * tensors in one launch; dst / src / row_bytes: HOST arrays; idx: DEVICE int64[n_rows]; row_bytes multiples of 4 */
+int grl_gather_rows_many(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
+                         hipStream_t stream);
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
 
 
