@@ -218,6 +218,72 @@ __global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherJobs jobs, 
   }
 }
 
+// ---- running observation normalisation + clip (collector side: geometry_rl/torchrl/envs/transforms.py:141-163 NDVecNorm on
+//      torchrl's VecNorm; configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:47-72) ----------------------------------------------
+// x viewed as [rows, K] (K = 3 for the vector groups: one statistic per axis shared by all points and environments; K = D for the
+// scalar group).  state = [sum K | ssq K | count 1] (float32 like the reference's tensordict entries):
+//   sum = decay*sum + colsum(x); ssq = decay*ssq + colsum(x^2); count = decay*count + rows
+//   mean = sum/count; std = sqrt(max(ssq/count - mean^2, eps)); y = clip((x - mean)/max(std, eps), lo, hi)
+constexpr int VN_KMAX = 64, VN_BLOCKS = 256;
+__global__ __launch_bounds__(256) void vecnorm_partial_kernel(const float* __restrict__ x, long long rows, int K,
+                                                              double* __restrict__ partial /*[VN_BLOCKS][2*K]*/) {
+  __shared__ double red[256][2];
+  // thread t handles column t % K of rows (t / K) + m * rows_per_iter: coalesced along the row-major layout
+  const int per = 256 / K;                     // rows covered by one sweep of the workgroup
+  const int c = threadIdx.x % K, r0 = threadIdx.x / K;
+  double s = 0, q = 0;
+  if (r0 < per)
+    for (long long r = (long long)blockIdx.x * per + r0; r < rows; r += (long long)gridDim.x * per) {
+      const double v = x[r * K + c];
+      s += v;
+      q += v * v;
+    }
+  red[threadIdx.x][0] = s;
+  red[threadIdx.x][1] = q;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double ts = 0, tq = 0;
+    for (int j = 0; j < per; ++j) { ts += red[j * K + threadIdx.x][0]; tq += red[j * K + threadIdx.x][1]; }
+    partial[(size_t)blockIdx.x * 2 * K + threadIdx.x] = ts;
+    partial[(size_t)blockIdx.x * 2 * K + K + threadIdx.x] = tq;
+  }
+}
+__global__ void vecnorm_update_kernel(const double* __restrict__ partial, int n_blocks, long long rows, int K, float decay, float eps,
+                                      int update, float* __restrict__ state, float* __restrict__ mean_std /*[2*K]*/) {
+  const int c = threadIdx.x;   // one wave; lanes >= K idle
+  float sum = 0.f, ssq = 0.f, count = 1.f;
+  if (c < K) {
+    sum = state[c]; ssq = state[K + c]; count = state[2 * K];
+    if (update) {
+      double ts = 0, tq = 0;
+      for (int b = 0; b < n_blocks; ++b) { ts += partial[(size_t)b * 2 * K + c]; tq += partial[(size_t)b * 2 * K + K + c]; }
+      sum = sum * decay + (float)ts;
+      ssq = ssq * decay + (float)tq;
+      count = count * decay + (float)rows;
+    }
+    const float mean = sum / count;
+    const float std_ = sqrtf(fmaxf(ssq / count - mean * mean, eps));
+    mean_std[c] = mean;
+    mean_std[K + c] = fmaxf(std_, eps);
+  }
+  __syncthreads();   // every lane has read the old count before lane 0 overwrites it
+  if (update && c < K) {
+    state[c] = sum;
+    state[K + c] = ssq;
+    if (c == 0) state[2 * K] = count;
+  }
+}
+__global__ __launch_bounds__(256) void vecnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean_std, long long n,
+                                                            int K, float lo, float hi, float* __restrict__ y_norm,
+                                                            float* __restrict__ y_clip) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % K);
+    const float v = x[i];
+    if (y_norm) y_norm[i] = fminf(fmaxf((v - mean_std[c]) / mean_std[K + c], lo), hi);
+    if (y_clip) y_clip[i] = fminf(fmaxf(v, lo), hi);
+  }
+}
+
 // ---- per-kernel event timing (off by default; bench.py's roofline leg switches it on for a few steps) ---------------------------
 #include <string>
 #include <vector>
@@ -357,6 +423,32 @@ int grl_gather_rows_many(void* const* dst, const void* const* src, const long lo
   GRL_CHECK_LAUNCH();
   return 0;
 }
+
+// x [rows, K] (K <= 64); state: device float[2K+1] = [sum | ssq | count] (updated in place when update != 0, as in training; frozen
+// statistics otherwise); scratch: device, >= 256*2K doubles + 2K floats; y_norm / y_clip: optional outputs [rows, K]
+int grl_vecnorm(const float* x, long long rows, int K, float decay, float eps, int update, float lo, float hi, float* state,
+                void* scratch, float* y_norm, float* y_clip, hipStream_t stream) {
+  if (K < 1 || K > VN_KMAX) return -2;
+  if (rows <= 0) return 0;
+  double* partial = reinterpret_cast<double*>(scratch);
+  float* mean_std = reinterpret_cast<float*>(partial + (size_t)VN_BLOCKS * 2 * K);
+  const int per = 256 / K;
+  long long nb = (rows + per - 1) / per;
+  if (nb > VN_BLOCKS) nb = VN_BLOCKS;
+  if (update) {
+    hipLaunchKernelGGL(vecnorm_partial_kernel, dim3((int)nb), dim3(256), 0, stream, x, rows, K, partial);
+    GRL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(vecnorm_update_kernel, dim3(1), dim3(64), 0, stream, partial, (int)nb, rows, K, decay, eps, update, state, mean_std);
+  GRL_CHECK_LAUNCH();
+  const long long n = rows * K;
+  long long ab = (n + 1023) / 1024;
+  if (ab > 1024) ab = 1024;
+  hipLaunchKernelGGL(vecnorm_apply_kernel, dim3((int)(ab < 1 ? 1 : ab)), dim3(256), 0, stream, x, mean_std, n, K, lo, hi, y_norm, y_clip);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+int grl_vecnorm_scratch_bytes(int K) { return (int)(sizeof(double) * VN_BLOCKS * 2 * K + sizeof(float) * 2 * K); }
 
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream) {
   if (n_points > KNN_PMAX || k > 8 || k < 1) return -2;

@@ -150,6 +150,13 @@ int grl_copy_many(void* const* dst, const void* const* src, const long long* byt
  * tensors in one launch; dst / src / row_bytes: HOST arrays; idx: DEVICE int64[n_rows]; row_bytes multiples of 4 */
 int grl_gather_rows_many(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
                          hipStream_t stream);
+/* ---- collector-side observation transform: NDVecNorm / VecNorm running normalisation + ClipTransform,
+ * geometry_rl/torchrl/envs/transforms.py:141-163 (on torchrl's VecNorm), configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:47-72.
+ * x [rows, K<=64]; state: device float[2K+1] = [sum | ssq | count], updated in place when update != 0;
+ * y_norm = clip((x - mean)/max(std, eps)), y_clip = clip(x) (either may be NULL); scratch: grl_vecnorm_scratch_bytes(K) device bytes */
+int grl_vecnorm(const float* x, long long rows, int K, float decay, float eps, int update, float lo, float hi, float* state,
+                void* scratch, float* y_norm, float* y_clip, hipStream_t stream);
+int grl_vecnorm_scratch_bytes(int K);
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
 
 
