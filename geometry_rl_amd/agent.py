@@ -333,3 +333,34 @@ def gae(reward, done, terminated, values, gamma=0.99, lmbda=0.95):
     hip.call("grl_gae_scan", reward.contiguous(), done.to(torch.uint8).contiguous(), terminated.to(torch.uint8).contiguous(),
              values.contiguous(), adv, tgt, N, T, float(gamma), float(lmbda))
     return adv, tgt
+
+
+# ---------------------------------------------------------------------------------------------------- checkpoints
+# train.py:336-368 saves {"env", "actor": actor.state_dict(), "critic": critic.state_dict(), "reward"} where ``actor`` is torchrl's
+# ProbabilisticActor(TensorDictModule(policy)) -- a TensorDictSequential whose first entry wraps the policy -- and ``critic`` is
+# ValueOperator(BaseCritic) (utils_algo_graph.py:146-158,200-203).  The wrappers only add key prefixes.
+ACTOR_PREFIX = "module.0.module."
+CRITIC_PREFIX = "module."
+
+
+def _strip(sd, prefix):
+    return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
+
+
+def load_reference_checkpoint(ckpt, actor, critic=None, strict=True):
+    """Load a reference ``model_checkpoint_*.pth`` (path or the loaded dict) into the HIP-backed actor / critic (play.py:194-205).
+    Parameter names are identical (PyG ModuleDict key mangling and the ``callibrated`` buffers included); returns ckpt["reward"]."""
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+    actor.load_state_dict(_strip(ckpt["actor"], ACTOR_PREFIX), strict=strict)
+    if critic is not None and "critic" in ckpt:
+        critic.load_state_dict(_strip(ckpt["critic"], CRITIC_PREFIX), strict=strict)
+    return ckpt.get("reward")
+
+
+def reference_checkpoint(actor, critic, reward=0.0, env_state=None):
+    """The dict train.py:343-351 writes, so the reference's play.py can load a policy trained here."""
+    return {"env": env_state if env_state is not None else {},
+            "actor": {ACTOR_PREFIX + k: v.detach().cpu().clone() for k, v in actor.state_dict().items()},
+            "critic": {CRITIC_PREFIX + k: v.detach().cpu().clone() for k, v in critic.state_dict().items()},
+            "reward": reward}
