@@ -96,10 +96,11 @@ class PolicyUpdater:
         a = [p for p in loss_module.actor_network.parameters() if p.requires_grad]
         c = [p for p in loss_module.critic_network.parameters() if p.requires_grad]
         self.params = a + c
-        self.n_actor = sum(p.numel() for p in a)
-        n = sum(p.numel() for p in self.params)
+        pad4 = lambda k: (k + 3) & ~3   # every parameter starts 16-byte aligned (vector loads in the weight-staging prologues)
+        self.n_actor = sum(pad4(p.numel()) for p in a)
+        n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.gflat = torch.zeros(n, device=dev, dtype=torch.float32)
         off = 0
         for p in self.params:
@@ -107,7 +108,7 @@ class PolicyUpdater:
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.gflat[off:off + k].view_as(p)
-            off += k
+            off += pad4(k)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
@@ -144,9 +145,9 @@ class PolicyUpdater:
             with torch.no_grad():
                 vf.train(True)
                 _, x = vf.hyper_data.build_data(*st["obs"], train=True)
-                # one zeroed fp64 workspace per step: critic sums (8) | advantage sums (2) | loss sums (11) | maxes (2 x u32) | clip (2)
+                # one zeroed fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (11) | maxes (2 x u32) | clip (2)
                 zw = st["zw"] = torch.zeros(24, device=x.device, dtype=torch.float64)
-                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world, zero_buf=zw[0:8])
+                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
                 st["pipe"].fwd1()
                 st["adv"] = None
                 if m.normalize_advantage and x.shape[0] * world > 1:
@@ -201,16 +202,16 @@ class PolicyUpdater:
 
         plan = [("run", s0)]
         if world > 1:
-            plan += [("sum", lambda: st["pipe"].stats[0:2]), ("sum", lambda: st["adv"])]
+            plan += [("sum", lambda: st["pipe"].stats1), ("sum", lambda: st["adv"])]
         plan += [("run", s1)]
         if world > 1:
-            plan += [("sum", lambda: st["pipe"].stats[2:4])]
+            plan += [("sum", lambda: st["pipe"].stats2)]
         plan += [("run", s2)]
         if world > 1:
-            plan += [("sum", lambda: st["pipe"].bst[0:2])]
+            plan += [("sum", lambda: st["pipe"].bst2)]
         plan += [("run", s3)]
         if world > 1:
-            plan += [("sum", lambda: st["pipe"].bst[2:4])]
+            plan += [("sum", lambda: st["pipe"].bst1)]
         plan += [("run", s4)]
         if world > 1:  # loss terms are already scaled by 1/B_global
             plan += [("sum", lambda: self.gflat), ("sum", lambda: st["sums"]), ("max", lambda: st["maxes"])]

@@ -3,10 +3,14 @@
 //   y1 = relu(LNg(h1))                      LNg: (h - mean_all) / (std_all + 1e-5) * gamma + beta  -- statistics over the
 //   h2 = Lin2(y1); z = sum_n h2             whole tensor, i.e. over the whole (global) minibatch
 //   u1 = Lin3(z); y2 = relu(LNg(u1)); u2 = Lin4(y2); V = Linv(u2)
-// The whole-tensor statistics split the pass into three launches forward and three backward; each launch leaves the
-// sums the next one needs in a tiny fp64 buffer (which is also what a data-parallel run all-reduces between launches).
-// One wave per sample; thread j owns feature j; weights live in LDS; weight gradients accumulate in registers over a
-// grid-stride loop and leave as per-block partial rows.
+// The whole-tensor statistics split the pass into three launches forward and three backward; each launch leaves the sums the
+// next one needs as per-workgroup fp64 pairs in a slot array (NSLOT pairs, unused slots zeroed by the producer) which the
+// consumer adds up in a fixed order -- no atomics (same-address fp64 atomics serialise in L2 at ~15 ns each: 1024 of them were a
+// fixed 15 us per launch) and bit-reproducible.  A data-parallel run all-reduces the slot arrays between the launches.
+// Four waves per workgroup, one wave per sample (or per node row), thread j owns feature j; 64x64 weights live in registers
+// (row j, and column j where the transpose is needed) or LDS; weight gradients accumulate in registers over a grid-stride loop
+// and leave as ONE partial row per workgroup.  Lin2 is followed directly by the sum over nodes, so z = W2 (sum_n y1_n) + n b2:
+// one 64x64 product per SAMPLE instead of one per node row, forward as well as backward.
 #include "grl_common.h"
 
 namespace {
@@ -26,10 +30,12 @@ GRL_DEVINL double wave_sum_d(double v) {
   return v;
 }
 
-// Wave sums -> one pair of fp64 atomics per WORKGROUP: same-address atomics serialise in L2 (~15 ns each, measured: 8192 of
-// them cost more than the kernel they ended), so their number, not the arithmetic, decides these kernels' run time.
-template <int WAVES>
-GRL_DEVINL void block_add_stats(double s0, double s1, double* __restrict__ out) {
+constexpr int DS_WAVES = 4;
+constexpr int NSLOT = 256;   // statistic slots = upper bound of every stage's grid
+
+// Wave sums -> this workgroup's slot (plain stores); workgroup 0 clears the slots no workgroup owns.
+template <int WAVES = DS_WAVES>
+GRL_DEVINL void block_put_stats(double s0, double s1, double* __restrict__ slots) {
   __shared__ double red_stats[WAVES][2];
   s0 = wave_sum_d(s0);
   s1 = wave_sum_d(s1);
@@ -40,13 +46,34 @@ GRL_DEVINL void block_add_stats(double s0, double s1, double* __restrict__ out) 
     double t0 = red_stats[0][0], t1 = red_stats[0][1];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) { t0 += red_stats[w][0]; t1 += red_stats[w][1]; }
-    atomicAdd(out, t0);
-    atomicAdd(out + 1, t1);
+    slots[2 * blockIdx.x] = t0;
+    slots[2 * blockIdx.x + 1] = t1;
   }
+  if (blockIdx.x == 0)
+    for (int s_ = gridDim.x + threadIdx.x; s_ < NSLOT; s_ += blockDim.x) { slots[2 * s_] = 0.0; slots[2 * s_ + 1] = 0.0; }
+}
+
+// Totals of up to DS_WAVES slot arrays (wave w adds up array w: lane-strided, then a butterfly -- a fixed order), via LDS.
+template <int K>
+GRL_DEVINL void slot_totals(const double* const (&arr)[K], double (&tot)[K][2]) {
+  __shared__ double tot_s[K][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < K) {
+    const double2* sl = reinterpret_cast<const double2*>(arr[wave]);
+    double a = 0, b = 0;
+#pragma unroll
+    for (int q = 0; q < NSLOT / 64; ++q) { const double2 v = sl[lane + 64 * q]; a += v.x; b += v.y; }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (lane == 0) { tot_s[wave][0] = a; tot_s[wave][1] = b; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) { tot[k][0] = tot_s[k][0]; tot[k][1] = tot_s[k][1]; }
 }
 
 struct LnStat { float mean, s, sigma; };  // s = sigma + eps
-GRL_DEVINL LnStat ln_stat(const double* sums, double count) {
+GRL_DEVINL LnStat ln_stat(const double (&sums)[2], double count) {
   const double m = sums[0] / count;
   double var = sums[1] / count - m * m;
   if (var < 0) var = 0;
@@ -57,31 +84,92 @@ GRL_DEVINL LnStat ln_stat(const double* sums, double count) {
   return st;
 }
 
-// ---- forward 1: h1 = x W1^T + b1 ; stats1 += (sum h1, sum h1^2).  Rows (sample, node) are independent: 4 waves per workgroup,
-//      grid-stride over the flattened rows (one wave per sample left every load latency exposed: 1 wave per SIMD).
-constexpr int DS_WAVES = 4;
-__global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd1(const float* __restrict__ x, const float* __restrict__ W1,
+// row j of a row-major 64x64 matrix -> registers
+GRL_DEVINL void load_row64(const float* __restrict__ Wm, int j, float (&w)[H]) {
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(Wm + j * H + k);
+    w[k] = a.x; w[k + 1] = a.y; w[k + 2] = a.z; w[k + 3] = a.w;
+  }
+}
+// 64-term dot product of an LDS vector (float4 broadcasts: 16 reads) with a register row
+GRL_DEVINL float dot64(const float* __restrict__ ys /*LDS, 16-byte aligned*/, const float (&w)[H]) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    const float4 y = *reinterpret_cast<const float4*>(ys + k);
+    a0 = fmaf(y.x, w[k], a0); a1 = fmaf(y.y, w[k + 1], a1); a2 = fmaf(y.z, w[k + 2], a2); a3 = fmaf(y.w, w[k + 3], a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+// acc[k] += s * ys[k]
+GRL_DEVINL void axpy64(const float* __restrict__ ys, float s_, float (&acc)[H]) {
+#pragma unroll
+  for (int k = 0; k < H; k += 4) {
+    const float4 y = *reinterpret_cast<const float4*>(ys + k);
+    acc[k] = fmaf(s_, y.x, acc[k]); acc[k + 1] = fmaf(s_, y.y, acc[k + 1]);
+    acc[k + 2] = fmaf(s_, y.z, acc[k + 2]); acc[k + 3] = fmaf(s_, y.w, acc[k + 3]);
+  }
+}
+// the four waves' register rows acc[.] (thread j = matrix row j) summed in wave order into out[64][64]; buf: LDS [64][65]
+GRL_DEVINL void fold_rows64(const float (&acc)[H], float* __restrict__ buf, float* __restrict__ out) {
+  const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w_ = 0; w_ < DS_WAVES; ++w_) {
+    if (wave == w_) {
+#pragma unroll
+      for (int k = 0; k < H; ++k) buf[j * (H + 1) + k] = w_ == 0 ? acc[k] : buf[j * (H + 1) + k] + acc[k];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < H * H; i += 64 * DS_WAVES) out[i] = buf[(i >> 6) * (H + 1) + (i & 63)];
+  __syncthreads();
+}
+// per-thread scalars of the four waves summed in wave order: out[q * 64 + j]; buf: LDS [Q][DS_WAVES][64]
+template <int Q>
+GRL_DEVINL void fold_scalars(const float (&v)[Q], float* __restrict__ buf, float* const (&out)[Q]) {
+  const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) buf[(q * DS_WAVES + wave) * H + j] = v[q];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float t = buf[(q * DS_WAVES) * H + j];
+#pragma unroll
+      for (int w_ = 1; w_ < DS_WAVES; ++w_) t += buf[(q * DS_WAVES + w_) * H + j];
+      out[q][j] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- forward 1: h1 = x W1^T + b1 ; slot sums of (h1, h1^2).  Rows (sample, node) are independent: grid-stride over the
+//      flattened rows, eight rows in flight per wave; a row's d inputs arrive with ONE load (lane k < d fetches x[row][k]) and
+//      are handed round with v_readlane.
+//      These two row kernels are latency-bound (one 60-byte and one 256-byte access per row): sixteen waves per workgroup keep
+//      4096 waves x 4 rows in flight under the NSLOT-workgroup cap.
+constexpr int ROWS_IN_FLIGHT = 4;
+constexpr int ROW_WAVES = 16;
+__global__ __launch_bounds__(64 * ROW_WAVES) void ds_fwd1(const float* __restrict__ x, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, float* __restrict__ h1,
-                                                        double* __restrict__ stats, int B, int n, int d) {
+                                                        double* __restrict__ slots, int B, int n, int d) {
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float w[DMAX];
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) w[k] = k < d ? W1[j * d + k] : 0.f;
   const float bj = b1[j];
   double s0 = 0, s1 = 0;
-  // four rows in flight per wave; a row's d inputs arrive with ONE load (lane k < d fetches x[row][k]) and are handed round
-  // with v_readlane -- d dependent broadcast loads per row left the kernel latency-bound
   const long long rows = (long long)B * n;
-  const long long stride = (long long)gridDim.x * DS_WAVES;
-  for (long long row0 = blockIdx.x * DS_WAVES + wave; row0 < rows; row0 += 4 * stride) {
-    float xv[4];
+  const long long stride = (long long)gridDim.x * ROW_WAVES;
+  for (long long row0 = blockIdx.x * ROW_WAVES + wave; row0 < rows; row0 += ROWS_IN_FLIGHT * stride) {
+    float xv[ROWS_IN_FLIGHT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
       const long long row = row0 + u * stride;
       xv[u] = (row < rows && j < d) ? x[row * d + j] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
       const long long row = row0 + u * stride;
       if (row >= rows) break;
       float acc = bj;
@@ -93,130 +181,121 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd1(const float* __restrict
       s1 += (double)acc * acc;
     }
   }
-  block_add_stats<DS_WAVES>(s0, s1, stats);
+  block_put_stats<ROW_WAVES>(s0, s1, slots);
 }
 
-// ---- forward 2: y1 = relu(LNg(h1)); h2 = y1 W2^T + b2; z = sum_n h2; u1 = z W3^T + b3; stats2 += (sum u1, sum u1^2)
-//      Thread j keeps row j of W2 and of W3 in registers; the activation vector is exchanged through a wave-private LDS line and
-//      read back as float4 broadcasts (16 LDS reads per 64-term dot product instead of 128).  4 waves (samples) per workgroup.
-GRL_DEVINL float dot64(const float* __restrict__ ys /*LDS, 16-byte aligned*/, const float (&w)[H]) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-  for (int k = 0; k < H; k += 4) {
-    const float4 y = *reinterpret_cast<const float4*>(ys + k);
-    a0 = fmaf(y.x, w[k], a0); a1 = fmaf(y.y, w[k + 1], a1); a2 = fmaf(y.z, w[k + 2], a2); a3 = fmaf(y.w, w[k + 3], a3);
-  }
-  return (a0 + a1) + (a2 + a3);
-}
-__global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict__ h1, const double* __restrict__ stats1, double count1,
+// ---- forward 2: y1 = relu(LNg(h1)); z = W2 sum_n y1 + n b2; u1 = z W3^T + b3; slot sums of (u1, u1^2)
+//      Thread j keeps row j of W2 and of W3 in registers; vectors are exchanged through wave-private LDS lines.
+__global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict__ h1, const double* __restrict__ slots1, double count1,
                                                         const float* __restrict__ g1, const float* __restrict__ be1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
                                                         const float* __restrict__ W3, const float* __restrict__ b3,
-                                                        float* __restrict__ z, float* __restrict__ u1, double* __restrict__ stats2,
+                                                        float* __restrict__ z, float* __restrict__ u1, double* __restrict__ slots2,
                                                         int B, int n) {
   __shared__ __attribute__((aligned(16))) float ys_all[DS_WAVES][2][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float (*ys)[H] = ys_all[wave];
   float w2[H], w3[H];
-#pragma unroll
-  for (int k = 0; k < H; k += 4) {
-    const float4 a = *reinterpret_cast<const float4*>(W2 + j * H + k), c = *reinterpret_cast<const float4*>(W3 + j * H + k);
-    w2[k] = a.x; w2[k + 1] = a.y; w2[k + 2] = a.z; w2[k + 3] = a.w;
-    w3[k] = c.x; w3[k + 1] = c.y; w3[k + 2] = c.z; w3[k + 3] = c.w;
-  }
-  const LnStat st = ln_stat(stats1, count1);
+  load_row64(W2, j, w2);
+  load_row64(W3, j, w3);
+  double tot[1][2];
+  const double* const arr[1] = {slots1};
+  slot_totals<1>(arr, tot);
+  const LnStat st = ln_stat(tot[0], count1);
   const float gj = g1[j], bj = be1[j], b2j = b2[j], b3j = b3[j];
   double s0 = 0, s1 = 0;
   for (int b = blockIdx.x * DS_WAVES + wave; b < B; b += gridDim.x * DS_WAVES) {
-    float zj = 0.f;
     const float* hrow = h1 + (size_t)b * n * H + j;
-    float hv = hrow[0];
-    for (int i = 0; i < n; ++i) {   // wave-private double-buffered line: no barrier, LDS ops of a wave complete in order
-      const float hn = i + 1 < n ? hrow[(size_t)(i + 1) * H] : 0.f;
-      float* line = ys[i & 1];
-      line[j] = fmaxf((hv - st.mean) / st.s * gj + bj, 0.f);
-      __builtin_amdgcn_wave_barrier();
-      zj += b2j + dot64(line, w2);
-      hv = hn;
+    float ysum = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 8) {   // eight rows in flight
+      float hv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hv[u] = i0 + u < n ? hrow[(size_t)(i0 + u) * H] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < n) ysum += fmaxf((hv[u] - st.mean) / st.s * gj + bj, 0.f);
     }
-    z[(size_t)b * H + j] = zj;
-    float* line = ys[n & 1];
-    line[j] = zj;
+    ys[0][j] = ysum;
     __builtin_amdgcn_wave_barrier();
-    const float acc = b3j + dot64(line, w3);
+    const float zj = fmaf((float)n, b2j, dot64(ys[0], w2));
+    z[(size_t)b * H + j] = zj;
+    ys[1][j] = zj;
+    __builtin_amdgcn_wave_barrier();
+    const float acc = b3j + dot64(ys[1], w3);
     u1[(size_t)b * H + j] = acc;
     s0 += acc;
     s1 += (double)acc * acc;
+    __builtin_amdgcn_wave_barrier();
   }
-  block_add_stats<DS_WAVES>(s0, s1, stats2);
+  block_put_stats(s0, s1, slots2);
 }
 
 // ---- forward 3: y2 = relu(LNg(u1)); u2 = y2 W4^T + b4; V = u2 . wv + bv
-__global__ __launch_bounds__(64) void ds_fwd3(const float* __restrict__ u1, const double* __restrict__ stats2, double count2,
-                                             const float* __restrict__ g2, const float* __restrict__ be2,
-                                             const float* __restrict__ W4, const float* __restrict__ b4,
-                                             const float* __restrict__ wv, const float* __restrict__ bv, float* __restrict__ value,
-                                             int B) {
-  __shared__ float W4s[H * (H + 1)], ys[H];
-  const int j = threadIdx.x;
-  for (int i = j; i < H * H; i += 64) W4s[(i / H) * (H + 1) + (i % H)] = W4[i];
-  __syncthreads();
-  const LnStat st = ln_stat(stats2, count2);
+__global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd3(const float* __restrict__ u1, const double* __restrict__ slots2, double count2,
+                                                        const float* __restrict__ g2, const float* __restrict__ be2,
+                                                        const float* __restrict__ W4, const float* __restrict__ b4,
+                                                        const float* __restrict__ wv, const float* __restrict__ bv,
+                                                        float* __restrict__ value, int B) {
+  __shared__ __attribute__((aligned(16))) float ys_all[DS_WAVES][H];
+  const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ys = ys_all[wave];
+  float w4[H];
+  load_row64(W4, j, w4);
+  double tot[1][2];
+  const double* const arr[1] = {slots2};
+  slot_totals<1>(arr, tot);
+  const LnStat st = ln_stat(tot[0], count2);
   const float gj = g2[j], bj = be2[j], b4j = b4[j], wvj = wv[j], bv0 = bv[0];
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int b = blockIdx.x * DS_WAVES + wave; b < B; b += gridDim.x * DS_WAVES) {
     ys[j] = fmaxf((u1[(size_t)b * H + j] - st.mean) / st.s * gj + bj, 0.f);
-    __syncthreads();
-    float acc = b4j;
-#pragma unroll 16
-    for (int k = 0; k < H; ++k) acc += ys[k] * W4s[j * (H + 1) + k];
+    __builtin_amdgcn_wave_barrier();
+    const float acc = b4j + dot64(ys, w4);
     const float v = wave_sum(acc * wvj);
     if (j == 0) value[b] = v + bv0;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// ---- backward 3: from dV.  Writes q2 = dy2 * relu'(.) * gamma2 (the LNg input-gradient numerator) and accumulates
-//      bstats2 += (sum q2, sum q2 * xhat2); weight grads of Lin4, Linv and LNg2 affine.
+// ---- backward 3: from dV.  Writes q2 = dy2 * relu'(.) * gamma2 (the LNg input-gradient numerator), slot sums of
+//      (q2, q2 * xhat2); weight grads of Lin4, Linv and LNg2 affine.  Row j AND column j of W4 in registers.
 // partial row: [dW4 64x64 | db4 64 | dwv 64 | dbv 1 | dg2 64 | dbe2 64]
 constexpr int P3 = H * H + H + H + 1 + H + H;
-__global__ __launch_bounds__(64) void ds_bwd3(const float* __restrict__ u1, const double* __restrict__ stats2, double count2,
-                                             const float* __restrict__ g2, const float* __restrict__ be2,
-                                             const float* __restrict__ W4, const float* __restrict__ b4,
-                                             const float* __restrict__ wv, const float* __restrict__ dvalue,
-                                             float* __restrict__ q2, double* __restrict__ bstats2, float* __restrict__ partial,
-                                             int B) {
-  __shared__ float W4s[H * (H + 1)], ys[H], du[H];
-  const int j = threadIdx.x;
-  for (int i = j; i < H * H; i += 64) W4s[(i / H) * (H + 1) + (i % H)] = W4[i];
-  __syncthreads();
-  const LnStat st = ln_stat(stats2, count2);
-  const float gj = g2[j], bj = be2[j], b4j = b4[j], wvj = wv[j];
-  float dW4[H];
+__global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd3(const float* __restrict__ u1, const double* __restrict__ slots2, double count2,
+                                                        const float* __restrict__ g2, const float* __restrict__ be2,
+                                                        const float* __restrict__ W4, const float* __restrict__ b4,
+                                                        const float* __restrict__ wv, const float* __restrict__ dvalue,
+                                                        float* __restrict__ q2, double* __restrict__ bslots2,
+                                                        float* __restrict__ partial, int B) {
+  __shared__ __attribute__((aligned(16))) float lines[DS_WAVES][2][H];
+  __shared__ float fold[H * (H + 1)];
+  const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ys = lines[wave][0];
+  float* du = lines[wave][1];
+  float w4r[H], w4c[H], dW4[H];
+  load_row64(W4, j, w4r);
 #pragma unroll
-  for (int k = 0; k < H; ++k) dW4[k] = 0.f;
+  for (int k = 0; k < H; ++k) { w4c[k] = W4[k * H + j]; dW4[k] = 0.f; }
+  double tot[1][2];
+  const double* const arr[1] = {slots2};
+  slot_totals<1>(arr, tot);
+  const LnStat st = ln_stat(tot[0], count2);
+  const float gj = g2[j], bj = be2[j], b4j = b4[j], wvj = wv[j];
   float db4 = 0.f, dwv = 0.f, dbv = 0.f, dg = 0.f, dbe = 0.f;
   double s0 = 0, s1 = 0;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int b = blockIdx.x * DS_WAVES + wave; b < B; b += gridDim.x * DS_WAVES) {
     const float xh = (u1[(size_t)b * H + j] - st.mean) / st.s;
     const float pre = xh * gj + bj;
-    const float y = fmaxf(pre, 0.f);
-    ys[j] = y;
-    __syncthreads();
-    float u2 = b4j;
-#pragma unroll 16
-    for (int k = 0; k < H; ++k) u2 += ys[k] * W4s[j * (H + 1) + k];
+    ys[j] = fmaxf(pre, 0.f);
     const float dv = dvalue[b];
     const float du2 = dv * wvj;
+    du[j] = du2;
+    __builtin_amdgcn_wave_barrier();
+    const float u2 = b4j + dot64(ys, w4r);
     dwv += dv * u2;
     dbv += dv;
     db4 += du2;
-#pragma unroll
-    for (int k = 0; k < H; ++k) dW4[k] += du2 * ys[k];
-    du[j] = du2;
-    __syncthreads();
-    float dy = 0.f;
-#pragma unroll 16
-    for (int k = 0; k < H; ++k) dy += du[k] * W4s[k * (H + 1) + j];
+    axpy64(ys, du2, dW4);
+    const float dy = dot64(du, w4c);
     const float dpre = pre > 0.f ? dy : 0.f;
     dg += dpre * xh;
     dbe += dpre;
@@ -224,47 +303,57 @@ __global__ __launch_bounds__(64) void ds_bwd3(const float* __restrict__ u1, cons
     q2[(size_t)b * H + j] = q;
     s0 += q;
     s1 += (double)q * xh;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
-  s0 = wave_sum_d(s0);
-  s1 = wave_sum_d(s1);
-  if (j == 0) { atomicAdd(bstats2, s0); atomicAdd(bstats2 + 1, s1); }
+  block_put_stats(s0, s1, bslots2);
   float* out = partial + (size_t)blockIdx.x * P3;
-#pragma unroll
-  for (int k = 0; k < H; ++k) out[j * H + k] = dW4[k];
-  out[H * H + j] = db4;
-  out[H * H + H + j] = dwv;
-  if (j == 0) out[H * H + 2 * H] = dbv;
-  out[H * H + 2 * H + 1 + j] = dg;
-  out[H * H + 3 * H + 1 + j] = dbe;
+  fold_rows64(dW4, fold, out);
+  const float sc[5] = {db4, dwv, dg, dbe, dbv};
+  float* const outs[5] = {out + H * H, out + H * H + H, out + H * H + 2 * H + 1, out + H * H + 3 * H + 1, fold + 5 * DS_WAVES * H};
+  fold_scalars<5>(sc, fold, outs);
+  if (threadIdx.x == 0) out[H * H + 2 * H] = fold[5 * DS_WAVES * H];   // dbv is the same in every lane: lane 0's folded value
 }
 
 // ---- backward 2: du1 (LNg2 backward) -> Lin3 -> dz; dz fans out to every node row of the sample -> Lin2 -> dy1 (same for
-//      all rows) -> q1 = dy1 * relu'(.) * gamma1 written per row; bstats1 += (sum q1, sum q1 xhat1).
+//      all rows) -> q1 = dy1 * relu'(.) * gamma1 written per row; slot sums of (q1, q1 xhat1).
 // partial row: [dW3 64x64 | db3 64 | dW2 64x64 | db2 64 | dg1 64 | dbe1 64]
 constexpr int P2 = H * H + H + H * H + H + H + H;
-__global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict__ h1, const double* __restrict__ stats1, double count1,
+__global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict__ h1, const double* __restrict__ slots1, double count1,
                                                         const float* __restrict__ g1, const float* __restrict__ be1,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ z, const float* __restrict__ u1,
-                                                        const double* __restrict__ stats2, double count2,
-                                                        const float* __restrict__ q2, const double* __restrict__ bstats2,
-                                                        float* __restrict__ q1, double* __restrict__ bstats1,
+                                                        const double* __restrict__ slots2, double count2,
+                                                        const float* __restrict__ q2, const double* __restrict__ bslots2,
+                                                        float* __restrict__ q1, double* __restrict__ bslots1,
                                                         float* __restrict__ partial, int B, int n) {
-  // 4 waves (samples) per workgroup share the weight images; every wave keeps its own gradient accumulators in registers and
-  // the four sets are folded through LDS at the end, so the workgroup still leaves ONE partial row
-  __shared__ __attribute__((aligned(16))) float W2s[H * (H + 1)], W3s[H * (H + 1)], sh_all[DS_WAVES][H], sy_all[DS_WAVES][H];
+  // the weight images (read by column) live in LDS and are shared by the four waves; their space is reused for the folds
+  __shared__ __attribute__((aligned(16))) float W2s[H * (H + 1)], W3s[H * (H + 1)];
+  __shared__ __attribute__((aligned(16))) float sh_all[DS_WAVES][H], sy_all[DS_WAVES][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* sh = sh_all[wave];
   float* sy = sy_all[wave];
-  for (int i = threadIdx.x; i < H * H; i += 64 * DS_WAVES) {
-    W2s[(i / H) * (H + 1) + (i % H)] = W2[i];
-    W3s[(i / H) * (H + 1) + (i % H)] = W3[i];
+  {
+    float4 a[4], c[4];   // 1024 quads per matrix / 256 threads: all loads in flight before the first LDS store
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = reinterpret_cast<const float4*>(W2)[threadIdx.x + 256 * u];
+      c[u] = reinterpret_cast<const float4*>(W3)[threadIdx.x + 256 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 4 * (threadIdx.x + 256 * u), r_ = i >> 6, k_ = i & 63;
+      float* d2 = W2s + r_ * (H + 1) + k_;
+      float* d3 = W3s + r_ * (H + 1) + k_;
+      d2[0] = a[u].x; d2[1] = a[u].y; d2[2] = a[u].z; d2[3] = a[u].w;
+      d3[0] = c[u].x; d3[1] = c[u].y; d3[2] = c[u].z; d3[3] = c[u].w;
+    }
   }
-  __syncthreads();
-  const LnStat st1 = ln_stat(stats1, count1), st2 = ln_stat(stats2, count2);
-  const float mq = (float)(bstats2[0] / count2);                               // mean(q2)
-  const float cq = st2.sigma > 0.f ? (float)(bstats2[1] / count2) / st2.sigma : 0.f;  // sum(q2 xhat2) / (N sigma2)
+  double tot[3][2];
+  const double* const arr[3] = {slots1, slots2, bslots2};
+  slot_totals<3>(arr, tot);   // (its barrier also publishes the weight images)
+  const LnStat st1 = ln_stat(tot[0], count1), st2 = ln_stat(tot[1], count2);
+  const float mq = (float)(tot[2][0] / count2);                               // mean(q2)
+  const float cq = st2.sigma > 0.f ? (float)(tot[2][1] / count2) / st2.sigma : 0.f;  // sum(q2 xhat2) / (N sigma2)
   const float gj = g1[j], bj = be1[j];
   float dW3[H], dW2[H];
 #pragma unroll
@@ -279,8 +368,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict
     sh[j] = du1;
     sy[j] = z[(size_t)b * H + j];
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < H; ++k) dW3[k] += du1 * sy[k];
+    axpy64(sy, du1, dW3);
     float dz = 0.f;
 #pragma unroll 16
     for (int k = 0; k < H; ++k) dz += sh[k] * W3s[k * (H + 1) + j];
@@ -292,88 +380,63 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict
 #pragma unroll 16
     for (int k = 0; k < H; ++k) dy1 += sh[k] * W2s[k * (H + 1) + j];
     float ysum = 0.f;
-    for (int i = 0; i < n; ++i) {
-      const size_t row = (size_t)b * n + i;
-      const float xh = (h1[row * H + j] - st1.mean) / st1.s;
-      const float pre = xh * gj + bj;
-      ysum += fmaxf(pre, 0.f);
-      const float dpre = pre > 0.f ? dy1 : 0.f;
-      dg += dpre * xh;
-      dbe += dpre;
-      const float q = dpre * gj;
-      q1[row * H + j] = q;
-      s0 += q;
-      s1 += (double)q * xh;
+    for (int i0 = 0; i0 < n; i0 += 8) {   // eight rows in flight
+      float hv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hv[u] = i0 + u < n ? h1[((size_t)b * n + i0 + u) * H + j] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u >= n) break;
+        const float xh = (hv[u] - st1.mean) / st1.s;
+        const float pre = xh * gj + bj;
+        ysum += fmaxf(pre, 0.f);
+        const float dpre = pre > 0.f ? dy1 : 0.f;
+        dg += dpre * xh;
+        dbe += dpre;
+        const float q = dpre * gj;
+        q1[((size_t)b * n + i0 + u) * H + j] = q;
+        s0 += q;
+        s1 += (double)q * xh;
+      }
     }
     sy[j] = ysum;
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < H; ++k) dW2[k] += dz * sy[k];
+    axpy64(sy, dz, dW2);
     __builtin_amdgcn_wave_barrier();
   }
-  block_add_stats<DS_WAVES>(s0, s1, bstats1);
-  // fold the four waves (fixed order) through the weight images' LDS space, then one partial row per workgroup
+  block_put_stats(s0, s1, bslots1);
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * P2;
-  for (int pass = 0; pass < 2; ++pass) {
-    float* acc = pass == 0 ? W3s : W2s;
-    for (int w_ = 0; w_ < DS_WAVES; ++w_) {
-      if (wave == w_) {
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-          const float v = pass == 0 ? dW3[k] : dW2[k];
-          acc[j * (H + 1) + k] = w_ == 0 ? v : acc[j * (H + 1) + k] + v;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < H * H; i += 64 * DS_WAVES) {
-    out[i] = W3s[(i / H) * (H + 1) + (i % H)];
-    out[H * H + H + i] = W2s[(i / H) * (H + 1) + (i % H)];
-  }
-  __syncthreads();
-  float* red = W3s;   // [4 quantities][DS_WAVES][64]
-  red[(0 * DS_WAVES + wave) * H + j] = db3;
-  red[(1 * DS_WAVES + wave) * H + j] = db2;
-  red[(2 * DS_WAVES + wave) * H + j] = dg;
-  red[(3 * DS_WAVES + wave) * H + j] = dbe;
-  __syncthreads();
-  if (wave == 0) {
-    float t[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      t[q] = red[(q * DS_WAVES) * H + j];
-#pragma unroll
-      for (int w_ = 1; w_ < DS_WAVES; ++w_) t[q] += red[(q * DS_WAVES + w_) * H + j];
-    }
-    out[H * H + j] = t[0];
-    out[2 * H * H + H + j] = t[1];
-    out[2 * H * H + 2 * H + j] = t[2];
-    out[2 * H * H + 3 * H + j] = t[3];
-  }
+  fold_rows64(dW3, W3s, out);
+  fold_rows64(dW2, W2s, out + H * H + H);
+  const float sc[4] = {db3, db2, dg, dbe};
+  float* const outs[4] = {out + H * H, out + 2 * H * H + H, out + 2 * H * H + 2 * H, out + 2 * H * H + 3 * H};
+  fold_scalars<4>(sc, W3s, outs);
 }
 
-// ---- backward 1: dh1 (LNg1 backward) -> dW1, db1.   partial row: [dW1 64 x d | db1 64]   (rows flattened, 4 waves per workgroup)
-__global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd1(const float* __restrict__ x, const float* __restrict__ h1,
-                                                        const double* __restrict__ stats1, double count1,
-                                                        const float* __restrict__ q1, const double* __restrict__ bstats1,
+// ---- backward 1: dh1 (LNg1 backward) -> dW1, db1.   partial row: [dW1 64 x d | db1 64]   (rows flattened, 16 waves per workgroup)
+__global__ __launch_bounds__(64 * ROW_WAVES) void ds_bwd1(const float* __restrict__ x, const float* __restrict__ h1,
+                                                        const double* __restrict__ slots1, double count1,
+                                                        const float* __restrict__ q1, const double* __restrict__ bslots1,
                                                         float* __restrict__ partial, int B, int n, int d) {
-  __shared__ float red[DS_WAVES][H][DMAX + 1];
+  __shared__ float red[ROW_WAVES / 2][DMAX + 1][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const LnStat st = ln_stat(stats1, count1);
-  const float mq = (float)(bstats1[0] / count1);
-  const float cq = st.sigma > 0.f ? (float)(bstats1[1] / count1) / st.sigma : 0.f;
+  double tot[2][2];
+  const double* const arr[2] = {slots1, bslots1};
+  slot_totals<2>(arr, tot);
+  const LnStat st = ln_stat(tot[0], count1);
+  const float mq = (float)(tot[1][0] / count1);
+  const float cq = st.sigma > 0.f ? (float)(tot[1][1] / count1) / st.sigma : 0.f;
   float dW1[DMAX];
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) dW1[k] = 0.f;
   float db1 = 0.f;
   const long long rows = (long long)B * n;
-  const long long stride = (long long)gridDim.x * DS_WAVES;
-  for (long long row0 = blockIdx.x * DS_WAVES + wave; row0 < rows; row0 += 4 * stride) {   // four rows in flight (see ds_fwd1)
-    float xv[4], hv[4], qv[4];
+  const long long stride = (long long)gridDim.x * ROW_WAVES;
+  for (long long row0 = blockIdx.x * ROW_WAVES + wave; row0 < rows; row0 += ROWS_IN_FLIGHT * stride) {
+    float xv[ROWS_IN_FLIGHT], hv[ROWS_IN_FLIGHT], qv[ROWS_IN_FLIGHT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
       const long long row = row0 + u * stride;
       const bool ok = row < rows;
       xv[u] = (ok && j < d) ? x[row * d + j] : 0.f;
@@ -381,7 +444,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd1(const float* __restrict
       qv[u] = ok ? q1[row * H + j] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
       if (row0 + u * stride >= rows) break;
       const float xh = (hv[u] - st.mean) / st.s;
       const float dh = (qv[u] - mq) / st.s - xh * cq;
@@ -391,82 +454,107 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd1(const float* __restrict
         if (k < d) dW1[k] += dh * __shfl(xv[u], k, 64);
     }
   }
+  // fixed-order fold of the sixteen waves: upper half -> LDS -> added by the lower half -> LDS -> wave 0
+  constexpr int HW = ROW_WAVES / 2;
+  if (wave >= HW) {
 #pragma unroll
-  for (int k = 0; k < DMAX; ++k) red[wave][j][k] = dW1[k];
-  red[wave][j][DMAX] = db1;
+    for (int k = 0; k < DMAX; ++k) red[wave - HW][k][j] = dW1[k];
+    red[wave - HW][DMAX][j] = db1;
+  }
+  __syncthreads();
+  if (wave < HW) {
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) dW1[k] += red[wave][k][j];
+    db1 += red[wave][DMAX][j];
+  }
+  __syncthreads();
+  if (wave < HW) {
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) red[wave][k][j] = dW1[k];
+    red[wave][DMAX][j] = db1;
+  }
   __syncthreads();
   if (wave == 0) {
     float* out = partial + (size_t)blockIdx.x * (H * d + H);
     for (int k = 0; k < d; ++k) {
-      float t = red[0][j][k];
+      float t = red[0][k][j];
 #pragma unroll
-      for (int w_ = 1; w_ < DS_WAVES; ++w_) t += red[w_][j][k];
+      for (int w_ = 1; w_ < HW; ++w_) t += red[w_][k][j];
       out[j * d + k] = t;
     }
-    float t = red[0][j][DMAX];
+    float t = red[0][DMAX][j];
 #pragma unroll
-    for (int w_ = 1; w_ < DS_WAVES; ++w_) t += red[w_][j][DMAX];
+    for (int w_ = 1; w_ < HW; ++w_) t += red[w_][DMAX][j];
     out[H * d + j] = t;
   }
 }
 
-int ds_blocks(int B) { return B < 1024 ? (B < 1 ? 1 : B) : 1024; }
+int ds_blocks(long long units) {   // one wave per unit (sample or row), four waves per workgroup, at most NSLOT workgroups
+  const long long b = (units + DS_WAVES - 1) / DS_WAVES;
+  return b < 1 ? 1 : (b < NSLOT ? (int)b : NSLOT);
+}
 
 }  // namespace
 
 extern "C" {
 
 int grl_deepsets_blocks(int batch) { return ds_blocks(batch); }
+int grl_deepsets_stat_slots(void) { return NSLOT; }
 int grl_deepsets_partial3() { return P3; }
 int grl_deepsets_partial2() { return P2; }
 
-// Forward, stage k of 3.  stats1/stats2: fp64[2] zero-initialised by the caller; in a data-parallel run the caller
-// all-reduces them (sum) between the stages and passes the GLOBAL element counts count1 = B_glob*n*64, count2 = B_glob*64.
-int grl_deepsets_fwd1(const float* x, const float* W1, const float* b1, float* h1, double* stats1, int batch, int n_nodes, int d,
+// Forward, stage k of 3.  slots1/slots2: fp64[grl_deepsets_stat_slots()][2], fully written by the producing stage (no
+// initialisation needed); in a data-parallel run the caller all-reduces them (sum) between the stages and passes the GLOBAL
+// element counts count1 = B_glob*n*64, count2 = B_glob*64.
+int grl_deepsets_fwd1(const float* x, const float* W1, const float* b1, float* h1, double* slots1, int batch, int n_nodes, int d,
                       hipStream_t stream) {
   if (d > DMAX) return -2;
-  hipLaunchKernelGGL(ds_fwd1, dim3(512), dim3(64 * DS_WAVES), 0, stream, x, W1, b1, h1, stats1, batch, n_nodes, d);
+  const long long rows = (long long)batch * n_nodes;
+  const long long wg = (rows + ROW_WAVES * ROWS_IN_FLIGHT - 1) / (ROW_WAVES * ROWS_IN_FLIGHT);
+  hipLaunchKernelGGL(ds_fwd1, dim3(wg < 1 ? 1 : (wg < NSLOT ? (int)wg : NSLOT)), dim3(64 * ROW_WAVES), 0, stream, x, W1, b1, h1,
+                     slots1, batch, n_nodes, d);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-int grl_deepsets_fwd2(const float* h1, const double* stats1, double count1, const float* g1, const float* be1, const float* W2,
-                      const float* b2, const float* W3, const float* b3, float* z, float* u1, double* stats2, int batch,
+int grl_deepsets_fwd2(const float* h1, const double* slots1, double count1, const float* g1, const float* be1, const float* W2,
+                      const float* b2, const float* W3, const float* b3, float* z, float* u1, double* slots2, int batch,
                       int n_nodes, hipStream_t stream) {
-  hipLaunchKernelGGL(ds_fwd2, dim3((batch + DS_WAVES - 1) / DS_WAVES < 512 ? (batch + DS_WAVES - 1) / DS_WAVES : 512),
-                     dim3(64 * DS_WAVES), 0, stream, h1, stats1, count1, g1, be1, W2, b2, W3, b3, z, u1, stats2, batch, n_nodes);
+  hipLaunchKernelGGL(ds_fwd2, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, b2, W3, b3, z,
+                     u1, slots2, batch, n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-int grl_deepsets_fwd3(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
+int grl_deepsets_fwd3(const float* u1, const double* slots2, double count2, const float* g2, const float* be2, const float* W4,
                       const float* b4, const float* wv, const float* bv, float* value, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(ds_fwd3, dim3(ds_blocks(batch)), dim3(64), 0, stream, u1, stats2, count2, g2, be2, W4, b4, wv, bv, value,
-                     batch);
+  hipLaunchKernelGGL(ds_fwd3, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, u1, slots2, count2, g2, be2, W4, b4, wv, bv,
+                     value, batch);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-// Backward stages (reverse order).  bstats1/bstats2: fp64[2] zero-initialised; all-reduced between stages when data parallel.
-int grl_deepsets_bwd3(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
-                      const float* b4, const float* wv, const float* dvalue, float* q2, double* bstats2, float* partial,
+// Backward stages (reverse order).  bslots1/bslots2: slot arrays like the forward's; all-reduced between stages when data
+// parallel.  Every partial slab has grl_deepsets_blocks(batch) rows.
+int grl_deepsets_bwd3(const float* u1, const double* slots2, double count2, const float* g2, const float* be2, const float* W4,
+                      const float* b4, const float* wv, const float* dvalue, float* q2, double* bslots2, float* partial,
                       int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(ds_bwd3, dim3(ds_blocks(batch)), dim3(64), 0, stream, u1, stats2, count2, g2, be2, W4, b4, wv, dvalue, q2,
-                     bstats2, partial, batch);
+  hipLaunchKernelGGL(ds_bwd3, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, u1, slots2, count2, g2, be2, W4, b4, wv, dvalue,
+                     q2, bslots2, partial, batch);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-int grl_deepsets_bwd2(const float* h1, const double* stats1, double count1, const float* g1, const float* be1, const float* W2,
-                      const float* W3, const float* z, const float* u1, const double* stats2, double count2, const float* q2,
-                      const double* bstats2, float* q1, double* bstats1, float* partial, int batch, int n_nodes,
+int grl_deepsets_bwd2(const float* h1, const double* slots1, double count1, const float* g1, const float* be1, const float* W2,
+                      const float* W3, const float* z, const float* u1, const double* slots2, double count2, const float* q2,
+                      const double* bslots2, float* q1, double* bslots1, float* partial, int batch, int n_nodes,
                       hipStream_t stream) {
-  hipLaunchKernelGGL(ds_bwd2, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, h1, stats1, count1, g1, be1, W2, W3, z, u1, stats2,
-                     count2, q2, bstats2, q1, bstats1, partial, batch, n_nodes);
+  hipLaunchKernelGGL(ds_bwd2, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, W3, z, u1,
+                     slots2, count2, q2, bslots2, q1, bslots1, partial, batch, n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-int grl_deepsets_bwd1(const float* x, const float* h1, const double* stats1, double count1, const float* q1,
-                      const double* bstats1, float* partial, int batch, int n_nodes, int d, hipStream_t stream) {
+int grl_deepsets_bwd1(const float* x, const float* h1, const double* slots1, double count1, const float* q1,
+                      const double* bslots1, float* partial, int batch, int n_nodes, int d, hipStream_t stream) {
   if (d > DMAX) return -2;
-  hipLaunchKernelGGL(ds_bwd1, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, x, h1, stats1, count1, q1, bstats1, partial, batch,
-                     n_nodes, d);
+  hipLaunchKernelGGL(ds_bwd1, dim3(ds_blocks(batch)), dim3(64 * ROW_WAVES), 0, stream, x, h1, slots1, count1, q1, bslots1, partial,
+                     batch, n_nodes, d);
   GRL_CHECK_LAUNCH();
   return 0;
 }

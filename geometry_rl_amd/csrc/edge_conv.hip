@@ -165,22 +165,10 @@ struct BwdW {
   unsigned short WkTh[64 * LDB], WkTl[64 * LDB];
 };
 
-// like stage_split for the TRANSPOSE of src [64][64]: image row k holds src[.][k]
-GRL_DEVINL void stage_split_T(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int ld) {
-  for (int idx = threadIdx.x; idx < 64 * 64; idx += blockDim.x) {
-    const int k = idx >> 6, p = idx & 63;
-    const int q = (p >> 2) & 3;
-    const int n = (p & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q) + (p & 3);
-    const float w = src[n * 64 + k];
-    hi[k * ld + p] = (unsigned short)(__float_as_uint(w) >> 16);
-    lo[k * ld + p] = (unsigned short)(pack_rn(w - trunc_bf16(w), 0.f) & 0xFFFFu);
-  }
-}
-
 GRL_DEVINL void load_chain_weights(ChainW& s, const EdgeParams& p) {
-  stage_split(s.W1h, s.W1l, p.W1, 64, 16, 14, LDB1);
-  stage_split(s.W2h, s.W2l, p.W2, 64, 64, 64, LDB);
-  stage_split(s.Wkh, s.Wkl, p.Wk, 64, 64, 64, LDB);
+  stage_split<64, 16, 14, 256>(s.W1h, s.W1l, p.W1, LDB1);
+  stage_split<64, 64, 64, 256>(s.W2h, s.W2l, p.W2, LDB);
+  stage_split<64, 64, 64, 256>(s.Wkh, s.Wkl, p.Wk, LDB);
   for (int idx = threadIdx.x; idx < 64; idx += blockDim.x) {
     s.b1s[idx] = p.b1[idx];
     s.b2s[idx] = p.b2[idx];
@@ -376,8 +364,8 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   BwdW& sb = *reinterpret_cast<BwdW*>(smem_raw + sizeof(ChainW) / 4);
   load_chain_weights(s, p);
-  stage_split_T(sb.W2Th, sb.W2Tl, p.W2, LDB);
-  stage_split_T(sb.WkTh, sb.WkTl, p.Wk, LDB);
+  stage_split_T<256>(sb.W2Th, sb.W2Tl, p.W2, LDB);
+  stage_split_T<256>(sb.WkTh, sb.WkTl, p.Wk, LDB);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;

@@ -223,16 +223,65 @@ GRL_DEVINL void split_frags(const float4 (&x)[K / 8], bf16x8 (&hi)[K / 16], bf16
 // LDS leading dimension (in bf16 elements) of a [rows][K] split-weight image: +8 elements (16 B) keeps ds_read_b128 conflict-free
 #define GRL_LDB(K) ((K) + 8)
 
-// stage W[rows][K] (fp32, global) as two bf16 images (hi, lo) with the per-16-block quad swap described above
-GRL_DEVINL void stage_split(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int rows, int K, int Ksrc, int ld) {
-  for (int idx = threadIdx.x; idx < rows * K; idx += blockDim.x) {
-    const int r = idx / K, p = idx - r * K;
-    const int q = (p >> 2) & 3;                                   // quad inside the 16-block
-    const int k = (p & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q) + (p & 3);
-    const float w = k < Ksrc ? src[(size_t)r * Ksrc + k] : 0.f;
-    const float wh = trunc_bf16(w);
-    hi[r * ld + p] = (unsigned short)(__float_as_uint(w) >> 16);
-    lo[r * ld + p] = (unsigned short)(pack_rn(w - wh, 0.f) & 0xFFFFu);
+// stage W[ROWS][K] (fp32, global, row length KSRC <= K) as two bf16 images (hi, lo) with the per-16-block quad swap described
+// above.  One quad (4 consecutive k = 4 consecutive image positions) per thread and iteration: a 16-byte global load, two 8-byte
+// LDS stores; the loads of up to 8 iterations are issued back to back before the first store, so the prologue costs a couple of
+// L2 round trips (the former scalar loop -- one dependent load per element -- was a fixed 25-35 us at the head of every launch).
+GRL_DEVINL void put_split_quad(unsigned short* hi, unsigned short* lo, const float4& w) {
+  uint2 h, l;
+  h.x = pack_hi(w.x, w.y); h.y = pack_hi(w.z, w.w);
+  l.x = pack_rn(w.x - trunc_bf16(w.x), w.y - trunc_bf16(w.y));
+  l.y = pack_rn(w.z - trunc_bf16(w.z), w.w - trunc_bf16(w.w));
+  *reinterpret_cast<uint2*>(hi) = h;
+  *reinterpret_cast<uint2*>(lo) = l;
+}
+template <int ROWS, int K, int KSRC, int NT>
+GRL_DEVINL void stage_split(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int ld) {
+  constexpr int Q = K / 4, N = ROWS * Q, IT = (N + NT - 1) / NT, G = IT < 8 ? IT : 8;
+  const bool vec = KSRC % 4 == 0 && (reinterpret_cast<size_t>(src) & 15) == 0;   // block-uniform
+#pragma unroll 1
+  for (int base = 0; base < IT; base += G) {
+    float4 w[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int idx = threadIdx.x + (base + g) * NT;
+      const int r = idx / Q, pq = idx - r * Q, q = pq & 3;
+      const int k = ((4 * pq) & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q);
+      w[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < N) {
+        const float* sp = src + (size_t)r * KSRC + k;
+        if (vec) {
+          w[g] = *reinterpret_cast<const float4*>(sp);
+        } else {
+          w[g].x = k < KSRC ? sp[0] : 0.f; w[g].y = k + 1 < KSRC ? sp[1] : 0.f;
+          w[g].z = k + 2 < KSRC ? sp[2] : 0.f; w[g].w = k + 3 < KSRC ? sp[3] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int idx = threadIdx.x + (base + g) * NT;
+      const int r = idx / Q, pq = idx - r * Q;
+      if (idx < N) put_split_quad(hi + r * ld + 4 * pq, lo + r * ld + 4 * pq, w[g]);
+    }
+  }
+}
+// the same for the TRANSPOSE of src [64][64]: image row k holds src[.][k] (lanes run along k: coalesced 4-byte loads)
+template <int NT>
+GRL_DEVINL void stage_split_T(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int ld) {
+  constexpr int N = 64 * 16, IT = (N + NT - 1) / NT;
+  float4 w[IT];
+#pragma unroll
+  for (int g = 0; g < IT; ++g) {
+    const int idx = threadIdx.x + g * NT, k = idx & 63, pq = idx >> 6, q = pq & 3;
+    const int n = ((4 * pq) & ~15) + ((q == 1) ? 8 : (q == 2) ? 4 : 4 * q);
+    w[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < N) w[g] = make_float4(src[n * 64 + k], src[(n + 1) * 64 + k], src[(n + 2) * 64 + k], src[(n + 3) * 64 + k]);
+  }
+#pragma unroll
+  for (int g = 0; g < IT; ++g) {
+    const int idx = threadIdx.x + g * NT, k = idx & 63, pq = idx >> 6;
+    if (idx < N) put_split_quad(hi + k * ld + 4 * pq, lo + k * ld + 4 * pq, w[g]);
   }
 }
 

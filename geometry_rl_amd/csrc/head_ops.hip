@@ -184,13 +184,14 @@ struct TrplCfg {
 
 GRL_DEVINL double kl_of_eta(double eta, const double* t, const double* o, int A) {
   double kl = 0.0;
-  for (int i = 0; i < A; ++i) {
+  _Pragma("unroll") for (int i = 0; i < A; ++i) {
     const double v = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]);
     kl += v / o[i] - 1.0 - log(v) + log(o[i]);
   }
   return 0.5 * kl;
 }
 
+template <int AT>
 __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __restrict__ mean, const float* __restrict__ sigma,
                                                   const float* __restrict__ action, const float* __restrict__ old_mean,
                                                   const float* __restrict__ old_var, const float* __restrict__ old_logp,
@@ -201,13 +202,13 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
                                                   const double* __restrict__ adv_stats, double* __restrict__ sums,
                                                   unsigned int* __restrict__ maxes, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int A = cfg.A;
+  const int A = AT > 0 ? AT : cfg.A;   // compile-time action width: the per-dimension loops unroll, arrays stay in registers
   double acc[10];
   for (int i = 0; i < 10; ++i) acc[i] = 0.0;
   float mmax = 0.f, cmax = 0.f;
   if (b < B) {
     double mu[AMAX], S[AMAX], mo[AMAX], So[AMAX], t[AMAX], o[AMAX], a[AMAX];
-    for (int i = 0; i < A; ++i) {
+    _Pragma("unroll") for (int i = 0; i < A; ++i) {
       mu[i] = mean[(size_t)b * A + i];
       const double sg = sigma[(size_t)b * A + i];
       S[i] = sg * sg;                      // policy covariance diagonal == "std" seen by the projection (trpl.py:241)
@@ -219,12 +220,12 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     }
     // ---- mean projection (base_projection_layer.py:71-100)
     double mp = 0.0;
-    for (int i = 0; i < A; ++i) { const double d = (mu[i] - mo[i]) / So[i]; mp += d * d; }
+    _Pragma("unroll") for (int i = 0; i < A; ++i) { const double d = (mu[i] - mo[i]) / So[i]; mp += d * d; }
     mp *= 0.5;
     const bool m_act = mp > cfg.mean_bound;
     double omega = 0.0, D = 1.0, pm[AMAX];
     if (m_act) { omega = sqrt(mp / cfg.mean_bound) - 1.0; D = 1.0 + omega + 1e-16; }
-    for (int i = 0; i < A; ++i) pm[i] = m_act ? (mu[i] + omega * mo[i]) / D : mu[i];
+    _Pragma("unroll") for (int i = 0; i < A; ++i) pm[i] = m_act ? (mu[i] + omega * mo[i]) / D : mu[i];
     // ---- covariance projection: eta >= 0 with KL_cov(eta) = cov_bound.  With rho_i = v_i/o_i = (eta+1)/(eta+c_i), c_i = o_i/t_i:
     //      KL = 1/2 sum(rho_i - 1 - log rho_i),  dKL/deta = -1/2 sum (1-c_i)^2 / ((eta+1)(eta+c_i)^2) < 0, KL convex in eta:
     //      Newton from eta = 0 approaches the root monotonically from the left (never overshoots).
@@ -232,28 +233,52 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     const bool c_act = kl_of_eta(0.0, t, o, A) > cfg.cov_bound;
     if (c_act) {
       double cr[AMAX];
-      for (int i = 0; i < A; ++i) cr[i] = o[i] / t[i];
+      _Pragma("unroll") for (int i = 0; i < A; ++i) cr[i] = o[i] / t[i];
+      // Phase 1, fp32 (hardware log2 / reciprocal): the same Newton iteration, cheap, until the step is below 1e-5 of eta.
+      {
+        float crf[AMAX], e32 = 0.f;
+        _Pragma("unroll") for (int i = 0; i < A; ++i) crf[i] = (float)cr[i];
+        const float bound = (float)cfg.cov_bound;
+        for (int it = 0; it < 60; ++it) {
+          float f = 0.f, df = 0.f;
+          const float r1 = __builtin_amdgcn_rcpf(e32 + 1.f);
+          _Pragma("unroll") for (int i = 0; i < A; ++i) {
+            const float rden = __builtin_amdgcn_rcpf(e32 + crf[i]), rho = (e32 + 1.f) * rden, om = 1.f - crf[i];
+            f += rho - 1.f - 0.69314718056f * __builtin_amdgcn_logf(rho);
+            df += om * om * r1 * rden * rden;
+          }
+          f = 0.5f * f - bound;
+          df *= 0.5f;
+          if (!(f > 0.f) || !(df > 0.f)) break;
+          const float step = f / df;
+          e32 += step;
+          if (!(step > 1e-5f * e32)) break;
+        }
+        if (e32 == e32 && e32 >= 0.f && e32 < 3.0e38f) eta = (double)e32;   // otherwise phase 2 starts from 0 as before
+      }
+      // Phase 2, fp64 polish.  KL is convex and decreasing in eta, so ONE Newton step from either side of the root lands left
+      // of it (the tangent lies below the curve); from there the iteration is monotone as before and stops at double precision.
       for (int it = 0; it < 100; ++it) {
         double f = 0.0, df = 0.0;
-        for (int i = 0; i < A; ++i) {
+        _Pragma("unroll") for (int i = 0; i < A; ++i) {
           const double den = eta + cr[i], rho = (eta + 1.0) / den, om = 1.0 - cr[i];
           f += rho - 1.0 - log(rho);
           df += om * om / ((eta + 1.0) * den * den);
         }
         f = 0.5 * f - cfg.cov_bound;
         df *= 0.5;
-        if (f <= 0.0 || df <= 0.0) break;
+        if (df <= 0.0 || (it > 0 && f <= 0.0)) break;
         const double step = f / df;
-        eta += step;
-        if (step <= 1e-15 * eta) break;
+        eta = fmax(eta + step, 0.0);
+        if (fabs(step) <= 1e-15 * eta) break;
       }
     }
     double v[AMAX], pS[AMAX];
-    for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }
+    _Pragma("unroll") for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }
     // ---- log-prob under the projected distribution (covariance = pS), importance weight, objective
     const double LOG2PI = 1.8378770664093454836;
     double q = 0.0, sl = 0.0;
-    for (int i = 0; i < A; ++i) { const double d = a[i] - pm[i]; q += d * d / pS[i]; sl += log(pS[i]); }
+    _Pragma("unroll") for (int i = 0; i < A; ++i) { const double d = a[i] - pm[i]; q += d * d / pS[i]; sl += log(pS[i]); }
     const double lw = -0.5 * (q + A * LOG2PI + sl) - (double)old_logp[b];
     const double ratio = exp(lw);
     // advantage normalisation (trpl.py:286-289): batch mean / unbiased std (clamped at 1e-6) from the device-side sums
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     acc[2] = ent;
     // ---- trust-region regression loss and metrics: gaussian_kl(p, stopgrad(proj_p))
     double mk = 0.0, ck = 0.0, ldS = 0.0, ldP = 0.0;
-    for (int i = 0; i < A; ++i) {
+    _Pragma("unroll") for (int i = 0; i < A; ++i) {
       const double d = (mu[i] - pm[i]) / pS[i];
       mk += d * d;
       const double rr = S[i] / pS[i];
@@ -293,7 +318,7 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     // ---- gradients of actor_loss = objective + entropy bonus + trust region  (all already scaled by 1/B)
     const double w_obj = -ratio * adv * cfg.inv_batch;
     double g_pm[AMAX], g_pS[AMAX];
-    for (int i = 0; i < A; ++i) {
+    _Pragma("unroll") for (int i = 0; i < A; ++i) {
       const double d = a[i] - pm[i];
       g_pm[i] = w_obj * d / pS[i];
       g_pS[i] = w_obj * 0.5 * (d * d / (pS[i] * pS[i]) - 1.0 / pS[i]) - cfg.ent_coef * cfg.inv_batch * 0.5 / pS[i];
@@ -301,34 +326,34 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     double gmu[AMAX], gS[AMAX];
     if (m_act) {
       double dot = 0.0;
-      for (int i = 0; i < A; ++i) dot += g_pm[i] * (mo[i] - pm[i]) / D;
+      _Pragma("unroll") for (int i = 0; i < A; ++i) dot += g_pm[i] * (mo[i] - pm[i]) / D;
       const double k = dot / (2.0 * (omega + 1.0) * cfg.mean_bound);
-      for (int i = 0; i < A; ++i) gmu[i] = g_pm[i] / D + k * (mu[i] - mo[i]) / (So[i] * So[i]);
+      _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i] / D + k * (mu[i] - mo[i]) / (So[i] * So[i]);
     } else {
-      for (int i = 0; i < A; ++i) gmu[i] = g_pm[i];
+      _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i];
     }
     {
       double gv[AMAX];
-      for (int i = 0; i < A; ++i) gv[i] = g_pS[i] / (2.0 * pS[i]);
+      _Pragma("unroll") for (int i = 0; i < A; ++i) gv[i] = g_pS[i] / (2.0 * pS[i]);
       if (c_act) {
         double dvt[AMAX], dve[AMAX], gk[AMAX], denom = 0.0, num = 0.0;
-        for (int i = 0; i < A; ++i) {
+        _Pragma("unroll") for (int i = 0; i < A; ++i) {
           dvt[i] = v[i] * v[i] / (t[i] * t[i] * (eta + 1.0));
           dve[i] = -v[i] * v[i] * (1.0 / o[i] - 1.0 / t[i]) / ((eta + 1.0) * (eta + 1.0));
           gk[i] = 0.5 * (1.0 / o[i] - 1.0 / v[i]);
           denom += gk[i] * dve[i];
           num += gv[i] * dve[i];
         }
-        for (int i = 0; i < A; ++i) {
+        _Pragma("unroll") for (int i = 0; i < A; ++i) {
           const double gt = gv[i] * dvt[i] - num * gk[i] * dvt[i] / denom;
           gS[i] = gt * 2.0 * S[i];
         }
       } else {
-        for (int i = 0; i < A; ++i) gS[i] = gv[i] * 2.0 * S[i];
+        _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = gv[i] * 2.0 * S[i];
       }
     }
     const double ctr = cfg.tr_coeff * cfg.inv_batch;
-    for (int i = 0; i < A; ++i) {
+    _Pragma("unroll") for (int i = 0; i < A; ++i) {
       gmu[i] += ctr * (mu[i] - pm[i]) / (pS[i] * pS[i]);
       gS[i] += ctr * (S[i] / (pS[i] * pS[i]) - 1.0 / S[i]);
       dmean[(size_t)b * A + i] = (float)gmu[i];
@@ -457,9 +482,17 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
                      unsigned int* maxes, int batch, hipStream_t stream) {
   if (action_dim > AMAX || action_dim < 1) return -2;
   TrplCfg c{cfg8[0], cfg8[1], cfg8[2], cfg8[3], cfg8[4], cfg8[5], cfg8[6], cfg8[7], action_dim};
-  hipLaunchKernelGGL(trpl_kernel, dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean, old_var,
-                     old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, sums,
-                     maxes, batch);
+#define GRL_TRPL_LAUNCH(AT)                                                                                                   \
+  hipLaunchKernelGGL(trpl_kernel<AT>, dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean, old_var, \
+                     old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, \
+                     sums, maxes, batch)
+  switch (action_dim) {   // the action widths of the reference tasks (G * n_vec * 3) get unrolled instances
+    case 3: GRL_TRPL_LAUNCH(3); break;
+    case 6: GRL_TRPL_LAUNCH(6); break;
+    case 12: GRL_TRPL_LAUNCH(12); break;
+    default: GRL_TRPL_LAUNCH(0); break;
+  }
+#undef GRL_TRPL_LAUNCH
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -327,17 +327,17 @@ class DeepSetsPipeline:
 
     PARAM_ORDER = ("w1", "b1", "g1", "be1", "w2", "b2", "w3", "b3", "g2", "be2", "w4", "b4", "wv", "bv")
 
-    def __init__(self, x, params, world=1, zero_buf=None):
-        """``zero_buf``: optional zeroed fp64[8] (stats | bst) from the caller's per-step workspace (saves two fill launches)."""
+    def __init__(self, x, params, world=1):
         hip.check_f32(x, *params)
         self.B, self.n, self.d = x.shape
         B, n, dev = self.B, self.n, x.device
         self.x = x.contiguous()
         self.P = [t.contiguous() for t in params]
-        if zero_buf is None:
-            zero_buf = torch.zeros(8, device=dev, dtype=torch.float64)
-        self.stats = zero_buf[0:4]  # [sum h1, sum h1^2, sum u1, sum u1^2]
-        self.bst = zero_buf[4:8]    # [sum q2, sum q2 xh2, sum q1, sum q1 xh1]
+        # per-workgroup (sum, sum of squares) slots, written in full by the producing stage: no zeroing, no atomics
+        ns = 2 * hip.query("grl_deepsets_stat_slots")
+        slots = torch.empty(4 * ns, device=dev, dtype=torch.float64)
+        self.stats1, self.stats2 = slots[0:ns], slots[ns:2 * ns]          # (h1, h1^2), (u1, u1^2)
+        self.bst2, self.bst1 = slots[2 * ns:3 * ns], slots[3 * ns:4 * ns]  # (q2, q2 xh2), (q1, q1 xh1)
         self.h1 = torch.empty(B, n, 64, device=dev, dtype=torch.float32)
         self.z = torch.empty(B, 64, device=dev, dtype=torch.float32)
         self.u1 = torch.empty(B, 64, device=dev, dtype=torch.float32)
@@ -346,16 +346,16 @@ class DeepSetsPipeline:
 
     def fwd1(self):
         w1, b1 = self.P[0], self.P[1]
-        hip.call("grl_deepsets_fwd1", self.x, w1, b1, self.h1, self.stats[0:2], self.B, self.n, self.d)
+        hip.call("grl_deepsets_fwd1", self.x, w1, b1, self.h1, self.stats1, self.B, self.n, self.d)
 
     def fwd2(self):
         w1, b1, g1, be1, w2, b2, w3, b3 = self.P[:8]
-        hip.call("grl_deepsets_fwd2", self.h1, self.stats[0:2], ctypes_double(self.c1), g1, be1, w2, b2, w3, b3, self.z, self.u1,
-                 self.stats[2:4], self.B, self.n)
+        hip.call("grl_deepsets_fwd2", self.h1, self.stats1, ctypes_double(self.c1), g1, be1, w2, b2, w3, b3, self.z, self.u1,
+                 self.stats2, self.B, self.n)
 
     def fwd3(self):
         g2, be2, w4, b4, wv, bv = self.P[8:]
-        hip.call("grl_deepsets_fwd3", self.u1, self.stats[2:4], ctypes_double(self.c2), g2, be2, w4, b4, wv, bv, self.value, self.B)
+        hip.call("grl_deepsets_fwd3", self.u1, self.stats2, ctypes_double(self.c2), g2, be2, w4, b4, wv, bv, self.value, self.B)
         return self.value
 
     def bwd3(self, dvalue):
@@ -367,19 +367,19 @@ class DeepSetsPipeline:
         self.q2 = torch.empty(self.B, 64, device=dev)
         self.q1 = torch.empty(self.B, self.n, 64, device=dev)
         g2, be2, w4, b4, wv, bv = self.P[8:]
-        hip.call("grl_deepsets_bwd3", self.u1, self.stats[2:4], ctypes_double(self.c2), g2, be2, w4, b4, wv, dvalue.contiguous(),
-                 self.q2, self.bst[0:2], self.part3, self.B)
+        hip.call("grl_deepsets_bwd3", self.u1, self.stats2, ctypes_double(self.c2), g2, be2, w4, b4, wv, dvalue.contiguous(),
+                 self.q2, self.bst2, self.part3, self.B)
 
     def bwd2(self):
         w1, b1, g1, be1, w2, b2, w3, b3 = self.P[:8]
-        hip.call("grl_deepsets_bwd2", self.h1, self.stats[0:2], ctypes_double(self.c1), g1, be1, w2, w3, self.z, self.u1,
-                 self.stats[2:4], ctypes_double(self.c2), self.q2, self.bst[0:2], self.q1, self.bst[2:4], self.part2, self.B, self.n)
+        hip.call("grl_deepsets_bwd2", self.h1, self.stats1, ctypes_double(self.c1), g1, be1, w2, w3, self.z, self.u1,
+                 self.stats2, ctypes_double(self.c2), self.q2, self.bst2, self.q1, self.bst1, self.part2, self.B, self.n)
 
     def bwd1(self, leaves):
         """Last stage + folding of the partial slabs.  ``leaves``: the 14 parameter tensors in PARAM_ORDER (gradients are
         accumulated in place into ``.grad`` where that buffer exists, see _emit_grads).  Returns the 14 gradients (or None)."""
         d = self.d
-        hip.call("grl_deepsets_bwd1", self.x, self.h1, self.stats[0:2], ctypes_double(self.c1), self.q1, self.bst[2:4], self.part1,
+        hip.call("grl_deepsets_bwd1", self.x, self.h1, self.stats1, ctypes_double(self.c1), self.q1, self.bst1, self.part1,
                  self.B, self.n, d)
         (pw1, pb1, pg1, pbe1, pw2, pb2, pw3, pb3, pg2, pbe2, pw4, pb4, pwv, pbv) = leaves
         dw4, db4, dwv, dbv, dg2, dbe2 = _emit_grads(self.part3, [(0, 4096, (64, 64), pw4), (4096, 64, (64,), pb4),
@@ -408,10 +408,10 @@ class DeepSetsValue(torch.autograd.Function):
         pipe = DeepSetsPipeline(x, leaves, world)
         pipe.fwd1()
         if world > 1:
-            dist.all_reduce(pipe.stats[0:2], group=group)
+            dist.all_reduce(pipe.stats1, group=group)
         pipe.fwd2()
         if world > 1:
-            dist.all_reduce(pipe.stats[2:4], group=group)
+            dist.all_reduce(pipe.stats2, group=group)
         value = pipe.fwd3()
         ctx.pipe, ctx.leaves, ctx.group, ctx.world = pipe, leaves, group, world
         return value
@@ -422,10 +422,10 @@ class DeepSetsValue(torch.autograd.Function):
         pipe.bwd3(dvalue)
         if world > 1:
             import torch.distributed as dist
-            dist.all_reduce(pipe.bst[0:2], group=group)
+            dist.all_reduce(pipe.bst2, group=group)
         pipe.bwd2()
         if world > 1:
-            dist.all_reduce(pipe.bst[2:4], group=group)
+            dist.all_reduce(pipe.bst1, group=group)
         grads = pipe.bwd1(ctx.leaves)
         return (None,) + tuple(grads) + (None,)
 

@@ -102,8 +102,11 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
 int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream);
 
 /* ---- DeepSets critic: geometry_rl/modules/pyg_models/deepsets.py:34-53, models/value/gnn_vf_net.py:50-86 ---------------------
- * three forward and three backward stages around the whole-tensor LayerNorm statistics (PyG LayerNorm mode="graph") */
+ * three forward and three backward stages around the whole-tensor LayerNorm statistics (PyG LayerNorm mode="graph").
+ * stats1/stats2/bstats1/bstats2 are slot arrays fp64[grl_deepsets_stat_slots()][2] (per-workgroup sums, fully written by the
+ * producing stage, added up in a fixed order by the consuming one; a data-parallel caller all-reduces the whole array) */
 int grl_deepsets_blocks(int batch);
+int grl_deepsets_stat_slots(void);
 int grl_deepsets_partial3(void);
 int grl_deepsets_partial2(void);
 int grl_deepsets_fwd1(const float* x, const float* W1, const float* b1, float* h1, double* stats1, int batch, int n_nodes, int d,

@@ -1,0 +1,5 @@
+# A/B on ONE box: bench of the committed baseline copy (_ab/base) vs the working tree, alternating (boxes differ by several %).
+for i in 1 2; do
+  (cd _ab/base && python bench.py --no-cpu-baseline --no-roofline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('base', l['value'], l['ms_per_step'])")
+  python bench.py --no-cpu-baseline --no-roofline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; l=json.loads(sys.stdin.read()); print('new ', l['value'], l['ms_per_step'])"
+done
