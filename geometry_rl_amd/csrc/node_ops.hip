@@ -15,6 +15,8 @@ struct FiberDfks { const float* p[4]; };
 
 // ------------------------------------------------------------------------------------------------ lift + encode
 // x[n,o,c] = sum_s scal[n,s] W[c,s] + sum_v (vec[n,v,:] . grid[o,:]) W[c,S+v]
+//          = A[n,c] + sum_d grid[o,d] Bv[n,c,d],   A = scal W_s^T,  Bv[.,.,d] = vec[.,.,d] W_v^T
+// i.e. 3 multiply-adds per output instead of S+V (the kernel was VALU-bound at ~2x its HBM time); A and Bv cost 3+3V per (n,c).
 __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const float* __restrict__ Wenc,
                                                               float* __restrict__ x, int N, int S, int V) {
@@ -22,83 +24,78 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
   const int KF = S + V;
   for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
   __syncthreads();
-  // the grid stride is a multiple of 16, so a thread keeps its channel quad for the whole launch: its 4 x KF weights live in
-  // registers (the LDS image they used to be read from had 1.5 bank conflicts per access, profiles/r01_pmc_*)
+  // thread = (node, channel quad); the grid stride is a multiple of 16, so a thread keeps its channel quad for the whole launch
+  // and its 4 x KF weights live in registers
   const int c4 = threadIdx.x & 15;
   float w[4][KF_MAX];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int k = 0; k < KF_MAX; ++k) w[j][k] = k < KF ? Wenc[(4 * c4 + j) * KF + k] : 0.f;
-  const size_t total = (size_t)N * O * (C / 4);
+  const size_t total = (size_t)N * 16;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t row = idx >> 4;
-    const int o = row & 15;
-    const size_t n = row >> 4;
-    float feat[KF_MAX];
+    const size_t n = idx >> 4;
+    float A[4] = {0.f, 0.f, 0.f, 0.f}, Bx[4] = {0.f, 0.f, 0.f, 0.f}, By[4] = {0.f, 0.f, 0.f, 0.f}, Bz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < KF_MAX; ++k) {
-      if (k < S) feat[k] = scal[n * S + k];
-      else if (k < KF) {
+      if (k < S) {
+        const float sv = scal[n * S + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[j] = fmaf(sv, w[j][k], A[j]);
+      } else if (k < KF) {
         const float* v = vec + (n * V + (k - S)) * 3;
-        feat[k] = v[0] * gs[3 * o] + v[1] * gs[3 * o + 1] + v[2] * gs[3 * o + 2];
-      } else feat[k] = 0.f;
-    }
-    float out[4];
+        const float vx = v[0], vy = v[1], vz = v[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < KF_MAX; ++k)
-        if (k < KF) acc += feat[k] * w[j][k];
-      out[j] = acc;
+        for (int j = 0; j < 4; ++j) { Bx[j] = fmaf(vx, w[j][k], Bx[j]); By[j] = fmaf(vy, w[j][k], By[j]); Bz[j] = fmaf(vz, w[j][k], Bz[j]); }
+      }
     }
-    reinterpret_cast<float4*>(x)[idx] = make_float4(out[0], out[1], out[2], out[3]);
+    float4* out = reinterpret_cast<float4*>(x) + n * (O * 16) + c4;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float gx = gs[3 * o], gy = gs[3 * o + 1], gz = gs[3 * o + 2];
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = fmaf(gz, Bz[j], fmaf(gy, By[j], fmaf(gx, Bx[j], A[j])));
+      out[o * 16] = make_float4(r[0], r[1], r[2], r[3]);
+    }
   }
 }
 
-// dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF].  A block streams 64-row tiles of dx: 64 threads build the
-// tile's lifted features once into LDS, then thread (c, part) folds its 16 rows (dx read coalesced, features broadcast).
+// dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF].  With D0[n,c] = sum_o dx and Dd[n,c] = sum_o grid[o,d] dx:
+// dW[c,s] = sum_n scal[n,s] D0,  dW[c,S+v] = sum_n vec[n,v,:] . D[n,c,:]  -- 4 multiply-adds per dx element instead of S+V.
+// Thread (c, part): channel c, nodes part, part+4, ...; a node's 16 rows of dx are 16 coalesced loads in flight.
 __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const float* __restrict__ dx,
                                                               float* __restrict__ partial, int N, int S, int V) {
   __shared__ float gs[O * 3];
-  __shared__ float feat[64][KF_MAX];
   __shared__ float red[4 * C * KF_MAX];
   const int KF = S + V;
   for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
+  __syncthreads();
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   float dw[KF_MAX];
 #pragma unroll
   for (int k = 0; k < KF_MAX; ++k) dw[k] = 0.f;
-  const size_t rows = (size_t)N * O;
-  const size_t n_tiles = (rows + 63) / 64;
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const size_t row = tile * 64 + threadIdx.x;
-      const int o = row & 15;
-      const size_t n = row >> 4;
+  for (size_t n = (size_t)blockIdx.x * 4 + part; n < (size_t)N; n += (size_t)gridDim.x * 4) {
+    const float* dp = dx + n * (O * C) + c;
+    float dv[O];
 #pragma unroll
-      for (int k = 0; k < KF_MAX; ++k) {
-        float f = 0.f;
-        if (row < rows) {
-          if (k < S) f = scal[n * S + k];
-          else if (k < KF) {
-            const float* v = vec + (n * V + (k - S)) * 3;
-            f = v[0] * gs[3 * o] + v[1] * gs[3 * o + 1] + v[2] * gs[3 * o + 2];
-          }
-        }
-        feat[threadIdx.x][k] = f;
-      }
+    for (int o = 0; o < O; ++o) dv[o] = dp[o * C];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      d0 += dv[o];
+      d1 = fmaf(gs[3 * o], dv[o], d1);
+      d2 = fmaf(gs[3 * o + 1], dv[o], d2);
+      d3 = fmaf(gs[3 * o + 2], dv[o], d3);
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int rr = part * 16; rr < part * 16 + 16; ++rr) {
-      const size_t row = tile * 64 + rr;
-      const float d = row < rows ? dx[row * C + c] : 0.f;
 #pragma unroll
-      for (int k = 0; k < KF_MAX; ++k) dw[k] += d * feat[rr][k];
+    for (int k = 0; k < KF_MAX; ++k) {
+      if (k < S) dw[k] = fmaf(scal[n * S + k], d0, dw[k]);
+      else if (k < KF) {
+        const float* v = vec + (n * V + (k - S)) * 3;
+        dw[k] += v[0] * d1 + v[1] * d2 + v[2] * d3;
+      }
     }
   }
 #pragma unroll
@@ -398,13 +395,13 @@ extern "C" {
 
 int grl_fiber_partial_size() { return FIBER_PARTIAL; }
 int grl_fiber_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
-int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks((long long)n_nodes * O, 64, 1024); }
+int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
 
 int grl_lift_encode_fwd(const float* scal, const float* vec, const float* grid, const float* Wenc, float* x, int n_nodes,
                         int n_scal, int n_vec, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   if (n_scal + n_vec > KF_MAX) return -2;
-  const int blocks = cap_blocks((long long)n_nodes * O * 16, 256, 2048);
+  const int blocks = cap_blocks((long long)n_nodes * 16, 256, 2048);
   hipLaunchKernelGGL(lift_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, scal, vec, grid, Wenc, x, n_nodes, n_scal,
                      n_vec);
   GRL_CHECK_LAUNCH();
