@@ -258,8 +258,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd3(const float* __restrict
 
 // ---- backward 3: from dV.  Writes q2 = dy2 * relu'(.) * gamma2 (the LNg input-gradient numerator), slot sums of
 //      (q2, q2 * xhat2); weight grads of Lin4, Linv and LNg2 affine.  Row j AND column j of W4 in registers.
-// partial row: [dW4 64x64 | db4 64 | dwv 64 | dbv 1 | dg2 64 | dbe2 64]
-constexpr int P3 = H * H + H + H + 1 + H + H;
+// partial row: [dW4 64x64 | db4 64 | dwv 64 | dg2 64 | dbe2 64 | dbv 1 | 3 unused]  (every segment 16-byte aligned)
+constexpr int P3 = H * H + 4 * H + 4;
 __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd3(const float* __restrict__ u1, const double* __restrict__ slots2, double count2,
                                                         const float* __restrict__ g2, const float* __restrict__ be2,
                                                         const float* __restrict__ W4, const float* __restrict__ b4,
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd3(const float* __restrict
   float* out = partial + (size_t)blockIdx.x * P3;
   fold_rows64(dW4, fold, out);
   const float sc[5] = {db4, dwv, dg, dbe, dbv};
-  float* const outs[5] = {out + H * H, out + H * H + H, out + H * H + 2 * H + 1, out + H * H + 3 * H + 1, fold + 5 * DS_WAVES * H};
+  float* const outs[5] = {out + H * H, out + H * H + H, out + H * H + 2 * H, out + H * H + 3 * H, fold + 5 * DS_WAVES * H};
   fold_scalars<5>(sc, fold, outs);
-  if (threadIdx.x == 0) out[H * H + 2 * H] = fold[5 * DS_WAVES * H];   // dbv is the same in every lane: lane 0's folded value
+  if (threadIdx.x == 0) out[H * H + 4 * H] = fold[5 * DS_WAVES * H];   // dbv is the same in every lane: lane 0's folded value
 }
 
 // ---- backward 2: du1 (LNg2 backward) -> Lin3 -> dz; dz fans out to every node row of the sample -> Lin2 -> dy1 (same for

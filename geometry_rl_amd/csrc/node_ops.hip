@@ -191,8 +191,22 @@ __global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const float* __rest
 // launches.  A workgroup owns 4 rows, thread = (row, column); weight rows are staged in LDS ([64][65], conflict-free by row and
 // by column).  The backward leaves one partial row per workgroup: [dWf_0 .. dWf_{n-1} (4096 each) | dW2 4096 | db2 64 | dW1 192 | db1 64].
 constexpr int FB_ROWS = 256, FB_RPB = 4, FB_MAXC = 4, FB_P = 3;
+// 256 threads x 4 quads: every load is issued before the first LDS store (a scalar loop of 16 dependent loads per matrix made
+// the staging, not the arithmetic, these two launches' run time)
 GRL_DEVINL void fb_stage(float* dst /*[64][65]*/, const float* __restrict__ src /*[64][64]*/) {
-  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) dst[(i >> 6) * 65 + (i & 63)] = src[i];
+  float4 q[4];
+  const bool vec = (reinterpret_cast<size_t>(src) & 15) == 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = 4 * (threadIdx.x + 256 * u);
+    q[u] = vec ? *reinterpret_cast<const float4*>(src + i) : make_float4(src[i], src[i + 1], src[i + 2], src[i + 3]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = 4 * (threadIdx.x + 256 * u);
+    float* d = dst + (i >> 6) * 65 + (i & 63);
+    d[0] = q[u].x; d[1] = q[u].y; d[2] = q[u].z; d[3] = q[u].w;
+  }
 }
 __global__ __launch_bounds__(256) void fiber_basis_fwd_kernel(const float* __restrict__ poly, const float* __restrict__ W1,
                                                               const float* __restrict__ b1, const float* __restrict__ W2,
@@ -306,17 +320,33 @@ __global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __res
 // (wave g: rows g, g+8, ..., four independent running sums each, combined in a fixed order) and the 8 wave sums are folded
 // through LDS in wave order.  No atomics, so the result does not depend on scheduling.
 constexpr int RED_WAVES = 8;
+// RED_DEPTH independent loads in flight per wave: the slabs are row-strided, so a wave's walk down its rows is a chain of
+// memory latencies -- with 4 in flight the longest columns (2048 rows: gradients fed by two convolutions) took 64 round trips.
+constexpr int RED_DEPTH = 16;
 GRL_DEVINL float column_sum(const float* __restrict__ src /*column base*/, size_t ld, int n_rows, int wave) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float a[RED_DEPTH];
+#pragma unroll
+  for (int u = 0; u < RED_DEPTH; ++u) a[u] = 0.f;
   int w = wave;
-  for (; w + 3 * RED_WAVES < n_rows; w += 4 * RED_WAVES) {
-    a0 += src[(size_t)w * ld];
-    a1 += src[(size_t)(w + RED_WAVES) * ld];
-    a2 += src[(size_t)(w + 2 * RED_WAVES) * ld];
-    a3 += src[(size_t)(w + 3 * RED_WAVES) * ld];
+  for (; w + (RED_DEPTH - 1) * RED_WAVES < n_rows; w += RED_DEPTH * RED_WAVES) {
+    float v[RED_DEPTH];
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) v[u] = src[(size_t)(w + u * RED_WAVES) * ld];
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) a[u] += v[u];
   }
-  for (; w < n_rows; w += RED_WAVES) a0 += src[(size_t)w * ld];
-  return (a0 + a1) + (a2 + a3);
+  {  // remainder: all of its (< RED_DEPTH) loads in flight together
+    float v[RED_DEPTH];
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) v[u] = w + u * RED_WAVES < n_rows ? src[(size_t)(w + u * RED_WAVES) * ld] : 0.f;
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) a[u] += v[u];
+  }
+#pragma unroll
+  for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
+#pragma unroll
+    for (int u = 0; u < st; ++u) a[u] += a[u + st];
+  return a[0];
 }
 GRL_DEVINL void fold_and_add(float v, float* __restrict__ dst, bool active, float (*red)[64], bool overwrite = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -368,19 +398,74 @@ struct ReduceMulti {
   int n_rows[RED_MULTI_MAX], ld[RED_MULTI_MAX], start[RED_MULTI_MAX];
   float* dst[RED_MULTI_MAX];                                           // destinations
   int len[RED_MULTI_MAX], first[RED_MULTI_MAX], count[RED_MULTI_MAX];
+  unsigned char vec[RED_MULTI_MAX];                                    // destination group eligible for the float4 path
 };
+// float4 variant: a wave covers 4 rows x 64 columns per load (16 lanes x float4 per row, lane >> 4 picks the row), so a
+// workgroup still owns only 64 columns -- tall thin slabs (1024-2048 rows x 4096 columns) need that many workgroups: with 256
+// columns per workgroup 16 CUs pulled the whole slab at ~95 GB/s each (tools/ubench/reduce_bench.py).
+GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_rows, int row0) {
+  constexpr int STEP = 4 * RED_WAVES;
+  float4 a[RED_DEPTH];
+#pragma unroll
+  for (int u = 0; u < RED_DEPTH; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int w = row0;
+  for (; w + (RED_DEPTH - 1) * STEP < n_rows; w += RED_DEPTH * STEP) {
+    float4 v[RED_DEPTH];
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u * STEP) * ld);
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) a[u] = f4_add(a[u], v[u]);
+  }
+  {  // remainder: all of its (< RED_DEPTH) loads in flight together
+    float4 v[RED_DEPTH];
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u)
+      v[u] = w + u * STEP < n_rows ? *reinterpret_cast<const float4*>(src + (size_t)(w + u * STEP) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < RED_DEPTH; ++u) a[u] = f4_add(a[u], v[u]);
+  }
+#pragma unroll
+  for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
+#pragma unroll
+    for (int u = 0; u < st; ++u) a[u] = f4_add(a[u], a[u + st]);
+  return a[0];
+}
+GRL_DEVINL float4 f4_shfl_xor(float4 v, int m) {
+  return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
+}
 __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(ReduceMulti m) {
-  __shared__ float red[RED_WAVES][64];
+  __shared__ float4 red[RED_WAVES][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = blockIdx.y;
   if (blockIdx.x * 64 >= m.len[d]) return;
+  if (m.vec[d]) {   // every source slab and the destination 16-byte aligned, lengths multiples of 4
+    const int j = blockIdx.x * 64 + 4 * (lane & 15);
+    const bool active = j < m.len[d];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active)
+      for (int q = m.first[d]; q < m.first[d] + m.count[d]; ++q)
+        v = f4_add(v, column_sum4(m.partial[q] + m.start[q] + j, (size_t)m.ld[q], m.n_rows[q], 4 * wave + (lane >> 4)));
+    v = f4_add(v, f4_shfl_xor(v, 16));
+    v = f4_add(v, f4_shfl_xor(v, 32));
+    if (lane < 16) red[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && lane < 16 && active) {
+      float4 t = red[0][lane];
+#pragma unroll
+      for (int g = 1; g < RED_WAVES; ++g) t = f4_add(t, red[g][lane]);
+      float4* dp = reinterpret_cast<float4*>(m.dst[d] + j);
+      *dp = f4_add(*dp, t);
+    }
+    return;
+  }
   const int j = blockIdx.x * 64 + lane;
   const bool active = j < m.len[d];
   float v = 0.f;
   if (active)
     for (int q = m.first[d]; q < m.first[d] + m.count[d]; ++q)
       v += column_sum(m.partial[q] + m.start[q] + j, (size_t)m.ld[q], m.n_rows[q], wave);
-  fold_and_add(v, m.dst[d] + j, active, red);
+  __shared__ float reds[RED_WAVES][64];
+  fold_and_add(v, m.dst[d] + j, active, reds);
 }
 
 int cap_blocks(long long work, int per_block, int cap) {
@@ -517,14 +602,17 @@ int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int*
     m.dst[n_dst] = dst[i];
     m.len[n_dst] = len[i];
     m.first[n_dst] = n_src;
+    bool vec = (len[i] & 3) == 0 && (reinterpret_cast<size_t>(dst[i]) & 15) == 0;
     for (int k = i; k < n_seg; ++k) {
       if (used[k] || dst[k] != dst[i]) continue;
       if (len[k] != len[i]) return -3;
       used[k] = true;
+      vec = vec && (ld[k] & 3) == 0 && (reinterpret_cast<size_t>(partial[k] + start[k]) & 15) == 0;
       m.partial[n_src] = partial[k]; m.n_rows[n_src] = n_rows[k]; m.ld[n_src] = ld[k]; m.start[n_src] = start[k];
       ++n_src;
     }
     m.count[n_dst] = n_src - m.first[n_dst];
+    m.vec[n_dst] = vec ? 1 : 0;
     if (len[i] > max_len) max_len = len[i];
     ++n_dst;
   }

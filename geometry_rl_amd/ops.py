@@ -383,8 +383,8 @@ class DeepSetsPipeline:
                  self.B, self.n, d)
         (pw1, pb1, pg1, pbe1, pw2, pb2, pw3, pb3, pg2, pbe2, pw4, pb4, pwv, pbv) = leaves
         dw4, db4, dwv, dbv, dg2, dbe2 = _emit_grads(self.part3, [(0, 4096, (64, 64), pw4), (4096, 64, (64,), pb4),
-                                                                 (4160, 64, (1, 64), pwv), (4224, 1, (1,), pbv),
-                                                                 (4225, 64, (64,), pg2), (4289, 64, (64,), pbe2)])
+                                                                 (4160, 64, (1, 64), pwv), (4352, 1, (1,), pbv),
+                                                                 (4224, 64, (64,), pg2), (4288, 64, (64,), pbe2)])
         dw3, db3, dw2, db2, dg1, dbe1 = _emit_grads(self.part2, [(0, 4096, (64, 64), pw3), (4096, 64, (64,), pb3),
                                                                  (4160, 4096, (64, 64), pw2), (8256, 64, (64,), pb2),
                                                                  (8320, 64, (64,), pg1), (8384, 64, (64,), pbe1)])
