@@ -208,9 +208,16 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 #define GRL_FWD_WAVES 4
 #endif
 constexpr int FWD_WAVES = GRL_FWD_WAVES;
+#ifndef GRL_FWD_SPLIT_TILES
+#define GRL_FWD_SPLIT_TILES 512   // at most this many destination tiles: one workgroup per tile (edge_conv_fwd_kernel<true>)
+#endif
 #ifndef GRL_FWD_MAX_BLOCKS
 #define GRL_FWD_MAX_BLOCKS 512   // two 4-wave workgroups per CU = two waves per SIMD (the chain is fenced for that)
 #endif
+// SPLIT: few destination tiles with long edge lists (e.g. the object -> gripper convolution of a small minibatch shard: a few
+// hundred tiles of 16+ passes would occupy a fraction of the SIMDs for the whole launch).  A workgroup then owns ONE tile, its
+// four waves take every fourth pass and the four partial messages are added in wave order through LDS.
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
 (EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
@@ -220,9 +227,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
   __syncthreads();
   const int o = r & 15, el = r >> 4;
   const int n_tiles = (p.n_anchor + TD - 1) / TD;
-  for (int tl = blockIdx.x * FWD_WAVES + wave; tl < n_tiles; tl += gridDim.x * FWD_WAVES) {
+  constexpr int ESTEP = SPLIT ? 2 * FWD_WAVES : 2;
+  for (int tl = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * FWD_WAVES + wave; tl < n_tiles;
+       tl += SPLIT ? (int)gridDim.x : (int)gridDim.x * FWD_WAVES) {
     const int d0 = tl * TD, d1 = min(d0 + TD, p.n_anchor);
-    const int e0 = p.rowptr[d0], e1 = p.rowptr[d1];
+    const int e0 = p.rowptr[d0] + (SPLIT ? 2 * wave : 0), e1 = p.rowptr[d1];
     float4 accA[8], accB[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { accA[t] = make_float4(0.f, 0.f, 0.f, 0.f); accB[t] = accA[t]; }
@@ -231,10 +240,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
       meta_indices(p, e0 + el, e1, cur);
       meta_invariants(p, s.grid_s, o, cur);
 #pragma unroll 1
-      for (int e = e0; e < e1; e += 2) {
+      for (int e = e0; e < e1; e += ESTEP) {
         PassMeta nxt;
-        const bool more = e + 2 < e1;
-        if (more) meta_indices(p, e + 2 + el, e1, nxt);                       // next pass: indices in flight
+        const bool more = e + ESTEP < e1;
+        if (more) meta_indices(p, e + ESTEP + el, e1, nxt);                   // next pass: indices in flight
         const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
         float4 xv[8];
 #pragma unroll
@@ -260,6 +269,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
     // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's
     const int node = d0 + el;
     float4* dstp = reinterpret_cast<float4*>(x1 + ((size_t)node * O + o) * C) + h;
+    float4* red = reinterpret_cast<float4*>(smem_raw + sizeof(ChainW) / 4);   // SPLIT only: [FWD_WAVES][8][64]
+    if (SPLIT) __syncthreads();   // the previous tile's sums have been read
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float4 a = accA[t], b = accB[t];
@@ -269,7 +280,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
       // one by index) -- slow, and the store->load ordering proved unreliable with two waves of a block per SIMD
       const bool is_a = el == 0;
       const float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
-      if (node < d1) dstp[2 * t] = v;
+      if (SPLIT) red[(wave * 8 + t) * 64 + lane] = v;
+      else if (node < d1) dstp[2 * t] = v;
+    }
+    if (SPLIT) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8 / FWD_WAVES; ++u) {   // wave w adds up and stores fragments t = w, w + FWD_WAVES, ...
+        const int t = wave + u * FWD_WAVES;
+        float4 v = red[t * 64 + lane];
+#pragma unroll
+        for (int w_ = 1; w_ < FWD_WAVES; ++w_) v = f4_add(v, red[(w_ * 8 + t) * 64 + lane]);
+        if (node < d1) dstp[2 * t] = v;
+      }
     }
   }
 }
@@ -526,15 +549,20 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
   if (n_dst <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int n_tiles = (n_dst + TD - 1) / TD;
-  int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
-  if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
-  const size_t smem = sizeof(ChainW);
+  const size_t smem = sizeof(ChainW), smem_split = smem + sizeof(float4) * FWD_WAVES * 8 * 64;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)edge_conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split);
     attr = true;
   }
-  hipLaunchKernelGGL(edge_conv_fwd_kernel, dim3(blocks), dim3(64 * FWD_WAVES), smem, stream, p, x1);
+  if (n_tiles <= GRL_FWD_SPLIT_TILES) {   // fewer tiles than SIMD groups: spread each tile's passes over a workgroup
+    hipLaunchKernelGGL(edge_conv_fwd_kernel<true>, dim3(n_tiles), dim3(64 * FWD_WAVES), smem_split, stream, p, x1);
+  } else {
+    int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
+    if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
+    hipLaunchKernelGGL(edge_conv_fwd_kernel<false>, dim3(blocks), dim3(64 * FWD_WAVES), smem, stream, p, x1);
+  }
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -39,7 +39,7 @@ def params(g, shapes):
 
 
 @pytest.mark.parametrize("n_src,n_dst,n_edges,dim,upper", [(37, 37, 150, 3, False), (50, 9, 211, 3, True), (21, 5, 1, 2, False),
-                                                             (300, 300, 900, 3, False)])
+                                                             (300, 300, 900, 3, False), (1500, 1500, 2500, 3, True)])  # last: > 512 tiles = the one-wave-per-tile forward
 def test_edge_conv(n_src, n_dst, n_edges, dim, upper):
     from geometry_rl_amd import ops
     d = dev()
