@@ -20,3 +20,28 @@ for k in A:
     print(f"{k:40s} {n:3d}  act {a['SQ_ACTIVE_INST_ANY']/wc:.2f} wait {a['SQ_WAIT_ANY']/wc:.2f} stall {a['SQ_WAIT_INST_ANY']/wc:.2f} | valu {a['SQ_ACTIVE_INST_VALU']/wc:.2f} | mfma {a['SQ_VALU_MFMA_BUSY_CYCLES']/(4*wc):.2f} | "
           f"valu/mfma {b['SQ_INSTS_VALU']/max(b['SQ_INSTS_MFMA'],1):6.1f} | lds {b['SQ_INSTS_LDS']/n:.3g} conf {b['SQ_LDS_BANK_CONFLICT']/max(b['SQ_ACTIVE_INST_LDS'],1):.2f} | "
           f"rd {2*C[k]['FETCH_SIZE']*1024/max(nC[k],1)/1e6:8.1f} wr {D[k]['WRITE_SIZE']*1024/max(nD[k],1)/1e6:8.1f}")
+
+# ---- JSON summary (profiles/r01_pmc_summary_*.json; bench.py reads hbm_*_bytes_per_launch of the dominant kernel from it)
+if len(sys.argv) > 2:
+    import json, re
+    out = {"_note": "rocprofv3 --pmc passes (tools/pmc_passes.sh) over tools/profile_step.py (calibration call + 2 policy updates, 4096 "
+                    "frames); per-launch averages over all launches of a kernel in that run; FETCH_SIZE doubled (gfx950 correction, "
+                    "MI355X_MICROARCH.md HBM section), KB -> bytes", "kernels": {}}
+    for k in A:
+        if not any(s in k for s in ("edge_conv", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
+            continue
+        a, b, n = A[k], B[k], nA[k]
+        wc = a["SQ_WAVE_CYCLES"] or 1
+        name = re.sub(r"<.*", "", k.split("(")[0]).strip()
+        e = out["kernels"].setdefault(name, None)
+        rec = {"launches": n,
+               "hbm_read_bytes_per_launch": 2 * C[k]["FETCH_SIZE"] * 1024 / max(nC[k], 1),
+               "hbm_write_bytes_per_launch": D[k]["WRITE_SIZE"] * 1024 / max(nD[k], 1),
+               "wave_active": round(a["SQ_ACTIVE_INST_ANY"] / wc, 3), "wave_wait": round(a["SQ_WAIT_ANY"] / wc, 3),
+               "wave_issue_stall": round(a["SQ_WAIT_INST_ANY"] / wc, 3), "valu_active": round(a["SQ_ACTIVE_INST_VALU"] / wc, 3),
+               "mfma_busy_per_wave_cycle": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc), 3),
+               "valu_per_mfma": round(b["SQ_INSTS_VALU"] / b["SQ_INSTS_MFMA"], 2) if b["SQ_INSTS_MFMA"] else None,
+               "lds_bank_conflict_ratio": round(b["SQ_LDS_BANK_CONFLICT"] / max(b["SQ_ACTIVE_INST_LDS"], 1), 3)}
+        if e is None or rec["launches"] > e["launches"]:   # template instances of one kernel: keep the one launched most
+            out["kernels"][name] = rec
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
