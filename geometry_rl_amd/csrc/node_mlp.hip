@@ -120,6 +120,12 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restri
   }
 }
 
+#ifdef GRL_MLP_PHASE_PROF
+__device__ unsigned long long g_phase[2][16];
+#define PH(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && (wave == 0 || wave == 5)) ph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PH(i)
+#endif
 // partial slab per workgroup: [dW3 256x64 | db3 256 | dW4 64x256 | db4 64 | dgamma 64 | dbeta 64]
 constexpr int MLP_PARTIAL = W * C + W + C * W + C + C + C;
 
@@ -232,8 +238,18 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
   };
   int ch = blockIdx.x;
   if (ch < n_chunks) fetch(ch);
+#ifdef GRL_MLP_PHASE_PROF
+  unsigned long long ph[16] = {0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
   for (; ch < n_chunks; ch += gridDim.x) {
+    PH(0);
+    // W3 fragments of this wave's hidden tile (its slab in L2): requested here, a whole LayerNorm stage and a barrier before
+    // their first use -- loaded inside the product groups their L2 latency was exposed four times per chunk (phase timing:
+    // 35-44 % of a chunk in the z / dH group)
+    u32x4 w3pre[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w3pre[q] = w3f[q * 64 + lane];
     // ------------------------------------------------------------ 1: LayerNorm + fragment images
     float4 xh;
     float rstd;
@@ -251,7 +267,9 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     }
     const int ch_next = ch + gridDim.x;
     if (ch_next < n_chunks) fetch(ch_next);
+    PH(1);
     __syncthreads();
+    PH(2);
     // ------------------------------------------------------------ 2: the four shared transposed tiles (waves 0-3)
     if (wave < 4) {
       const unsigned short* ih = (wave < 2 ? s.Ah : s.Dh) + r * LDF + 32 * (wave & 1) + 8 * h;
@@ -265,6 +283,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       s.TT[wave][2][lane] = __builtin_bit_cast(u32x4, t.l0);
       s.TT[wave][3][lane] = __builtin_bit_cast(u32x4, t.l1);
     }
+    PH(3);
     // (no barrier yet: z, dH and the activation below only read the fragment images; the transposed tiles are first needed by dW3)
     // ------------------------------------------------------------ 3: this wave's hidden tile
     f32x16 z, dh = zero16();
@@ -277,8 +296,8 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int sidx = 2 * half + u;
-        w3h[u] = __builtin_bit_cast(bf16x8, w3f[(sidx * 2 + 0) * 64 + lane]);
-        w3l[u] = __builtin_bit_cast(bf16x8, w3f[(sidx * 2 + 1) * 64 + lane]);
+        w3h[u] = __builtin_bit_cast(bf16x8, w3pre[sidx * 2 + 0]);
+        w3l[u] = __builtin_bit_cast(bf16x8, w3pre[sidx * 2 + 1]);
         ah[u] = *reinterpret_cast<const bf16x8*>(s.Ah + r * LDF + 16 * sidx + 8 * h);
         al[u] = *reinterpret_cast<const bf16x8*>(s.Al + r * LDF + 16 * sidx + 8 * h);
       }
@@ -315,6 +334,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    PH(4);
     float4 hv[4], dz[4];
     float csum = 0.f;
 #pragma unroll
@@ -331,7 +351,10 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     split_pair(dz[0], dz[1], zT.h0, zT.l0);
     split_pair(dz[2], dz[3], zT.h1, zT.l1);
     __builtin_amdgcn_sched_barrier(0);
+    PH(5);
     __syncthreads();   // transposed shared tiles (stage 2) complete
+    PH(6);
+
     {
       const TTile ta0 = load_ttile(s.TT[0], lane), ta1 = load_ttile(s.TT[1], lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       mfma_fence(aW3[1], sink);
       __builtin_amdgcn_sched_barrier(0);
     }
+
     {
       const TTile td0 = load_ttile(s.TT[2], lane), td1 = load_ttile(s.TT[3], lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -348,7 +372,11 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       mfma_fence(aW4[1], sink);
       __builtin_amdgcn_sched_barrier(0);
     }
+    PH(7);
     // dZ back to row layout, then dA^T per 32-column tile: partial rows to LDS (waves 0-3 write, waves 4-7 add)
+    u32x4 w3d[8];      // the same W3 fragments again, for dA: the first column tile's in flight behind the dZ transposes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w3d[q] = w3f[q * 64 + lane];
     bf16x8 zrh0, zrh1, zrl0, zrl1;
     acc_to_bf(transpose32(zT.h0, zT.h1, sel0, sel1), zrh0, zrh1);
     acc_to_bf(transpose32(zT.l0, zT.l1, sel0, sel1), zrl0, zrl1);
@@ -357,11 +385,15 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       bf16x8 th0, th1, tl0, tl1;
+      if (ct == 1) {
+#pragma unroll
+        for (int q = 4; q < 8; ++q) w3d[q] = w3f[q * 64 + lane];
+      }
       {
-        const bf16x8 ch0 = __builtin_bit_cast(bf16x8, w3f[((2 * ct) * 2 + 0) * 64 + lane]);
-        const bf16x8 ch1 = __builtin_bit_cast(bf16x8, w3f[((2 * ct + 1) * 2 + 0) * 64 + lane]);
-        const bf16x8 cl0 = __builtin_bit_cast(bf16x8, w3f[((2 * ct) * 2 + 1) * 64 + lane]);
-        const bf16x8 cl1 = __builtin_bit_cast(bf16x8, w3f[((2 * ct + 1) * 2 + 1) * 64 + lane]);
+        const bf16x8 ch0 = __builtin_bit_cast(bf16x8, w3d[(2 * ct) * 2 + 0]);
+        const bf16x8 ch1 = __builtin_bit_cast(bf16x8, w3d[(2 * ct + 1) * 2 + 0]);
+        const bf16x8 cl0 = __builtin_bit_cast(bf16x8, w3d[(2 * ct) * 2 + 1]);
+        const bf16x8 cl1 = __builtin_bit_cast(bf16x8, w3d[(2 * ct + 1) * 2 + 1]);
         __builtin_amdgcn_sched_barrier(0);
         acc_to_bf(transpose32(ch0, ch1, sel0, sel1), th0, th1);
         acc_to_bf(transpose32(cl0, cl1, sel0, sel1), tl0, tl1);
@@ -372,12 +404,14 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       acc_to_frag(da, daf[4 * ct], daf[4 * ct + 1], daf[4 * ct + 2], daf[4 * ct + 3]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    PH(8);
     float* drow = s.DA[wave & 3] + r * LDD + 4 * h;
     if (wave < 4) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = daf[t];
     }
     __syncthreads();
+    PH(9);
     if (wave >= 4) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -386,6 +420,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       }
     }
     __syncthreads();
+    PH(10);
     // ------------------------------------------------------------ 4: LayerNorm backward
     {
       const int row = ch * 32 + lrow;
@@ -402,7 +437,12 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       dbet = f4_add(dbet, da);
     }
     // (stage 1 of the next chunk only writes the A / D images, last read before the two barriers above)
+    PH(11);
   }
+#ifdef GRL_MLP_PHASE_PROF
+  if (lane == 0 && (wave == 0 || wave == 5))
+    for (int i = 0; i < 12; ++i) atomicAdd(&g_phase[wave == 5][i], ph[i]);
+#endif
 
   // ---- partial slab.  accumulator element i of lane (n = r, h) holds row m = 8(i>>2) + 4h + (i&3) of the 32x32 tile
   __syncthreads();   // every wave is done with its W3 fragments (same slab)
@@ -480,4 +520,11 @@ int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const 
   return 0;
 }
 
+#ifdef GRL_MLP_PHASE_PROF
+int grl_mlp_phase_read(unsigned long long* out32, int reset) {
+  hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+  return 0;
+}
+#endif
 }  // extern "C"
