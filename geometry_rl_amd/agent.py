@@ -89,8 +89,9 @@ class PolicyUpdater:
     The collectives themselves stay ordinary eager torch.distributed calls between the replays."""
 
     def __init__(self, loss_module: TRPLLoss, lr=3e-4, eps=1e-5, betas=(0.9, 0.999), clip_grad_norm=False, max_grad_norm=1.0,
-                 group=None, use_graph=False):
+                 group=None, use_graph=False, overlap_critic=True):
         self.loss_module, self.group = loss_module, group
+        self.overlap_critic = overlap_critic   # one rank only: critic kernels on a second stream beside the actor's
         self.lr, self.eps, self.betas = lr, eps, betas
         self.clip, self.max_norm = clip_grad_norm, max_grad_norm
         a = [p for p in loss_module.actor_network.parameters() if p.requires_grad]
@@ -200,6 +201,51 @@ class PolicyUpdater:
                 out.update(mt)
                 st["out"] = out
 
+        # ---- one rank: no reduction separates the critic stages, so the whole critic (small, latency-bound launches) runs on
+        #      a second stream beside the actor -- forward beside the actor forward, backward beside the actor backward -- and
+        #      fills the SIMDs the big kernels leave idle at their heads and tails.  Recorded into the graph as a fork / join.
+        def o_fwd():
+            self.gflat.zero_()
+            b = dict(batch)
+            if "var" not in b:
+                b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
+            st["b"] = b
+            st["obs"] = [b[k] for k in m.in_features]
+            cur, cs = torch.cuda.current_stream(), self._critic_stream()
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs), torch.no_grad():
+                vf.train(True)
+                _, x = vf.hyper_data.build_data(*st["obs"], train=True)
+                pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
+                pipe.fwd1()
+                pipe.fwd2()
+                value = pipe.fwd3()
+            with torch.no_grad():
+                zw = st["zw"] = torch.zeros(24, device=self.flat.device, dtype=torch.float64)
+                st["adv"] = None
+                if m.normalize_advantage and st["obs"][0].shape[0] > 1:
+                    st["adv"] = zw[8:10]
+                    adv_stats_local(m, b, st["adv"])
+            ops.DEFERRED = []
+            loc, sigma = actor.forward_diag(*st["obs"], train=True)
+            cur.wait_stream(cs)   # join: the fused loss kernel needs the values
+            with torch.no_grad():
+                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:21],
+                                                                maxes=zw[21:22].view(torch.int32))
+            cs.wait_stream(cur)   # fork: critic backward beside the actor backward
+            with torch.cuda.stream(cs), torch.no_grad():
+                pipe.bwd3(dvalue)
+                pipe.bwd2()
+                grads = pipe.bwd1(leaves)
+            assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
+            torch.autograd.backward([loc, sigma], [dloc, dsigma])
+            cur.wait_stream(cs)   # join: every partial slab is complete
+            ops.flush_deferred_grads()
+            ops.DEFERRED = None
+            st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes)
+
+        if world == 1 and self.overlap_critic:
+            return [("run", o_fwd), ("run", s5)]
         plan = [("run", s0)]
         if world > 1:
             plan += [("sum", lambda: st["pipe"].stats1), ("sum", lambda: st["adv"])]
@@ -217,6 +263,11 @@ class PolicyUpdater:
             plan += [("sum", lambda: self.gflat), ("sum", lambda: st["sums"]), ("max", lambda: st["maxes"])]
         plan += [("run", s5)]
         return plan
+
+    def _critic_stream(self):
+        if getattr(self, "_cstream", None) is None:
+            self._cstream = torch.cuda.Stream()
+        return self._cstream
 
     def _reduce(self, kind, t):
         if t is None:
