@@ -24,6 +24,9 @@ GRL_DEVINL float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// lane k's value to every lane through an SGPR (v_readlane_b32; k is a compile-time constant after unrolling).  __shfl is a
+// ds_bpermute: 16 of them per row made the two row kernels LDS-crossbar-bound (cloth critic: 1 M rows, 0.45 ms for 0.07 ms of HBM time)
+GRL_DEVINL float bcast_lane(float v, int k) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), k)); }
 GRL_DEVINL double wave_sum_d(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ds_fwd1(const float* __restric
       float acc = bj;
 #pragma unroll
       for (int k = 0; k < DMAX; ++k)
-        if (k < d) acc += __shfl(xv[u], k, 64) * w[k];
+        if (k < d) acc += bcast_lane(xv[u], k) * w[k];
       h1[row * H + j] = acc;
       s0 += acc;
       s1 += (double)acc * acc;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ds_bwd1(const float* __restric
       db1 += dh;
 #pragma unroll
       for (int k = 0; k < DMAX; ++k)
-        if (k < d) dW1[k] += dh * __shfl(xv[u], k, 64);
+        if (k < d) dW1[k] += dh * bcast_lane(xv[u], k);
     }
   }
   // fixed-order fold of the sixteen waves: upper half -> LDS -> added by the lower half -> LDS -> wave 0
