@@ -436,6 +436,28 @@ __global__ void loss_values_kernel(const double* __restrict__ sums, const unsign
   out[12] = actor - (tr + ent);
 }
 
+// ---- collector-side action sampling: torch.distributions.MultivariateNormal(loc, covariance_matrix = diag(sigma^2)).rsample()
+//      with return_log_prob (utils_algo_graph.py:146-158, configs/algorithm/policy/default.yaml:6): action = loc + sigma * eps,
+//      log p = -1/2 sum eps_eff^2 - sum log sigma - A/2 log(2 pi), eps_eff = (action - loc) / sigma as the distribution computes it
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ loc, const float* __restrict__ sigma,
+                                                             const float* __restrict__ eps, float* __restrict__ action,
+                                                             float* __restrict__ logp, float* __restrict__ var, int B, int A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float q = 0.f, ls = 0.f;
+  for (int i = 0; i < A; ++i) {
+    const size_t k = (size_t)b * A + i;
+    const float m = loc[k], sg = sigma[k];
+    const float a = fmaf(sg, eps[k], m);
+    const float d = (a - m) / sg;
+    action[k] = a;
+    if (var) var[k] = sg * sg;
+    q = fmaf(d, d, q);
+    ls += logf(sg);
+  }
+  logp[b] = -0.5f * q - ls - 0.5f * (float)A * 1.8378770664093454836f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -502,6 +524,16 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
 // mean_constraint_max, cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective]
 int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream) {
   hipLaunchKernelGGL(loss_values_kernel, dim3(1), dim3(1), 0, stream, sums, maxes, entropy_coef, out13);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// action [B,A] = loc + sigma * eps, logp [B], var [B,A] = sigma^2 (optional, NULL to skip); eps: standard normal draws [B,A]
+int grl_gaussian_sample(const float* loc, const float* sigma, const float* eps, float* action, float* logp, float* var, int batch,
+                        int action_dim, hipStream_t stream) {
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, loc, sigma, eps, action, logp, var,
+                     batch, action_dim);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -93,3 +93,55 @@ class RolloutDriver:
         for idx in self.minibatches(buf):
             out = self.updater.step_from(buf, idx)
         return out
+
+
+class PolicyActor:
+    """Collector-side actor: ``ProbabilisticActor(TensorDictModule(policy, in_keys, ["loc", "covariance_matrix"]),
+    distribution_class=MultivariateNormal, return_log_prob=True, default_interaction_type=RANDOM)`` of
+    examples/torchrl/builders/utils_algo_graph.py:146-158 -- one no-grad policy pass per environment step (train.py:114-123) with the
+    same forward kernels as the update, followed by the sampling kernel.  ``__call__(obs)`` returns the keys the collector writes
+    into the rollout: ``loc``, ``var`` (the diagonal of covariance_matrix), ``action``, ``sample_log_prob``.
+
+    ``use_graph``: after the first call (which builds the cached topology and, on a fresh policy, calibrates the convolutions --
+    the collector calls the module with its default ``train=True``, gnn_gaussian_policy_diag.py:65) the pass is recorded into a
+    hipGraph and replayed on static input buffers."""
+
+    def __init__(self, policy, spec, use_graph: bool = True, seed: int = 0, deterministic: bool = False):
+        self.policy, self.spec, self.use_graph, self.deterministic = policy, spec, use_graph, deterministic
+        self.gen, self.seed = None, seed
+        self._graph, self._static, self._out, self._calls = None, None, None, 0
+
+    def _pass(self, obs):
+        from . import hip
+        loc, sigma = self.policy.forward_diag(*[obs[k] for k in self.spec.in_features], train=True)
+        B, A = loc.shape
+        eps = torch.zeros_like(loc) if self.deterministic else torch.randn(loc.shape, device=loc.device, dtype=loc.dtype, generator=self.gen)
+        action, var = torch.empty_like(loc), torch.empty_like(loc)
+        logp = torch.empty(B, device=loc.device, dtype=torch.float32)
+        hip.call("grl_gaussian_sample", loc.contiguous(), sigma.contiguous(), eps, action, logp, var, B, A)
+        return {"loc": loc, "var": var, "action": action, "sample_log_prob": logp}
+
+    @torch.no_grad()
+    def __call__(self, obs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        dev = obs[self.spec.in_features[0]].device
+        if self.gen is None and not self.deterministic:
+            self.gen = torch.Generator(device=dev)
+            self.gen.manual_seed(self.seed)
+        self._calls += 1
+        if not self.use_graph or self._calls == 1:
+            return self._pass(obs)
+        if self._graph is None:
+            self._static = {k: obs[k].clone() for k in self.spec.in_features}
+            g = torch.cuda.CUDAGraph()
+            if self.gen is not None and hasattr(g, "register_generator_state"):
+                g.register_generator_state(self.gen)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                self._out = self._pass(self._static)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = g
+        for k in self.spec.in_features:
+            self._static[k].copy_(obs[k])
+        self._graph.replay()
+        return self._out

@@ -101,6 +101,11 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
  *          cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective] */
 int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream);
 
+/* ---- collector-side sampling: ProbabilisticActor(..., torch.distributions.MultivariateNormal, return_log_prob=True)
+ * (examples/torchrl/builders/utils_algo_graph.py:146-158; configs/algorithm/policy/default.yaml:6) */
+int grl_gaussian_sample(const float* loc, const float* sigma, const float* eps, float* action, float* logp, float* var, int batch,
+                        int action_dim, hipStream_t stream);
+
 /* ---- DeepSets critic: geometry_rl/modules/pyg_models/deepsets.py:34-53, models/value/gnn_vf_net.py:50-86 ---------------------
  * three forward and three backward stages around the whole-tensor LayerNorm statistics (PyG LayerNorm mode="graph").
  * stats1/stats2/bstats1/bstats2 are slot arrays fp64[grl_deepsets_stat_slots()][2] (per-workgroup sums, fully written by the
