@@ -159,6 +159,72 @@ def kl_projection(p, q, mean_bound, cov_bound):
     return proj_mean, proj_S
 
 
+# --------------------------------------------------------------------------- Frobenius / Wasserstein projections (diagonal policy)
+def frobenius_value(p, q):
+    """putils.py:70-104 (scale_prec=True): (maha(mean, mean_o, S_o), |S_o^2 - S^2|_F^2)."""
+    (mean, S), (mean_o, S_o) = p, q
+    return maha(mean, mean_o, S_o), (S_o.pow(2) - S.pow(2)).pow(2).sum(-1)
+
+
+def wasserstein_value(p, q):
+    """putils.py:107-149 (commutative, scale_prec=True): (maha, tr(I + S_o^-1 S^2 S_o^-1 - 2 S_o^-1 S)) = (maha, sum (1 - S/S_o)^2)."""
+    (mean, S), (mean_o, S_o) = p, q
+    return maha(mean, mean_o, S_o), (1.0 - S / S_o).pow(2).sum(-1)
+
+
+def _eta_from_part(cov_part, eps_cov):
+    """frob_projection_layer.py:49-56 / w2_projection_layer.py:58-64: eta = |sqrt(part/eps) - 1| where the bound is violated, 1 elsewhere
+    (those rows are masked out afterwards)."""
+    mask = cov_part > eps_cov
+    eta = torch.ones_like(cov_part)
+    eta[mask] = torch.sqrt(cov_part[mask] / eps_cov) - 1.0
+    return mask, torch.max(-eta, eta)
+
+
+def frobenius_projection(p, q, mean_bound, cov_bound):
+    """frob_projection_layer.py:10-63 (+ identity entropy projection): new_cov = (S^2 + eta S_o^2) / (1 + eta), proj_S = chol = sqrt."""
+    (mean, S), (mean_o, S_o) = p, q
+    mean_part, cov_part = frobenius_value(p, q)
+    proj_mean = mean_projection(mean, mean_o, mean_part, mean_bound)
+    mask, eta = _eta_from_part(cov_part, cov_bound)
+    if mask.any():
+        new_cov = (S.pow(2) + eta[..., None] * S_o.pow(2)) / (1.0 + eta + 1e-16)[..., None]
+        proj_S = torch.where(mask[..., None], new_cov.sqrt(), S)
+    else:
+        proj_S = S
+    return proj_mean, proj_S
+
+
+def wasserstein_projection(p, q, mean_bound, cov_bound):
+    """w2_projection_layer.py:15-68: new_sqrt = (S + eta S_o) / (1 + eta)."""
+    (mean, S), (mean_o, S_o) = p, q
+    mean_part, cov_part = wasserstein_value(p, q)
+    proj_mean = mean_projection(mean, mean_o, mean_part, mean_bound)
+    mask, eta = _eta_from_part(cov_part, cov_bound)
+    if mask.any():
+        new_S = (S + eta[..., None] * S_o) / (1.0 + eta + 1e-16)[..., None]
+        proj_S = torch.where(mask[..., None], new_S, S)
+    else:
+        proj_S = S
+    return proj_mean, proj_S
+
+
+def frobenius_trust_region_loss(p, proj_p, coeff):
+    """frob_projection_layer.py:73-88 (contextual std): maha(mean, proj_mean, S) + |S - proj_S|^2, proj_p NOT detached."""
+    mean_diff = maha(p[0], proj_p[0], p[1])
+    cov_diff = (p[1] - proj_p[1]).pow(2).sum(-1)
+    return (mean_diff + cov_diff).mean() * coeff
+
+
+def wasserstein_trust_region_loss(p, proj_p, coeff):
+    """base.py:292-327 with trust_region_value = w2 value: (p, stopgrad(proj_p))."""
+    m_d, c_d = wasserstein_value(p, (proj_p[0].detach(), proj_p[1].detach()))
+    return (m_d + c_d).mean() * coeff
+
+
+PROJECTIONS = {"kl": (kl_projection, gaussian_kl), "frob": (frobenius_projection, frobenius_value), "w2": (wasserstein_projection, wasserstein_value)}
+
+
 # --------------------------------------------------------------------------- TRPL loss
 def mvn_diag_log_prob(x, mean, var):
     """torch.distributions.MultivariateNormal(mean, diag(var)).log_prob (trpl.py:245-246)."""
@@ -195,6 +261,7 @@ def trpl_loss(
     clip_value=0.2,
     normalize_advantage=True,
     adv_stats=None,
+    proj_type="kl",
 ) -> Dict[str, torch.Tensor]:
     """trpl.py:275-321 TRPLLoss.forward.
 
@@ -212,15 +279,19 @@ def trpl_loss(
         adv = (adv - a_loc) / a_scale
     p = (loc, var)  # trpl.py:241 (covariance diagonal used as "std")
     q = (batch["loc"], batch["var"])
-    proj_mean, proj_S = kl_projection(p, q, mean_bound, cov_bound)  # trpl.py:244
+    project, tr_value = PROJECTIONS[proj_type]
+    proj_mean, proj_S = project(p, q, mean_bound, cov_bound)  # trpl.py:244
     log_prob = mvn_diag_log_prob(batch["action"], proj_mean, proj_S)  # trpl.py:245-246 (proj_S as covariance)
     lw = log_prob - batch["sample_log_prob"]
     with torch.no_grad():  # trpl.py:294-300
         ess = (2 * lw.logsumexp(0) - (2 * lw).logsumexp(0)).exp() / lw.shape[0]
     out = {"loss_objective": -(lw.exp() * adv.reshape(-1)).mean()}  # trpl.py:302-303
     # base.py:292-327: gaussian_kl(p, stopgrad(proj_p)), summed parts, mean, times coefficient
-    m_d, c_d = gaussian_kl(p, (proj_mean.detach(), proj_S.detach()))
-    out["loss_trust_region"] = (m_d + c_d).mean() * trust_region_coeff
+    if proj_type == "frob":
+        out["loss_trust_region"] = frobenius_trust_region_loss(p, (proj_mean, proj_S), trust_region_coeff)
+    else:
+        m_d, c_d = tr_value(p, (proj_mean.detach(), proj_S.detach()))
+        out["loss_trust_region"] = (m_d + c_d).mean() * trust_region_coeff
     ent = mvn_diag_entropy(proj_S)  # trpl.py:309-312
     out["entropy_dist"] = ent.mean().detach()
     out["loss_entropy"] = -entropy_coef * ent.mean()
@@ -232,10 +303,11 @@ def trpl_loss(
     out["ESS"] = ess
     with torch.no_grad():  # trpl.py:255-273 -> base.py:332-384 called with (p, proj_p)
         pq = (proj_mean, proj_S)
-        mk, ck = gaussian_kl(p, pq)
+        km, kc = gaussian_kl(p, pq)
+        mk, ck = tr_value(p, pq)
         e_old, e_new = entropy_std(proj_S), entropy_std(var)
         out.update(
-            kl=(mk + ck).mean(), constraint=(mk + ck).mean(), mean_constraint=mk.mean(), mean_constraint_max=mk.max(),
+            kl=(km + kc).mean(), constraint=(mk + ck).mean(), mean_constraint=mk.mean(), mean_constraint_max=mk.max(),
             cov_constraint=ck.mean(), cov_constraint_max=ck.max(), entropy=e_new.mean(),
             entropy_diff=(e_old - e_new).mean(),
         )

@@ -197,3 +197,34 @@ def test_gae_shifted_matches_recursion():
             ref[n, t] = run
     close(adv, ref.float(), 1e-5)
     close(tgt, (ref + v[:, :-1]).float(), 1e-5)
+
+
+@pytest.mark.parametrize("name", ["frob", "w2"])
+def test_frobenius_and_wasserstein_projections(golden_dir, name):
+    """oracle/trpl.py restatements against the reference's FrobeniusProjectionLayer / WassersteinProjectionLayer (tier2c fixtures)."""
+    from oracle import trpl as tr
+    z = load(golden_dir, f"tier2c_projection_{name}.npz")
+    project, value = tr.PROJECTIONS[name]
+    mean, S = z["mean"].clone().requires_grad_(True), z["S"].clone().requires_grad_(True)
+    q = (z["mean_o"], z["S_o"])
+    pm, pS = project((mean, S), q, float(z["mean_bound"]), float(z["cov_bound"]))
+    close(pm, z["proj_mean"], 2e-6)
+    close(pS, z["proj_S"], 2e-6)
+    ((pm * z["R1"]).sum() + (pS * z["R2"]).sum()).backward(retain_graph=True)
+    close(mean.grad, z["grad_mean"], 1e-5, 1e-4)
+    close(S.grad, z["grad_S"], 1e-5, 1e-4)
+    mean.grad, S.grad = None, None
+    loss = (tr.frobenius_trust_region_loss if name == "frob" else tr.wasserstein_trust_region_loss)((mean, S), (pm, pS), float(z["coeff"]))
+    close(loss, z["tr_loss"], 1e-5, 1e-5)
+    loss.backward()
+    close(mean.grad, z["tr_grad_mean"], 1e-5, 1e-4)
+    close(S.grad, z["tr_grad_S"], 1e-5, 1e-4)
+    vm, vc = value((z["mean"], z["S"]), q)
+    close(vm, z["value_mean"], 1e-5, 1e-5)
+    close(vc, z["value_cov"], 1e-5, 1e-5)
+    with torch.no_grad():
+        mk, ck = value((z["mean"], z["S"]), (pm, pS))
+        km, kc = tr.gaussian_kl((z["mean"], z["S"]), (pm, pS))
+    close(mk.mean(), z["metric.mean_constraint"], 1e-5, 1e-4)
+    close(ck.max(), z["metric.cov_constraint_max"], 1e-5, 1e-4)
+    close((km + kc).mean(), z["metric.kl"], 1e-5, 1e-4)

@@ -299,6 +299,62 @@ def tier2b():
         np.savez(os.path.join(OUT, f"tier2b_hepi_{name}.npz"), **npd(rec))
 
 
+# ----------------------------------------------------------------------------------------------- tier 2c
+def tier2c():
+    """Frobenius and Wasserstein projection layers (frob_projection_layer.py:9-88, w2_projection_layer.py:14-76) on the diagonal
+    policy: projection outputs, gradients through the projection, trust-region loss + gradients, metrics."""
+    from geometry_rl.algorithms.trust_region_projections.projections.frob_projection_layer import FrobeniusProjectionLayer
+    from geometry_rl.algorithms.trust_region_projections.projections.w2_projection_layer import WassersteinProjectionLayer
+    from geometry_rl.algorithms.trust_region_projections.models.policy.gnn_gaussian_policy_diag import (
+        GNNGaussianPolicyDiag)
+
+    class FakeGNN(nn.Module):
+        device = "cpu"
+
+    class FakeData:
+        pass
+
+    torch.manual_seed(3)
+    B, A = 11, 6
+    policy = GNNGaussianPolicyDiag(gnn=FakeGNN(), hyper_data=FakeData(), action_dim=A, num_actuators=1, init="orthogonal",
+                                   hidden_sizes=(64, 64), contextual_std=True, init_std=1.0, minimal_std=1e-5,
+                                   share_action_dim=True, post_fc=False)
+    for name, cls in (("frob", FrobeniusProjectionLayer), ("w2", WassersteinProjectionLayer)):
+        g = torch.Generator().manual_seed(17)
+        mean = torch.randn(B, A, generator=g)
+        S = (torch.rand(B, A, generator=g) + 0.5)
+        mean_o = mean + 0.3 * torch.randn(B, A, generator=g)
+        S_o = (torch.rand(B, A, generator=g) + 0.5)
+        mean_o[0] = mean[0] + 1e-3          # inside the mean bound
+        S_o[1] = S[1] * (1 + 1e-3)          # inside the covariance bound
+        mean_o[2] = mean[2] + 1e-3
+        S_o[2] = S[2] * (1 - 1e-3)          # inside both
+        R1, R2 = torch.randn(B, A, generator=g), torch.randn(B, A, generator=g)
+        layer = cls(proj_type=name, mean_bound=0.05, cov_bound=0.0025, trust_region_coeff=4.0, scale_prec=True,
+                    entropy_schedule=False, action_dim=A, total_train_steps=100, cpu=True, dtype=torch.float32)
+        mean_g = mean.clone().requires_grad_(True)
+        S_g = S.clone().requires_grad_(True)
+        p = (mean_g, S_g.diag_embed())
+        q = (mean_o, S_o.diag_embed())
+        pm, pS = layer(policy, p, q, 0)
+        rec = {"mean": mean, "S": S, "mean_o": mean_o, "S_o": S_o, "R1": R1, "R2": R2, "proj_mean": pm,
+               "proj_S": pS.diagonal(dim1=-2, dim2=-1), "mean_bound": torch.tensor(0.05), "cov_bound": torch.tensor(0.0025),
+               "coeff": torch.tensor(4.0)}
+        ((pm * R1).sum() + (pS.diagonal(dim1=-2, dim2=-1) * R2).sum()).backward(retain_graph=True)
+        rec["grad_mean"], rec["grad_S"] = mean_g.grad.clone(), S_g.grad.clone()
+        mean_g.grad = None
+        S_g.grad = None
+        trl = layer.get_trust_region_loss(policy, p, (pm, pS))
+        trl.backward()
+        rec["tr_loss"], rec["tr_grad_mean"], rec["tr_grad_S"] = trl, mean_g.grad.clone(), S_g.grad.clone()
+        m = layer.compute_metrics(policy, (mean, S.diag_embed()), (pm.detach(), pS.detach()), step=0)
+        for k, v in m.items():
+            rec["metric." + k] = v
+        mp, cp = layer.trust_region_value(policy, (mean, S.diag_embed()), q)
+        rec["value_mean"], rec["value_cov"] = mp, cp
+        np.savez(os.path.join(OUT, f"tier2c_projection_{name}.npz"), **npd(rec))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -306,5 +362,6 @@ if __name__ == "__main__":
     install_stubs()
     tier2()
     tier2b()
+    tier2c()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
