@@ -30,6 +30,7 @@ class AgentConfig:
     minimal_std: float = 1e-5
     mean_bound: float = 0.05
     cov_bound: float = 0.0025
+    proj_type: str = "kl"  # kl | frob | w2
     trust_region_coeff: float = 1.0
     entropy_coef: float = 0.005
     critic_coef: float = 0.5
@@ -68,7 +69,7 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
     c_gnn = DeepSets(input_dim_node=len(spec.node_types) + 3 * spec.n_vec, output_dim=64, hidden_dim=64, device=device)
     critic = BaseCritic(GNNVFNet(gnn=c_gnn, hyper_data=c_data))
     critic._network1.group = group
-    projection = KLProjectionLayer(proj_type="kl", mean_bound=cfg.mean_bound, cov_bound=cfg.cov_bound,
+    projection = KLProjectionLayer(proj_type=cfg.proj_type, mean_bound=cfg.mean_bound, cov_bound=cfg.cov_bound,
                                    trust_region_coeff=cfg.trust_region_coeff, scale_prec=True, entropy_schedule=False, action_dim=A)
     loss = TRPLLoss(actor, critic, projection=projection, entropy_coef=cfg.entropy_coef, critic_coef=cfg.critic_coef,
                     clip_value=cfg.clip_value, loss_critic_type="l2", normalize_advantage=True, in_features=spec.in_features,
@@ -146,8 +147,8 @@ class PolicyUpdater:
             with torch.no_grad():
                 vf.train(True)
                 _, x = vf.hyper_data.build_data(*st["obs"], train=True)
-                # one zeroed fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (11) | maxes (2 x u32) | clip (2)
-                zw = st["zw"] = torch.zeros(24, device=x.device, dtype=torch.float64)
+                # one zeroed fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (12) | maxes (2 x u32) | clip (2)
+                zw = st["zw"] = torch.zeros(26, device=x.device, dtype=torch.float64)
                 st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
                 st["pipe"].fwd1()
                 st["adv"] = None
@@ -165,8 +166,8 @@ class PolicyUpdater:
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
             with torch.no_grad():
                 zw = st["zw"]
-                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, st["b"], st["adv"], sums=zw[10:21],
-                                                                maxes=zw[21:22].view(torch.int32))
+                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, st["b"], st["adv"], sums=zw[10:22],
+                                                                maxes=zw[22:23].view(torch.int32))
             torch.autograd.backward([loc, sigma], [dloc, dsigma])
             with torch.no_grad():
                 pipe.bwd3(dvalue)
@@ -189,7 +190,7 @@ class PolicyUpdater:
                 for i_, (lo, hi) in enumerate(((0, na), (na, n))):
                     coef = None
                     if self.clip:  # train.py:308-310
-                        sq = st["zw"][22 + i_:23 + i_]
+                        sq = st["zw"][23 + i_:24 + i_]
                         coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
                         hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
                     hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
@@ -221,7 +222,7 @@ class PolicyUpdater:
                 pipe.fwd2()
                 value = pipe.fwd3()
             with torch.no_grad():
-                zw = st["zw"] = torch.zeros(24, device=self.flat.device, dtype=torch.float64)
+                zw = st["zw"] = torch.zeros(26, device=self.flat.device, dtype=torch.float64)
                 st["adv"] = None
                 if m.normalize_advantage and st["obs"][0].shape[0] > 1:
                     st["adv"] = zw[8:10]
@@ -230,8 +231,8 @@ class PolicyUpdater:
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
             cur.wait_stream(cs)   # join: the fused loss kernel needs the values
             with torch.no_grad():
-                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:21],
-                                                                maxes=zw[21:22].view(torch.int32))
+                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],
+                                                                maxes=zw[22:23].view(torch.int32))
             cs.wait_stream(cur)   # fork: critic backward beside the actor backward
             with torch.cuda.stream(cs), torch.no_grad():
                 pipe.bwd3(dvalue)

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------ TRPL
 constexpr int AMAX = 12;
 // sums layout (fp64): 0 loss_objective 1 loss_trust_region 2 entropy(dist) 3 loss_critic 4 sum exp(lw) 5 sum exp(2 lw)
-//                     6 mean_constraint 7 cov_constraint 8 entropy(p) 9 entropy_diff 10 count
+//                     6 mean_constraint 7 cov_constraint 8 entropy(p) 9 entropy_diff 10 count 11 kl(p || proj_p)
+// (6, 7: the projection's own trust-region measure of (p, proj_p); equal to the KL parts for the KL projection)
 // maxes layout (fp32 bits, values >= 0): 0 mean_constraint_max 1 cov_constraint_max
 struct TrplCfg {
   double mean_bound, cov_bound, tr_coeff, ent_coef, critic_coef, clip_value, inv_batch, adv_count;
@@ -191,7 +192,9 @@ GRL_DEVINL double kl_of_eta(double eta, const double* t, const double* o, int A)
   return 0.5 * kl;
 }
 
-template <int AT>
+// PROJ: 0 = KL (kl_projection_layer.py + ITPAL), 1 = Frobenius (frob_projection_layer.py:10-88), 2 = Wasserstein, commutative,
+//       precision-scaled (w2_projection_layer.py:15-76, projection_utils.py:107-149); diagonal policy throughout
+template <int AT, int PROJ>
 __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __restrict__ mean, const float* __restrict__ sigma,
                                                   const float* __restrict__ action, const float* __restrict__ old_mean,
                                                   const float* __restrict__ old_var, const float* __restrict__ old_logp,
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
                                                   unsigned int* __restrict__ maxes, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int A = AT > 0 ? AT : cfg.A;   // compile-time action width: the per-dimension loops unroll, arrays stay in registers
-  double acc[10];
-  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+  double acc[11];
+  for (int i = 0; i < 11; ++i) acc[i] = 0.0;
   float mmax = 0.f, cmax = 0.f;
   if (b < B) {
     double mu[AMAX], S[AMAX], mo[AMAX], So[AMAX], t[AMAX], o[AMAX], a[AMAX];
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     // ---- mean projection (base_projection_layer.py:71-100)
     double mp = 0.0;
     _Pragma("unroll") for (int i = 0; i < A; ++i) { const double d = (mu[i] - mo[i]) / So[i]; mp += d * d; }
-    mp *= 0.5;
+    if (PROJ == 0) mp *= 0.5;   // KL: 1/2 maha (projection_utils.py:34-67); Frobenius / W2: maha (mean_distance, :9-31)
     const bool m_act = mp > cfg.mean_bound;
     double omega = 0.0, D = 1.0, pm[AMAX];
     if (m_act) { omega = sqrt(mp / cfg.mean_bound) - 1.0; D = 1.0 + omega + 1e-16; }
@@ -230,51 +233,68 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     //      KL = 1/2 sum(rho_i - 1 - log rho_i),  dKL/deta = -1/2 sum (1-c_i)^2 / ((eta+1)(eta+c_i)^2) < 0, KL convex in eta:
     //      Newton from eta = 0 approaches the root monotonically from the left (never overshoots).
     double eta = 0.0;
-    const bool c_act = kl_of_eta(0.0, t, o, A) > cfg.cov_bound;
-    if (c_act) {
-      double cr[AMAX];
-      _Pragma("unroll") for (int i = 0; i < A; ++i) cr[i] = o[i] / t[i];
-      // Phase 1, fp32 (hardware log2 / reciprocal): the same Newton iteration, cheap, until the step is below 1e-5 of eta.
-      {
-        float crf[AMAX], e32 = 0.f;
-        _Pragma("unroll") for (int i = 0; i < A; ++i) crf[i] = (float)cr[i];
-        const float bound = (float)cfg.cov_bound;
-        for (int it = 0; it < 60; ++it) {
-          float f = 0.f, df = 0.f;
-          const float r1 = __builtin_amdgcn_rcpf(e32 + 1.f);
-          _Pragma("unroll") for (int i = 0; i < A; ++i) {
-            const float rden = __builtin_amdgcn_rcpf(e32 + crf[i]), rho = (e32 + 1.f) * rden, om = 1.f - crf[i];
-            f += rho - 1.f - 0.69314718056f * __builtin_amdgcn_logf(rho);
-            df += om * om * r1 * rden * rden;
+    bool c_act;
+    double v[AMAX], pS[AMAX];
+    if (PROJ == 0) {
+      c_act = kl_of_eta(0.0, t, o, A) > cfg.cov_bound;
+      if (c_act) {
+        double cr[AMAX];
+        _Pragma("unroll") for (int i = 0; i < A; ++i) cr[i] = o[i] / t[i];
+        // Phase 1, fp32 (hardware log2 / reciprocal): the same Newton iteration, cheap, until the step is below 1e-5 of eta.
+        {
+          float crf[AMAX], e32 = 0.f;
+          _Pragma("unroll") for (int i = 0; i < A; ++i) crf[i] = (float)cr[i];
+          const float bound = (float)cfg.cov_bound;
+          for (int it = 0; it < 60; ++it) {
+            float f = 0.f, df = 0.f;
+            const float r1 = __builtin_amdgcn_rcpf(e32 + 1.f);
+            _Pragma("unroll") for (int i = 0; i < A; ++i) {
+              const float rden = __builtin_amdgcn_rcpf(e32 + crf[i]), rho = (e32 + 1.f) * rden, om = 1.f - crf[i];
+              f += rho - 1.f - 0.69314718056f * __builtin_amdgcn_logf(rho);
+              df += om * om * r1 * rden * rden;
+            }
+            f = 0.5f * f - bound;
+            df *= 0.5f;
+            if (!(f > 0.f) || !(df > 0.f)) break;
+            const float step = f / df;
+            e32 += step;
+            if (!(step > 1e-5f * e32)) break;
           }
-          f = 0.5f * f - bound;
-          df *= 0.5f;
-          if (!(f > 0.f) || !(df > 0.f)) break;
-          const float step = f / df;
-          e32 += step;
-          if (!(step > 1e-5f * e32)) break;
+          if (e32 == e32 && e32 >= 0.f && e32 < 3.0e38f) eta = (double)e32;   // otherwise phase 2 starts from 0 as before
         }
-        if (e32 == e32 && e32 >= 0.f && e32 < 3.0e38f) eta = (double)e32;   // otherwise phase 2 starts from 0 as before
+        // Phase 2, fp64 polish.  KL is convex and decreasing in eta, so ONE Newton step from either side of the root lands left
+        // of it (the tangent lies below the curve); from there the iteration is monotone as before and stops at double precision.
+        for (int it = 0; it < 100; ++it) {
+          double f = 0.0, df = 0.0;
+          _Pragma("unroll") for (int i = 0; i < A; ++i) {
+            const double den = eta + cr[i], rho = (eta + 1.0) / den, om = 1.0 - cr[i];
+            f += rho - 1.0 - log(rho);
+            df += om * om / ((eta + 1.0) * den * den);
+          }
+          f = 0.5 * f - cfg.cov_bound;
+          df *= 0.5;
+          if (df <= 0.0 || (it > 0 && f <= 0.0)) break;
+          const double step = f / df;
+          eta = fmax(eta + step, 0.0);
+          if (fabs(step) <= 1e-15 * eta) break;
+        }
       }
-      // Phase 2, fp64 polish.  KL is convex and decreasing in eta, so ONE Newton step from either side of the root lands left
-      // of it (the tangent lies below the curve); from there the iteration is monotone as before and stops at double precision.
-      for (int it = 0; it < 100; ++it) {
-        double f = 0.0, df = 0.0;
-        _Pragma("unroll") for (int i = 0; i < A; ++i) {
-          const double den = eta + cr[i], rho = (eta + 1.0) / den, om = 1.0 - cr[i];
-          f += rho - 1.0 - log(rho);
-          df += om * om / ((eta + 1.0) * den * den);
-        }
-        f = 0.5 * f - cfg.cov_bound;
-        df *= 0.5;
-        if (df <= 0.0 || (it > 0 && f <= 0.0)) break;
-        const double step = f / df;
-        eta = fmax(eta + step, 0.0);
-        if (fabs(step) <= 1e-15 * eta) break;
+      _Pragma("unroll") for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }
+    } else {
+      // closed forms: eta = sqrt(part / bound) - 1 where the bound is violated
+      double part = 0.0;
+      _Pragma("unroll") for (int i = 0; i < A; ++i) {
+        const double d = PROJ == 1 ? o[i] - t[i] : 1.0 - S[i] / So[i];   // |S_o^2 - S^2|_F^2  |  tr(I + S_o^-1 S^2 S_o^-1 - 2 S_o^-1 S)
+        part += d * d;
+      }
+      c_act = part > cfg.cov_bound;
+      if (c_act) eta = fabs(sqrt(part / cfg.cov_bound) - 1.0);
+      const double den = 1.0 + eta + 1e-16;
+      _Pragma("unroll") for (int i = 0; i < A; ++i) {
+        if (PROJ == 1) { v[i] = c_act ? (t[i] + eta * o[i]) / den : t[i]; pS[i] = c_act ? sqrt(v[i]) : S[i]; }   // chol of the mixed covariance
+        else { pS[i] = c_act ? (S[i] + eta * So[i]) / den : S[i]; v[i] = pS[i] * pS[i]; }
       }
     }
-    double v[AMAX], pS[AMAX];
-    _Pragma("unroll") for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }
     // ---- log-prob under the projected distribution (covariance = pS), importance weight, objective
     const double LOG2PI = 1.8378770664093454836;
     double q = 0.0, sl = 0.0;
@@ -295,8 +315,10 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     acc[5] = ratio * ratio;
     const double ent = 0.5 * (A * (1.0 + LOG2PI) + sl);
     acc[2] = ent;
-    // ---- trust-region regression loss and metrics: gaussian_kl(p, stopgrad(proj_p))
-    double mk = 0.0, ck = 0.0, ldS = 0.0, ldP = 0.0;
+    // ---- trust-region regression loss and metrics.  KL of (p, proj_p) is always reported; the constraint metrics are the
+    //      projection's own measure of (p, proj_p) (base_projection_layer.py:332-384), the loss is base.py:292-327 with that
+    //      measure (KL, W2: proj_p detached) or frob_projection_layer.py:73-88 (maha by the live S + squared distance, NOT detached)
+    double mk = 0.0, ck = 0.0, ldS = 0.0, ldP = 0.0, cd = 0.0, mS = 0.0, sq = 0.0;
     _Pragma("unroll") for (int i = 0; i < A; ++i) {
       const double d = (mu[i] - pm[i]) / pS[i];
       mk += d * d;
@@ -304,17 +326,24 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
       ck += rr * rr;
       ldS += log(S[i]);
       ldP += log(pS[i]);
+      if (PROJ == 1) {
+        const double f = pS[i] * pS[i] - S[i] * S[i], dm = (mu[i] - pm[i]) / S[i], ds = S[i] - pS[i];
+        cd += f * f; mS += dm * dm; sq += ds * ds;
+      }
+      if (PROJ == 2) cd += (1.0 - rr) * (1.0 - rr);
     }
+    const double md = mk;            // maha(mean, proj_mean, proj_S)
     mk *= 0.5;
     ck = 0.5 * (ck - A + 2.0 * ldP - 2.0 * ldS);
-    acc[1] = (mk + ck) * cfg.tr_coeff;
-    acc[6] = mk;
-    acc[7] = ck;
+    acc[10] = mk + ck;
+    if (PROJ == 0) { acc[1] = (mk + ck) * cfg.tr_coeff; acc[6] = mk; acc[7] = ck; }
+    if (PROJ == 1) { acc[1] = (mS + sq) * cfg.tr_coeff; acc[6] = md; acc[7] = cd; }
+    if (PROJ == 2) { acc[1] = (md + cd) * cfg.tr_coeff; acc[6] = md; acc[7] = cd; }
     const double c_ent = 0.5 * A * 2.8378770664093454836;  // 0.5 k log(2 pi e)
     acc[8] = c_ent + ldS;                                   // policy.entropy(p) with S as "std"
     acc[9] = (c_ent + ldP) - (c_ent + ldS);
-    mmax = (float)mk;
-    cmax = (float)fmax(ck, 0.0);
+    mmax = (float)acc[6];
+    cmax = (float)fmax(acc[7], 0.0);
     // ---- gradients of actor_loss = objective + entropy bonus + trust region  (all already scaled by 1/B)
     const double w_obj = -ratio * adv * cfg.inv_batch;
     double g_pm[AMAX], g_pS[AMAX];
@@ -323,16 +352,23 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
       g_pm[i] = w_obj * d / pS[i];
       g_pS[i] = w_obj * 0.5 * (d * d / (pS[i] * pS[i]) - 1.0 / pS[i]) - cfg.ent_coef * cfg.inv_batch * 0.5 / pS[i];
     }
+    const double ctr = cfg.tr_coeff * cfg.inv_batch;
+    if (PROJ == 1) {   // the Frobenius regression loss also reaches the parameters THROUGH the projection
+      _Pragma("unroll") for (int i = 0; i < A; ++i) {
+        g_pm[i] -= ctr * 2.0 * (mu[i] - pm[i]) / (S[i] * S[i]);
+        g_pS[i] -= ctr * 2.0 * (S[i] - pS[i]);
+      }
+    }
     double gmu[AMAX], gS[AMAX];
     if (m_act) {
       double dot = 0.0;
       _Pragma("unroll") for (int i = 0; i < A; ++i) dot += g_pm[i] * (mo[i] - pm[i]) / D;
-      const double k = dot / (2.0 * (omega + 1.0) * cfg.mean_bound);
+      const double k = dot / (2.0 * (omega + 1.0) * cfg.mean_bound) * (PROJ == 0 ? 1.0 : 2.0);   // d(mean part)/d maha = 1/2 | 1
       _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i] / D + k * (mu[i] - mo[i]) / (So[i] * So[i]);
     } else {
       _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i];
     }
-    {
+    if (PROJ == 0) {
       double gv[AMAX];
       _Pragma("unroll") for (int i = 0; i < A; ++i) gv[i] = g_pS[i] / (2.0 * pS[i]);
       if (c_act) {
@@ -351,11 +387,31 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
       } else {
         _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = gv[i] * 2.0 * S[i];
       }
+    } else if (c_act) {
+      // proj = (x + eta y) / (1 + eta) with eta = sqrt(part / bound) - 1: d proj_i / d S_j = delta_ij x'_j / den + (y_i - proj_i) / den * d eta / d S_j
+      const double den = 1.0 + eta + 1e-16, deta = 1.0 / (2.0 * (eta + 1.0) * cfg.cov_bound);
+      double st_ = 0.0;
+      _Pragma("unroll") for (int i = 0; i < A; ++i)
+        st_ += PROJ == 1 ? g_pS[i] / (2.0 * pS[i]) * (o[i] - v[i]) / den : g_pS[i] * (So[i] - pS[i]) / den;
+      _Pragma("unroll") for (int i = 0; i < A; ++i) {
+        if (PROJ == 1) gS[i] = g_pS[i] / (2.0 * pS[i]) * 2.0 * S[i] / den + st_ * deta * (-4.0 * (o[i] - t[i]) * S[i]);
+        else gS[i] = g_pS[i] / den + st_ * deta * (-2.0 * (1.0 - S[i] / So[i]) / So[i]);
+      }
+    } else {
+      _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = g_pS[i];
     }
-    const double ctr = cfg.tr_coeff * cfg.inv_batch;
     _Pragma("unroll") for (int i = 0; i < A; ++i) {
-      gmu[i] += ctr * (mu[i] - pm[i]) / (pS[i] * pS[i]);
-      gS[i] += ctr * (S[i] / (pS[i] * pS[i]) - 1.0 / S[i]);
+      if (PROJ == 0) {
+        gmu[i] += ctr * (mu[i] - pm[i]) / (pS[i] * pS[i]);
+        gS[i] += ctr * (S[i] / (pS[i] * pS[i]) - 1.0 / S[i]);
+      } else if (PROJ == 1) {
+        const double dm = mu[i] - pm[i];
+        gmu[i] += ctr * 2.0 * dm / (S[i] * S[i]);
+        gS[i] += ctr * (-2.0 * dm * dm / (S[i] * S[i] * S[i]) + 2.0 * (S[i] - pS[i]));
+      } else {
+        gmu[i] += ctr * 2.0 * (mu[i] - pm[i]) / (pS[i] * pS[i]);
+        gS[i] += ctr * (-2.0 * (1.0 - S[i] / pS[i]) / pS[i]);
+      }
       dmean[(size_t)b * A + i] = (float)gmu[i];
       dsigma[(size_t)b * A + i] = (float)(gS[i] * 2.0 * (double)sigma[(size_t)b * A + i]);
       if (proj_mean_out) { proj_mean_out[(size_t)b * A + i] = (float)pm[i]; proj_var_out[(size_t)b * A + i] = (float)pS[i]; }
@@ -377,10 +433,10 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     }
   }
   // block reduction (2 waves) -> fp64 atomics
-  __shared__ double red[2][10];
+  __shared__ double red[2][11];
   __shared__ float redm[2][2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < 11; ++i) {
     double x = acc[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -394,6 +450,7 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
   if (lane == 0) { redm[wv][0] = mmax; redm[wv][1] = cmax; }
   __syncthreads();
   if (threadIdx.x < 10) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x]);
+  if (threadIdx.x == 13) atomicAdd(sums + 11, red[0][10] + red[1][10]);
   if (threadIdx.x == 10) {
     const int n_here = min(B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x);
     atomicAdd(sums + 10, (double)(n_here > 0 ? n_here : 0));
@@ -426,7 +483,7 @@ __global__ void loss_values_kernel(const double* __restrict__ sums, const unsign
   out[3] = ent;
   out[4] = (float)(sums[4] * sums[4] / sums[5] / n);   // exp(2 lse(lw) - lse(2 lw)) / B   (trpl.py:294-300,316)
   const float mc = (float)(sums[6] / n), cc = (float)(sums[7] / n);
-  out[5] = mc + cc;
+  out[5] = (float)(sums[11] / n);
   out[6] = mc;
   out[7] = __uint_as_float(maxes[0]);
   out[8] = cc;
@@ -434,6 +491,7 @@ __global__ void loss_values_kernel(const double* __restrict__ sums, const unsign
   out[10] = (float)(sums[8] / n);
   out[11] = (float)(sums[9] / n);
   out[12] = actor - (tr + ent);
+  out[13] = mc + cc;   // "constraint": the projection's own measure (= kl for the KL projection)
 }
 
 // ---- collector-side action sampling: torch.distributions.MultivariateNormal(loc, covariance_matrix = diag(sigma^2)).rsample()
@@ -493,26 +551,34 @@ int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t 
   return 0;
 }
 
-// cfg8 (HOST pointer): 8 doubles {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
-// 1/B_global, B_global}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
-// grl_adv_stats, all-reduced when data parallel) or NULL for no normalisation.  sums: fp64[11], maxes: u32[2], zeroed by the caller.  value/old_value/value_target/dvalue may be
+// cfg9 (HOST pointer): 9 doubles {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
+// 1/B_global, B_global, projection type (0 KL, 1 Frobenius, 2 Wasserstein)}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
+// grl_adv_stats, all-reduced when data parallel) or NULL for no normalisation.  sums: fp64[12], maxes: u32[2], zeroed by the caller.  value/old_value/value_target/dvalue may be
 // NULL together (actor-only call); proj_mean/proj_var may be NULL.
-int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, const float* sigma, const float* action,
+int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
                      const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
                      const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
                      float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
                      unsigned int* maxes, int batch, hipStream_t stream) {
   if (action_dim > AMAX || action_dim < 1) return -2;
-  TrplCfg c{cfg8[0], cfg8[1], cfg8[2], cfg8[3], cfg8[4], cfg8[5], cfg8[6], cfg8[7], action_dim};
-#define GRL_TRPL_LAUNCH(AT)                                                                                                   \
-  hipLaunchKernelGGL(trpl_kernel<AT>, dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean, old_var, \
-                     old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, \
-                     sums, maxes, batch)
-  switch (action_dim) {   // the action widths of the reference tasks (G * n_vec * 3) get unrolled instances
-    case 3: GRL_TRPL_LAUNCH(3); break;
-    case 6: GRL_TRPL_LAUNCH(6); break;
-    case 12: GRL_TRPL_LAUNCH(12); break;
-    default: GRL_TRPL_LAUNCH(0); break;
+  TrplCfg c{cfg9[0], cfg9[1], cfg9[2], cfg9[3], cfg9[4], cfg9[5], cfg9[6], cfg9[7], action_dim};
+  const int proj = (int)cfg9[8];
+  if (proj < 0 || proj > 2) return -3;
+#define GRL_TRPL_LAUNCH(AT, PJ)                                                                                               \
+  hipLaunchKernelGGL((trpl_kernel<AT, PJ>), dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean,  \
+                     old_var, old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var,   \
+                     adv_stats, sums, maxes, batch)
+  if (proj == 0) {
+    switch (action_dim) {   // the action widths of the reference tasks (G * n_vec * 3) get unrolled instances
+      case 3: GRL_TRPL_LAUNCH(3, 0); break;
+      case 6: GRL_TRPL_LAUNCH(6, 0); break;
+      case 12: GRL_TRPL_LAUNCH(12, 0); break;
+      default: GRL_TRPL_LAUNCH(0, 0); break;
+    }
+  } else if (proj == 1) {
+    if (action_dim == 6) GRL_TRPL_LAUNCH(6, 1); else GRL_TRPL_LAUNCH(0, 1);
+  } else {
+    if (action_dim == 6) GRL_TRPL_LAUNCH(6, 2); else GRL_TRPL_LAUNCH(0, 2);
   }
 #undef GRL_TRPL_LAUNCH
   GRL_CHECK_LAUNCH();
@@ -521,9 +587,9 @@ int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, cons
 
 // Reported values from the (globally reduced) sums / maxes of the fused kernel (trpl.py:280-321), one tiny launch instead of a
 // chain of scalar tensor ops:  out = [actor loss, critic loss, loss_trust_region, loss_entropy, ESS, kl, mean_constraint,
-// mean_constraint_max, cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective]
-int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream) {
-  hipLaunchKernelGGL(loss_values_kernel, dim3(1), dim3(1), 0, stream, sums, maxes, entropy_coef, out13);
+// mean_constraint_max, cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective, constraint]
+int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_values_kernel, dim3(1), dim3(1), 0, stream, sums, maxes, entropy_coef, out14);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -436,20 +436,22 @@ def ctypes_double(v: float):
 
 
 TRPL_SUM_KEYS = ("loss_objective", "loss_trust_region", "entropy_dist", "loss_critic", "sum_w", "sum_w2", "mean_constraint",
-                 "cov_constraint", "entropy", "entropy_diff", "count")
+                 "cov_constraint", "entropy", "entropy_diff", "count", "kl")
 
 
 def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
-                 global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False, sums=None, maxes=None):
-    """Launches the fused TRPL kernel.  Returns (sums fp64[11], maxes u32[2], dloc, dsigma, dvalue, proj_mean, proj_var)."""
+                 global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False, sums=None, maxes=None,
+                 proj_type: int = 0):
+    """Launches the fused TRPL kernel (proj_type 0 KL | 1 Frobenius | 2 Wasserstein).  Returns (sums fp64[12], maxes u32[2], dloc,
+    dsigma, dvalue, proj_mean, proj_var)."""
     import ctypes
     hip.check_f32(loc, sigma)
     B, A = loc.shape
     dev = loc.device
-    cfg = (ctypes.c_double * 8)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
-                                clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch))
+    cfg = (ctypes.c_double * 9)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
+                                clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch), float(proj_type))
     if sums is None:   # otherwise: zeroed views of the caller's per-step workspace
-        sums = torch.zeros(11, device=dev, dtype=torch.float64)
+        sums = torch.zeros(12, device=dev, dtype=torch.float64)
         maxes = torch.zeros(2, device=dev, dtype=torch.int32)
     dloc, dsigma = torch.empty_like(loc), torch.empty_like(sigma)
     dvalue = torch.empty(B, device=dev, dtype=torch.float32) if value is not None else None

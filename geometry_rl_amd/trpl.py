@@ -22,9 +22,11 @@ class KLProjectionLayer:
                  entropy_eq=False, entropy_first=False, cpu=False, dtype=torch.float32, **ignored):
         if entropy_schedule:
             raise NotImplementedError("entropy_schedule is False in every reference TRPL config (kl.yaml:9)")
-        if proj_type.lower() != "kl" or mean_eq or not scale_prec:
-            raise NotImplementedError("only the KL projection with Mahalanobis mean bound is on the hot path")
+        kinds = {"kl": 0, "frob": 1, "frobenius": 1, "w2": 2, "wasserstein": 2}
+        if proj_type.lower() not in kinds or mean_eq or not scale_prec:
+            raise NotImplementedError("projections: kl | frob | w2 (commutative), each with the Mahalanobis (scale_prec) mean bound")
         self.proj_type, self.mean_bound, self.cov_bound = proj_type, float(mean_bound), float(cov_bound)
+        self.proj_code = kinds[proj_type.lower()]
         self.trust_region_coeff = float(trust_region_coeff)
         self.initial_entropy = None
 
@@ -38,9 +40,23 @@ class KLProjectionLayer:
                  "advantage": torch.zeros(B, device=dev)}
         out = ops.trpl_fwd_bwd(mean.detach().float(), d(S).detach().float().sqrt(), batch, None, mean_bound=self.mean_bound,
                                cov_bound=self.cov_bound, trust_region_coeff=self.trust_region_coeff, entropy_coef=0.0, critic_coef=0.0,
-                               clip_value=0.0, global_batch=B, adv_stats=None, want_projection=True)
+                               clip_value=0.0, global_batch=B, adv_stats=None, want_projection=True, proj_type=self.proj_code)
         pm, pv = out[5], out[6]
         return pm, (pv.diag_embed() if S.dim() == 3 else pv)
+
+
+class FrobeniusProjectionLayer(KLProjectionLayer):
+    """frob_projection_layer.py:9-88 on the diagonal policy (closed form; its regression loss is NOT detached from the projection)."""
+
+    def __init__(self, proj_type="frob", **kw):
+        super().__init__(proj_type="frob", **kw)
+
+
+class WassersteinProjectionLayer(KLProjectionLayer):
+    """w2_projection_layer.py:14-76 (commutative W2, precision-scaled) on the diagonal policy."""
+
+    def __init__(self, proj_type="w2", **kw):
+        super().__init__(proj_type="w2", **kw)
 
 
 class _InjectGrad(torch.autograd.Function):
@@ -75,17 +91,17 @@ def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None):
         cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
         entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, critic_coef=m.critic_coef,
         clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats,
-        sums=sums, maxes=maxes)
+        sums=sums, maxes=maxes, proj_type=getattr(p, "proj_code", 0))
     return sums, maxes, dloc, dsigma, dvalue
 
 
 def loss_values(m, sums, maxes):
     """(actor loss, critic loss, metrics dict) from the globally reduced sums / maxes (trpl.py:280-321): one launch, the entries
-    are views of its 13-float output."""
+    are views of its 14-float output."""
     ent_coef = m.entropy_coef if m.entropy_bonus else 0.0
-    o = torch.empty(13, device=sums.device, dtype=torch.float32)
+    o = torch.empty(14, device=sums.device, dtype=torch.float32)
     hip.call("grl_trpl_loss_values", sums, maxes, float(ent_coef), o)
-    metrics = {"loss_trust_region": o[2], "loss_entropy": o[3], "ESS": o[4], "kl": o[5], "constraint": o[5], "mean_constraint": o[6],
+    metrics = {"loss_trust_region": o[2], "loss_entropy": o[3], "ESS": o[4], "kl": o[5], "constraint": o[13], "mean_constraint": o[6],
                "mean_constraint_max": o[7], "cov_constraint": o[8], "cov_constraint_max": o[9], "entropy": o[10],
                "entropy_diff": o[11], "loss_objective_value": o[12]}
     return o[0], o[1], metrics

@@ -87,19 +87,21 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
 /* ---- TRPL objective: objectives/trpl.py:231-321, projections/base_projection_layer.py:71-100,292-384,
  *      projections/kl_projection_layer.py:15-111 (+ ITPAL BatchedDiagCovOnlyProjection), utils/projection_utils.py:34-67,
  *      objectives/utils.py:5-28 ---------------------------------------------------------------------------------------------
- * cfg8 (HOST): {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value, 1/B_global, B_global}
- * sums fp64[11]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
- *               cov_constraint, entropy(p), entropy_diff, count  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
+ *      projections/frob_projection_layer.py:9-88, projections/w2_projection_layer.py:14-76 (diagonal policy, closed forms)
+ * cfg9 (HOST): {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value, 1/B_global, B_global,
+ *               projection type: 0 KL | 1 Frobenius | 2 Wasserstein (commutative, precision-scaled)}
+ * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
+ *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
 int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream);
-int grl_trpl_fwd_bwd(const double* cfg8, int action_dim, const float* mean, const float* sigma, const float* action,
+int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
                      const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
                      const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
                      float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
                      unsigned int* maxes, int batch, hipStream_t stream);
 /* reported loss-dict values (trpl.py:280-321) from the globally reduced sums / maxes:
- * out13 = [actor loss, critic loss, loss_trust_region, loss_entropy, ESS, kl, mean_constraint, mean_constraint_max,
- *          cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective] */
-int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out13, hipStream_t stream);
+ * out14 = [actor loss, critic loss, loss_trust_region, loss_entropy, ESS, kl, mean_constraint, mean_constraint_max,
+ *          cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective, constraint] */
+int grl_trpl_loss_values(const double* sums, const unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 
 /* ---- collector-side sampling: ProbabilisticActor(..., torch.distributions.MultivariateNormal, return_log_prob=True)
  * (examples/torchrl/builders/utils_algo_graph.py:146-158; configs/algorithm/policy/default.yaml:6) */

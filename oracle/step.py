@@ -27,6 +27,7 @@ class AgentConfig:
     minimal_std: float = 1e-5
     mean_bound: float = 0.05
     cov_bound: float = 0.0025
+    proj_type: str = "kl"  # kl | frob | w2 (configs/algorithm/projection/*.yaml)
     trust_region_coeff: float = 1.0
     entropy_coef: float = 0.005
     critic_coef: float = 0.5
@@ -108,7 +109,7 @@ class OracleAgent:
         value = self.critic_forward(obs, stats_fn)
         out = tr.trpl_loss(loc, var, b, value, mean_bound=c.mean_bound, cov_bound=c.cov_bound,
                            trust_region_coeff=c.trust_region_coeff, entropy_coef=c.entropy_coef,
-                           critic_coef=c.critic_coef, clip_value=c.clip_value, adv_stats=adv_stats)
+                           critic_coef=c.critic_coef, clip_value=c.clip_value, adv_stats=adv_stats, proj_type=c.proj_type)
         out["loc"], out["var"], out["state_value"] = loc, var, value
         return out
 

@@ -110,3 +110,16 @@ def test_reference_checkpoint_round_trip(tmp_path):
         loc2, cov2 = actor2(*args, train=True)   # must NOT re-calibrate
         val2 = critic2(*args)
     assert torch.equal(loc, loc2) and torch.equal(cov, cov2) and torch.equal(val, val2)
+
+
+@pytest.mark.parametrize("name", ["frob", "w2"])
+def test_projection_layers_match_reference_fixture(golden_dir, name):
+    """Frobenius / Wasserstein projections of the fused kernel against the reference layers' own outputs (tier2c fixtures)."""
+    from geometry_rl_amd import trpl
+    dev = torch.device("cuda:0")
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, f"tier2c_projection_{name}.npz")).items()}
+    layer = (trpl.FrobeniusProjectionLayer if name == "frob" else trpl.WassersteinProjectionLayer)(
+        mean_bound=float(z["mean_bound"]), cov_bound=float(z["cov_bound"]), trust_region_coeff=float(z["coeff"]))
+    pm, pS = layer(None, (z["mean"].to(dev), z["S"].to(dev)), (z["mean_o"].to(dev), z["S_o"].to(dev)))
+    close(pm, z["proj_mean"], 2e-6, what="proj_mean")
+    close(pS, z["proj_S"], 2e-6, what="proj_S")

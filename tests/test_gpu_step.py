@@ -56,6 +56,11 @@ def make_case(name, B):
         spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
         kw = dict(model="empn")
         obs = syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=8)
+    elif name in ("rigid_frob", "rigid_w2"):   # the other two projection layers (frob_projection_layer.py, w2_projection_layer.py)
+        o_spec = ogr.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+        spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+        kw = dict(proj_type=name.split("_")[1], trust_region_coeff=2.0)
+        obs = syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=12)
     elif name == "cloth":
         o_spec, spec = ogr.cloth_spec(n_particles=25, E_cloth=40), graph.cloth_spec(n_particles=25, E_cloth=40)
         kw = dict(trust_region_coeff=4.0, cov_bound=0.001)
@@ -78,7 +83,7 @@ def load_params(module, params, dev):
 
 
 @pytest.mark.parametrize("name,B", [("rigid_g1", 24), ("rigid_g2", 16), ("cloth", 8), ("rope", 8), ("empn_g2", 12),
-                                    ("rigid_tiny", 6), ("rigid_one", 1)])
+                                    ("rigid_tiny", 6), ("rigid_one", 1), ("rigid_frob", 12), ("rigid_w2", 12)])
 def test_policy_update_step(name, B):
     from geometry_rl_amd import agent
     dev = torch.device("cuda:0")
