@@ -64,7 +64,7 @@ def workload(name):
     return spec, cfg, make, cfg_name
 
 
-def cpu_baseline(wl_name, minibatch, sample=128, steps=2, max_threads=32):
+def cpu_baseline(wl_name, minibatch, sample=1024, steps=3, max_threads=32):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
     from oracle import graph as ogr, step as ost
     from geometry_rl_amd import synthetic as syn
