@@ -289,7 +289,7 @@ def main():
                 "per_kernel_ms_per_step": {k: v[1] for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and args.workload == "rigid_hepi":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rigid_hepi":   # N = 1 only
         cpu = cpu_baseline(args.workload, args.minibatch)
 
     if rank == 0:
