@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
 //             dK = dM * x_src; dWk += dK^T g2; dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2;
 //             dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
 // Weight-gradient accumulators live in registers for the whole launch and leave as one partial row per wave:
-//   partial[(block*4 + wave)][9344] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64].
+//   partial[block][9216] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64]   (the four waves folded through LDS at the end).
 constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
 
@@ -511,8 +511,36 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
     cur = nxt;
   }
 
-  // ---- write this wave's partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
-  float* out = partial + (size_t)(blockIdx.x * 4 + wave) * EDGE_PARTIAL;
+  // ---- fold the four waves' accumulators through LDS (the weight images are dead): pairs (1 -> 0, 3 -> 2), then 2 -> 0; every
+  //      lane reads back exactly the slots its partner lane wrote ([register][lane]: conflict-free, no address arithmetic), so
+  //      the order is fixed and ONE partial row per workgroup leaves (a quarter of the slab the folding launch has to read)
+  constexpr int NACC = 10 * 16 + 4;
+  float* fold = smem_raw;
+  auto visit = [&](auto&& f) {
+    int k = 0;
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accB[a_][i] = f(accB[a_][i], k++);
+#pragma unroll
+      for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accA[a_][b_][i] = f(accA[a_][b_][i], k++); accK[a_][b_][i] = f(accK[a_][b_][i], k++); }
+      db1[a_] = f(db1[a_], k++);
+      db2[a_] = f(db2[a_], k++);
+    }
+  };
+  __syncthreads();
+  if (wave & 1) visit([&](float v_, int k) { fold[((wave >> 1) * NACC + k) * 64 + lane] = v_; return v_; });
+  __syncthreads();
+  if (!(wave & 1)) visit([&](float v_, int k) { return v_ + fold[((wave >> 1) * NACC + k) * 64 + lane]; });
+  __syncthreads();
+  if (wave == 2) visit([&](float v_, int k) { fold[k * 64 + lane] = v_; return v_; });
+  __syncthreads();
+  if (wave != 0) return;
+  visit([&](float v_, int k) { return v_ + fold[k * 64 + lane]; });
+  // ---- write the workgroup's partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
+  float* out = partial + (size_t)blockIdx.x * EDGE_PARTIAL;
   float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64, *oWk = ob2 + 64;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -570,7 +598,7 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
 // The same edge set in both orders: destination-sorted (rowptr, e_src, e_dst: the forward's arrays) for the weight kernel and
 // source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten:
 // dx_src = (dres ? dres : 0) + sum over out-edges; dres [n_src,16,64] = gradient of another use of x_src (the residual branch), or NULL.
-// partial must hold grl_edge_bwd_blocks(n_edges)*4 rows of grl_edge_partial_size() floats.
+// partial must hold grl_edge_bwd_blocks(n_edges) rows of grl_edge_partial_size() floats.
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -586,7 +614,8 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
   EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
   const int blocks = grl_edge_bwd_blocks(n_edges);
   const size_t smem_x = sizeof(ChainW);
-  const size_t smem_w = smem_x + sizeof(BwdW);
+  size_t smem_w = smem_x + sizeof(BwdW);
+  if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x);

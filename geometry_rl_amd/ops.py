@@ -152,7 +152,7 @@ class EdgeConv(torch.autograd.Function):
         dev = dx1.device
         blocks = hip.query("grl_edge_bwd_blocks", e.n_edges)
         psize = hip.query("grl_edge_partial_size")
-        partial = torch.empty(blocks * 4, psize, device=dev, dtype=torch.float32)
+        partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
         dx_src = torch.empty_like(x_src)
         dres = ctx.residual.pop("dres", None) if ctx.residual is not None else None
         hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.src_s,
