@@ -118,6 +118,7 @@ class PolicyUpdater:
         self.use_graph = use_graph
         self._static = None
         self._program = None
+        self._pending = []   # asynchronous collectives in flight
         if group is not None:  # replicas start identical (parameter init incl. calibration is rank 0's)
             import torch.distributed as dist
             dist.broadcast(self.flat, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
@@ -247,21 +248,36 @@ class PolicyUpdater:
 
         if world == 1 and self.overlap_critic:
             return [("run", o_fwd), ("run", s5)]
-        plan = [("run", s0)]
-        if world > 1:
-            plan += [("sum", lambda: st["pipe"].stats1), ("sum", lambda: st["adv"])]
-        plan += [("run", s1)]
-        if world > 1:
-            plan += [("sum", lambda: st["pipe"].stats2)]
-        plan += [("run", s2)]
-        if world > 1:
-            plan += [("sum", lambda: st["pipe"].bst2)]
-        plan += [("run", s3)]
-        if world > 1:
-            plan += [("sum", lambda: st["pipe"].bst1)]
-        plan += [("run", s4)]
-        if world > 1:  # loss terms are already scaled by 1/B_global
-            plan += [("sum", lambda: self.gflat), ("sum", lambda: st["sums"]), ("max", lambda: st["maxes"])]
+        if world == 1:   # (overlap_critic switched off) one rank, one stream
+            return [("run", s0), ("run", s1), ("run", s2), ("run", s3), ("run", s4), ("run", s5)]
+
+        # ---- several ranks.  Two of the critic's reductions travel BEHIND the actor: the first-stage statistics (+ advantage sums)
+        #      are all-reduced asynchronously while the actor forward runs, the last-stage backward sums while the actor backward
+        #      runs; the step then waits for six collectives instead of eight.
+        def a_fwd():
+            ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch in s4
+            st["loc_g"], st["sigma_g"] = actor.forward_diag(*st["obs"], train=True)
+
+        def c_head():  # value head, fused TRPL kernel, last critic stage backward
+            pipe = st["pipe"]
+            value = pipe.fwd3()
+            loc, sigma = st["loc_g"], st["sigma_g"]
+            with torch.no_grad():
+                zw = st["zw"]
+                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, st["b"], st["adv"], sums=zw[10:22],
+                                                                maxes=zw[22:23].view(torch.int32))
+                pipe.bwd3(dvalue)
+            st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma)
+
+        def a_bwd():
+            torch.autograd.backward([st.pop("loc_g"), st.pop("sigma_g")], [st.pop("dloc"), st.pop("dsigma")])
+
+        plan = [("run", s0), ("sum_async", lambda: st["pipe"].stats1), ("sum_async", lambda: st["adv"]), ("run", a_fwd), ("wait", None),
+                ("run", s1), ("sum", lambda: st["pipe"].stats2),
+                ("run", c_head), ("sum_async", lambda: st["pipe"].bst2), ("run", a_bwd), ("wait", None),
+                ("run", s3), ("sum", lambda: st["pipe"].bst1),
+                ("run", s4),  # loss terms are already scaled by 1/B_global
+                ("sum", lambda: self.gflat), ("sum", lambda: st["sums"]), ("max", lambda: st["maxes"])]
         plan += [("run", s5)]
         return plan
 
@@ -271,9 +287,17 @@ class PolicyUpdater:
         return self._cstream
 
     def _reduce(self, kind, t):
+        import torch.distributed as dist
+        if kind == "wait":
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            return
         if t is None:
             return
-        import torch.distributed as dist
+        if kind == "sum_async":
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=self.group)
 
     def _compile(self, batch):
@@ -355,7 +379,7 @@ class PolicyUpdater:
                 if kind == "run":
                     item()
                 else:
-                    self._reduce(kind, item())
+                    self._reduce(kind, item() if item is not None else None)
             return st["out"]
         if self._program is None:
             try:
@@ -373,7 +397,7 @@ class PolicyUpdater:
             if kind == "graph":
                 item.replay()
             else:
-                self._reduce(kind, item())
+                self._reduce(kind, item() if item is not None else None)
         return self._st["out"]
 
 
