@@ -253,7 +253,8 @@ class PolicyUpdater:
 
         # ---- several ranks.  Two of the critic's reductions travel BEHIND the actor: the first-stage statistics (+ advantage sums)
         #      are all-reduced asynchronously while the actor forward runs, the last-stage backward sums while the actor backward
-        #      runs; the step then waits for six collectives instead of eight.
+        #      (and the loss sums / maxes, which only feed the reported values) while the actor backward runs; the step then waits
+        #      for four collectives instead of eight.
         def a_fwd():
             ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch in s4
             st["loc_g"], st["sigma_g"] = actor.forward_diag(*st["obs"], train=True)
@@ -274,10 +275,11 @@ class PolicyUpdater:
 
         plan = [("run", s0), ("sum_async", lambda: st["pipe"].stats1), ("sum_async", lambda: st["adv"]), ("run", a_fwd), ("wait", None),
                 ("run", s1), ("sum", lambda: st["pipe"].stats2),
-                ("run", c_head), ("sum_async", lambda: st["pipe"].bst2), ("run", a_bwd), ("wait", None),
+                ("run", c_head), ("sum_async", lambda: st["pipe"].bst2),
+                ("sum_async", lambda: st["sums"]), ("max_async", lambda: st["maxes"]),   # loss terms: already scaled by 1/B_global
+                ("run", a_bwd), ("wait", None),
                 ("run", s3), ("sum", lambda: st["pipe"].bst1),
-                ("run", s4),  # loss terms are already scaled by 1/B_global
-                ("sum", lambda: self.gflat), ("sum", lambda: st["sums"]), ("max", lambda: st["maxes"])]
+                ("run", s4), ("sum", lambda: self.gflat)]
         plan += [("run", s5)]
         return plan
 
@@ -295,8 +297,9 @@ class PolicyUpdater:
             return
         if t is None:
             return
-        if kind == "sum_async":
-            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if kind in ("sum_async", "max_async"):
+            op = dist.ReduceOp.SUM if kind == "sum_async" else dist.ReduceOp.MAX
+            self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
             return
         dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=self.group)
 
