@@ -37,3 +37,19 @@ run("mlp slab (256 rows)", [(256, M)], [(0, 0, 16384, "w3"), (0, 16384, 256, "b3
 run("mlp slab W3 only", [(256, M)], [(0, 0, 16384, "w3")])
 run("tall thin: 4096 rows x 4096", [(4096, 4096)], [(0, 0, 4096, "a")])
 run("square-ish 1024 x 16384", [(1024, 16384)], [(0, 0, 16384, "a")])
+
+# ---- the step's whole folding launch at a 512-frame shard (slab shapes of the deferred list, tools: ops.flush_deferred_grads)
+mlp = [(0, 16384, "w3"), (16384, 256, "b3"), (16640, 16384, "w4"), (33024, 64, "b4"), (33088, 64, "g"), (33152, 64, "be")]
+E2 = 9216
+slabs = [(256, M), (256, E2), (256, M), (256, E2), (128, 4356), (128, 8448), (128, 1024), (1024, 448), (128, 448), (64, 12608)]
+segs = []
+for si, tag in ((0, "a"), (2, "b")):
+    segs += [(si, s_, l, k + tag) for s_, l, k in mlp]
+for si, tag in ((1, "a"), (3, "b")):
+    segs += [(si, s_, l, k) for s_, l, k in edge] + [(si, 5120, 4096, "wk" + tag)]
+segs += [(4, 0, 4096, "dsw4"), (5, 0, 4096, "dsw3"), (5, 4160, 4096, "dsw2"), (6, 0, 960, "dsw1"), (7, 0, 448, "enc"), (8, 0, 448, "enc"),
+         (9, 0, 4096, "fb0"), (9, 4096, 4096, "fb1"), (9, 8192, 4096, "fb2")]
+run("whole fold, 512-frame shard", slabs, segs)
+run("  only the two MLP slabs", slabs, [s_ for s_ in segs if s_[0] in (0, 2)])
+run("  only the two edge slabs", slabs, [s_ for s_ in segs if s_[0] in (1, 3)])
+run("  the rest", slabs, [s_ for s_ in segs if s_[0] >= 4])
