@@ -251,35 +251,75 @@ class PolicyUpdater:
         if world == 1:   # (overlap_critic switched off) one rank, one stream
             return [("run", s0), ("run", s1), ("run", s2), ("run", s3), ("run", s4), ("run", s5)]
 
-        # ---- several ranks.  Two of the critic's reductions travel BEHIND the actor: the first-stage statistics (+ advantage sums)
-        #      are all-reduced asynchronously while the actor forward runs, the last-stage backward sums while the actor backward
-        #      (and the loss sums / maxes, which only feed the reported values) while the actor backward runs; the step then waits
-        #      for four collectives instead of eight.
+        # ---- several ranks: two lanes.  The critic with ALL FOUR of its reductions runs on a second stream ("s" items) beside the
+        #      actor forward / backward; the loss sums / maxes (reported values only) are reduced asynchronously behind the actor
+        #      backward.  The main lane waits for ONE collective per step: the gradient all-reduce.  Tensors that cross lanes stay
+        #      referenced in ``st`` for the whole step, so neither allocator pool can hand their memory out while the other lane
+        #      still uses it.
+        def m_prep():
+            self.gflat.zero_()
+            b = dict(batch)
+            if "var" not in b:
+                b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
+            st["b"] = b
+            st["obs"] = [b[k] for k in m.in_features]
+            st["zw"] = torch.zeros(26, device=self.flat.device, dtype=torch.float64)
+
+        def c_fwd1():
+            with torch.no_grad():
+                vf.train(True)
+                _, x = vf.hyper_data.build_data(*st["obs"], train=True)
+                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
+                st["pipe"].fwd1()
+                st["adv"] = None
+                if m.normalize_advantage and x.shape[0] * world > 1:
+                    st["adv"] = st["zw"][8:10]
+                    adv_stats_local(m, st["b"], st["adv"])
+
+        def c_fwd3():
+            st["value"] = st["pipe"].fwd3()
+
         def a_fwd():
-            ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch in s4
+            ops.DEFERRED = []   # leaf-gradient folds of both backward passes are queued and executed by one launch in ``fold``
             st["loc_g"], st["sigma_g"] = actor.forward_diag(*st["obs"], train=True)
 
-        def c_head():  # value head, fused TRPL kernel, last critic stage backward
-            pipe = st["pipe"]
-            value = pipe.fwd3()
+        def head():  # fused TRPL kernel
             loc, sigma = st["loc_g"], st["sigma_g"]
             with torch.no_grad():
                 zw = st["zw"]
-                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, st["b"], st["adv"], sums=zw[10:22],
+                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, st["value"], st["b"], st["adv"], sums=zw[10:22],
                                                                 maxes=zw[22:23].view(torch.int32))
-                pipe.bwd3(dvalue)
-            st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma)
+            st.update(loc=loc.detach(), sigma=sigma.detach(), sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma, dvalue=dvalue)
+
+        def c_bwd3():
+            with torch.no_grad():
+                st["pipe"].bwd3(st["dvalue"])
+
+        def c_bwd1():
+            with torch.no_grad():
+                grads = st["pipe"].bwd1(leaves)
+            assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
 
         def a_bwd():
-            torch.autograd.backward([st.pop("loc_g"), st.pop("sigma_g")], [st.pop("dloc"), st.pop("dsigma")])
+            torch.autograd.backward([st.pop("loc_g"), st.pop("sigma_g")], [st["dloc"], st["dsigma"]])
 
-        plan = [("run", s0), ("sum_async", lambda: st["pipe"].stats1), ("sum_async", lambda: st["adv"]), ("run", a_fwd), ("wait", None),
-                ("run", s1), ("sum", lambda: st["pipe"].stats2),
-                ("run", c_head), ("sum_async", lambda: st["pipe"].bst2),
+        def fold():
+            ops.flush_deferred_grads()
+            ops.DEFERRED = None
+
+        S = "s"
+        plan = [("run", m_prep), ("fork", None),
+                ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S), ("sum", lambda: st["adv"], S),
+                ("run", a_fwd),
+                ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S), ("run", c_fwd3, S),
+                ("join", None),
+                ("run", head), ("fork", None),
+                ("run", c_bwd3, S), ("sum", lambda: st["pipe"].bst2, S), ("run", s3, S), ("sum", lambda: st["pipe"].bst1, S),
+                ("run", c_bwd1, S),
                 ("sum_async", lambda: st["sums"]), ("max_async", lambda: st["maxes"]),   # loss terms: already scaled by 1/B_global
-                ("run", a_bwd), ("wait", None),
-                ("run", s3), ("sum", lambda: st["pipe"].bst1),
-                ("run", s4), ("sum", lambda: self.gflat)]
+                ("run", a_bwd),
+                ("join", None), ("wait", None),
+                ("run", fold), ("sum", lambda: self.gflat)]
         plan += [("run", s5)]
         return plan
 
@@ -308,31 +348,37 @@ class PolicyUpdater:
         self._static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         st = self._st = {}
         plan = self._plan(self._static, st)
-        groups, cur = [], []
-        for kind, item in plan:
-            if kind == "run":
+        groups, cur, cur_lane = [], [], None
+        for entry in plan:
+            kind, item, lane = entry[0], entry[1], (entry[2] if len(entry) > 2 else "m")
+            if kind == "run" and (not cur or lane == cur_lane):
                 cur.append(item)
+                cur_lane = lane
+                continue
+            if cur:
+                groups.append(("run", cur, cur_lane))
+                cur, cur_lane = [], None
+            if kind == "run":
+                cur, cur_lane = [item], lane
             else:
-                if cur:
-                    groups.append(("run", cur))
-                    cur = []
-                groups.append((kind, item))
+                groups.append((kind, item, lane))
         if cur:
-            groups.append(("run", cur))
-        program, pool = [], None
+            groups.append(("run", cur, cur_lane))
+        program, pools = [], {}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        for kind, item in groups:
+        for kind, item, lane in groups:
             if kind != "run":
-                program.append((kind, item))
+                program.append((kind, item, lane))
                 continue
             g = torch.cuda.CUDAGraph()
+            # one allocator pool per lane: graphs of different lanes are replayed concurrently and must not share scratch memory
             # thread_local: background threads of the process (the collectives' watchdog) may keep issuing event queries
-            with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=pools.get(lane), stream=side, capture_error_mode="thread_local"):
                 for fn in item:
                     fn()
-            pool = g.pool()
-            program.append(("graph", g))
+            pools[lane] = g.pool()
+            program.append(("graph", g, lane))
         torch.cuda.current_stream().wait_stream(side)
         self._program = program
 
@@ -378,11 +424,7 @@ class PolicyUpdater:
         self.steps += 1
         if not self.use_graph or self.steps == 1:   # the first step always runs eagerly: it builds the cached topology of
             st = {}                                 # this batch size and the kernels' one-time attributes (not capturable)
-            for kind, item in self._plan(batch, st):
-                if kind == "run":
-                    item()
-                else:
-                    self._reduce(kind, item() if item is not None else None)
+            self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m") for e in self._plan(batch, st)])
             return st["out"]
         if self._program is None:
             try:
@@ -396,12 +438,33 @@ class PolicyUpdater:
                 self.steps -= 1
                 return self.step(batch)
         self._refresh_static(batch)
-        for kind, item in self._program:
-            if kind == "graph":
-                item.replay()
-            else:
-                self._reduce(kind, item() if item is not None else None)
+        self._execute(self._program)
         return self._st["out"]
+
+    def _execute(self, program):
+        """Run a program: ("run" closure | "graph" replay | collective | "fork" | "join" | "wait", item, lane).  Lane "m" is the
+        caller's stream, lane "s" the critic stream; "fork": the side lane waits for the main lane, "join": the reverse."""
+        main = torch.cuda.current_stream()
+        side = None
+        for kind, item, lane in program:
+            if kind in ("fork", "join"):
+                side = side or self._critic_stream()
+                (side if kind == "fork" else main).wait_stream(main if kind == "fork" else side)
+                continue
+            if lane == "s":
+                side = side or self._critic_stream()
+                with torch.cuda.stream(side):
+                    self._do(kind, item)
+            else:
+                self._do(kind, item)
+
+    def _do(self, kind, item):
+        if kind == "run":
+            item()
+        elif kind == "graph":
+            item.replay()
+        else:
+            self._reduce(kind, item() if item is not None else None)
 
 
 def gae(reward, done, terminated, values, gamma=0.99, lmbda=0.95):

@@ -95,16 +95,18 @@ def test_graph_replay_matches_eager():
     assert (flat - ref_flat).abs().max().item() <= 1e-7
 
 
-def test_two_ranks_with_graph_segments_match_single_rank():
-    """Data parallel with the step recorded as hipGraph segments between the (eager) collectives, 2 steps."""
+@pytest.mark.parametrize("n_steps", [2, 5])
+def test_two_ranks_with_graph_segments_match_single_rank(n_steps):
+    """Data parallel with the step recorded as hipGraph segments on two lanes (actor | critic + its collectives) between the
+    eager collectives: step 1 eager, step 2 records, later steps replay (5 steps: four replays of both lanes' graphs)."""
     B, world = 16, 2
-    ref_losses, ref_flat = _run_single(B, 2, use_graph=False)
+    ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, 2), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
         losses, flat = ret[r]
         for k, v in ref_losses.items():
-            assert abs(losses[k] - v) <= 1e-5 * max(1.0, abs(v)), (r, k, losses[k], v)
-        assert (flat - ref_flat).abs().max().item() <= 4e-6
+            assert abs(losses[k] - v) <= (1e-5 if n_steps == 2 else 1e-4) * max(1.0, abs(v)), (r, k, losses[k], v)
+        assert (flat - ref_flat).abs().max().item() <= (4e-6 if n_steps == 2 else 3e-5)
