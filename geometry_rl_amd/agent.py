@@ -82,12 +82,14 @@ class PolicyUpdater:
     eps=1e-5) steps (train.py:279-316).  Parameters of both networks live in ONE flat fp32 buffer (gradients likewise), so a
     data-parallel run needs a single RCCL all-reduce of the gradient per step and Adam is a single kernel per optimizer.
 
-    The step is laid out as an explicit plan of device-only segments separated by the data-parallel reduction points
-    (advantage / critic-LayerNorm statistics forward, their two backward counterparts, gradient + loss sums): every segment is
-    free of host synchronisation, so with ``use_graph=True`` each one is recorded once into a hipGraph (torch.cuda.CUDAGraph;
-    a single graph when there is no process group) and replayed -- the ~3.4 ms of per-step launch overhead of the ~250 small
-    launches disappears, which is what strong scaling over 8 GPUs needs (512 frames per GPU are ~1 ms of device time).
-    The collectives themselves stay ordinary eager torch.distributed calls between the replays."""
+    The step is laid out as an explicit plan (``_plan``) of device-only segments, each free of host synchronisation, so with
+    ``use_graph=True`` they are recorded once into hipGraphs (torch.cuda.CUDAGraph) and replayed -- the ~3 ms of per-step launch
+    overhead disappears, which is what strong scaling over 8 GPUs needs (512 frames per GPU are < 1 ms of device time).
+      * one rank: a single graph; the critic's small kernels run on a second stream beside the actor's (fork / join inside the graph);
+      * several ranks: a two-lane program (``_execute``): the main lane carries the actor, the TRPL kernel, the gradient folding and
+        Adam, the side lane the critic together with its four statistic all-reduces; segments are separate graphs and the
+        collectives stay ordinary eager torch.distributed calls between the replays.  The main lane waits for one collective per
+        step, the all-reduce of the flat gradient."""
 
     def __init__(self, loss_module: TRPLLoss, lr=3e-4, eps=1e-5, betas=(0.9, 0.999), clip_grad_norm=False, max_grad_norm=1.0,
                  group=None, use_graph=False, overlap_critic=True):
