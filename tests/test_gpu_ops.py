@@ -164,3 +164,32 @@ def test_reduce_partials_multi_all_paths():
     for k in dsts:
         err = (dsts[k].double() - ref[k]).abs().max().item()
         assert err <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, err)
+
+
+@pytest.mark.parametrize("B,n,d", [(1, 3, 15), (7, 35, 15), (130, 241, 12), (1030, 9, 7)])
+def test_deepsets_critic_shapes(B, n, d):
+    """The six critic kernels (slot statistics, register-resident weights, 16-wave row kernels) against the oracle's DeepSets over
+    batch / set / feature sizes around the kernels' tiling (fewer samples than waves, more workgroups than statistic slots ...)."""
+    from geometry_rl_amd import ops
+    from oracle import graph as ogr
+    dv = dev()
+    P = ogr.init_critic_params(d, seed=5)
+    g = torch.Generator().manual_seed(B + n)
+    x = torch.randn(B, n, d, generator=g)
+    R = torch.randn(B, generator=g)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = ogr.value_forward(Pg, x).reshape(B)
+    (ref * R).sum().backward()
+    order = ["gnn.mlp_inner.lins.0.weight", "gnn.mlp_inner.lins.0.bias", "gnn.mlp_inner.norms.0.weight", "gnn.mlp_inner.norms.0.bias",
+             "gnn.mlp_inner.lins.1.weight", "gnn.mlp_inner.lins.1.bias", "gnn.mlp_outer.lins.0.weight", "gnn.mlp_outer.lins.0.bias",
+             "gnn.mlp_outer.norms.0.weight", "gnn.mlp_outer.norms.0.bias", "gnn.mlp_outer.lins.1.weight", "gnn.mlp_outer.lins.1.bias",
+             "final.weight", "final.bias"]
+    leaves = [P[k].clone().to(dv).requires_grad_(True) for k in order]
+    val = ops.DeepSetsValue.apply(x.to(dv), *leaves, None)
+    (val * R.to(dv)).sum().backward()
+    scale = max(1.0, float(ref.detach().abs().max()))
+    assert float((val.detach().cpu() - ref.detach()).abs().max()) <= 2e-5 * scale
+    for k, t in zip(order, leaves):
+        gr = Pg[k].grad
+        err = float((t.grad.cpu() - gr).abs().max())
+        assert err <= 1e-4 * max(1.0, float(gr.abs().max())), (k, err, float(gr.abs().max()))
