@@ -34,6 +34,7 @@ def test_rope_actor_is_rotation_equivariant(k):
         loc_r, sig_r = actor.forward_diag(*[rot[k_] for k_ in spec.in_features], train=False)
     assert float(loc.abs().max()) > 1e-4
     scale = float(loc.abs().max())
+    print(f"k={k}: equivariance error {float((loc_r - _rot(loc, c, s)).abs().max()) / scale:.2e} (relative), sigma {float((sig_r - sig).abs().max()):.2e}")
     assert float((loc_r - _rot(loc, c, s)).abs().max()) <= 2e-4 * scale + 1e-6
     assert float((sig_r - sig).abs().max()) <= 1e-5 * float(sig.abs().max())
     # and a rotation that is NOT on the grid is not a symmetry of the discretised fiber: the check above is not vacuous

@@ -41,6 +41,7 @@ def test_kl_projection_meets_the_bound():
     before, after = kl(S, So), kl(pS, So)
     active = before > 0.0025
     assert active.sum() > 10 and (~active).sum() >= 1
+    print(f"KL bound residual {float((after[active] - 0.0025).abs().max()):.2e}")
     assert float((after[active] - 0.0025).abs().max()) <= 2e-6
     assert torch.equal(pS[~active].float(), S[~active].float())
     # mean part: 1/2 maha <= bound everywhere after the projection
