@@ -134,7 +134,8 @@ constexpr int MLP_PARTIAL = W * C + W + C * W + C + C + C;
 // chunks; wave w owns hidden tile w (32 of the 256 hidden units):
 //   1. all 512 threads: load x2 / dOut (one float4 per thread, prefetched a chunk ahead), LayerNorm by 16-lane reductions, write
 //      a = LN(x2) and dOut as split-bf16 fragment images to LDS; per-thread column sums for db4
-//   2. waves 0-3 transpose the four shared 32-column tiles (a | dOut) in registers (transpose32) -> LDS
+//   2. the four shared 32-column tiles (a | dOut) are transposed in registers (transpose32; hi parts by waves 0-3, lo parts by
+//      waves 4-7) -> LDS
 //   3. every wave, its hidden tile: z^T, dH^T with the hidden unit on the lane (activation on the A side: the layout the row
 //      reductions need, no transpose); dZ = dH * gelu'(z); dW3 += dZ^T a, dW4 += dOut^T h (split-bf16, accumulators in registers
 //      for the whole launch); dZ back to row layout (one register transpose) and dA^T += W3^T dZ with the W3 tile transposed in
@@ -270,18 +271,17 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     PH(1);
     __syncthreads();
     PH(2);
-    // ------------------------------------------------------------ 2: the four shared transposed tiles (waves 0-3)
-    if (wave < 4) {
-      const unsigned short* ih = (wave < 2 ? s.Ah : s.Dh) + r * LDF + 32 * (wave & 1) + 8 * h;
-      const unsigned short* il = (wave < 2 ? s.Al : s.Dl) + r * LDF + 32 * (wave & 1) + 8 * h;
-      const bf16x8 c0h = *reinterpret_cast<const bf16x8*>(ih), c1h = *reinterpret_cast<const bf16x8*>(ih + 16);
-      const bf16x8 c0l = *reinterpret_cast<const bf16x8*>(il), c1l = *reinterpret_cast<const bf16x8*>(il + 16);
+    // ------------------------------------------------------------ 2: the four shared transposed tiles (all eight waves)
+    {  // tile = wave & 3 (a | a | dOut | dOut column halves); waves 0-3 transpose the hi parts, waves 4-7 the lo parts
+      const int tile = wave & 3;
+      const bool lo_part = wave >= 4;
+      const unsigned short* img = (tile < 2 ? (lo_part ? s.Al : s.Ah) : (lo_part ? s.Dl : s.Dh)) + r * LDF + 32 * (tile & 1) + 8 * h;
+      const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(img), c1 = *reinterpret_cast<const bf16x8*>(img + 16);
       __builtin_amdgcn_sched_barrier(0);
-      const TTile t = transpose_split(c0h, c1h, c0l, c1l, sel0, sel1);   // reads its accumulators (packs): fenced by construction
-      s.TT[wave][0][lane] = __builtin_bit_cast(u32x4, t.h0);
-      s.TT[wave][1][lane] = __builtin_bit_cast(u32x4, t.h1);
-      s.TT[wave][2][lane] = __builtin_bit_cast(u32x4, t.l0);
-      s.TT[wave][3][lane] = __builtin_bit_cast(u32x4, t.l1);
+      bf16x8 t0, t1;
+      acc_to_bf(transpose32(c0, c1, sel0, sel1), t0, t1);   // reads its accumulator (packs): fenced by construction
+      s.TT[tile][lo_part ? 2 : 0][lane] = __builtin_bit_cast(u32x4, t0);
+      s.TT[tile][lo_part ? 3 : 1][lane] = __builtin_bit_cast(u32x4, t1);
     }
     PH(3);
     // (no barrier yet: z, dH and the activation below only read the fragment images; the transposed tiles are first needed by dW3)
