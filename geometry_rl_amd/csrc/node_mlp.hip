@@ -405,16 +405,27 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       __builtin_amdgcn_sched_barrier(0);
     }
     PH(8);
+    // waves w and w + 4 share buffer DA[w]: each writes one column half in the first round and adds its other half onto the
+    // partner's in the second, so all eight waves move data in both rounds (fixed order per element: first writer, then adder)
     float* drow = s.DA[wave & 3] + r * LDD + 4 * h;
-    if (wave < 4) {
+    if (wave < 4) {   // (static register indices: a run-time fragment offset would push daf into scratch)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = daf[t];
+      for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = daf[t];
+    } else {
+#pragma unroll
+      for (int t = 4; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = daf[t];
     }
     __syncthreads();
     PH(9);
-    if (wave >= 4) {
+    if (wave < 4) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 4; t < 8; ++t) {
+        float4* p = reinterpret_cast<float4*>(drow + 8 * t);
+        *p = f4_add(*p, daf[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
         float4* p = reinterpret_cast<float4*>(drow + 8 * t);
         *p = f4_add(*p, daf[t]);
       }
