@@ -33,9 +33,11 @@ def test_no_oracle_import_in_product():
     """The product package must never route through the CPU oracle."""
     pkg = os.path.join(ROOT, "geometry_rl_amd")
     for fn in os.listdir(pkg):
-        if fn.endswith(".py") and fn != "smoke.py":
+        if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
-            assert "oracle" not in src.replace("CPU oracle", ""), fn
+            assert "import oracle" not in src and "from oracle" not in src, fn
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and "def cpu_baseline" in bench   # only the timed CPU baseline leg
 
 
 def test_product_fails_loudly_without_extension(monkeypatch, tmp_path):
