@@ -145,3 +145,23 @@ class PolicyActor:
             self._static[k].copy_(obs[k])
         self._graph.replay()
         return self._out
+
+
+def collect(env_step, first_obs: Dict[str, torch.Tensor], actor: PolicyActor, T: int, normalizer=None):
+    """The data-collection half of one training iteration (train.py:114-123, 232-247) with everything on the device: for T steps the
+    (optionally normalised) observation goes through the collector-side actor, the action into ``env_step(action) -> (next raw
+    observation groups, reward [N], done [N] bool, terminated [N] bool)``; the frames are stacked into a ``RolloutBuffer`` [N, T, ...].
+    Returns ``(buffer, next_last)`` as ``RolloutDriver.run`` takes them (``next_last``: the observation after the last step, [N, 1, width])."""
+    raw = first_obs
+    frames = []
+    for _ in range(T):
+        obs = normalizer(raw) if normalizer is not None else raw
+        out = actor(obs)
+        rec = {k: v.clone() for k, v in obs.items()}
+        rec.update({k: out[k].clone() for k in ("loc", "var", "action", "sample_log_prob")})
+        raw, reward, done, terminated = env_step(out["action"])
+        rec.update(reward=reward.reshape(-1, 1).float(), done=done.reshape(-1, 1), terminated=terminated.reshape(-1, 1))
+        frames.append(rec)
+    last = normalizer(raw, update=False) if normalizer is not None else raw
+    data = {k: torch.stack([f[k] for f in frames], dim=1) for k in frames[0]}
+    return RolloutBuffer(data), {k: v.unsqueeze(1) for k, v in last.items()}
