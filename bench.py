@@ -64,29 +64,63 @@ def workload(name):
     return spec, cfg, make, cfg_name
 
 
-def cpu_baseline(wl_name, minibatch, sample=1024, steps=3, max_threads=32):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
+LOSS_KEYS = ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic", "ESS", "kl", "constraint", "mean_constraint",
+             "mean_constraint_max", "cov_constraint", "cov_constraint_max", "entropy", "entropy_diff")
+
+
+def cpu_baseline_and_parity(wl_name, minibatch, dev, sample=1024, steps=3, max_threads=32):
+    """(1) BASELINE.md section 3's parity gate: one update of a ``sample``-frame minibatch (config 2's size) through the HIP path and
+    through the oracle (CPU restatement of the reference path) from identical parameters and inputs -- loc, var, state_value and
+    every loss-dict entry within 1e-4 * max(1, |ref|), post-Adam parameters within 2e-5;
+    (2) the oracle timed on this box's host cores on that bounded sample (the reported cpu_baseline, kind "port")."""
     from oracle import graph as ogr, step as ost
-    from geometry_rl_amd import synthetic as syn
+    from geometry_rl_amd import agent, graph, synthetic as syn
     assert wl_name == "rigid_hepi"
-    cores = min(os.cpu_count() or 1, max_threads)  # more intra-op threads than this only slow the small CPU ops down
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, max_threads)  # more intra-op threads than this only slow the small CPU ops of the oracle down
     torch.set_num_threads(cores)
-    spec = ogr.rigid_spec()
-    cfg = ost.AgentConfig(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
-    a, c = ost.init_agent_params(spec, cfg, seed=0)
-    ag = ost.OracleAgent(spec, cfg, a, c)
+    kw = dict(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
+    o_spec, spec = ogr.rigid_spec(), graph.rigid_spec()
+    a, c = ost.init_agent_params(o_spec, ost.AgentConfig(**kw), seed=0)
+    ag = ost.OracleAgent(o_spec, ost.AgentConfig(**kw), a, c)
     batch = dict(syn.make_rigid_obs(sample, seed=1))
     batch.update(syn.make_ppo_fields(sample, 6, seed=1))
     with torch.no_grad():
-        ag.actor_forward({k: batch[k] for k in spec.in_features}, calibrate=True)
-    ag.update(batch)
+        ag.actor_forward({k: batch[k] for k in o_spec.in_features}, calibrate=True)
+    # HIP twin from the oracle's calibrated parameters
+    actor, critic, proj, loss = agent.build_agent(spec, agent.AgentConfig(**kw), device=dev)
+    actor.load_state_dict({k: v.detach().to(dev) for k, v in ag.actor.items()}, strict=False)
+    critic.load_state_dict({"_network1." + k: v.detach().to(dev) for k, v in ag.critic.items()}, strict=False)
+    for conv_round in actor.gnn.processor:
+        for _, conv in conv_round.items():
+            conv.callibrated.fill_(True)
+    actor._calib_checked = True
+    upd = agent.PolicyUpdater(loss)
+    out = upd.step({k: v.to(dev) for k, v in batch.items()})
+    ref, _ = ag.update(batch)      # also the warm-up of the timed loop below
+    worst, worst_key, ok = 0.0, None, True
+    pairs = [("loc", out["loc"], ref["loc"]), ("var", out["sigma"] ** 2, ref["var"]), ("state_value", out["state_value"], ref["state_value"])]
+    pairs += [(k, out[k], ref[k]) for k in LOSS_KEYS]
+    for k, g, r in pairs:
+        r = torch.as_tensor(r).detach().double().cpu()
+        e = (torch.as_tensor(g).detach().double().cpu().reshape(r.shape) - r).abs().max().item() / max(1.0, r.abs().max().item())
+        if not (e <= 1e-4):
+            ok = False
+        if e > worst or e != e:
+            worst, worst_key = e, k
+    p_err = max(max((p.detach().cpu() - ag.actor[k]).abs().max().item() for k, p in actor.named_parameters()),
+                max((p.detach().cpu() - ag.critic[k[len("_network1."):]]).abs().max().item() for k, p in critic.named_parameters()))
+    ok = ok and p_err <= 2e-5
+    gate = {"passed": bool(ok), "frames": sample, "tolerance": "1e-4 * max(1, |ref|) on loc / var / state_value / 13 loss entries; 2e-5 on post-Adam parameters",
+            "worst_value_err_over_scale": worst, "worst_key": worst_key, "post_adam_param_err": p_err}
     t0 = time.perf_counter()
     for _ in range(steps):
         ag.update(batch)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": (sample / minibatch) / dt, "unit": "policy-update steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} oracle updates of a {sample}-frame minibatch ({dt:.2f} s each), scaled linearly to {minibatch} frames",
-            "torch_threads": torch.get_num_threads()}
+    cpu = {"value": (sample / minibatch) / dt, "unit": "policy-update steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+           "sample": f"{steps} oracle updates of a {sample}-frame minibatch ({dt:.2f} s each), scaled linearly to {minibatch} frames",
+           "torch_threads": torch.get_num_threads()}
+    return cpu, gate
 
 
 def main():
@@ -96,14 +130,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="rigid_hepi")
     ap.add_argument("--minibatch", type=int, default=4096, help="global frames per policy update (= num_envs)")
-    ap.add_argument("--pool", type=int, default=8, help="time steps of the synthetic device-resident rollout the minibatches are "
-                    "sampled from (without replacement, one frame per env: train.py:128,258); the full 128-step rollout is 1.6 GB")
+    ap.add_argument("--pool", type=int, default=128, help="time steps of the synthetic device-resident rollout the minibatches are "
+                    "sampled from (without replacement, one frame per env: train.py:128,258); 128 = the whole 4096 x 128 rollout "
+                    "(1.6 GB of observations in HBM)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the 1024-frame oracle comparison (and the CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the recorded hipGraph(s)")
     args = ap.parse_args()
 
+    # ---- `python bench.py --gpus N` outside a launcher: start the N ranks ourselves.  Nothing above has touched the GPU (no HIP call,
+    #      no torch.cuda query), so the child launcher and its ranks are ordinary fresh processes; this process only relays their
+    #      output and exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     group = None
@@ -133,20 +187,25 @@ def main():
         b = dict(obs)
         b.update(syn.make_ppo_fields(B, A, seed=1000 * rank + i))
         pool.append({k: v.to(dev) for k, v in b.items()})
-    with torch.no_grad():  # first training call: data-dependent calibration (conv.py:104-105) on rank-local data, then broadcast
-        actor.forward_diag(*[pool[0][k] for k in spec.in_features], train=True)
+    # the natural order: the updater is built first; the data-dependent calibration (conv.py:104-105) happens inside its first step,
+    # from statistics summed over the ranks (every replica computes the factors of the whole minibatch)
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group,
                               use_graph=not args.no_graph)
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == world
     # device-resident rollout [B envs, pool steps, ...] + the reference's once-per-rollout work (critic over T+1 frames, shifted GAE)
     from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
     T_roll = len(pool)
     data = {k: torch.stack([f[k] for f in pool], dim=1) for k in pool[0]}
+    first_frame = {k: pool[0][k].clone() for k in pool[0]}
+    pool = None   # the frames now live in `data` only
     g_in = syn.make_gae_inputs(B, T_roll, seed=rank)
     data.update(reward=g_in["reward"].reshape(B, T_roll, 1).to(dev), done=g_in["done"].reshape(B, T_roll, 1).to(dev),
                 terminated=g_in["terminated"].reshape(B, T_roll, 1).to(dev))
     buf = RolloutBuffer(data)
     drv = RolloutDriver(upd, spec, ppo_epochs=5, seed=rank)
-    next_last = {k: pool[0][k].unsqueeze(1) for k in spec.in_features}
+    next_last = {k: first_frame[k].unsqueeze(1) for k in spec.in_features}
     torch.cuda.synchronize()
     t_adv = time.perf_counter()
     drv.compute_advantages(buf, next_last)
@@ -182,6 +241,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
+    upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else f" ({'one hipGraph' if world == 1 else 'hipGraph segments between the collectives'})")
 
     # ---- GAE + shifted critic pass over the whole 4096 x 128 rollout (once per 640 updates; outside the timed region)
     gae_ms = None
@@ -245,7 +305,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_pmc_summary_*.json")))[-1]
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary_*.json")))[-1]
             pk = json.load(open(f))["kernels"].get(name)
             if pk:
                 traffic = pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"]
@@ -259,8 +319,12 @@ def main():
             O_, C_, W_ = 16, 64, 256
             F_ = O_ * C_ * 4
             n_of = lambda t: topo_b["n_main"] if t == topo_b["main"] else B * topo_b["n_per"][t]
-            convs = [(et, topo_b["edges"][et].n_src, topo_b["edges"][et].n_dst, topo_b["edges"][et].n_edges)
-                     for rnd in actor.gnn.processor for et, _c in rnd.items() if et in topo_b["edges"]] if hasattr(actor.gnn, "processor") else []
+            if hasattr(actor.gnn, "processor"):   # HEPi: one conv per (round, edge type)
+                convs = [(et, topo_b["edges"][et].n_src, topo_b["edges"][et].n_dst, topo_b["edges"][et].n_edges)
+                         for rnd in actor.gnn.processor for et, _c in rnd.items() if et in topo_b["edges"]]
+            else:                                 # EMPN: every layer runs over every (merged) edge type (ponita_gcn.py:102-126)
+                convs = [(et, es.n_src, es.n_dst, es.n_edges) for _l in actor.gnn.ponita.interaction_layers
+                         for et, es in topo_b["edges"].items()]
             types_used = {t for et, _, _, _ in convs for t in (et[0], et[2])}
             n_nodes = sum(n_of(t) for t in types_used)
             c_in = len(spec.node_types) + spec.n_vec
@@ -270,33 +334,37 @@ def main():
                        + 8 * nd * O_ * C_ for _, _, nd, E in convs)
             fwd += B * spec.num_actuators * O_ * C_ * (cfg.output_dim + cfg.output_dim_vec) * 2
             n_params = upd.flat.numel()
-            obs_bytes = sum(v.numel() * 4 for k, v in pool[0].items() if k in spec.in_features)
+            obs_bytes = sum(v.numel() * 4 for k, v in first_frame.items() if k in spec.in_features)
             byt = sum(((ns + 2 * nd) + (2 * ns + 3 * nd)) * F_ for _, ns, nd, _ in convs) + 2 * n_nodes * F_ \
                 + sum(2 * 16 * E for _, _, _, E in convs) + 2 * obs_bytes + B * (4 * A + A * A + 7) * 4 + 10 * 4 * n_params
             t_step = ms * 1e-3
             step_fig = {"alg_tflop": 3 * fwd / 1e12, "alg_gbyte": byt / 1e9,
-                        "mfma_f32_frac": 3 * fwd / t_step / 1e12 / PEAK_F32_MFMA, "hbm_frac": byt / t_step / 8.0e12,
+                        "bf16x3_frac": 3 * fwd / t_step / 1e12 / PEAK_BF16X3, "mfma_f32_frac": 3 * fwd / t_step / 1e12 / PEAK_F32_MFMA,
+                        "hbm_frac": byt / t_step / 8.0e12,
                         "note": "formulas of SURVEY.md 8(d) with the realised node / edge counts of this minibatch; time = the timed region"}
         except Exception as e:  # never let bookkeeping break the benchmark line
             step_fig = {"error": repr(e)}
-        roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                "frac": d["frac"], "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
+        roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_BF16X3, "unit": "TFLOP/s",
+                "frac": d["frac_of_bf16x3"], "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
-                "peak_note": "f32-exact MFMA peak; the kernel forms each f32 product from three bf16 MFMAs (split-bf16), whose "
-                             f"f32-equivalent peak is {PEAK_BF16X3:.0f} TFLOP/s: frac_of_bf16x3",
-                "frac_of_bf16x3": d["frac_of_bf16x3"], "whole_step": step_fig, "mfma_kernels": kernels,
+                "peak_note": "peak = the pipe the kernel runs on: every f32 product is three dense bf16 MFMAs (split-bf16, f32 "
+                             f"accumulate), 2500 / 3 = {PEAK_BF16X3:.0f} TFLOP/s of f32-equivalent products (MI355X_MICROARCH.md: ~2.5 PF "
+                             "dense bf16); achieved = algorithmic f32 FLOP per launch / HIP-event launch time",
+                "frac_of_f32_mfma_peak": d["frac"], "f32_mfma_peak": PEAK_F32_MFMA, "whole_step": step_fig, "mfma_kernels": kernels,
                 "per_kernel_ms_per_step": {k: v[1] for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "rigid_hepi":   # N = 1 only
-        cpu = cpu_baseline(args.workload, args.minibatch)
+    cpu, gate = None, None
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.no_parity_gate) and args.workload == "rigid_hepi":   # N = 1 only
+        cpu, gate = cpu_baseline_and_parity(args.workload, args.minibatch, dev)
 
     if rank == 0:
         line = {
             "metric": "policy-update steps/sec, HEPi 4096 envs x 128 steps", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 storage/accumulate, bf16x3 products (three bf16 MFMAs per f32 product)", "data": "synthetic",
+            "mode": upd.mode_timed, "host_cores": os.cpu_count(),
             "config": {"workload": f"{cfg_name}, 4096 synthetic envs x 128 steps, minibatch {args.minibatch} frames "
                                    f"({B} per GPU), 640 updates per rollout", "global_minibatch": args.minibatch,
                        "parallelism": f"dp{world}"},
@@ -304,8 +372,12 @@ def main():
             "minibatches": f"sampled without replacement from a device-resident {B} x {T_roll}-frame rollout per GPU (one frame per env), "
                            "gathered into the static inputs of the recorded step by one launch",
             "loss": {k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity_gate": gate,
         }
+        if gate is not None and not gate["passed"]:   # no speed number without parity
+            line["invalid_value"], line["value"] = line["value"], None
+            print(json.dumps(line))
+            raise SystemExit("parity gate failed: " + json.dumps(gate))
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

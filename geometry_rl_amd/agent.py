@@ -65,6 +65,7 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
     actor = GNNGaussianPolicyDiag(gnn=gnn, hyper_data=a_data, action_dim=A, num_actuators=spec.num_actuators, init="orthogonal",
                                   hidden_sizes=(64, 64), contextual_std=True, init_std=cfg.init_std, minimal_std=cfg.minimal_std,
                                   share_action_dim=True, post_fc=False)
+    actor.group = group
     c_data = HyperData(spec, full_graph_obs=True, dist_as_pos=False, output_mask_key=None, concat_input_vector=True)
     c_gnn = DeepSets(input_dim_node=len(spec.node_types) + 3 * spec.n_vec, output_dim=64, hidden_dim=64, device=device)
     critic = BaseCritic(GNNVFNet(gnn=c_gnn, hyper_data=c_data))
@@ -92,11 +93,12 @@ class PolicyUpdater:
         step, the all-reduce of the flat gradient."""
 
     def __init__(self, loss_module: TRPLLoss, lr=3e-4, eps=1e-5, betas=(0.9, 0.999), clip_grad_norm=False, max_grad_norm=1.0,
-                 group=None, use_graph=False, overlap_critic=True):
+                 group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False):
         self.loss_module, self.group = loss_module, group
         self.overlap_critic = overlap_critic   # one rank only: critic kernels on a second stream beside the actor's
-        self.lr, self.eps, self.betas = lr, eps, betas
-        self.clip, self.max_norm = clip_grad_norm, max_grad_norm
+        self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
+        self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
+        self._hyper = dict(eps=eps, betas=tuple(betas), clip=clip_grad_norm, max_norm=max_grad_norm)
         a = [p for p in loss_module.actor_network.parameters() if p.requires_grad]
         c = [p for p in loss_module.critic_network.parameters() if p.requires_grad]
         self.params = a + c
@@ -117,13 +119,60 @@ class PolicyUpdater:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)  # optimizer step, device side (graph replays)
+        # learning rate, device side: the recorded Adam launches read it, so an annealed rate (train.py:264-271 writes
+        # ``group["lr"] = lr * alpha`` before every iteration; configs/algorithm/optim/default.yaml:5) takes effect under replay
+        self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+        self._lr = float(lr)
         self.use_graph = use_graph
         self._static = None
         self._program = None
         self._pending = []   # asynchronous collectives in flight
-        if group is not None:  # replicas start identical (parameter init incl. calibration is rank 0's)
-            import torch.distributed as dist
-            dist.broadcast(self.flat, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
+        if group is not None:
+            self.sync_replicas()
+
+    # ---- hyper-parameters.  ``lr`` lives in device memory (no re-recording); the others are baked into recorded launches as
+    #      scalars, so changing one drops the recorded program (it is re-recorded by the next step)
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):
+        if float(value) != self._lr:
+            self._lr = float(value)
+            self.lr_dev.fill_(self._lr)
+
+    def _set_hyper(self, key, value):
+        if self._hyper[key] != value:
+            self._hyper[key] = value
+            self._program = None   # recorded launches carry the old scalar
+
+    eps = property(lambda self: self._hyper["eps"], lambda self, v: self._set_hyper("eps", v))
+    betas = property(lambda self: self._hyper["betas"], lambda self, v: self._set_hyper("betas", tuple(v)))
+    clip = property(lambda self: self._hyper["clip"], lambda self, v: self._set_hyper("clip", bool(v)))
+    max_norm = property(lambda self: self._hyper["max_norm"], lambda self, v: self._set_hyper("max_norm", float(v)))
+
+    def anneal_lr(self, base_lr: float, iteration: int, total_iterations: int) -> float:
+        """train.py:264-271: ``alpha = 1 - i / total; lr = base_lr * alpha`` for both optimisers."""
+        self.lr = base_lr * (1.0 - iteration / float(total_iterations))
+        return self.lr
+
+    def sync_replicas(self):
+        """Data parallel: every replica takes rank 0's parameters AND its ``callibrated`` latches (the data-dependent
+        re-initialisation of conv.py:104-105 is rank-local arithmetic on rank-local data; replicas must not each run their own)."""
+        if self.group is None:
+            return
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.group, 0) if hasattr(dist, "get_global_rank") else 0
+        dist.broadcast(self.flat, src=src, group=self.group)
+        actor = self.loss_module.actor_network
+        flags = [b for n, b in actor.named_buffers() if n.endswith("callibrated")]
+        if flags:
+            t = torch.stack([f.to(torch.uint8) for f in flags]).to(self.flat.device)
+            dist.broadcast(t, src=src, group=self.group)
+            for f, v in zip(flags, t):
+                f.fill_(bool(v))
+        actor._calib_checked = False   # re-inspect the latches on the next training forward
 
     # ---- the plan: [("run", fn) | ("sum", tensor getter) | ("max", tensor getter)] --------------------------------------
     def _plan(self, batch: Dict[str, torch.Tensor], st: dict):
@@ -197,7 +246,7 @@ class PolicyUpdater:
                         coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
                         hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
                     hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                             hi - lo, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef,
+                             hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef,
                              1.0)
                 a_loss, c_loss, mt = loss_values(m, st["sums"], st["maxes"])
                 out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": c_loss, "loc": st["loc"], "sigma": st["sigma"],
@@ -347,6 +396,9 @@ class PolicyUpdater:
 
     def _compile(self, batch):
         """Record the plan's segments into hipGraphs (adjacent segments without a reduction between them share one graph)."""
+        m = self.loss_module
+        for hd in (m.actor_network.hyper_data, m.critic_network._network1.hyper_data):   # one sync, before anything is captured:
+            hd.check_topology(*[batch[k] for k in m.in_features])                         # the cached topology fits this minibatch
         self._static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         st = self._st = {}
         plan = self._plan(self._static, st)
@@ -392,7 +444,10 @@ class PolicyUpdater:
             src = batch[k]
             if src is v:
                 continue
-            if src.dtype != v.dtype or src.shape != v.shape or not src.is_contiguous() or src.device != v.device:
+            if src.shape != v.shape:
+                raise ValueError(f"minibatch tensor '{k}' has shape {tuple(src.shape)}, the recorded step was captured for "
+                                 f"{tuple(v.shape)}: call PolicyUpdater.reset_graph() before changing the minibatch size")
+            if src.dtype != v.dtype or not src.is_contiguous() or src.device != v.device:
                 v.copy_(src)  # host-resident / strided / other dtype: the ordinary path
             else:
                 jobs.append((v.data_ptr(), src.data_ptr(), v.numel() * v.element_size()))
@@ -408,7 +463,7 @@ class PolicyUpdater:
         import ctypes
         keys = list(self.loss_module.in_features) + ["action", "loc", "var" if "var" in buf.data else "covariance_matrix",
                                                      "sample_log_prob", "state_value", "advantage", "value_target"]
-        if not self.use_graph or self._program is None or self.steps < 2:
+        if not self.use_graph or self._program is None or int(idx.numel()) != self._static[keys[0]].shape[0]:
             return self.step(buf.rows(idx, keys))
         jobs = []
         for k in keys:
@@ -421,22 +476,56 @@ class PolicyUpdater:
                  (ctypes.c_longlong * n)(*[j[2] for j in jobs]), n, idx, int(idx.numel()))
         return self.step(self._static)
 
+    def reset_graph(self):
+        """Drop the recorded step (next step re-records): needed when the minibatch size changes."""
+        self._program, self._static = None, None
+        self._eager_sizes = set()
+
+    def _check_calibrated(self):
+        """Data parallel: the first training forward of a fresh actor re-initialises the conv kernels from rank-local data
+        (conv.py:104-105).  Let it happen once, on every rank, BEFORE the first update, then adopt rank 0's result -- otherwise each
+        replica would rescale its own weights (views of ``flat``) and the replicas would diverge for good."""
+        actor = self.loss_module.actor_network
+        gnn = getattr(actor, "gnn", None)
+        if self.group is None or gnn is None or not hasattr(gnn, "calibrated") or getattr(self, "_calib_synced", False):
+            return None
+        self._calib_synced = True
+        return not gnn.calibrated   # True: this rank's actor still has to calibrate -> the caller syncs afterwards
+
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         self.loss_module._global_steps = self.steps
+        need_sync = self._check_calibrated()
+        if need_sync:
+            actor, m = self.loss_module.actor_network, self.loss_module
+            with torch.no_grad():
+                actor.forward_diag(*[batch[k] for k in m.in_features], train=True)   # calibrates on this rank's shard
+            self.sync_replicas()                                                       # ... and rank 0's factors win everywhere
         self.steps += 1
-        if not self.use_graph or self.steps == 1:   # the first step always runs eagerly: it builds the cached topology of
-            st = {}                                 # this batch size and the kernels' one-time attributes (not capturable)
+        B = next(v.shape[0] for v in batch.values() if torch.is_tensor(v))
+        seen = getattr(self, "_eager_sizes", None)
+        if seen is None:
+            seen = self._eager_sizes = set()
+        if not self.use_graph or B not in seen:     # the first step of a minibatch size always runs eagerly: it builds the
+            seen.add(B)                             # cached topology of that size and the kernels' one-time attributes
+            st = {}
             self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m") for e in self._plan(batch, st)])
             return st["out"]
+        if self._program is not None and any(self._static[k].shape != batch[k].shape for k in self._static if k in batch):
+            self.reset_graph()                      # another minibatch size: record again for it
+            self._eager_sizes.add(B)
         if self._program is None:
             try:
                 self._compile(batch)
-            except Exception as e:  # keep training eagerly rather than die on a capture restriction of the runtime at hand
-                import sys
-                print(f"[geometry_rl_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches",
-                      file=sys.stderr)
+            except Exception as e:
                 torch.cuda.synchronize()
-                self.use_graph, self._program, self._static = False, None, None
+                if not self.allow_eager_fallback:
+                    raise RuntimeError(
+                        f"hipGraph capture of the policy-update step failed ({type(e).__name__}: {e}).  Pass use_graph=False, or "
+                        "allow_eager_fallback=True to continue with eager launches (several times slower for small minibatches).") from e
+                import sys
+                print(f"[geometry_rl_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches "
+                      "(allow_eager_fallback=True)", file=sys.stderr)
+                self.use_graph, self._program, self._static, self.mode = False, None, None, "eager (graph capture failed)"
                 self.steps -= 1
                 return self.step(batch)
         self._refresh_static(batch)
@@ -492,11 +581,24 @@ def _strip(sd, prefix):
     return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
 
 
-def load_reference_checkpoint(ckpt, actor, critic=None, strict=True):
+def load_reference_checkpoint(ckpt, actor, critic=None, strict=True, trust=False):
     """Load a reference ``model_checkpoint_*.pth`` (path or the loaded dict) into the HIP-backed actor / critic (play.py:194-205).
-    Parameter names are identical (PyG ModuleDict key mangling and the ``callibrated`` buffers included); returns ckpt["reward"]."""
+    Parameter names are identical (PyG ModuleDict key mangling and the ``callibrated`` buffers included); returns ckpt["reward"].
+
+    The file is read with ``weights_only=True`` (tensors and plain containers only).  The reference also pickles ``env.state_dict()``
+    into the same file (train.py:343-351), which may hold arbitrary objects: if the safe load fails, pass ``trust=True`` to fall back
+    to a full unpickle -- only for files you produced yourself, unpickling executes code.
+
+    Note on parity of a loaded policy: the KL covariance projection used when training continues here is validated against this
+    repository's KKT restatement (ITPAL's source is not in the reference checkout), see DESIGN.md section 2."""
     if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
-        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        try:
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=True)
+        except Exception as e:
+            if not trust:
+                raise RuntimeError(f"{ckpt!r} cannot be read with weights_only=True ({type(e).__name__}: {e}); pass trust=True to "
+                                   "unpickle it fully (executes code from the file)") from e
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
     actor.load_state_dict(_strip(ckpt["actor"], ACTOR_PREFIX), strict=strict)
     if critic is not None and "critic" in ckpt:
         critic.load_state_dict(_strip(ckpt["critic"], CRITIC_PREFIX), strict=strict)

@@ -6,9 +6,9 @@
 // destination-sorted edge order:
 //   forward : a wave owns TD = 2 consecutive destination nodes, sums their messages in registers and stores the finished rows
 //             with plain stores (no atomics, no workgroup barrier in the loop);
-//   backward: recomputes the chain, accumulates the five weight gradients in registers for the whole launch, stores each
-//             edge's d x_src row once ([E,16,64] scratch) and sums them per source node in a second streaming pass
-//             (store pass + per-destination sum pass, cdna_hip_programming.md "Scatter / gather"): no atomics anywhere.
+//   backward: two launches, each recomputing the chain (see "backward" below): the x kernel walks the edges in SOURCE-sorted order
+//             and sums d x_src per source node in registers exactly like the forward sums per destination node; the w kernel
+//             accumulates the five weight gradients in registers for the whole launch.  No per-edge scratch, no atomics.
 // The next pass's indices / positions and this pass's x_src rows are requested before the MFMA chain starts, so the gather
 // latency hides behind it.
 #include "grl_common.h"
@@ -578,12 +578,7 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int n_tiles = (n_dst + TD - 1) / TD;
   const size_t smem = sizeof(ChainW), smem_split = smem + sizeof(float4) * FWD_WAVES * 8 * 64;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split);
-    attr = true;
-  }
+  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split));
   if (n_tiles <= GRL_FWD_SPLIT_TILES) {   // fewer tiles than SIMD groups: spread each tile's passes over a workgroup
     hipLaunchKernelGGL(edge_conv_fwd_kernel<true>, dim3(n_tiles), dim3(64 * FWD_WAVES), smem_split, stream, p, x1);
   } else {
@@ -616,12 +611,7 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
   const size_t smem_x = sizeof(ChainW);
   size_t smem_w = smem_x + sizeof(BwdW);
   if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x);
-    hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w);
-    attr = true;
-  }
+  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
   grl_prof_begin("edge_conv_bwd_x_kernel", stream);
   {
     const int n_tiles_s = (n_src + TD - 1) / TD;

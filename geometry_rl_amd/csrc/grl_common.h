@@ -173,6 +173,15 @@ GRL_DEVINL void stage_matrix(float* dst, const float* __restrict__ src, int rows
 void grl_prof_begin(const char* name, hipStream_t stream);
 void grl_prof_end(hipStream_t stream);
 
+// One-time, thread-safe initialisation of per-process kernel attributes (max dynamic LDS): replaces the former `static bool`
+// latches.  One process drives one device, so "once per process" is "once per device".
+#include <mutex>
+#define GRL_ONCE(...)                               \
+  do {                                              \
+    static std::once_flag grl_once_flag_;           \
+    std::call_once(grl_once_flag_, [&] { __VA_ARGS__; }); \
+  } while (0)
+
 #define GRL_CHECK_LAUNCH()                       \
   do {                                           \
     hipError_t e_ = hipGetLastError();           \

@@ -178,6 +178,7 @@ constexpr int AMAX = 12;
 //                     6 mean_constraint 7 cov_constraint 8 entropy(p) 9 entropy_diff 10 count 11 kl(p || proj_p)
 // (6, 7: the projection's own trust-region measure of (p, proj_p); equal to the KL parts for the KL projection)
 // maxes layout (fp32 bits, values >= 0): 0 mean_constraint_max 1 cov_constraint_max
+constexpr int TRPL_SLOT = 14;   // per-workgroup record: the 12 sums + the 2 maxes
 struct TrplCfg {
   double mean_bound, cov_bound, tr_coeff, ent_coef, critic_coef, clip_value, inv_batch, adv_count;
   int A;
@@ -202,9 +203,12 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
                                                   const float* __restrict__ old_value, const float* __restrict__ value_target,
                                                   float* __restrict__ dmean, float* __restrict__ dsigma, float* __restrict__ dvalue,
                                                   float* __restrict__ proj_mean_out, float* __restrict__ proj_var_out,
-                                                  const double* __restrict__ adv_stats, double* __restrict__ sums,
-                                                  unsigned int* __restrict__ maxes, int B) {
+                                                  const double* __restrict__ adv_stats, double* __restrict__ slots,
+                                                  const float* __restrict__ tgt_mean, const float* __restrict__ tgt_S, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // external target (boundary methods get_trust_region_loss / compute_metrics, base_projection_layer.py:292-384): the projection is
+  // skipped, (tgt_mean, tgt_S) stands for the DETACHED proj_p / q and only the regression term's direct gradient is produced
+  const bool ext = tgt_mean != nullptr;
   const int A = AT > 0 ? AT : cfg.A;   // compile-time action width: the per-dimension loops unroll, arrays stay in registers
   double acc[11];
   for (int i = 0; i < 11; ++i) acc[i] = 0.0;
@@ -295,6 +299,13 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
         else { pS[i] = c_act ? (S[i] + eta * So[i]) / den : S[i]; v[i] = pS[i] * pS[i]; }
       }
     }
+    if (ext) {
+      _Pragma("unroll") for (int i = 0; i < A; ++i) {
+        pm[i] = tgt_mean[(size_t)b * A + i];
+        pS[i] = tgt_S[(size_t)b * A + i];
+        v[i] = pS[i] * pS[i];
+      }
+    }
     // ---- log-prob under the projected distribution (covariance = pS), importance weight, objective
     const double LOG2PI = 1.8378770664093454836;
     double q = 0.0, sl = 0.0;
@@ -353,14 +364,16 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
       g_pS[i] = w_obj * 0.5 * (d * d / (pS[i] * pS[i]) - 1.0 / pS[i]) - cfg.ent_coef * cfg.inv_batch * 0.5 / pS[i];
     }
     const double ctr = cfg.tr_coeff * cfg.inv_batch;
-    if (PROJ == 1) {   // the Frobenius regression loss also reaches the parameters THROUGH the projection
+    if (ext) {   // detached target: nothing flows through the projection
+      _Pragma("unroll") for (int i = 0; i < A; ++i) { g_pm[i] = 0.0; g_pS[i] = 0.0; }
+    } else if (PROJ == 1) {   // the Frobenius regression loss also reaches the parameters THROUGH the projection
       _Pragma("unroll") for (int i = 0; i < A; ++i) {
         g_pm[i] -= ctr * 2.0 * (mu[i] - pm[i]) / (S[i] * S[i]);
         g_pS[i] -= ctr * 2.0 * (S[i] - pS[i]);
       }
     }
     double gmu[AMAX], gS[AMAX];
-    if (m_act) {
+    if (m_act && !ext) {
       double dot = 0.0;
       _Pragma("unroll") for (int i = 0; i < A; ++i) dot += g_pm[i] * (mo[i] - pm[i]) / D;
       const double k = dot / (2.0 * (omega + 1.0) * cfg.mean_bound) * (PROJ == 0 ? 1.0 : 2.0);   // d(mean part)/d maha = 1/2 | 1
@@ -368,7 +381,9 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     } else {
       _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i];
     }
-    if (PROJ == 0) {
+    if (ext) {
+      _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = 0.0;
+    } else if (PROJ == 0) {
       double gv[AMAX];
       _Pragma("unroll") for (int i = 0; i < A; ++i) gv[i] = g_pS[i] / (2.0 * pS[i]);
       if (c_act) {
@@ -432,7 +447,8 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
       dvalue[b] = (float)(g * cfg.critic_coef * cfg.inv_batch);
     }
   }
-  // block reduction (2 waves) -> fp64 atomics
+  // block reduction (2 waves) -> this workgroup's own slot (plain stores; trpl_fold_kernel adds the slots up in a fixed order:
+  // no atomics, the reported values are bitwise reproducible)
   __shared__ double red[2][11];
   __shared__ float redm[2][2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -449,14 +465,30 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
   }
   if (lane == 0) { redm[wv][0] = mmax; redm[wv][1] = cmax; }
   __syncthreads();
-  if (threadIdx.x < 10) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x]);
-  if (threadIdx.x == 13) atomicAdd(sums + 11, red[0][10] + red[1][10]);
+  double* slot = slots + (size_t)blockIdx.x * TRPL_SLOT;
+  if (threadIdx.x < 10) slot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];
+  if (threadIdx.x == 13) slot[11] = red[0][10] + red[1][10];
   if (threadIdx.x == 10) {
     const int n_here = min(B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x);
-    atomicAdd(sums + 10, (double)(n_here > 0 ? n_here : 0));
+    slot[10] = (double)(n_here > 0 ? n_here : 0);
   }
-  if (threadIdx.x == 11) atomicMax(maxes, __float_as_uint(fmaxf(redm[0][0], redm[1][0])));
-  if (threadIdx.x == 12) atomicMax(maxes + 1, __float_as_uint(fmaxf(redm[0][1], redm[1][1])));
+  if (threadIdx.x == 11) slot[12] = (double)fmaxf(redm[0][0], redm[1][0]);
+  if (threadIdx.x == 12) slot[13] = (double)fmaxf(redm[0][1], redm[1][1]);
+}
+
+// slots [n_blocks][14] -> sums[12] (written, not accumulated) and maxes[2] (float bits), block order fixed
+__global__ __launch_bounds__(64) void trpl_fold_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
+                                                      unsigned int* __restrict__ maxes) {
+  const int i = threadIdx.x;
+  if (i < 12) {
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
+    sums[i] = s;
+  } else if (i < 14) {
+    double m = 0.0;
+    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
+    maxes[i - 12] = __float_as_uint((float)m);
+  }
 }
 
 // sum and sum of squares of the advantages (fp64) -> stats[0..1]
@@ -555,19 +587,21 @@ int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t 
 // 1/B_global, B_global, projection type (0 KL, 1 Frobenius, 2 Wasserstein)}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
 // grl_adv_stats, all-reduced when data parallel) or NULL for no normalisation.  sums: fp64[12], maxes: u32[2], zeroed by the caller.  value/old_value/value_target/dvalue may be
 // NULL together (actor-only call); proj_mean/proj_var may be NULL.
-int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
-                     const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
-                     const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
-                     float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
-                     unsigned int* maxes, int batch, hipStream_t stream) {
-  if (action_dim > AMAX || action_dim < 1) return -2;
+int grl_trpl_slot_doubles(int batch) { return TRPL_SLOT * ((batch + 127) / 128 < 1 ? 1 : (batch + 127) / 128); }
+
+static int trpl_launch(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
+                       const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
+                       const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
+                       float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
+                       unsigned int* maxes, double* slots, const float* tgt_mean, const float* tgt_S, int batch, hipStream_t stream) {
+  if (action_dim > AMAX || action_dim < 1 || batch < 1 || !slots) return -2;
   TrplCfg c{cfg9[0], cfg9[1], cfg9[2], cfg9[3], cfg9[4], cfg9[5], cfg9[6], cfg9[7], action_dim};
   const int proj = (int)cfg9[8];
   if (proj < 0 || proj > 2) return -3;
 #define GRL_TRPL_LAUNCH(AT, PJ)                                                                                               \
   hipLaunchKernelGGL((trpl_kernel<AT, PJ>), dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean,  \
                      old_var, old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var,   \
-                     adv_stats, sums, maxes, batch)
+                     adv_stats, slots, tgt_mean, tgt_S, batch)
   if (proj == 0) {
     switch (action_dim) {   // the action widths of the reference tasks (G * n_vec * 3) get unrolled instances
       case 3: GRL_TRPL_LAUNCH(3, 0); break;
@@ -582,7 +616,32 @@ int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, cons
   }
 #undef GRL_TRPL_LAUNCH
   GRL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes);
+  GRL_CHECK_LAUNCH();
   return 0;
+}
+
+int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
+                     const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
+                     const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
+                     float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
+                     unsigned int* maxes, double* slots, int batch, hipStream_t stream) {
+  return trpl_launch(cfg9, action_dim, mean, sigma, action, old_mean, old_var, old_logp, advantage, value, old_value, value_target,
+                     dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, sums, maxes, slots, nullptr, nullptr, batch, stream);
+}
+
+// Boundary methods of the projection layer (base_projection_layer.py:292-327 get_trust_region_loss, :332-384 compute_metrics) for
+// an ARBITRARY detached target distribution (tgt_mean, tgt_S = the target's "std" diagonal as the layer sees it, i.e. the covariance
+// diagonal of the policy): the same kernel with its projection step skipped.  sums / maxes as grl_trpl_fwd_bwd (objective, entropy
+// and critic entries are meaningless here); dmean / dsigma = gradient of trust_region_coeff * mean(measure(p, target)).
+int grl_trpl_target_terms(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* tgt_mean,
+                          const float* tgt_S, float* dmean, float* dsigma, double* sums, unsigned int* maxes, double* slots,
+                          const float* zeros_b /* device float[batch] of zeros: advantage / old log-prob stand-ins */, int batch,
+                          hipStream_t stream) {
+  if (!tgt_mean || !tgt_S || !zeros_b) return -2;
+  // action := target mean, old distribution := target (finite arithmetic in the skipped projection), advantage := 0
+  return trpl_launch(cfg9, action_dim, mean, sigma, tgt_mean, tgt_mean, tgt_S, zeros_b, zeros_b, nullptr, nullptr, nullptr, dmean,
+                     dsigma, nullptr, nullptr, nullptr, nullptr, sums, maxes, slots, tgt_mean, tgt_S, batch, stream);
 }
 
 // Reported values from the (globally reduced) sums / maxes of the fused kernel (trpl.py:280-321), one tiny launch instead of a

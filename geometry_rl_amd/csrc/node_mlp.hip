@@ -504,11 +504,7 @@ int grl_node_mlp_bwd_blocks(int n_rows) { return blocks_for(n_rows, 32, 256); }
 int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream) {
   if (n_rows <= 0) return 0;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf));
-    attr = true;
-  }
+  GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
   hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
                      W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate);
   GRL_CHECK_LAUNCH();
@@ -520,11 +516,7 @@ int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const 
                      const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream) {
   (void)b4;
   if (n_rows <= 0) return 0;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem));
-    attr = true;
-  }
+  GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem)));
   hipLaunchKernelGGL(node_mlp_bwd_fused_kernel, dim3(grl_node_mlp_bwd_blocks(n_rows)), dim3(512), sizeof(MlpBwdSmem), stream, x2,
                      dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows);
   GRL_CHECK_LAUNCH();

@@ -532,12 +532,7 @@ int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, con
   w.n = n_conv;
   for (int i = 0; i < n_conv; ++i) { w.w[i] = wf[i]; f.p[i] = fk[i]; }
   const size_t smem = sizeof(float) * (64 * 65 * (1 + n_conv) + 2 * FB_RPB * 64);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)fiber_basis_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void*)fiber_basis_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    attr = true;
-  }
+  GRL_ONCE(hipFuncSetAttribute((const void*)fiber_basis_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); hipFuncSetAttribute((const void*)fiber_basis_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   hipLaunchKernelGGL(fiber_basis_fwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), smem, stream, poly, W1, b1, W2, b2, w, saved, f);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -27,10 +27,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // Same update with the step count read from device memory (bias corrections computed in-kernel), so that the launch can be
 // recorded once into a hipGraph and replayed: *step_dev is advanced by the caller before each replay.
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                      float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
-                                                      const int* __restrict__ step_dev, const float* __restrict__ scale_dev,
-                                                      float scale_host) {
+                                                      float* __restrict__ v, int n, const float* __restrict__ lr_dev, float b1,
+                                                      float b2, float eps, const int* __restrict__ step_dev,
+                                                      const float* __restrict__ scale_dev, float scale_host) {
   const float t = (float)step_dev[0];
+  const float lr = lr_dev[0];   // learning rate in device memory: an annealed rate (train.py:264-271) reaches a replayed graph
   const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
   const float scale = scale_host * (scale_dev ? scale_dev[0] : 1.f);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -311,6 +312,10 @@ void grl_prof_end(hipStream_t stream) {
 
 extern "C" {
 
+// ABI version of this library: major * 10000 + minor * 100 + patch.  Bumped whenever a declared signature changes
+// (include/grl_hip.h GRL_HIP_VERSION must agree: geometry_rl_amd/hip.py checks it at load time).
+int grl_version(void) { return 200; }
+
 // step = 1-based Adam step count.  scale_dev: optional device scalar multiplied into the gradient (clip coefficient).
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream) {
@@ -324,13 +329,15 @@ int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
   return 0;
 }
 
-// step_dev: device int[1] holding the (1-based) optimizer step of THIS update
-int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
-                      float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream) {
+// step_dev: device int[1] holding the (1-based) optimizer step of THIS update; lr_dev: device float[1], the learning rate of THIS
+// update (both are read by the kernel, so a recorded launch follows the host's schedule without being re-recorded)
+int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, const float* lr_dev, float beta1,
+                      float beta2, float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream) {
   if (n <= 0) return 0;
+  if (!lr_dev || !step_dev) return -2;
   const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                     eps, step_dev, scale_dev, scale_host);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1,
+                     beta2, eps, step_dev, scale_dev, scale_host);
   GRL_CHECK_LAUNCH();
   return 0;
 }

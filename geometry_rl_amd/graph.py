@@ -12,6 +12,7 @@ Differences from the reference that do not change any output:
 The topology is built once per batch size and reused for every later batch of that size, like the reference cache
 (rigid_tasks_data.py:254-255).
 """
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -35,6 +36,7 @@ class TaskSpec:
     angular_velocity: bool = True
     n_vec: int = 4
     in_features: List[str] = field(default_factory=list)
+    knn_to_actuators_k: int = -1   # > 0: task edges only from the k points nearest to each actuator (rigid_tasks_data.py:303-311)
 
     @property
     def actuator(self) -> str:
@@ -129,6 +131,35 @@ class HyperData:
         else:
             self.node_type_list = list(spec.node_types)
         self._cache = {}
+        self.check_topology_always = bool(int(os.environ.get("GRL_CHECK_TOPOLOGY", "0")))
+
+    # ---- cached topology: invariant and guards
+    def reset_cache(self):
+        """Forget the cached topologies.  INVARIANT of the cache (the reference's, rigid_tasks_data.py:254-255, keyed on the batch
+        size alone): every later batch of a cached size has the same per-row point counts -- and is expected to have the same
+        neighbourhoods -- as the batch the topology was built from, i.e. row i of every minibatch of that size belongs to the
+        same environment (``rollout.RolloutDriver`` samples env-aligned for exactly this reason).  Call this before feeding a batch
+        of a cached size that breaks the invariant (another env set, shuffled rows, another data-parallel shard offset)."""
+        self._cache.clear()
+
+    def check_topology(self, *args) -> None:
+        """Raise if the batch's per-row valid point counts differ from those the cached topology of this batch size was built
+        from (padded points are DROPPED from the actor graph according to the cached counts, so a mismatch silently mis-assigns
+        nodes).  One device->host sync: called by PolicyUpdater when it records the step, by every eager build when
+        GRL_CHECK_TOPOLOGY=1, never inside a replayed graph."""
+        obs = dict(zip(self.spec.in_features, args))
+        B = obs["scalars"].shape[0]
+        topo = self._cache.get(B)
+        if topo is None or self.spec.family != "rigid":
+            return
+        names, dims = self.spec.obs_names["infos"], self.spec.obs_dims["infos"]
+        off = sum(dims[:names.index("object_num_points")])
+        P = topo["n_per"][topo["main"]]
+        now = obs["infos"][:, off].reshape(B).long().clamp(max=P)
+        if not torch.equal(now, topo["n_valid"]):
+            bad = int((now != topo["n_valid"]).sum())
+            raise RuntimeError(f"HyperData: {bad} of {B} rows have a different object_num_points than the batch the cached topology "
+                               "of this batch size was built from; call reset_cache() (see its docstring for the invariant)")
 
     # ---- observation split (rigid_tasks_data.py:93-150)
     def _split(self, obs: Dict[str, torch.Tensor]):
@@ -202,8 +233,20 @@ class HyperData:
                                                  B * G, B * G)
         else:
             edges[et_agent] = None  # empty edge set: the conv is skipped (hetero_fiber_conv.py:48-49)
-        # task edges: every valid point -> every actuator of its sample
-        if need_edges and et_task[0] in self.node_type_list:
+        # task edges: every valid point -> every actuator of its sample; with knn_to_actuators_k > 0 only the k valid points
+        # nearest to each actuator (rigid_tasks_data.py:303-311: torch_geometric.nn.knn(points[:n], actuator[None], k).flip(0))
+        kta = getattr(spec, "knn_to_actuators_k", -1)
+        if need_edges and et_task[0] in self.node_type_list and kta > 0:
+            pm, pg = posv[main].float(), posv["grippers"].float()                      # [B,P,3], [B,G,3]
+            d2 = ((pm[:, None, :, :] - pg[:, :, None, :]) ** 2).sum(-1)                 # [B,G,P]
+            d2 = d2.masked_fill(~valid[:, None, :], float("inf"))
+            kk = min(kta, P)
+            order = torch.argsort(d2, dim=-1, stable=True)[..., :kk]                    # ties: lower index first
+            ok = torch.gather(d2, -1, order) < float("inf")                             # fewer than k valid points: no edge
+            src = (offset[:, None, None] + order)[ok]
+            dst = (torch.arange(B, device=dev)[:, None, None] * G + torch.arange(G, device=dev)[None, :, None]).expand_as(order)[ok]
+            edges[et_task] = ops.build_edge_set(torch.stack([src, dst]), n_main, B * G)
+        elif need_edges and et_task[0] in self.node_type_list:
             src = cid[:, None].expand(-1, G).reshape(-1)
             dst = (b_of[:, None] * G + torch.arange(G, device=dev)[None, :]).reshape(-1)
             edges[et_task] = ops.build_edge_set(torch.stack([src, dst]), n_main, B * G)
@@ -264,6 +307,8 @@ class HyperData:
             topo = self._cache.get(B)
             if topo is None:
                 topo = self._topology(self._split(obs), B, dev)
+            elif self.check_topology_always and not torch.cuda.is_current_stream_capturing():
+                self.check_topology(*[obs[k] for k in spec.in_features])
             main, gm = topo["main"], topo["gather_main"]
             full = topo["n_main"] == B * topo["n_per"][main]
             n_types, n_vec = len(spec.node_types), spec.n_vec
@@ -312,3 +357,74 @@ class HyperData:
             if dense:
                 return graph, x_dense
             return graph, (scalar_dict, vector_dict)
+
+
+# ---------------------------------------------------------------------------------------------------- reference constructors
+# The reference builds its data objects from the environment's observation manager (builders/utils_algo_graph.py:79-110):
+#   RigidTasksData(observation_dim=env.observation_manager.group_obs_term_dim, observation_names=..._term_names, full_graph_obs=...,
+#                  dist_as_pos=..., output_mask_key=..., training_noise=..., concat_input_vector=..., angular_velocity=..., knn_k=...,
+#                  knn_to_actuators_k=...)                                   (rigid_tasks_data.py:53-67; cloth :51-62; rope :51-63)
+# ``observation_dim``: {group: [shape tuple per term]} (only shape[0] is read, rigid_tasks_data.py:82), ``observation_names``:
+# {group: [term name per term]}.  The classes below take exactly those kwargs and derive the TaskSpec from them.
+_FAMILY = {
+    "rigid": dict(node_types=["object_geometry", "grippers", "target_geometry"], main="object_geometry", n_vec=4,
+                  edge_types=[("object_geometry", "internal", "object_geometry"), ("grippers", "agent", "grippers"),
+                              ("object_geometry", "task", "grippers")], in_features=list(_IN6)),
+    "cloth": dict(node_types=["particles", "grippers", "hole_boundary", "target_hook"], main="hole_boundary", n_vec=3,
+                  edge_types=[("hole_boundary", "internal", "hole_boundary"), ("grippers", "agent", "grippers"),
+                              ("hole_boundary", "task", "grippers")], in_features=_IN6[:5]),
+    "rope": dict(node_types=["links", "grippers", "target_geometry"], main="links", n_vec=3,
+                 edge_types=[("links", "internal", "links"), ("grippers", "agent", "grippers"), ("links", "task", "grippers")],
+                 in_features=_IN6[:5]),
+}
+
+
+def spec_from_observation(family: str, observation_dim: Dict, observation_names: Dict, *, knn_k: int = 3,
+                          knn_to_actuators_k: int = -1, angular_velocity: bool = True) -> TaskSpec:
+    """TaskSpec from the observation manager's ``group_obs_term_dim`` / ``group_obs_term_names`` dictionaries."""
+    f = _FAMILY[family]
+    first = lambda d: int(d[0]) if isinstance(d, (tuple, list, torch.Size)) else int(d)
+    dims = {g: [first(d) for d in ds] for g, ds in observation_dim.items() if not g.startswith("norm_")}
+    names = {g: list(ns) for g, ns in observation_names.items() if not g.startswith("norm_")}
+    for g in names:
+        if len(names[g]) != len(dims[g]):
+            raise ValueError(f"observation group '{g}': {len(names[g])} names for {len(dims[g])} terms")
+    pv = dict(zip(names["position_vectors"], dims["position_vectors"]))
+    if "grippers" not in pv or f["main"] not in pv:
+        raise ValueError(f"{family}: position_vectors must contain 'grippers' and '{f['main']}' (got {list(pv)})")
+    if family == "rigid" and "infos" not in names:
+        raise ValueError("rigid tasks need the 'infos' group (object_num_points, rigid_tasks_data.py:270)")
+    return TaskSpec(family, list(f["node_types"]), [tuple(e) for e in f["edge_types"]], ["internal", "task", "agent"], names, dims,
+                    pv["grippers"] // 3, knn_k=knn_k, angular_velocity=angular_velocity, n_vec=f["n_vec"],
+                    in_features=list(f["in_features"]), knn_to_actuators_k=knn_to_actuators_k)
+
+
+class _RefData(HyperData):
+    FAMILY = None
+
+    def __init__(self, observation_dim: Dict, observation_names: Dict, full_graph_obs: bool = False, dist_as_pos: bool = False,
+                 output_mask_key: Optional[str] = None, training_noise: bool = False, training_noise_std: float = 1e-2,
+                 concat_input_vector: bool = True, angular_velocity: bool = True, knn_k: int = 3, knn_to_actuators_k: int = -1,
+                 **kwargs):
+        spec = spec_from_observation(self.FAMILY, observation_dim, observation_names, knn_k=knn_k,
+                                     knn_to_actuators_k=knn_to_actuators_k, angular_velocity=angular_velocity)
+        super().__init__(spec, full_graph_obs=full_graph_obs, dist_as_pos=dist_as_pos, output_mask_key=output_mask_key,
+                         training_noise=training_noise, training_noise_std=training_noise_std,
+                         concat_input_vector=concat_input_vector, **kwargs)
+        self.observation_dim, self.observation_names = spec.obs_dims, spec.obs_names
+        self.angular_velocity, self.knn_k, self.knn_to_actuators_k = angular_velocity, knn_k, knn_to_actuators_k
+
+
+class RigidTasksData(_RefData):
+    """geometry_rl/modules/pyg_data/rigid_tasks_data.py:53-91."""
+    FAMILY = "rigid"
+
+
+class ClothTasksData(_RefData):
+    """geometry_rl/modules/pyg_data/cloth_tasks_data.py:51-86."""
+    FAMILY = "cloth"
+
+
+class RopeTasksData(_RefData):
+    """geometry_rl/modules/pyg_data/rope_tasks_data.py:51-89."""
+    FAMILY = "rope"

@@ -64,6 +64,20 @@ class FiberBundleConv(nn.Module):
                                       nn.Linear(out_channels * widening_factor, out_channels))
 
 
+def global_std(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Unbiased std over ALL elements of ``t`` (conv.py:151-157 uses ``tensor.std()``); with a process group the three moments are
+    summed over the ranks first, so every data-parallel replica computes the calibration factors of the WHOLE minibatch -- the same
+    numbers a single device would (no rank-local re-initialisation, no divergence between replicas)."""
+    if group is None:
+        return t.std()
+    import torch.distributed as dist
+    td = t.double()
+    m = torch.stack([td.sum(), (td * td).sum(), torch.tensor(float(t.numel()), dtype=torch.float64, device=t.device)])
+    dist.all_reduce(m, group=group)
+    n, mean = m[2], m[0] / m[2]
+    return ((m[1] - n * mean * mean) / (n - 1)).clamp_min(0).sqrt().float()
+
+
 def conv_key(edge_type: EdgeType) -> str:
     return "<" + "___".join(edge_type) + ">"
 
@@ -192,10 +206,11 @@ class HEPi(nn.Module):
         return mean.reshape(-1, 3), hidden
 
     @torch.no_grad()
-    def calibrate(self, graph_full: GraphBatch, u_dict) -> None:
+    def calibrate(self, graph_full: GraphBatch, u_dict, group=None) -> None:
         """First-training-call re-initialisation (conv.py:104-105,151-157) on the FULL (padded) graph: kernel.weight *=
         std(x_dst)/std(x_1), fiber_kernel.weight *= std(x_1)/std(x_2) with x_2 taken before the bias; the call that
-        calibrates continues with the un-rescaled activations, so later rounds see the same inputs as in the reference."""
+        calibrates continues with the un-rescaled activations, so later rounds see the same inputs as in the reference.
+        ``group``: data-parallel process group -- the statistics are then those of the whole (sharded) minibatch."""
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
         x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight) for t in graph_full.node_types}
@@ -209,7 +224,7 @@ class HEPi(nn.Module):
                 out, x1, fk = self._conv(conv, x[s], x[d], graph_full, et, grid3, fks, outs.get(d))
                 if not bool(conv.callibrated):
                     x2 = ops.FiberConv.apply(x1, fk, torch.zeros_like(conv.bias))
-                    s_in, s_1, s_2 = x[d].std(), x1.std(), x2.std()
+                    s_in, s_1, s_2 = global_std(x[d], group), global_std(x1, group), global_std(x2, group)
                     conv.kernel.weight.mul_(s_in / s_1)
                     conv.fiber_kernel.weight.mul_(s_1 / s_2)
                     conv.callibrated.fill_(True)

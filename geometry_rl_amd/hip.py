@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
+ABI_VERSION = 200   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
 
 
@@ -58,6 +59,10 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'). "
                 "geometry_rl_amd has no CPU or PyTorch fallback path.")
         _lib = ctypes.CDLL(LIB_PATH)
+        _lib.grl_version.restype = ctypes.c_int
+        if _lib.grl_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {_lib.grl_version()}, this package binds version {ABI_VERSION} "
+                               "(include/grl_hip.h GRL_HIP_VERSION): rebuild the extension (__graft_entry__.build())")
     return _lib
 
 

@@ -450,9 +450,10 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
     dev = loc.device
     cfg = (ctypes.c_double * 9)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
                                 clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch), float(proj_type))
-    if sums is None:   # otherwise: zeroed views of the caller's per-step workspace
-        sums = torch.zeros(12, device=dev, dtype=torch.float64)
-        maxes = torch.zeros(2, device=dev, dtype=torch.int32)
+    if sums is None:   # otherwise: views of the caller's per-step workspace (written in full by the launch)
+        sums = torch.empty(12, device=dev, dtype=torch.float64)
+        maxes = torch.empty(2, device=dev, dtype=torch.int32)
+    slots = torch.empty(hip.query("grl_trpl_slot_doubles", B), device=dev, dtype=torch.float64)   # per-workgroup sums
     dloc, dsigma = torch.empty_like(loc), torch.empty_like(sigma)
     dvalue = torch.empty(B, device=dev, dtype=torch.float32) if value is not None else None
     pm = torch.empty_like(loc) if want_projection else None
@@ -463,5 +464,25 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
              value.reshape(B).contiguous() if value is not None else None,
              batch["state_value"].reshape(B).contiguous() if value is not None else None,
              batch["value_target"].reshape(B).contiguous() if value is not None else None,
-             dloc, dsigma, dvalue, pm, pv, adv_stats, sums, maxes, B)
+             dloc, dsigma, dvalue, pm, pv, adv_stats, sums, maxes, slots, B)
     return sums, maxes, dloc, dsigma, dvalue, pm, pv
+
+
+def trpl_target_terms(loc, sigma, tgt_mean, tgt_S, *, mean_bound, cov_bound, trust_region_coeff, global_batch: int, proj_type: int = 0):
+    """Trust-region measure of (p, detached target) with its gradient -- the fused kernel with the projection skipped
+    (grl_trpl_target_terms).  ``sigma`` = sqrt of the policy's covariance diagonal, ``tgt_S`` = the target's covariance diagonal.
+    Returns (sums fp64[12], maxes u32[2], dloc, dsigma)."""
+    import ctypes
+    hip.check_f32(loc, sigma, tgt_mean, tgt_S)
+    B, A = loc.shape
+    dev = loc.device
+    cfg = (ctypes.c_double * 9)(mean_bound, cov_bound, trust_region_coeff, 0.0, 0.0, 0.0, 1.0 / global_batch, float(global_batch),
+                                float(proj_type))
+    sums = torch.empty(12, device=dev, dtype=torch.float64)
+    maxes = torch.empty(2, device=dev, dtype=torch.int32)
+    slots = torch.empty(hip.query("grl_trpl_slot_doubles", B), device=dev, dtype=torch.float64)
+    dloc, dsigma = torch.empty_like(loc), torch.empty_like(sigma)
+    zeros_b = torch.zeros(B, device=dev, dtype=torch.float32)
+    hip.call("grl_trpl_target_terms", cfg, A, loc.contiguous(), sigma.contiguous(), tgt_mean.contiguous(), tgt_S.contiguous(), dloc,
+             dsigma, sums, maxes, slots, zeros_b, B)
+    return sums, maxes, dloc, dsigma

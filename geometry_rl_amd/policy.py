@@ -51,6 +51,7 @@ class GNNGaussianPolicyDiag(nn.Module):
         self.hyper_data = hyper_data
         self.gnn = gnn
         self._calib_checked = False  # host-side latch: the per-conv `callibrated` buffers are inspected once, not every step
+        self.group = None            # torch.distributed group (data parallel): calibration statistics are summed over it
         self.to(next(gnn.parameters()).device)
 
     @property
@@ -67,7 +68,7 @@ class GNNGaussianPolicyDiag(nn.Module):
             full = HyperData(hd.spec, full_graph_obs=hd.full_graph_obs, dist_as_pos=hd.dist_as_pos,
                              output_mask_key=hd._output_mask_key, concat_input_vector=False, drop_padding=False)
             graph, u = full.build_data(*args, train=True)
-            gnn.calibrate(graph, u)
+            gnn.calibrate(graph, u, group=self.group)
 
     def load_state_dict(self, *a, **k):
         self._calib_checked = False

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .graph import GraphBatch
-from .hepi import basis_sequential, make_grid
+from .hepi import basis_sequential, global_std, make_grid
 
 
 class SeparableFiberBundleConv(nn.Module):
@@ -132,7 +132,7 @@ class PonitaGCN(nn.Module):
         return mean.reshape(-1, 3), hidden
 
     @torch.no_grad()
-    def calibrate(self, graph_full: GraphBatch, u_dict) -> None:
+    def calibrate(self, graph_full: GraphBatch, u_dict, group=None) -> None:
         """ponita.py:178-180,187-192: statistics over ALL nodes of the homogeneous graph (all node types, padding included)."""
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
@@ -146,7 +146,7 @@ class PonitaGCN(nn.Module):
             if not bool(layer.conv.callibrated):
                 x1 = {t: col[t][0] for t in col}
                 x2 = {t: ops.FiberConv.apply(col[t][0], col[t][1], torch.zeros_like(layer.conv.bias)) for t in col}
-                s_in, s_1, s_2 = cat(x).std(), cat(x1).std(), cat(x2).std()
+                s_in, s_1, s_2 = global_std(cat(x), group), global_std(cat(x1), group), global_std(cat(x2), group)
                 layer.conv.kernel.weight.mul_(s_in / s_1)
                 layer.conv.fiber_kernel.weight.mul_(s_1 / s_2)
                 layer.conv.callibrated.fill_(True)

@@ -7,10 +7,20 @@ The reference keeps the rollout in a CPU ``LazyTensorStorage`` and moves every m
 here the rollout stays resident in HBM (4096 x 128 rigid frames are 1.6 GB) and a minibatch is assembled by ONE gather launch
 (``grl_gather_rows_many``) straight into the static input buffers of the recorded update step.
 
-Minibatches are env-aligned: minibatch j takes, for every environment n, the frame (n, perm_n[j]) of a per-environment random
-permutation of the T time steps -- every frame is used exactly once per epoch (sampling without replacement, mini_batch_size =
-num_envs as in configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:44,138) and position n of every minibatch belongs to environment
-n, which is what the graph topology cached per batch size assumes (rigid_tasks_data.py:254-255)."""
+Sampling (``RolloutDriver(mini_batch_size=, sampling=)``), always without replacement, every frame exactly once per epoch:
+
+* ``"env_aligned"`` (default): per environment a random permutation of its T time steps; a minibatch of ``k * N`` frames
+  (``mini_batch_size`` must be a multiple of the number of environments N; k = 1 for rigid / rope whose configs set
+  mini_batch_size = num_envs, k = 2 for cloth: configs/cloth_hanging_multi_hepi_trpl_cfg.yaml:40,125) takes k permutation columns,
+  laid out column after column, so row i of EVERY minibatch belongs to environment i mod N.  That is what the graph topology
+  cached per batch size assumes (rigid_tasks_data.py:254-255: valid point counts and kNN edges are those of the first batch of
+  that size).  DEVIATION from the reference, which draws uniformly from the flattened N*T frames (SamplerWithoutReplacement,
+  train.py:128) and therefore pairs its cached placeholders with rows of other environments -- harmless only when all
+  environments share one topology.
+* ``"uniform"``: the reference's sampler -- a random permutation of the N*T frames cut into minibatches of ``mini_batch_size``
+  (last one dropped if short: the recorded step has one size).  Allowed for task families whose topology does not depend on the
+  row (cloth: fully connected hole boundary, fixed sizes); for rigid (ragged point counts) it raises unless
+  ``allow_stale_topology=True`` reproduces the reference quirk knowingly."""
 from typing import Dict, Iterator, Optional
 
 import torch
@@ -42,11 +52,19 @@ class RolloutBuffer:
 
 class RolloutDriver:
     def __init__(self, updater: "_agent.PolicyUpdater", spec, gamma: float = 0.99, lmbda: float = 0.95, ppo_epochs: int = 5,
-                 seed: int = 0):
+                 seed: int = 0, mini_batch_size: Optional[int] = None, sampling: str = "env_aligned",
+                 allow_stale_topology: bool = False):
         self.updater, self.spec = updater, spec
         self.gamma, self.lmbda, self.ppo_epochs = gamma, lmbda, ppo_epochs
         self.gen = None
         self.seed = seed
+        self.mini_batch_size = mini_batch_size   # None: one frame per environment (= num_envs)
+        if sampling not in ("env_aligned", "uniform"):
+            raise ValueError(sampling)
+        if sampling == "uniform" and getattr(spec, "family", None) == "rigid" and not allow_stale_topology:
+            raise ValueError("uniform sampling pairs the topology cached per batch size with rows of other environments; rigid "
+                             "tasks have ragged point counts (pass allow_stale_topology=True to reproduce the reference quirk)")
+        self.sampling = sampling
 
     # ---- train.py:134-140,249-251: critic over the T+1 frames of every environment, then the shifted GAE scan
     @torch.no_grad()
@@ -79,11 +97,26 @@ class RolloutDriver:
         perm = torch.argsort(torch.rand(N, T, device=device, generator=self.gen), dim=1)       # per-environment permutation of time
         return (torch.arange(N, device=device)[:, None] * T + perm).t().contiguous()
 
+    def epoch_minibatches(self, N: int, T: int, device):
+        """List of int64 index tensors into the flattened [N*T] rollout, one per minibatch of this epoch."""
+        mbs = self.mini_batch_size or N
+        if self.sampling == "uniform":
+            if self.gen is None:
+                self.gen = torch.Generator(device=device)
+                self.gen.manual_seed(self.seed)
+            perm = torch.randperm(N * T, device=device, generator=self.gen)
+            return [perm[i:i + mbs] for i in range(0, N * T - mbs + 1, mbs)]
+        if mbs % N:
+            raise ValueError(f"env-aligned sampling needs mini_batch_size ({mbs}) to be a multiple of the number of environments ({N})")
+        k = mbs // N
+        idx = self.epoch_indices(N, T, device)                    # [T, N]
+        return [idx[j:j + k].reshape(-1) for j in range(0, T - k + 1, k)]   # k columns, column after column
+
     def minibatches(self, buf: RolloutBuffer) -> Iterator[torch.Tensor]:
+        dev = next(iter(buf.data.values())).device
         for _ in range(self.ppo_epochs):
-            idx = self.epoch_indices(buf.N, buf.T, next(iter(buf.data.values())).device)
-            for j in range(buf.T):
-                yield idx[j]
+            for idx in self.epoch_minibatches(buf.N, buf.T, dev):
+                yield idx
 
     def run(self, buf: RolloutBuffer, next_last: Optional[Dict[str, torch.Tensor]] = None):
         """One rollout pass: [GAE] + ppo_epochs * T policy updates.  Returns the loss dict of the last update."""

@@ -5,12 +5,63 @@
 The reference moves (mean, covariance) to the CPU, calls ITPAL per sample and comes back (trpl.py:241-245).  Here the
 projection, log-ratio objective, trust-region regression, entropy bonus, clipped value loss, all metrics AND their
 analytic gradients come out of one launch of ``grl_trpl_fwd_bwd``; nothing leaves the device and there is no host sync."""
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
 
 from . import hip, ops
+
+try:   # torchrl / tensordict are optional: with them the loss module IS a torchrl LossModule and returns a TensorDict
+    from tensordict import TensorDict as _TensorDict
+except Exception:   # pragma: no cover - not installed in the build image
+    _TensorDict = None
+try:
+    from torchrl.objectives import LossModule as _LossBase
+except Exception:   # pragma: no cover
+    _LossBase = nn.Module
+
+
+class LossDict(dict):
+    """What ``TRPLLoss.forward`` returns when ``tensordict`` is not installed: a dict of scalar tensors with the slice of the
+    TensorDict protocol that examples/torchrl/train.py:279-316 uses on the loss output -- ``loss[key]``, ``loss.select(*keys)``,
+    ``.detach()``, ``.get(key[, default])``, ``.set(key, value)``, ``.apply(fn)``, ``.items()`` / ``.keys()`` -- so that loop
+    runs unchanged on either return type."""
+
+    batch_size = torch.Size([])
+
+    def select(self, *keys, strict: bool = True):
+        missing = [k for k in keys if k not in self]
+        if missing and strict:
+            raise KeyError(f"keys {missing} not found in the loss output (has {sorted(self)})")
+        return LossDict((k, self[k]) for k in keys if k in self)
+
+    def exclude(self, *keys):
+        return LossDict((k, v) for k, v in self.items() if k not in keys)
+
+    def detach(self):
+        return LossDict((k, v.detach() if torch.is_tensor(v) else v) for k, v in self.items())
+
+    def clone(self, recurse: bool = True):
+        return LossDict((k, v.clone() if (recurse and torch.is_tensor(v)) else v) for k, v in self.items())
+
+    def set(self, key, value):
+        self[key] = value
+        return self
+
+    def apply(self, fn, batch_size=None, **kw):
+        return LossDict((k, fn(v)) for k, v in self.items())
+
+    def to(self, *a, **k):
+        return LossDict((key, v.to(*a, **k) if torch.is_tensor(v) else v) for key, v in self.items())
+
+    def to_dict(self):
+        return dict(self)
+
+
+def _diag(t):
+    return t.diagonal(dim1=-2, dim2=-1) if t.dim() == 3 else t
 
 
 class KLProjectionLayer:
@@ -43,6 +94,42 @@ class KLProjectionLayer:
                                clip_value=0.0, global_batch=B, adv_stats=None, want_projection=True, proj_type=self.proj_code)
         pm, pv = out[5], out[6]
         return pm, (pv.diag_embed() if S.dim() == 3 else pv)
+
+    # ---- base_projection_layer.py:292-327.  p = (mean, S) live (S = what the policy returns as covariance: the layer's "std"),
+    #      proj_p = the projection's output, treated as a constant.  Value AND gradient come from the fused kernel with its projection
+    #      step skipped (grl_trpl_target_terms); autograd sees one node whose backward hands the kernel's gradients to p.
+    def _target_terms(self, p, target):
+        mean, S = p
+        Sd, tm, tS = _diag(S), target[0].detach(), _diag(target[1]).detach()
+        B = mean.shape[0]
+        sigma = Sd.detach().float().sqrt()
+        sums, maxes, dloc, dsigma = ops.trpl_target_terms(mean.detach().float(), sigma, tm.float().contiguous(), tS.float().contiguous(),
+                                                          mean_bound=self.mean_bound, cov_bound=self.cov_bound,
+                                                          trust_region_coeff=self.trust_region_coeff, global_batch=B,
+                                                          proj_type=self.proj_code)
+        return mean, Sd, sigma, sums, maxes, dloc, dsigma
+
+    def get_trust_region_loss(self, policy, p, proj_p):
+        mean, Sd, sigma, sums, maxes, dloc, dsigma = self._target_terms(p, proj_p)
+        value = (sums[1] / sums[10]).float()
+        if not (mean.requires_grad or Sd.requires_grad):
+            return value
+        dS = dsigma / (2.0 * sigma)   # the kernel differentiates with respect to sigma = sqrt(S)
+        return _InjectGrad.apply(value, 2, mean, Sd, dloc, dS)
+
+    def compute_metrics(self, policy, p, q, step=None, aggregate=True):
+        """base_projection_layer.py:332-384 (aggregate=True): means and maxima of the projection's own measure of (p, q), the KL, and the
+        entropies.  The *_max entries the loss module never reads (kl_max, constraint_max, entropy_max, entropy_diff_max) are not produced."""
+        if not aggregate:
+            raise NotImplementedError("per-sample metrics (aggregate=False) are not used on the policy-update path")
+        with torch.no_grad():
+            _, _, _, sums, maxes, _, _ = self._target_terms((p[0].detach(), p[1].detach()), q)
+            n = sums[10]
+            mx = maxes.view(torch.float32)
+            mc, cc = (sums[6] / n).float(), (sums[7] / n).float()
+            return OrderedDict(kl=(sums[11] / n).float(), constraint=mc + cc, mean_constraint=mc, cov_constraint=cc,
+                               entropy=(sums[8] / n).float(), entropy_diff=(sums[9] / n).float(), mean_constraint_max=mx[0],
+                               cov_constraint_max=mx[1])
 
 
 class FrobeniusProjectionLayer(KLProjectionLayer):
@@ -130,12 +217,34 @@ def _run_trpl(m, loc, sigma, value, batch):
     return actor, critic, metrics
 
 
-class TRPLLoss(nn.Module):
+_TD_KEYS = ("action", "loc", "covariance_matrix", "var", "sample_log_prob", "advantage", "value_target", "state_value")
+
+
+def _as_batch(td, in_features) -> Dict[str, torch.Tensor]:
+    """A plain dict of the tensors the loss reads, from a Mapping or any object with the TensorDict ``.get(key[, default])``."""
+    if isinstance(td, dict):
+        return dict(td)
+    out = {}
+    for k in tuple(in_features) + _TD_KEYS:
+        try:
+            v = td.get(k, None)
+        except TypeError:
+            v = td.get(k) if k in td.keys() else None
+        if v is not None:
+            out[k] = v
+    return out
+
+
+class TRPLLoss(_LossBase):
     """trpl.py:105-321.  ``actor_network`` is a GNNGaussianPolicyDiag (the reference digs the same module out of the
-    ProbabilisticActor, trpl.py:243); ``critic_network`` a GNNVFNet/BaseCritic.  ``forward(batch)`` takes a mapping with the
-    reference tensordict keys (observation groups, action, loc, covariance_matrix or var, sample_log_prob, advantage,
-    value_target, state_value) and returns the loss dict consumed by examples/torchrl/train.py:280-301:
-    loss_objective + loss_entropy + loss_trust_region carries the actor gradient, loss_critic the critic gradient."""
+    ProbabilisticActor, trpl.py:243: ``actor_network.get_submodule("0").module`` is tried first, so a ProbabilisticActor wrapping
+    the policy is accepted too); ``critic_network`` a GNNVFNet/BaseCritic (or a ValueOperator around one).
+    ``forward(tensordict)`` takes a TensorDict -- or any mapping / object with ``.get(key)`` -- holding the reference keys
+    (observation groups, action, loc, covariance_matrix or var, sample_log_prob, advantage, value_target, state_value) and returns
+    a TensorDict when ``tensordict`` is installed, else a :class:`LossDict` with the same access protocol, so
+    examples/torchrl/train.py:279-316 runs on it unchanged: ``loss.select(*loss_types).detach()``,
+    ``loss["loss_objective"] (+= loss_entropy, loss_trust_region)`` carries the actor gradient, ``loss["loss_critic"]`` the critic
+    gradient.  With torchrl importable the class is a ``torchrl.objectives.LossModule``."""
 
     def __init__(self, actor_network, critic_network, *, projection: KLProjectionLayer, clip_epsilon=0.2, entropy_bonus=True,
                  samples_mc_entropy=1, entropy_coef=0.01, critic_coef=1.0, trust_region_coef=1.0, loss_critic_type="l2",
@@ -143,7 +252,19 @@ class TRPLLoss(nn.Module):
         super().__init__()
         if loss_critic_type != "l2":
             raise NotImplementedError("loss_critic_type is l2 in configs/algorithm/objective/trpl.yaml:12")
+        def unwrap(m, attr):   # ProbabilisticActor(TensorDictModule(policy)) / ValueOperator(critic): the wrapped nn.Module
+            for path in ("0.module", "module.0.module", "module"):
+                try:
+                    inner = m.get_submodule(path)
+                except Exception:
+                    continue
+                if hasattr(inner, attr):
+                    return inner
+            return m
+        actor_network = unwrap(actor_network, "forward_diag")
+        critic_network = unwrap(critic_network, "_network1")
         self.actor_network, self.critic_network, self.projection = actor_network, critic_network, projection
+        self.trust_region_coef = trust_region_coef
         self.entropy_bonus, self.entropy_coef, self.critic_coef = entropy_bonus, float(entropy_coef), float(critic_coef)
         self.normalize_advantage, self.clip_value = normalize_advantage, clip_value
         self.in_features = in_features or actor_network.hyper_data.spec.in_features
@@ -157,8 +278,18 @@ class TRPLLoss(nn.Module):
         import torch.distributed as dist
         return dist.get_world_size(self.group)
 
-    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        b = dict(batch)
+    @property
+    def out_keys(self):   # trpl.py:155-170 (+ the TRPL entries forward() sets, :302-321)
+        keys = ["loss_objective", "loss_trust_region"]
+        if self.entropy_bonus:
+            keys += ["entropy", "loss_entropy"]
+        if self.critic_coef:
+            keys.append("loss_critic")
+        return keys + ["ESS", "kl", "constraint", "mean_constraint", "mean_constraint_max", "cov_constraint", "cov_constraint_max",
+                       "entropy_diff"]
+
+    def forward(self, tensordict):
+        b = _as_batch(tensordict, self.in_features)
         if "var" not in b:
             b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
         obs = [b[k] for k in self.in_features]
@@ -170,4 +301,9 @@ class TRPLLoss(nn.Module):
             "loss_critic": critic, "loc": loc, "sigma": sigma, "state_value": value,
         }
         out.update({k: v for k, v in mt.items() if k != "loss_objective_value"})
-        return out
+        if _TensorDict is not None:   # the reference's return type (trpl.py:302)
+            extra = {k: out.pop(k) for k in ("loc", "sigma", "state_value")}
+            td = _TensorDict(out, [])
+            td.__dict__["_grl_outputs"] = extra
+            return td
+        return LossDict(out)

@@ -5,7 +5,11 @@
  *   - every pointer is a DEVICE pointer borrowed for the duration of the call unless marked HOST; the caller allocates
  *     every output and workspace; fp32 row-major tensors; index arrays are int32;
  *   - launches are asynchronous on `stream`; return value 0 = enqueued, -2 = unsupported shape, <= -1000 = -(1000+hipError_t);
- *   - no global mutable state: thread-safe per stream;
+ *   - thread safety: launches on different streams may be issued from different host threads; the library keeps three pieces of
+ *     process-wide state, all initialised once under std::call_once or guarded explicitly: (1) the per-kernel
+ *     "max dynamic LDS" function attributes (set once per process), (2) the optional event-timing records of grl_prof_*
+ *     (measurement aid: NOT thread-safe, keep it off in multi-threaded hosts), (3) nothing else -- there is no cached device
+ *     memory, no allocator and no stream owned by the library;
  *   - "partial" buffers are per-workgroup weight-gradient rows [n_rows][partial_size]; sum them with grl_reduce_partials.
  * The reference has no native ABI for this path (it is Python on PyG / torch_scatter / ITPAL); each group below cites the
  * reference code it replaces (paths relative to the reference checkout).
@@ -15,6 +19,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
+#define GRL_HIP_VERSION 200
+int grl_version(void);
 
 /* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
  * x[n,o,:] = [scal[n,:] | vec[n,v,:] . grid[o,:]] W_enc^T ;  scal [N,S], vec [N,V,3], grid [16,3] (z = 0 for S1), W_enc [64,S+V] */
@@ -30,7 +38,8 @@ int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, 
  * backward: rowptr_s [n_src+1] / src_s [E] / dst_s [E] = the same edges in SOURCE-sorted CSR order (d x_src rows are summed
  *           in registers per source node, like the forward sums per destination node: no scratch, no atomics);
  *           dx_src [n_src,16,64] fully overwritten;
- *           partial [grl_edge_bwd_blocks(n_edges)*4][grl_edge_partial_size()] = [dW1 64x14 | db1 64 | dW2 64x64 | db2 64 | dWk 64x64] */
+ *           partial [grl_edge_bwd_blocks(n_edges)][grl_edge_partial_size()] = [dW1 64x14 | db1 64 | dW2 64x64 | db2 64 | dWk 64x64]
+ *           (one row per workgroup: its four waves are folded through LDS at the end of the launch) */
 int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
@@ -93,11 +102,21 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
  *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
 int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream);
+int grl_trpl_slot_doubles(int batch);   /* size (in doubles) of the per-workgroup slot workspace `slots` below */
 int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
                      const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
                      const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
                      float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
-                     unsigned int* maxes, int batch, hipStream_t stream);
+                     unsigned int* maxes, double* slots /* scratch, grl_trpl_slot_doubles(batch) doubles: per-workgroup sums, folded
+                     in a fixed order into sums / maxes (written, not accumulated; bitwise reproducible) */, int batch,
+                     hipStream_t stream);
+/* projection-layer boundary methods for an arbitrary DETACHED target (base_projection_layer.py:292-327 get_trust_region_loss,
+ * :332-384 compute_metrics): the same kernel with its projection step skipped.  tgt_S = the target's "std" diagonal as the layer
+ * sees it (= covariance diagonal of the policy).  sums[1] = trust_region_coeff * sum measure(p, target), sums[6..9,11] / maxes = the
+ * metrics; dmean / dsigma = gradient of sums[1] / B_global.  zeros_b: device float[batch] of zeros. */
+int grl_trpl_target_terms(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* tgt_mean,
+                          const float* tgt_S, float* dmean, float* dsigma, double* sums, unsigned int* maxes, double* slots,
+                          const float* zeros_b, int batch, hipStream_t stream);
 /* reported loss-dict values (trpl.py:280-321) from the globally reduced sums / maxes:
  * out14 = [actor loss, critic loss, loss_trust_region, loss_entropy, ESS, kl, mean_constraint, mean_constraint_max,
  *          cov_constraint, cov_constraint_max, entropy, entropy_diff, loss_objective, constraint] */
@@ -143,9 +162,10 @@ int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int*
                               const int* len, float* const* dst, hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
-/* the same update with the step count in device memory (int[1]): recordable into a hipGraph */
-int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
-                      float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream);
+/* the same update with the step count (int[1]) AND the learning rate (float[1]) in device memory: recordable into a hipGraph, and
+ * a learning-rate schedule (anneal_lr, train.py:264-271; configs/algorithm/optim/default.yaml:5) reaches the replayed launch */
+int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, const float* lr_dev, float beta1,
+                      float beta2, float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream);
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream);
 int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned char* terminated, const float* values,
                  float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream);

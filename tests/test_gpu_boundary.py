@@ -1,0 +1,214 @@
+"""The drop-in boundary: the objects a maintainer would hand to examples/torchrl/train.py.
+
+* ``test_reference_training_loop_protocol``: the call sequence of train.py:264-316 -- anneal the learning rate of two stock
+  ``torch.optim.Adam(eps=1e-5)``, ``loss = loss_module(batch)``, ``loss.select(*loss_types).detach()``, the in-place assembly of
+  the actor loss, two ``backward()`` calls, ``clip_grad_norm_``, two optimizer steps, ``zero_grad`` -- written out here on
+  ``TRPLLoss`` / ``RigidTasksData`` objects built from the reference's constructor kwargs, with the minibatch handed over as an
+  object that only offers ``.get(key)`` (the TensorDict protocol; a real TensorDict when ``tensordict`` is installed).  It has to land
+  on the parameters the fused ``PolicyUpdater`` produces (and through it on the oracle's: tests/test_gpu_step.py).
+* ``test_projection_layer_methods``: ``proj_p = projection(policy, p, q, step)``, ``get_trust_region_loss(policy, p, proj_p)`` (value
+  and gradient) and ``compute_metrics(policy, p, proj_p)`` (base_projection_layer.py:200-206,292-384, trpl.py:241-262) against the
+  oracle's restatement of the same reference lines.
+* ``test_knn_to_actuators_topology``: the ``knn_to_actuators_k > 0`` branch (rigid_tasks_data.py:303-311) against a brute-force CPU
+  construction of the edge set.
+"""
+import copy
+
+import pytest
+import torch
+
+from oracle import trpl as otr
+from geometry_rl_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _GetOnly:
+    """The slice of the TensorDict protocol the loss module may rely on: ``.get(key, default)`` and ``.keys()``."""
+
+    def __init__(self, d):
+        self._d = d
+
+    def get(self, key, default=None):
+        return self._d.get(key, default)
+
+    def keys(self):
+        return self._d.keys()
+
+
+def _build(seed=0):
+    from geometry_rl_amd import agent, graph
+    from geometry_rl_amd.hepi import HEPi, FiberBundleConv
+    from geometry_rl_amd.policy import BaseCritic, DeepSets, GNNGaussianPolicyDiag, GNNVFNet
+    from geometry_rl_amd.trpl import KLProjectionLayer, TRPLLoss
+    dev = torch.device(DEV)
+    ref = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+    # what env.observation_manager.group_obs_term_dim / group_obs_term_names hold (builders/utils_algo_graph.py:79-110)
+    observation_dim = {g: [(d,) for d in ds] for g, ds in ref.obs_dims.items()}
+    observation_names = {g: list(ns) for g, ns in ref.obs_names.items()}
+    a_data = graph.RigidTasksData(observation_dim, observation_names, full_graph_obs=False, dist_as_pos=True,
+                                  output_mask_key="grippers", training_noise=False, concat_input_vector=False,
+                                  angular_velocity=False, knn_k=3, knn_to_actuators_k=-1)
+    c_data = graph.RigidTasksData(observation_dim, observation_names, full_graph_obs=True, dist_as_pos=False, output_mask_key=None,
+                                  concat_input_vector=True, angular_velocity=False)
+    spec = a_data.spec
+    torch.manual_seed(seed)
+    codes = ((1, 0), (0, 1), (0, 1))
+    mp = [[FiberBundleConv(64, 64, 64, groups=64, separable=True, widening_factor=4) if codes[l][k] else None for k in range(2)]
+          for l in range(3)]
+    gnn = HEPi(input_dim_node=len(spec.node_types) + spec.n_vec, input_dim_edge=7, hidden_dim=64, latent_dim=64, output_dim=1,
+               output_dim_vec=1, node_type_mapping=spec.node_types, edge_type_mapping=spec.edge_types,
+               edge_level_mapping=spec.edge_levels, message_passing=mp, num_messages=2, device=dev, num_ori=16, ponita_dim=3)
+    actor = GNNGaussianPolicyDiag(gnn=gnn, hyper_data=a_data, action_dim=6, num_actuators=2, contextual_std=True, post_fc=False)
+    critic = BaseCritic(GNNVFNet(gnn=DeepSets(input_dim_node=len(spec.node_types) + 3 * spec.n_vec, device=dev), hyper_data=c_data))
+    proj = KLProjectionLayer(proj_type="kl", mean_bound=0.05, cov_bound=0.0025, trust_region_coeff=1.0, scale_prec=True,
+                             entropy_schedule=False, action_dim=6)
+    loss = TRPLLoss(actor, critic, projection=proj, entropy_coef=0.005, critic_coef=0.5, clip_value=0.2, loss_critic_type="l2",
+                    normalize_advantage=True)
+    return spec, actor, critic, proj, loss
+
+
+def test_reference_training_loop_protocol():
+    from geometry_rl_amd import agent
+    from geometry_rl_amd.trpl import LossDict
+    B, lr0, max_norm, total = 12, 3e-4, 0.5, 10
+    spec, actor, critic, proj, loss_module = _build()
+    batch = dict(syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=21))
+    batch.update(syn.make_ppo_fields(B, 6, seed=21))
+    batch["covariance_matrix"] = batch.pop("var").diag_embed()      # the collector stores the full matrix (utils_algo_graph.py:146-158)
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    with torch.no_grad():
+        actor(*[batch[k] for k in spec.in_features])                # first training call: calibration
+    start = copy.deepcopy({"actor": actor.state_dict(), "critic": critic.state_dict()})
+
+    # ---- (A) the reference loop, statement by statement (train.py:145-146, 264-316)
+    actor_optim = torch.optim.Adam(actor.parameters(), lr=lr0, eps=1e-5)
+    critic_optim = torch.optim.Adam(critic.parameters(), lr=lr0, eps=1e-5)
+    try:
+        from tensordict import TensorDict
+        td = TensorDict(batch, [B])
+    except Exception:
+        td = _GetOnly(batch)
+    kept = []
+    for n_upd in range(3):
+        alpha = 1 - (n_upd / total)
+        for group in actor_optim.param_groups:
+            group["lr"] = lr0 * alpha
+        for group in critic_optim.param_groups:
+            group["lr"] = lr0 * alpha
+        loss_module._global_steps = n_upd
+        loss = loss_module(td)
+        loss_types = ["loss_critic", "loss_objective", "loss_entropy", "loss_trust_region", "kl", "constraint", "mean_constraint",
+                      "mean_constraint_max", "cov_constraint", "cov_constraint_max", "entropy", "entropy_diff"]
+        kept.append(loss.select(*loss_types).detach())
+        critic_loss = loss["loss_critic"]
+        actor_loss = loss["loss_objective"]
+        actor_loss += loss["loss_entropy"]
+        actor_loss += loss["loss_trust_region"]
+        actor_loss.backward()
+        critic_loss.backward()
+        torch.nn.utils.clip_grad_norm_(actor.parameters(), max_norm)
+        torch.nn.utils.clip_grad_norm_(critic.parameters(), max_norm)
+        actor_optim.step()
+        critic_optim.step()
+        actor_optim.zero_grad()
+        critic_optim.zero_grad()
+    assert all(set(k.keys()) == set(loss_types) for k in kept)
+    assert not any(v.requires_grad for v in kept[-1].values())
+    got = {"actor": {k: v.clone() for k, v in actor.state_dict().items()}, "critic": {k: v.clone() for k, v in critic.state_dict().items()}}
+
+    # ---- (B) the fused driver from the same starting point
+    actor.load_state_dict(start["actor"])
+    critic.load_state_dict(start["critic"])
+    actor._calib_checked = True
+    upd = agent.PolicyUpdater(loss_module, lr=lr0, clip_grad_norm=True, max_grad_norm=max_norm, use_graph=True)
+    for n_upd in range(3):
+        upd.anneal_lr(lr0, n_upd, total)
+        out = upd.step(batch)
+    worst = 0.0
+    for net, mod in (("actor", actor), ("critic", critic)):
+        for k, v in mod.state_dict().items():
+            if v.dtype.is_floating_point:
+                worst = max(worst, (v - got[net][k]).abs().max().item())
+    print(f"reference loop protocol vs PolicyUpdater after 3 annealed, clipped updates: max |param diff| = {worst:.2e}")
+    assert worst <= 2e-6
+    for k in ("loss_critic", "loss_trust_region", "kl"):
+        assert abs(float(out[k]) - float(kept[-1][k])) <= 1e-5 * max(1.0, abs(float(out[k])))
+
+
+@pytest.mark.parametrize("kind", ["kl", "frob", "w2"])
+def test_projection_layer_methods(kind):
+    from geometry_rl_amd.trpl import KLProjectionLayer
+    from geometry_rl_amd.policy import GNNGaussianPolicyDiag
+    B, A = 257, 6
+    g = torch.Generator().manual_seed(5)
+    mean = torch.randn(B, A, generator=g)
+    std = torch.rand(B, A, generator=g) + 0.5                       # policy std; what the layer sees as "std" is std**2 (trpl.py:241)
+    q_mean = mean + 0.4 * torch.randn(B, A, generator=g)
+    q_S = (std * (1 + 0.3 * torch.randn(B, A, generator=g)).abs().clamp_min(0.2)) ** 2
+    layer = KLProjectionLayer(proj_type=kind, mean_bound=0.05, cov_bound=0.0025, trust_region_coeff=1.7, scale_prec=True)
+    # ---- oracle (CPU): projection, regression loss with gradient, metrics of (p, proj_p)
+    m_c = mean.clone().requires_grad_(True)
+    s_c = std.clone().requires_grad_(True)
+    p_c = (m_c, s_c ** 2)                                            # the oracle keeps the diagonals as vectors
+    q_c = (q_mean, q_S)
+    proj_fn = {"kl": otr.kl_projection, "frob": otr.frobenius_projection, "w2": otr.wasserstein_projection}[kind]
+    pm_c, pS_c = proj_fn(p_c, q_c, 0.05, 0.0025)
+    tgt = (pm_c.detach(), pS_c.detach())
+    value_fn = {"kl": otr.gaussian_kl, "frob": otr.frobenius_value, "w2": otr.wasserstein_value}[kind]
+    md, cd = value_fn(p_c, tgt)
+    if kind == "frob":   # frob_projection_layer.py:73-88 has its own regression measure; the target is a constant here
+        ref_loss = otr.frobenius_trust_region_loss(p_c, tgt, 1.7)
+    else:                # base_projection_layer.py:308-327
+        ref_loss = (md + cd).mean() * 1.7
+    ref_loss.backward()
+    kl_m, kl_c = otr.gaussian_kl(p_c, tgt)
+    ref_metrics = {"kl": (kl_m + kl_c).mean(), "mean_constraint": md.mean(), "cov_constraint": cd.mean(), "constraint": (md + cd).mean(),
+                   "mean_constraint_max": md.max(), "cov_constraint_max": cd.max(),
+                   "entropy": otr.entropy_std(p_c[1]).mean(), "entropy_diff": (otr.entropy_std(tgt[1]) - otr.entropy_std(p_c[1])).mean()}
+    # ---- HIP layer
+    m_g = mean.to(DEV).requires_grad_(True)
+    s_g = std.to(DEV).requires_grad_(True)
+    p_g = (m_g, (s_g ** 2).diag_embed())
+    q_g = (q_mean.to(DEV), q_S.to(DEV).diag_embed())
+    proj_p = layer(None, p_g, q_g, 0)
+    assert (proj_p[0].cpu() - pm_c.detach()).abs().max() <= 1e-5
+    assert proj_p[1].dim() == 3
+    assert (proj_p[1].diagonal(dim1=-2, dim2=-1).cpu() - pS_c.detach()).abs().max() <= 1e-5 * pS_c.abs().max()
+    tr = layer.get_trust_region_loss(None, p_g, proj_p)
+    tr.backward()
+    print(kind, "trust region loss", float(tr), float(ref_loss))
+    assert abs(float(tr) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
+    assert (m_g.grad.cpu() - m_c.grad).abs().max() <= 2e-5 * max(1e-3, m_c.grad.abs().max().item())
+    assert (s_g.grad.cpu() - s_c.grad).abs().max() <= 2e-5 * max(1e-3, s_c.grad.abs().max().item())
+    mt = layer.compute_metrics(None, p_g, proj_p, step=0)
+    for k, v in ref_metrics.items():
+        assert abs(float(mt[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), (k, float(mt[k]), float(v))
+
+
+def test_knn_to_actuators_topology():
+    from geometry_rl_amd import graph
+    B, G, K = 9, 2, 4
+    spec = graph.rigid_spec(G=G, angular_velocity=False, object_velocity=False)
+    spec.knn_to_actuators_k = K
+    hd = graph.HyperData(spec, full_graph_obs=False, dist_as_pos=True, output_mask_key="grippers", concat_input_vector=False)
+    obs = syn.make_rigid_obs(B, G=G, angular_velocity=False, object_velocity=False, seed=13)
+    obs["infos"][:, 0] = torch.tensor([1, 2, 3, 5, 8, 32, 4, 6, 20]).float()    # fewer valid points than K for some samples
+    g, _ = hd.build_data(*[obs[k].to(DEV) for k in spec.in_features])
+    es = g.edges[("object_geometry", "task", "grippers")]
+    got = set(zip(es.src_d.cpu().tolist(), es.dst_d.cpu().tolist()))
+    # brute force: per sample and actuator the K valid points closest to it (all of them if fewer than K)
+    pos = obs["position_vectors"]
+    grip = pos[:, :3 * G].reshape(B, G, 3)
+    pts = pos[:, 3 * G:3 * G + 96].reshape(B, 32, 3)
+    nv = obs["infos"][:, 0].long()
+    want, off = set(), 0
+    for b in range(B):
+        n = int(nv[b])
+        for k in range(G):
+            d = ((pts[b, :n] - grip[b, k]) ** 2).sum(-1)
+            for j in torch.argsort(d, stable=True)[:K].tolist():
+                want.add((off + j, b * G + k))
+        off += n
+    assert got == want, (len(got), len(want))

@@ -110,3 +110,83 @@ def test_two_ranks_with_graph_segments_match_single_rank(n_steps):
         for k, v in ref_losses.items():
             assert abs(losses[k] - v) <= (1e-5 if n_steps == 2 else 1e-4) * max(1.0, abs(v)), (r, k, losses[k], v)
         assert (flat - ref_flat).abs().max().item() <= (4e-6 if n_steps == 2 else 3e-5)
+
+
+def _worker_natural(rank, world, port, B, ret, backend="gloo", anneal=False):
+    """The natural construction order -- build_agent -> PolicyUpdater -> step(shard) -- with NO manual pre-calibration: the
+    data-dependent conv re-initialisation (conv.py:104-105) happens inside the first step, from statistics summed over the ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from geometry_rl_amd import agent, graph, synthetic as syn
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+    cfg = agent.AgentConfig()
+    torch.manual_seed(100 + rank)   # replicas are built from DIFFERENT seeds: rank 0's parameters must win
+    actor, critic, proj, loss = agent.build_agent(spec, cfg, device=dev, group=dist.group.WORLD)
+    batch = dict(syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=4))
+    batch.update(syn.make_ppo_fields(B, 6, seed=4))
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    shard = {k: v[lo:hi].contiguous().to(dev) for k, v in batch.items()}
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, group=dist.group.WORLD, use_graph=True)
+    for i in range(4):
+        if anneal:
+            upd.anneal_lr(cfg.lr, i, 8)
+        out = upd.step(shard)
+    ret[rank] = ({k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")},
+                 upd.flat.detach().cpu())
+    dist.destroy_process_group()
+
+
+def _single_natural(B, anneal=False):
+    from geometry_rl_amd import agent, graph, synthetic as syn
+    dev = torch.device("cuda:0")
+    spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+    cfg = agent.AgentConfig()
+    torch.manual_seed(100)
+    actor, critic, proj, loss = agent.build_agent(spec, cfg, device=dev)
+    batch = dict(syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=4))
+    batch.update(syn.make_ppo_fields(B, 6, seed=4))
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=False)
+    for i in range(4):
+        if anneal:
+            upd.anneal_lr(cfg.lr, i, 8)
+        out = upd.step(batch)
+    return ({k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")}, upd.flat.detach().cpu())
+
+
+@pytest.mark.parametrize("anneal", [False, True])
+def test_replicas_calibrate_together_and_follow_the_lr_schedule(anneal):
+    """No pre-calibration, replicas initialised from different seeds, the step replayed from hipGraph segments, and (anneal=True)
+    the learning rate changed before every step (train.py:264-271): two ranks must land on the single-rank eager parameters."""
+    B, world = 16, 2
+    ref_losses, ref_flat = _single_natural(B, anneal)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_natural, args=(world, _free_port(), B, ret, "gloo", anneal), nprocs=world, join=True)
+    for r in range(world):
+        losses, flat = ret[r]
+        for k, v in ref_losses.items():
+            assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (r, k, losses[k], v)
+        err = (flat - ref_flat).abs().max().item()
+        print(f"rank {r}: max |param - single-rank param| = {err:.3e}")
+        assert err <= 3e-5
+    assert torch.equal(ret[0][1], ret[1][1]), "replicas diverged"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (RCCL over xGMI)")
+def test_two_ranks_rccl():
+    """The same natural-order run with backend nccl (= RCCL), one rank per GPU -- only where two devices are visible."""
+    B, world = 16, 2
+    ref_losses, ref_flat = _single_natural(B)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_natural, args=(world, _free_port(), B, ret, "nccl"), nprocs=world, join=True)
+    for r in range(world):
+        losses, flat = ret[r]
+        for k, v in ref_losses.items():
+            assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (r, k, losses[k], v)
+        assert (flat - ref_flat).abs().max().item() <= 3e-5
+    assert torch.equal(ret[0][1], ret[1][1]), "replicas diverged"
