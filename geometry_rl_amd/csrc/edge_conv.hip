@@ -447,8 +447,8 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
             const TTile tk = transpose_split(dh_[2 * ct], dh_[2 * ct + 1], dl_[2 * ct], dl_[2 * ct + 1], sel0, sel1);
-            mma_tn_bf(tk, tg0, accK[ct][0]);
-            mma_tn_bf(tk, tg1, accK[ct][1]);
+            mma_tn_bf_acc(tk, tg0, accK[ct][0]);
+            mma_tn_bf_acc(tk, tg1, accK[ct][1]);
           }
         }
         GRL_SCHED_BARRIER();
@@ -474,8 +474,8 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const TTile tz = transpose_split(zh[2 * nt], zh[2 * nt + 1], zl[2 * nt], zl[2 * nt + 1], sel0, sel1, &db2[nt]);
-          mma_tn_bf(tz, tg0, accA[nt][0]);
-          mma_tn_bf(tz, tg1, accA[nt][1]);
+          mma_tn_bf_acc(tz, tg0, accA[nt][0]);
+          mma_tn_bf_acc(tz, tg1, accA[nt][1]);
         }
       }
       GRL_SCHED_BARRIER();
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const TTile ty = transpose_split(yh[2 * nt], yh[2 * nt + 1], yl[2 * nt], yl[2 * nt + 1], sel0, sel1, &db1[nt]);
-          mma_tn_bf(ty, tp, accB[nt]);
+          mma_tn_bf_acc(ty, tp, accB[nt]);
         }
       }
       GRL_SCHED_BARRIER();
@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
   //      the order is fixed and ONE partial row per workgroup leaves (a quarter of the slab the folding launch has to read)
   constexpr int NACC = 10 * 16 + 4;
   float* fold = smem_raw;
+  asm_acc_drain();   // the last in-place (asm) MFMAs of the weight-gradient accumulators have finished before they are read
   auto visit = [&](auto&& f) {
     int k = 0;
 #pragma unroll

@@ -315,22 +315,71 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
 // still queued MFMA has not read yet (the register allocator reuses dead operand registers; with one wave per SIMD the queue
 // never gets deep enough).  The cure is structural: load EVERY operand fragment of the group first, then issue the MFMAs, then
 // run an epilogue that reads the accumulator (it cannot start before the group has finished), and only then let the next loads go.
+// GRL_MFMA_PRIO (build switch, on by default): the wave raises its issue priority for the duration of an MFMA group.  Two waves
+// share a SIMD; with equal priority the partner's (older) VALU stream can delay the issue of this wave's dependent MFMAs, which
+// stretches the chain that everything behind it waits for; with the priority raised the MFMAs issue back to back and the
+// partner's VALU work fills the 32-cycle gaps between them (MI355X_MICROARCH.md "Two waves per SIMD", items 2 and 4).
+#ifndef GRL_MFMA_PRIO
+#define GRL_MFMA_PRIO 1
+#endif
+#if GRL_MFMA_PRIO
+#define GRL_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define GRL_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define GRL_PRIO_HI()
+#define GRL_PRIO_LO()
+#endif
+template <int K>
+struct WFrags { bf16x8 h[K / 16], l[K / 16]; };
+template <int K>
+GRL_DEVINL void load_wfrags(WFrags<K>& w, const unsigned short* whi, const unsigned short* wlo) {
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    w.h[s] = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
+    w.l[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
+  }
+}
+// a real VALU read of the accumulator: everything after it is ordered behind the completion of the MFMA group that produced acc
+GRL_DEVINL void acc_fence(const f32x16& acc, float& sink) {
+  sink += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, acc[0]), 0xE4, 0xF, 0xF, false));
+}
 template <int K, class Epi>
 GRL_DEVINL void mma_wx_bf_fenced(const unsigned short* whi, const unsigned short* wlo, const bf16x8 (&xh)[K / 16],
                                  const bf16x8 (&xl)[K / 16], f32x16 acc, Epi&& epilogue) {
-  bf16x8 wh[K / 16], wl[K / 16];
-#pragma unroll
-  for (int s = 0; s < K / 16; ++s) {
-    wh[s] = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
-    wl[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
-  }
+  WFrags<K> w;
+  load_wfrags<K>(w, whi, wlo);
   __builtin_amdgcn_sched_barrier(0);
+  GRL_PRIO_HI();
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
-    acc = mfma_bf(wh[s], xh[s], acc);
-    acc = mfma_bf(wl[s], xh[s], acc);
-    acc = mfma_bf(wh[s], xl[s], acc);
+    acc = mfma_bf(w.h[s], xh[s], acc);
+    acc = mfma_bf(w.l[s], xh[s], acc);
+    acc = mfma_bf(w.h[s], xl[s], acc);
   }
+  GRL_PRIO_LO();
+  epilogue(acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// Pipelined form of the fenced group: the weight fragments of THIS group were loaded by the previous call (``cur``); the fragments
+// of the NEXT group (``nhi`` / ``nlo``, K_NEXT deep) are requested right after a real read of the finished accumulator -- no MFMA
+// is in flight any more (the hazard the fence exists for) -- and land while the epilogue (activation, splits) runs, instead of
+// exposing their LDS latency in front of the next group.
+template <int K, int K_NEXT, class Epi>
+GRL_DEVINL void mma_wx_bf_piped(const WFrags<K>& cur, const bf16x8 (&xh)[K / 16], const bf16x8 (&xl)[K / 16], f32x16 acc,
+                                WFrags<K_NEXT>* next, const unsigned short* nhi, const unsigned short* nlo, float& sink,
+                                Epi&& epilogue) {
+  __builtin_amdgcn_sched_barrier(0);
+  GRL_PRIO_HI();
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    acc = mfma_bf(cur.h[s], xh[s], acc);
+    acc = mfma_bf(cur.l[s], xh[s], acc);
+    acc = mfma_bf(cur.h[s], xl[s], acc);
+  }
+  GRL_PRIO_LO();
+  acc_fence(acc, sink);
+  __builtin_amdgcn_sched_barrier(0);
+  if (next) load_wfrags<K_NEXT>(*next, nhi, nlo);
   epilogue(acc);
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -396,4 +445,29 @@ GRL_DEVINL TTile transpose_split(const bf16x8& ch0, const bf16x8& ch1, const bf1
 GRL_DEVINL void mma_tn_bf(const TTile& p, const TTile& q, f32x16& acc) {
   acc = mfma_bf(p.h0, q.h0, acc); acc = mfma_bf(p.l0, q.h0, acc); acc = mfma_bf(p.h0, q.l0, acc);
   acc = mfma_bf(p.h1, q.h1, acc); acc = mfma_bf(p.l1, q.h1, acc); acc = mfma_bf(p.h1, q.l1, acc);
+}
+// The same for accumulators that live for a whole launch (weight gradients).  hipcc (ROCm 7.2) splits the live ranges of such
+// loop-carried 16-register tuples and pays for it with AGPR-to-AGPR copies in front of the MFMA groups and at the loop header
+// (256 v_accvgpr_mov per pass of edge_conv_bwd_w: 13 % of its vector issue slots).  With the accumulator tied as a read-write AGPR
+// operand of an asm MFMA there is nothing to copy: it is updated in place.  GRL_ASM_ACC = 0 restores the builtin form.
+// The asm is opaque to the compiler's hazard recognizer: the s_nop covers a VALU-written operand, and whoever reads such an
+// accumulator with VALU code later must let the last MFMA drain first (asm_acc_drain()).
+#ifndef GRL_ASM_ACC
+#define GRL_ASM_ACC 1
+#endif
+GRL_DEVINL void mfma_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
+#if GRL_ASM_ACC
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+  c = mfma_bf(a, b, c);
+#endif
+}
+GRL_DEVINL void asm_acc_drain() {
+#if GRL_ASM_ACC
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // 32 wait states > the 18 an MFMA result needs before a VALU read
+#endif
+}
+GRL_DEVINL void mma_tn_bf_acc(const TTile& p, const TTile& q, f32x16& acc) {
+  mfma_acc(p.h0, q.h0, acc); mfma_acc(p.l0, q.h0, acc); mfma_acc(p.h0, q.l0, acc);
+  mfma_acc(p.h1, q.h1, acc); mfma_acc(p.l1, q.h1, acc); mfma_acc(p.h1, q.l1, acc);
 }
