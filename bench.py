@@ -54,6 +54,13 @@ def workload(name):
         cfg = agent.AgentConfig(dim=2, clip_grad_norm=True)
         make = lambda B, seed, off: syn.make_rope_obs(B, seed=seed)
         cfg_name = "rope_shaping_hepi_trpl"
+    elif name in ("rope_hepi_var", "rope_hepi_bf16"):
+        # BASELINE config 5: variable-length rope graphs (80- and 40-link ropes mixed in every minibatch); "_bf16": one bf16 MFMA per
+        # dense product in the actor (fp32 accumulation and storage), tolerance tests/test_gpu_bf16_rope.py
+        spec = graph.rope_spec(variable_length=True)
+        cfg = agent.AgentConfig(dim=2, clip_grad_norm=True, precision="bf16" if name.endswith("bf16") else "fp32")
+        make = lambda B, seed, off: syn.make_rope_obs(B, seed=seed, variable_length=True, env_offset=off)
+        cfg_name = "rope_shaping_hepi_trpl (variable-length ropes" + (", bf16 products)" if name.endswith("bf16") else ")")
     elif name == "rigid2_empn":
         spec = graph.rigid_spec(G=2)
         cfg = agent.AgentConfig(model="empn")  # configs/rigid_insertion_two_agents_multi_empn_trpl_cfg.yaml
@@ -276,6 +283,7 @@ def main():
             entry = hip.kernel_time_summary()
             inner = hip.kernel_prof_summary()   # the kernels inside grl_edge_conv_bwd / grl_node_mlp_bwd, one by one
             hip.kernel_prof_enable(False)
+            entry = {k.replace("_bf16", ""): v for k, v in entry.items()}
             rec = {ENTRY_TO_KERNEL.get(k, k): v for k, v in entry.items() if k != "grl_edge_conv_bwd"}
             rec.update(inner)
             per_step.append(rec)
@@ -287,7 +295,8 @@ def main():
         rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_x_kernel": "grl_edge_conv_bwd",
                    "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
                    "node_mlp_bwd_fused_kernel": "grl_node_mlp_bwd"}
-        rows_step = dict(hip.KERNEL_ROWS)      # rows handed to each entry point during the last profiled step
+        rows_step = {k.replace("_bf16", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
+        pipe_peak = 2500.0 if cfg.precision == "bf16" else PEAK_BF16X3
         kernels = {}
         for k, fl in FLOPS_PER_ROW.items():
             if k not in summ:
@@ -297,7 +306,7 @@ def main():
             ach = flops_step / (ms_step * 1e-3) / 1e12
             kernels[k] = {"launches_per_step": launches, "avg_launch_ms": ms_step / launches, "ms_per_step": ms_step,
                           "rows_per_step": rows_step[rows_of[k]], "gflop_per_launch": flops_step / launches / 1e9, "achieved": ach,
-                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / PEAK_BF16X3}
+                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / pipe_peak}
         name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         d = kernels[name]
         # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the committed
@@ -339,12 +348,12 @@ def main():
                 + sum(2 * 16 * E for _, _, _, E in convs) + 2 * obs_bytes + B * (4 * A + A * A + 7) * 4 + 10 * 4 * n_params
             t_step = ms * 1e-3
             step_fig = {"alg_tflop": 3 * fwd / 1e12, "alg_gbyte": byt / 1e9,
-                        "bf16x3_frac": 3 * fwd / t_step / 1e12 / PEAK_BF16X3, "mfma_f32_frac": 3 * fwd / t_step / 1e12 / PEAK_F32_MFMA,
+                        "pipe_frac": 3 * fwd / t_step / 1e12 / pipe_peak, "mfma_f32_frac": 3 * fwd / t_step / 1e12 / PEAK_F32_MFMA,
                         "hbm_frac": byt / t_step / 8.0e12,
                         "note": "formulas of SURVEY.md 8(d) with the realised node / edge counts of this minibatch; time = the timed region"}
         except Exception as e:  # never let bookkeeping break the benchmark line
             step_fig = {"error": repr(e)}
-        roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": PEAK_BF16X3, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": pipe_peak, "unit": "TFLOP/s",
                 "frac": d["frac_of_bf16x3"], "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
@@ -363,7 +372,8 @@ def main():
             "metric": "policy-update steps/sec, HEPi 4096 envs x 128 steps", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 storage/accumulate, bf16x3 products (three bf16 MFMAs per f32 product)", "data": "synthetic",
+            "dtype": ("f32 storage/accumulate, bf16 products (one bf16 MFMA per product)" if cfg.precision == "bf16" else
+                      "f32 storage/accumulate, bf16x3 products (three bf16 MFMAs per f32 product)"), "data": "synthetic",
             "mode": upd.mode_timed, "host_cores": os.cpu_count(),
             "config": {"workload": f"{cfg_name}, 4096 synthetic envs x 128 steps, minibatch {args.minibatch} frames "
                                    f"({B} per GPU), 640 updates per rollout", "global_minibatch": args.minibatch,

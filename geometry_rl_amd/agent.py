@@ -38,6 +38,7 @@ class AgentConfig:
     lr: float = 3e-4
     clip_grad_norm: bool = False
     max_grad_norm: float = 1.0
+    precision: str = "fp32"   # "bf16": one bf16 MFMA per dense product in the actor (BASELINE config 5), fp32 storage / accumulation
 
 
 def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
@@ -52,12 +53,12 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
                    output_dim=cfg.output_dim, output_dim_vec=cfg.output_dim_vec, node_type_mapping=spec.node_types,
                    edge_type_mapping=[tuple(e) for e in spec.edge_types], edge_level_mapping=spec.edge_levels,
                    message_passing=mp, num_messages=len(cfg.codes[0]), device=device, num_ori=cfg.num_ori,
-                   ponita_dim=cfg.dim, only_upper_hemisphere=cfg.only_upper_hemisphere)
+                   ponita_dim=cfg.dim, only_upper_hemisphere=cfg.only_upper_hemisphere, precision=cfg.precision)
     elif cfg.model == "empn":
         from .ponita_gcn import PonitaGCN
         gnn = PonitaGCN(input_dim_node=n_in, output_dim=cfg.output_dim, output_dim_vec=cfg.output_dim_vec,
                         num_layers=cfg.num_layers, hidden_dim=64, num_ori=cfg.num_ori, ponita_dim=cfg.dim,
-                        only_upper_hemisphere=cfg.only_upper_hemisphere, device=device)
+                        only_upper_hemisphere=cfg.only_upper_hemisphere, device=device, precision=cfg.precision)
     else:
         raise ValueError(cfg.model)
     a_data = HyperData(spec, full_graph_obs=False, dist_as_pos=True, output_mask_key=spec.actuator, concat_input_vector=False)

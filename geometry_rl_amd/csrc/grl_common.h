@@ -157,6 +157,15 @@ GRL_DEVINL float gelu_grad_f(float x) {
   return gp;
 }
 
+// streaming (non-temporal) 16-byte accesses: global_load/store_dwordx4 ... nt -- for data touched once per launch
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+GRL_DEVINL float4 load_nt4(const float* p) {
+  const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+GRL_DEVINL void store_nt4(float* p, const float4& v) {
+  __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(p));
+}
 GRL_DEVINL float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 GRL_DEVINL float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 GRL_DEVINL float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
@@ -197,6 +206,20 @@ void grl_prof_end(hipStream_t stream);
 // k = 16s + 8(j>>2) + 4h + (j&3): exactly fragments x[2s] (j<4) and x[2s+1] (j>=4) of the fp32 convention above.  Weight rows
 // are staged in LDS as bf16 with the two middle quads of every 16-block swapped, so a lane reads its 8 weights with one
 // ds_read_b128.
+// GRL_PREC (per translation unit): 0 = split-bf16 products (three MFMAs per product, fp32-accurate: the default library),
+// 1 = plain bf16 products (ONE MFMA per product, operands rounded to nearest bf16, fp32 accumulation) -- the reduced-precision
+// variant of BASELINE config 5 (rope_shaping_hepi_trpl, bf16): the same kernels compiled a second time with -DGRL_PREC=1 and the
+// entry points suffixed _bf16.  In that build the "lo" halves below are never formed and every lo product is dropped.
+#ifndef GRL_PREC
+#define GRL_PREC 0
+#endif
+#if GRL_PREC
+#define GRL_LO(...)
+#define GRL_ENTRY(name) name##_bf16
+#else
+#define GRL_LO(...) __VA_ARGS__
+#define GRL_ENTRY(name) name
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -215,11 +238,16 @@ GRL_DEVINL unsigned pack_rn(float a, float b) {  // round-to-nearest bf16 of a (
 // fragments x[2s], x[2s+1] (fp32) -> hi / lo bf16 operands of K-step s
 GRL_DEVINL void split_pair(const float4& f0, const float4& f1, bf16x8& hi, bf16x8& lo) {
   u32x4 h, l;
+#if GRL_PREC
+  h[0] = pack_rn(f0.x, f0.y); h[1] = pack_rn(f0.z, f0.w); h[2] = pack_rn(f1.x, f1.y); h[3] = pack_rn(f1.z, f1.w);
+  l[0] = l[1] = l[2] = l[3] = 0u;   // never used: every lo product is compiled out
+#else
   h[0] = pack_hi(f0.x, f0.y); h[1] = pack_hi(f0.z, f0.w); h[2] = pack_hi(f1.x, f1.y); h[3] = pack_hi(f1.z, f1.w);
   l[0] = pack_rn(f0.x - trunc_bf16(f0.x), f0.y - trunc_bf16(f0.y));
   l[1] = pack_rn(f0.z - trunc_bf16(f0.z), f0.w - trunc_bf16(f0.w));
   l[2] = pack_rn(f1.x - trunc_bf16(f1.x), f1.y - trunc_bf16(f1.y));
   l[3] = pack_rn(f1.z - trunc_bf16(f1.z), f1.w - trunc_bf16(f1.w));
+#endif
   hi = __builtin_bit_cast(bf16x8, h);
   lo = __builtin_bit_cast(bf16x8, l);
 }
@@ -238,11 +266,17 @@ GRL_DEVINL void split_frags(const float4 (&x)[K / 8], bf16x8 (&hi)[K / 16], bf16
 // L2 round trips (the former scalar loop -- one dependent load per element -- was a fixed 25-35 us at the head of every launch).
 GRL_DEVINL void put_split_quad(unsigned short* hi, unsigned short* lo, const float4& w) {
   uint2 h, l;
+#if GRL_PREC
+  h.x = pack_rn(w.x, w.y); h.y = pack_rn(w.z, w.w);
+  *reinterpret_cast<uint2*>(hi) = h;
+  (void)lo; (void)l;
+#else
   h.x = pack_hi(w.x, w.y); h.y = pack_hi(w.z, w.w);
   l.x = pack_rn(w.x - trunc_bf16(w.x), w.y - trunc_bf16(w.y));
   l.y = pack_rn(w.z - trunc_bf16(w.z), w.w - trunc_bf16(w.w));
   *reinterpret_cast<uint2*>(hi) = h;
   *reinterpret_cast<uint2*>(lo) = l;
+#endif
 }
 template <int ROWS, int K, int KSRC, int NT>
 GRL_DEVINL void stage_split(unsigned short* hi, unsigned short* lo, const float* __restrict__ src, int ld) {
@@ -302,10 +336,10 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
     const bf16x8 wh = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
-    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
+    GRL_LO(const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);)
     acc = mfma_bf(wh, xh[s], acc);
-    acc = mfma_bf(wl, xh[s], acc);
-    acc = mfma_bf(wh, xl[s], acc);
+    GRL_LO(acc = mfma_bf(wl, xh[s], acc);)
+    GRL_LO(acc = mfma_bf(wh, xl[s], acc);)
   }
 }
 
@@ -315,12 +349,12 @@ GRL_DEVINL void mma_wx_bf(const unsigned short* whi, const unsigned short* wlo, 
 // still queued MFMA has not read yet (the register allocator reuses dead operand registers; with one wave per SIMD the queue
 // never gets deep enough).  The cure is structural: load EVERY operand fragment of the group first, then issue the MFMAs, then
 // run an epilogue that reads the accumulator (it cannot start before the group has finished), and only then let the next loads go.
-// GRL_MFMA_PRIO (build switch, on by default): the wave raises its issue priority for the duration of an MFMA group.  Two waves
-// share a SIMD; with equal priority the partner's (older) VALU stream can delay the issue of this wave's dependent MFMAs, which
-// stretches the chain that everything behind it waits for; with the priority raised the MFMAs issue back to back and the
-// partner's VALU work fills the 32-cycle gaps between them (MI355X_MICROARCH.md "Two waves per SIMD", items 2 and 4).
+// GRL_MFMA_PRIO (build switch, off): the wave raises its issue priority for the duration of an MFMA group, so that a SIMD
+// partner's VALU stream cannot delay the issue of this wave's dependent MFMAs (MI355X_MICROARCH.md "Two waves per SIMD", items 2
+// and 4).  Measured round 2 (tools/run_variants.sh, one box, two alternating rounds): 237-245 steps/s against 239-240 without --
+// inside the box-internal noise for every kernel; left off.
 #ifndef GRL_MFMA_PRIO
-#define GRL_MFMA_PRIO 1
+#define GRL_MFMA_PRIO 0
 #endif
 #if GRL_MFMA_PRIO
 #define GRL_PRIO_HI() __builtin_amdgcn_s_setprio(1)
@@ -336,7 +370,7 @@ GRL_DEVINL void load_wfrags(WFrags<K>& w, const unsigned short* whi, const unsig
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
     w.h[s] = *reinterpret_cast<const bf16x8*>(whi + 16 * s);
-    w.l[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);
+    GRL_LO(w.l[s] = *reinterpret_cast<const bf16x8*>(wlo + 16 * s);)
   }
 }
 // a real VALU read of the accumulator: everything after it is ordered behind the completion of the MFMA group that produced acc
@@ -353,8 +387,8 @@ GRL_DEVINL void mma_wx_bf_fenced(const unsigned short* whi, const unsigned short
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
     acc = mfma_bf(w.h[s], xh[s], acc);
-    acc = mfma_bf(w.l[s], xh[s], acc);
-    acc = mfma_bf(w.h[s], xl[s], acc);
+    GRL_LO(acc = mfma_bf(w.l[s], xh[s], acc);)
+    GRL_LO(acc = mfma_bf(w.h[s], xl[s], acc);)
   }
   GRL_PRIO_LO();
   epilogue(acc);
@@ -373,8 +407,8 @@ GRL_DEVINL void mma_wx_bf_piped(const WFrags<K>& cur, const bf16x8 (&xh)[K / 16]
 #pragma unroll
   for (int s = 0; s < K / 16; ++s) {
     acc = mfma_bf(cur.h[s], xh[s], acc);
-    acc = mfma_bf(cur.l[s], xh[s], acc);
-    acc = mfma_bf(cur.h[s], xl[s], acc);
+    GRL_LO(acc = mfma_bf(cur.l[s], xh[s], acc);)
+    GRL_LO(acc = mfma_bf(cur.h[s], xl[s], acc);)
   }
   GRL_PRIO_LO();
   acc_fence(acc, sink);
@@ -430,7 +464,18 @@ struct TTile { bf16x8 h0, h1, l0, l1; };
 GRL_DEVINL TTile transpose_split(const bf16x8& ch0, const bf16x8& ch1, const bf16x8& cl0, const bf16x8& cl1, const bf16x8& sel0,
                                  const bf16x8& sel1, float* colsum = nullptr) {
   TTile t;
-  const f32x16 th = transpose32(ch0, ch1, sel0, sel1), tl = transpose32(cl0, cl1, sel0, sel1);
+  const f32x16 th = transpose32(ch0, ch1, sel0, sel1);
+#if GRL_PREC
+  if (colsum) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sacc += th[q];
+    *colsum += sacc;
+  }
+  acc_to_bf(th, t.h0, t.h1);
+  t.l0 = t.h0; t.l1 = t.h1;   // placeholders, never used
+#else
+  const f32x16 tl = transpose32(cl0, cl1, sel0, sel1);
   if (colsum) {  // sum over this lane's 16 rows of (hi + lo) = the column sum restricted to them; the other 16 rows: lane ^ 32
     float sacc = 0.f;
 #pragma unroll
@@ -439,21 +484,24 @@ GRL_DEVINL TTile transpose_split(const bf16x8& ch0, const bf16x8& ch1, const bf1
   }
   acc_to_bf(th, t.h0, t.h1);
   acc_to_bf(tl, t.l0, t.l1);
+#endif
   return t;
 }
 // acc[m][n] += sum over the 32 rows r of P[r][m] Q[r][n]  (both operands transposed-split; split-bf16, 6 MFMAs)
 GRL_DEVINL void mma_tn_bf(const TTile& p, const TTile& q, f32x16& acc) {
-  acc = mfma_bf(p.h0, q.h0, acc); acc = mfma_bf(p.l0, q.h0, acc); acc = mfma_bf(p.h0, q.l0, acc);
-  acc = mfma_bf(p.h1, q.h1, acc); acc = mfma_bf(p.l1, q.h1, acc); acc = mfma_bf(p.h1, q.l1, acc);
+  acc = mfma_bf(p.h0, q.h0, acc); GRL_LO(acc = mfma_bf(p.l0, q.h0, acc); acc = mfma_bf(p.h0, q.l0, acc);)
+  acc = mfma_bf(p.h1, q.h1, acc); GRL_LO(acc = mfma_bf(p.l1, q.h1, acc); acc = mfma_bf(p.h1, q.l1, acc);)
 }
 // The same for accumulators that live for a whole launch (weight gradients).  hipcc (ROCm 7.2) splits the live ranges of such
 // loop-carried 16-register tuples and pays for it with AGPR-to-AGPR copies in front of the MFMA groups and at the loop header
 // (256 v_accvgpr_mov per pass of edge_conv_bwd_w: 13 % of its vector issue slots).  With the accumulator tied as a read-write AGPR
-// operand of an asm MFMA there is nothing to copy: it is updated in place.  GRL_ASM_ACC = 0 restores the builtin form.
+// operand of an asm MFMA there is nothing to copy at the instruction: it is updated in place.  Measured round 2: the register
+// allocator then places the same number of copies elsewhere (288 instead of 256 v_accvgpr_mov per pass) and the launch time does
+// not move (1.20 vs 1.19 ms per step): GRL_ASM_ACC stays 0 (builtin form); the switch is kept for compiler upgrades.
 // The asm is opaque to the compiler's hazard recognizer: the s_nop covers a VALU-written operand, and whoever reads such an
 // accumulator with VALU code later must let the last MFMA drain first (asm_acc_drain()).
 #ifndef GRL_ASM_ACC
-#define GRL_ASM_ACC 1
+#define GRL_ASM_ACC 0
 #endif
 GRL_DEVINL void mfma_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
 #if GRL_ASM_ACC
@@ -468,6 +516,6 @@ GRL_DEVINL void asm_acc_drain() {
 #endif
 }
 GRL_DEVINL void mma_tn_bf_acc(const TTile& p, const TTile& q, f32x16& acc) {
-  mfma_acc(p.h0, q.h0, acc); mfma_acc(p.l0, q.h0, acc); mfma_acc(p.h0, q.l0, acc);
-  mfma_acc(p.h1, q.h1, acc); mfma_acc(p.l1, q.h1, acc); mfma_acc(p.h1, q.l1, acc);
+  mfma_acc(p.h0, q.h0, acc); GRL_LO(mfma_acc(p.l0, q.h0, acc); mfma_acc(p.h0, q.l0, acc);)
+  mfma_acc(p.h1, q.h1, acc); GRL_LO(mfma_acc(p.l1, q.h1, acc); mfma_acc(p.h1, q.l1, acc);)
 }

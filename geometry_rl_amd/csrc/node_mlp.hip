@@ -8,6 +8,9 @@
 
 namespace {
 
+#ifndef GRL_MLP_NT
+#define GRL_MLP_NT 1
+#endif
 constexpr int C = 64, O = 16, W = 256;
 constexpr float LN_EPS = 1e-5f;
 // split-bf16 weight images for the forward kernel (same bytes as the fp32 image)
@@ -233,8 +236,14 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     const int row = c * 32 + lrow;
     const bool ok = row < n_rows;
     const size_t g = (size_t)(ok ? row : 0) * C + 4 * cq;
+#if GRL_MLP_NT   // streamed once: keep these lines from displacing the workgroup's W3 fragment slab in L2 (profiles/r01_pmc_table_v12:
+                 // the launch fetched 2.9x its algorithmic bytes from the fabric)
+    px = load_nt4(x2 + g);
+    pd = load_nt4(dout + g);
+#else
     px = *reinterpret_cast<const float4*>(x2 + g);
     pd = *reinterpret_cast<const float4*>(dout + g);
+#endif
     if (!ok) pd = make_float4(0.f, 0.f, 0.f, 0.f);
   };
   int ch = blockIdx.x;
@@ -278,10 +287,12 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       const unsigned short* img = (tile < 2 ? (lo_part ? s.Al : s.Ah) : (lo_part ? s.Dl : s.Dh)) + r * LDF + 32 * (tile & 1) + 8 * h;
       const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(img), c1 = *reinterpret_cast<const bf16x8*>(img + 16);
       __builtin_amdgcn_sched_barrier(0);
-      bf16x8 t0, t1;
-      acc_to_bf(transpose32(c0, c1, sel0, sel1), t0, t1);   // reads its accumulator (packs): fenced by construction
-      s.TT[tile][lo_part ? 2 : 0][lane] = __builtin_bit_cast(u32x4, t0);
-      s.TT[tile][lo_part ? 3 : 1][lane] = __builtin_bit_cast(u32x4, t1);
+      if (!(GRL_PREC && lo_part)) {   // plain-bf16 build: there are no lo parts (waves 4-7 idle here)
+        bf16x8 t0, t1;
+        acc_to_bf(transpose32(c0, c1, sel0, sel1), t0, t1);   // reads its accumulator (packs): fenced by construction
+        s.TT[tile][lo_part ? 2 : 0][lane] = __builtin_bit_cast(u32x4, t0);
+        s.TT[tile][lo_part ? 3 : 1][lane] = __builtin_bit_cast(u32x4, t1);
+      }
     }
     PH(3);
     // (no barrier yet: z, dH and the activation below only read the fragment images; the transposed tiles are first needed by dW3)
@@ -302,12 +313,14 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
         al[u] = *reinterpret_cast<const bf16x8*>(s.Al + r * LDF + 16 * sidx + 8 * h);
       }
       __builtin_amdgcn_sched_barrier(0);
+      GRL_PRIO_HI();
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         z = mfma_bf(ah[u], w3h[u], z);
-        z = mfma_bf(al[u], w3h[u], z);
-        z = mfma_bf(ah[u], w3l[u], z);
+        GRL_LO(z = mfma_bf(al[u], w3h[u], z);)
+        GRL_LO(z = mfma_bf(ah[u], w3l[u], z);)
       }
+      GRL_PRIO_LO();
       mfma_fence(z, sink);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -323,12 +336,14 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
         w4l[u] = __builtin_bit_cast(bf16x8, s.W4F[wave][sidx][1][lane]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      GRL_PRIO_HI();
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         dh = mfma_bf(dyh[u], w4h[u], dh);
-        dh = mfma_bf(dyl[u], w4h[u], dh);
-        dh = mfma_bf(dyh[u], w4l[u], dh);
+        GRL_LO(dh = mfma_bf(dyl[u], w4h[u], dh);)
+        GRL_LO(dh = mfma_bf(dyh[u], w4l[u], dh);)
       }
+      GRL_PRIO_LO();
       if (half == 0) {
         mfma_fence(dh, sink);
         __builtin_amdgcn_sched_barrier(0);
@@ -358,8 +373,10 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     {
       const TTile ta0 = load_ttile(s.TT[0], lane), ta1 = load_ttile(s.TT[1], lane);
       __builtin_amdgcn_sched_barrier(0);
+      GRL_PRIO_HI();
       mma_tn_bf(zT, ta0, aW3[0]);
       mma_tn_bf(zT, ta1, aW3[1]);
+      GRL_PRIO_LO();
       mfma_fence(aW3[1], sink);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -367,8 +384,10 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     {
       const TTile td0 = load_ttile(s.TT[2], lane), td1 = load_ttile(s.TT[3], lane);
       __builtin_amdgcn_sched_barrier(0);
+      GRL_PRIO_HI();
       mma_tn_bf(td0, hT, aW4[0]);
       mma_tn_bf(td1, hT, aW4[1]);
+      GRL_PRIO_LO();
       mfma_fence(aW4[1], sink);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     for (int q = 0; q < 4; ++q) w3d[q] = w3f[q * 64 + lane];
     bf16x8 zrh0, zrh1, zrl0, zrl1;
     acc_to_bf(transpose32(zT.h0, zT.h1, sel0, sel1), zrh0, zrh1);
-    acc_to_bf(transpose32(zT.l0, zT.l1, sel0, sel1), zrl0, zrl1);
+    GRL_LO(acc_to_bf(transpose32(zT.l0, zT.l1, sel0, sel1), zrl0, zrl1);)
     __builtin_amdgcn_sched_barrier(0);
     float4 daf[8];
 #pragma unroll
@@ -396,11 +415,11 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
         const bf16x8 cl1 = __builtin_bit_cast(bf16x8, w3d[(2 * ct + 1) * 2 + 1]);
         __builtin_amdgcn_sched_barrier(0);
         acc_to_bf(transpose32(ch0, ch1, sel0, sel1), th0, th1);
-        acc_to_bf(transpose32(cl0, cl1, sel0, sel1), tl0, tl1);
+        GRL_LO(acc_to_bf(transpose32(cl0, cl1, sel0, sel1), tl0, tl1);)
       }
       f32x16 da = zero16();
-      da = mfma_bf(th0, zrh0, da); da = mfma_bf(tl0, zrh0, da); da = mfma_bf(th0, zrl0, da);
-      da = mfma_bf(th1, zrh1, da); da = mfma_bf(tl1, zrh1, da); da = mfma_bf(th1, zrl1, da);
+      da = mfma_bf(th0, zrh0, da); GRL_LO(da = mfma_bf(tl0, zrh0, da); da = mfma_bf(th0, zrl0, da);)
+      da = mfma_bf(th1, zrh1, da); GRL_LO(da = mfma_bf(tl1, zrh1, da); da = mfma_bf(th1, zrl1, da);)
       acc_to_frag(da, daf[4 * ct], daf[4 * ct + 1], daf[4 * ct + 2], daf[4 * ct + 3]);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -443,7 +462,11 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       const float mgx = row16_sum((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w)) * (1.f / C);
       const float4 dx = make_float4(rstd * (g.x - mg - xh.x * mgx), rstd * (g.y - mg - xh.y * mgx), rstd * (g.z - mg - xh.z * mgx),
                                     rstd * (g.w - mg - xh.w * mgx));
+#if GRL_MLP_NT
+      if (row < n_rows) store_nt4(dx2 + (size_t)row * C + 4 * cq, dx);
+#else
       if (row < n_rows) *reinterpret_cast<float4*>(dx2 + (size_t)row * C + 4 * cq) = dx;
+#endif
       dgam = make_float4(fmaf(da.x, xh.x, dgam.x), fmaf(da.y, xh.y, dgam.y), fmaf(da.z, xh.z, dgam.z), fmaf(da.w, xh.w, dgam.w));
       dbet = f4_add(dbet, da);
     }
@@ -497,11 +520,15 @@ int blocks_for(int n_rows, int rows_per_block, int cap) {
 
 extern "C" {
 
+#if !GRL_PREC   // shape queries: shared by both precision builds of this file
 int grl_node_mlp_partial_size() { return MLP_PARTIAL; }
 int grl_node_mlp_bwd_blocks(int n_rows) { return blocks_for(n_rows, 32, 256); }
+#else
+int grl_node_mlp_bwd_blocks(int n_rows);
+#endif
 
 // rows = n_nodes*16.  out = (accumulate ? out : 0) + x_dst + MLP(LN(x2))
-int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+int GRL_ENTRY(grl_node_mlp_fwd)(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream) {
   if (n_rows <= 0) return 0;
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
@@ -512,7 +539,7 @@ int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const
 }
 
 // partial [grl_node_mlp_bwd_blocks(n_rows)][grl_node_mlp_partial_size()].  d x_dst is simply dout (residual), not produced here.
-int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+int GRL_ENTRY(grl_node_mlp_bwd)(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream) {
   (void)b4;
   if (n_rows <= 0) return 0;

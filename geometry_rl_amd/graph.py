@@ -76,8 +76,21 @@ def cloth_spec(n_particles=225, n_hole=10, G=4, E_cloth=600) -> TaskSpec:
         G, n_vec=3, in_features=_IN6[:5])
 
 
-def rope_spec(n_links=80, G=2) -> TaskSpec:
-    """rope_tasks_data.py:21-46 + rope_tasks/config/common_cfg/observations_cfg.py:131-160."""
+def rope_spec(n_links=80, G=2, variable_length=False) -> TaskSpec:
+    """rope_tasks_data.py:21-46 + rope_tasks/config/common_cfg/observations_cfg.py:131-160.
+
+    ``variable_length`` (BASELINE config 5; not in the reference, which requires equal rope sizes within a batch,
+    rope_tasks_data.py:127): an extra ``infos`` group carries ``links_num_points`` [B,1]; links / target points beyond that count are
+    zero padding, treated exactly like the rigid tasks' padded object points -- no edges, dropped from the actor graph, still summed by
+    the DeepSets critic."""
+    spec = _rope_spec(n_links, G)
+    if variable_length:
+        spec.obs_names["infos"], spec.obs_dims["infos"] = ["links_num_points"], [1]
+        spec.in_features = list(_IN6)
+    return spec
+
+
+def _rope_spec(n_links=80, G=2) -> TaskSpec:
     return TaskSpec(
         "rope", ["links", "grippers", "target_geometry"],
         [("links", "internal", "links"), ("grippers", "agent", "grippers"), ("links", "task", "grippers")],
@@ -150,15 +163,16 @@ class HyperData:
         obs = dict(zip(self.spec.in_features, args))
         B = obs["scalars"].shape[0]
         topo = self._cache.get(B)
-        if topo is None or self.spec.family != "rigid":
+        count_name = {"rigid": "object_num_points", "rope": "links_num_points"}.get(self.spec.family)
+        if topo is None or count_name not in self.spec.obs_names.get("infos", []):
             return
         names, dims = self.spec.obs_names["infos"], self.spec.obs_dims["infos"]
-        off = sum(dims[:names.index("object_num_points")])
+        off = sum(dims[:names.index(count_name)])
         P = topo["n_per"][topo["main"]]
         now = obs["infos"][:, off].reshape(B).long().clamp(max=P)
         if not torch.equal(now, topo["n_valid"]):
             bad = int((now != topo["n_valid"]).sum())
-            raise RuntimeError(f"HyperData: {bad} of {B} rows have a different object_num_points than the batch the cached topology "
+            raise RuntimeError(f"HyperData: {bad} of {B} rows have a different {count_name} than the batch the cached topology "
                                "of this batch size was built from; call reset_cache() (see its docstring for the invariant)")
 
     # ---- observation split (rigid_tasks_data.py:93-150)
@@ -187,6 +201,8 @@ class HyperData:
         P = n_per[main]
         if spec.family == "rigid":
             n_valid = split["infos"]["object_num_points"].reshape(B).long().clamp(max=P)
+        elif "links_num_points" in split.get("infos", {}):   # variable-length ropes
+            n_valid = split["infos"]["links_num_points"].reshape(B).long().clamp(max=P)
         else:
             n_valid = torch.full((B,), P, dtype=torch.long, device=dev)
         ar = torch.arange(P, device=dev)

@@ -100,8 +100,11 @@ class HEPi(nn.Module):
                  edge_encoder_layers=2, node_decoder_layers=2, node_type_mapping=None, edge_type_mapping=None,
                  edge_level_mapping=None, message_passing=None, num_messages=2, concat_global=False, shared_processor=False,
                  shared_node_encoder=True, shared_edge_encoder=True, device="cuda", num_ori=16, basis_dim=None, degree=2,
-                 ponita_dim=3, only_upper_hemisphere=False, **ignored):
+                 ponita_dim=3, only_upper_hemisphere=False, precision="fp32", **ignored):
         super().__init__()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision: 'fp32' (split-bf16 products, fp32-accurate) or 'bf16' (one bf16 MFMA per product)")
+        self.precision, self._prec = precision, ("_bf16" if precision == "bf16" else "")
         if hidden_dim != 64 or latent_dim != 64 or num_ori != 16 or degree != 2 or concat_global or shared_processor:
             raise NotImplementedError("HIP kernels are specialised for hidden=latent=64, 16 orientations, degree 2")
         self.input_dim_node, self.output_dim, self.output_dim_vec = input_dim_node, output_dim, output_dim_vec
@@ -172,11 +175,12 @@ class HEPi(nn.Module):
         # x feeds the convolution AND the residual of its own node block: the two gradients are summed inside the d x_src kernel
         res = {} if (x_src is x_dst and prev is None and torch.is_grad_enabled() and x_src.requires_grad) else None
         x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
-                                conv.kernel.weight, es, self.dim, res)
+                                conv.kernel.weight, es, self.dim, res, self._prec)
         fk = fks[id(conv)]
         x2 = ops.FiberConv.apply(x1, fk, conv.bias)
         m = conv.node_mlp
-        return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res), x1, fk
+        return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res,
+                                 self._prec), x1, fk
 
     # ------------------------------------------------------------------ forward
     def latent_step(self, graph: GraphBatch, u_dict) -> torch.Tensor:

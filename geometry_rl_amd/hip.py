@@ -16,25 +16,29 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
 ABI_VERSION = 200   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
+# (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
+# product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
+VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16")]
 
 
 def build(verbose: bool = True, force: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libgrl_hip.so in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "grl_common.h")]
+    deps = srcs + [os.path.join(CSRC, "grl_common.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
-    for s in srcs:
-        o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
+    jobs = [(s, [], "") for s in srcs] + [(os.path.join(CSRC, s), fl, sfx) for s, fl, sfx in VARIANTS]
+    for s, flags, sfx in jobs:
+        o = os.path.join(CSRC, "build", os.path.basename(s) + sfx + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d)
-                                                    for d in [s, os.path.join(CSRC, "grl_common.h")]):
+                                                    for d in [s, os.path.join(CSRC, "grl_common.h"), os.path.abspath(__file__)]):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))

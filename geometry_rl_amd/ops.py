@@ -132,16 +132,16 @@ class EdgeConv(torch.autograd.Function):
     """x1[d] = sum_{e->d} Wk(basis_mlp(invariants_e)) * x_src[src(e)]   (reference hepi.py:145-157, conv.py:79-86,115-149)."""
 
     @staticmethod
-    def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int, residual=None):
+    def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int, residual=None, prec: str = ""):
         """``residual``: optional dict shared with the NodeMLP of the same layer when x_src is also that block's residual input:
         NodeMLP.backward leaves d(out)/d(x_dst) there and this backward adds it inside the d x_src kernel (no separate add pass)."""
         hip.check_f32(x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
         x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=torch.float32)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
-        hip.call("grl_edge_conv_fwd", x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
+        hip.call("grl_edge_conv_fwd" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
                  dim, *args, x1, rows=edges.n_edges * 16)
         ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
-        ctx.edges, ctx.dim, ctx.residual = edges, dim, residual
+        ctx.edges, ctx.dim, ctx.residual, ctx.prec = edges, dim, residual, prec
         ctx.params = (w1, b1, w2, b2, wk)
         return x1
 
@@ -155,12 +155,12 @@ class EdgeConv(torch.autograd.Function):
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
         dx_src = torch.empty_like(x_src)
         dres = ctx.residual.pop("dres", None) if ctx.residual is not None else None
-        hip.call("grl_edge_conv_bwd", x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.src_s,
+        hip.call("grl_edge_conv_bwd" + ctx.prec, x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.src_s,
                  e.dst_s, e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dres, dx_src, partial, rows=e.n_edges * 16)
         pw1, pb1, pw2, pb2, pwk = ctx.params
         dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
                                                          (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])
-        return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None, None)
+        return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None, None, None)
 
 
 class FiberConv(torch.autograd.Function):
@@ -245,14 +245,14 @@ class NodeMLP(torch.autograd.Function):
     """out = [prev +] x_dst + W4 GELU(W3 LN(x2) + b3) + b4   (reference conv.py:64-69,112; hetero_fiber_conv.py:63-64)."""
 
     @staticmethod
-    def forward(ctx, x2, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor], residual=None):
+    def forward(ctx, x2, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor], residual=None, prec: str = ""):
         hip.check_f32(x2, x_dst, gamma, beta, w3, b3, w4, b4)
         ws = [a.contiguous() for a in (w3, b3, w4, b4, gamma, beta)]
         n_rows = x2.shape[0] * 16
         out = prev.clone() if prev is not None else torch.empty_like(x2)
-        hip.call("grl_node_mlp_fwd", x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0, rows=n_rows)
+        hip.call("grl_node_mlp_fwd" + prec, x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0, rows=n_rows)
         ctx.save_for_backward(x2, *ws)
-        ctx.has_prev = prev is not None
+        ctx.has_prev, ctx.prec = prev is not None, prec
         ctx.residual = residual
         ctx.params = (w3, b3, w4, b4, gamma, beta)
         return out
@@ -267,7 +267,7 @@ class NodeMLP(torch.autograd.Function):
         blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
         psize = hip.query("grl_node_mlp_partial_size")
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
-        hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows, rows=n_rows)
+        hip.call("grl_node_mlp_bwd" + ctx.prec, x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows, rows=n_rows)
         pw3, pb3, pw4, pb4, pg, pbt = ctx.params
         dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
                                                                (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),
@@ -276,7 +276,7 @@ class NodeMLP(torch.autograd.Function):
         if ctx.residual is not None:   # handed to the EdgeConv backward of the same layer (same tensor x feeds both)
             ctx.residual["dres"] = dout
             d_dst = None
-        return (dx2, d_dst, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None, None)
+        return (dx2, d_dst, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None, None, None)
 
 
 class Readout(torch.autograd.Function):

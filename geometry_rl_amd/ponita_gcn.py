@@ -57,8 +57,10 @@ class Ponita(nn.Module):
 
 class PonitaGCN(nn.Module):
     def __init__(self, input_dim_node, output_dim, output_dim_vec, num_layers=2, hidden_dim=64, dropout=0.0, num_ori=16, degree=2,
-                 widening_factor=4, attention=False, ponita_dim=3, only_upper_hemisphere=False, device="cuda", **ignored):
+                 widening_factor=4, attention=False, ponita_dim=3, only_upper_hemisphere=False, device="cuda", precision="fp32",
+                 **ignored):
         super().__init__()
+        self.precision, self._prec = precision, ("_bf16" if precision == "bf16" else "")
         if hidden_dim != 64 or num_ori != 16 or degree != 2 or widening_factor != 4 or attention:
             raise NotImplementedError("HIP kernels are specialised for configs/algorithm/pyg_agent/model/ponita_gcn.yaml")
         self.input_dim, self.dim = input_dim_node, ponita_dim
@@ -100,7 +102,7 @@ class PonitaGCN(nn.Module):
         for et, es in graph.edges.items():  # spatial conv summed over all (merged) edge types: ponita.py:153,161
             s, _, d = et
             part = ops.EdgeConv.apply(x[s], graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
-                                      layer.conv.kernel.weight, es, self.dim)
+                                      layer.conv.kernel.weight, es, self.dim, None, self._prec)
             x1[d] = part if d not in x1 else x1[d] + part
         fk = fks[id(layer.conv)]
         out = {}
@@ -110,7 +112,7 @@ class PonitaGCN(nn.Module):
                 x1t = torch.zeros_like(xt)
             x2 = ops.FiberConv.apply(x1t, fk, layer.conv.bias)
             out[t] = ops.NodeMLP.apply(x2, xt, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
-                                       layer.linear_2.weight, layer.linear_2.bias, None)
+                                       layer.linear_2.weight, layer.linear_2.bias, None, None, self._prec)
             if collect is not None:
                 collect[t] = (x1t, fk)
         return out

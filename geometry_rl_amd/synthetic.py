@@ -63,8 +63,28 @@ def make_cloth_obs(B: int, *, n_particles: int = 225, n_hole: int = 10, G: int =
     }
 
 
-def make_rope_obs(B: int, *, n_links: int = 80, G: int = 2, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """rope_tasks/config/common_cfg/observations_cfg.py:131-160 layout."""
+ROPE_NUM_LINKS = (80, 40)   # valid links per env (env % 2) of the variable-length synthetic ropes: shaping 80 / closing 40 links
+
+
+def make_rope_obs(B: int, *, n_links: int = 80, G: int = 2, seed: int = 0, variable_length: bool = False,
+                  env_offset: int = 0) -> Dict[str, torch.Tensor]:
+    """rope_tasks/config/common_cfg/observations_cfg.py:131-160 layout.  ``variable_length``: adds ``infos`` = links_num_points [B,1]
+    (ROPE_NUM_LINKS by env % 2, scaled by n_links / 80) and zero-pads the raw link / target positions beyond it."""
+    obs = _make_rope_obs(B, n_links=n_links, G=G, seed=seed)
+    if variable_length:
+        env = torch.arange(B) + env_offset
+        nl = torch.tensor([max(2, v * n_links // 80) for v in ROPE_NUM_LINKS])[env % 2]   # 80 / 40 links at full size
+        valid = (torch.arange(n_links)[None, :] < nl[:, None]).float()[..., None]       # [B,L,1]
+        pos = obs["position_vectors"].clone()
+        for blk in range(2):   # links, target_geometry
+            sl = slice(3 * G + blk * 3 * n_links, 3 * G + (blk + 1) * 3 * n_links)
+            pos[:, sl] = (pos[:, sl].reshape(B, n_links, 3) * valid).reshape(B, -1)
+        obs["position_vectors"] = pos
+        obs["infos"] = nl.float().reshape(B, 1)
+    return obs
+
+
+def _make_rope_obs(B: int, *, n_links: int = 80, G: int = 2, seed: int = 0) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     n_pos = G + 2 * n_links
     n_vel = G + n_links

@@ -78,8 +78,21 @@ def cloth_spec(n_particles=225, n_hole=10, G=4, E_cloth=600) -> TaskSpec:
     )
 
 
-def rope_spec(n_links=80, G=2) -> TaskSpec:
-    """orbit/tasks/manipulation/rope_tasks/config/common_cfg/observations_cfg.py:131-160."""
+def rope_spec(n_links=80, G=2, variable_length=False) -> TaskSpec:
+    """orbit/tasks/manipulation/rope_tasks/config/common_cfg/observations_cfg.py:131-160.
+
+    ``variable_length`` (BASELINE config 5 "variable-length rope graphs"; NOT in the reference, which asserts equal rope sizes within
+    a batch, rope.py:127): an extra ``infos`` group carries ``links_num_points`` [B,1]; links / target points beyond it are zero
+    padding exactly like the rigid tasks' padded object points (orbit/tasks/common/utils.py:193-211): no edges touch them."""
+    spec = _rope_spec(n_links, G)
+    if variable_length:
+        spec.obs_names["infos"] = ["links_num_points"]
+        spec.obs_dims["infos"] = [1]
+        spec.in_features = spec.in_features + ["infos"]
+    return spec
+
+
+def _rope_spec(n_links=80, G=2) -> TaskSpec:
     return TaskSpec(
         family="rope",
         node_types=["links", "grippers", "target_geometry"],  # rope.py:21-24
@@ -170,7 +183,9 @@ def build_topology(spec: TaskSpec, split: dict, full_graph_obs: bool) -> dict:
                    spec.edge_types[2]: full_edges(H, G, False)}
         else:
             L = n_per["links"]
-            loc = {spec.edge_types[0]: knn_edges(posv["links"][i], spec.knn_k),  # rope.py:251
+            if "infos" in split and "links_num_points" in split["infos"]:   # variable-length ropes: only the valid links have edges
+                L = min(L, int(split["infos"]["links_num_points"][i].long().item()))
+            loc = {spec.edge_types[0]: knn_edges(posv["links"][i][:L], spec.knn_k),  # rope.py:251
                    spec.edge_types[1]: full_edges(G, G, True), spec.edge_types[2]: full_edges(L, G, False)}
         for et, ei in loc.items():
             src, _, dst = et
