@@ -54,6 +54,10 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
                    edge_type_mapping=[tuple(e) for e in spec.edge_types], edge_level_mapping=spec.edge_levels,
                    message_passing=mp, num_messages=len(cfg.codes[0]), device=device, num_ori=cfg.num_ori,
                    ponita_dim=cfg.dim, only_upper_hemisphere=cfg.only_upper_hemisphere, precision=cfg.precision)
+    elif cfg.model == "transformer":   # BASELINE config 1: stock-torch baseline actor + post_fc head on the same loss / critic / updater
+        from .transformer import TransformerVanilla
+        gnn = TransformerVanilla(input_dim_node=len(spec.node_types) + 3 * spec.n_vec, output_dim=64, num_layers=cfg.num_layers,
+                                 num_heads=2, hidden_dim=64, dropout=0.0, concat_global=False, device=device)
     elif cfg.model == "empn":
         from .ponita_gcn import PonitaGCN
         gnn = PonitaGCN(input_dim_node=n_in, output_dim=cfg.output_dim, output_dim_vec=cfg.output_dim_vec,
@@ -61,11 +65,12 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
                         only_upper_hemisphere=cfg.only_upper_hemisphere, device=device, precision=cfg.precision)
     else:
         raise ValueError(cfg.model)
-    a_data = HyperData(spec, full_graph_obs=False, dist_as_pos=True, output_mask_key=spec.actuator, concat_input_vector=False)
+    post_fc = cfg.model == "transformer"
+    a_data = HyperData(spec, full_graph_obs=False, dist_as_pos=True, output_mask_key=spec.actuator, concat_input_vector=post_fc)
     A = spec.num_actuators * cfg.output_dim_vec * 3
     actor = GNNGaussianPolicyDiag(gnn=gnn, hyper_data=a_data, action_dim=A, num_actuators=spec.num_actuators, init="orthogonal",
                                   hidden_sizes=(64, 64), contextual_std=True, init_std=cfg.init_std, minimal_std=cfg.minimal_std,
-                                  share_action_dim=True, post_fc=False)
+                                  share_action_dim=True, post_fc=post_fc)
     actor.group = group
     c_data = HyperData(spec, full_graph_obs=True, dist_as_pos=False, output_mask_key=None, concat_input_vector=True)
     c_gnn = DeepSets(input_dim_node=len(spec.node_types) + 3 * spec.n_vec, output_dim=64, hidden_dim=64, device=device)
@@ -73,9 +78,11 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
     critic._network1.group = group
     projection = KLProjectionLayer(proj_type=cfg.proj_type, mean_bound=cfg.mean_bound, cov_bound=cfg.cov_bound,
                                    trust_region_coeff=cfg.trust_region_coeff, scale_prec=True, entropy_schedule=False, action_dim=A)
+    # config 1 hands its actor the NORMALISED vectors in the raw-vector slots (configs/rigid_insertion_multi_transformer_trpl_cfg.yaml:88-94)
+    a_in = [k if k.startswith("norm_") or "vectors" not in k else "norm_" + k for k in spec.in_features] if post_fc else spec.in_features
     loss = TRPLLoss(actor, critic, projection=projection, entropy_coef=cfg.entropy_coef, critic_coef=cfg.critic_coef,
-                    clip_value=cfg.clip_value, loss_critic_type="l2", normalize_advantage=True, in_features=spec.in_features,
-                    group=group)
+                    clip_value=cfg.clip_value, loss_critic_type="l2", normalize_advantage=True, in_features=a_in,
+                    critic_in_features=spec.in_features, group=group)
     return actor, critic, projection, loss
 
 
@@ -197,9 +204,10 @@ class PolicyUpdater:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
             st["b"] = b
             st["obs"] = [b[k] for k in m.in_features]
+            st["cobs"] = [b[k] for k in m.critic_in_features]
             with torch.no_grad():
                 vf.train(True)
-                _, x = vf.hyper_data.build_data(*st["obs"], train=True)
+                _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
                 # one zeroed fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (12) | maxes (2 x u32) | clip (2)
                 zw = st["zw"] = torch.zeros(26, device=x.device, dtype=torch.float64)
                 st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
@@ -265,11 +273,12 @@ class PolicyUpdater:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
             st["b"] = b
             st["obs"] = [b[k] for k in m.in_features]
+            st["cobs"] = [b[k] for k in m.critic_in_features]
             cur, cs = torch.cuda.current_stream(), self._critic_stream()
             cs.wait_stream(cur)
             with torch.cuda.stream(cs), torch.no_grad():
                 vf.train(True)
-                _, x = vf.hyper_data.build_data(*st["obs"], train=True)
+                _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
                 pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                 pipe.fwd1()
                 pipe.fwd2()
@@ -315,12 +324,13 @@ class PolicyUpdater:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
             st["b"] = b
             st["obs"] = [b[k] for k in m.in_features]
+            st["cobs"] = [b[k] for k in m.critic_in_features]
             st["zw"] = torch.zeros(26, device=self.flat.device, dtype=torch.float64)
 
         def c_fwd1():
             with torch.no_grad():
                 vf.train(True)
-                _, x = vf.hyper_data.build_data(*st["obs"], train=True)
+                _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
                 st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
                 st["pipe"].fwd1()
                 st["adv"] = None
@@ -398,8 +408,9 @@ class PolicyUpdater:
     def _compile(self, batch):
         """Record the plan's segments into hipGraphs (adjacent segments without a reduction between them share one graph)."""
         m = self.loss_module
-        for hd in (m.actor_network.hyper_data, m.critic_network._network1.hyper_data):   # one sync, before anything is captured:
-            hd.check_topology(*[batch[k] for k in m.in_features])                         # the cached topology fits this minibatch
+        # one sync, before anything is captured: the cached topology fits this minibatch
+        m.actor_network.hyper_data.check_topology(*[batch[k] for k in m.in_features])
+        m.critic_network._network1.hyper_data.check_topology(*[batch[k] for k in m.critic_in_features])
         self._static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
         st = self._st = {}
         plan = self._plan(self._static, st)
@@ -462,7 +473,7 @@ class PolicyUpdater:
         """One update on the minibatch made of rows ``idx`` (device int64 [B]) of a device-resident ``rollout.RolloutBuffer``.
         With recorded graphs the rows are gathered by ONE launch straight into the static input buffers."""
         import ctypes
-        keys = list(self.loss_module.in_features) + ["action", "loc", "var" if "var" in buf.data else "covariance_matrix",
+        keys = list(dict.fromkeys(list(self.loss_module.in_features) + list(self.loss_module.critic_in_features))) + ["action", "loc", "var" if "var" in buf.data else "covariance_matrix",
                                                      "sample_log_prob", "state_value", "advantage", "value_target"]
         if not self.use_graph or self._program is None or int(idx.numel()) != self._static[keys[0]].shape[0]:
             return self.step(buf.rows(idx, keys))

@@ -35,9 +35,9 @@ class GNNGaussianPolicyDiag(nn.Module):
                  share_weights=False, vf_model=None, minimal_std=1e-5, scale=1e-4, gain=0.01, share_action_dim=True, post_fc=False,
                  **kwargs):
         super().__init__()
-        if not contextual_std or post_fc or not share_action_dim or isinstance(action_dim, list) or use_tanh_mean:
-            raise NotImplementedError("HIP policy head implements the HEPi/EMPN configuration: contextual_std=True, post_fc=False, "
-                                      "share_action_dim=True (configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:85-99)")
+        if not contextual_std or not share_action_dim or isinstance(action_dim, list) or use_tanh_mean:
+            raise NotImplementedError("policy head: contextual_std=True, share_action_dim=True, no tanh mean "
+                                      "(configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:85-99; post_fc either way)")
         if init != "orthogonal":
             raise NotImplementedError("only the 'orthogonal' initialisation of configs/algorithm/policy/default.yaml is mirrored")
         self.action_dim, self.num_actuators = action_dim, num_actuators
@@ -77,6 +77,16 @@ class GNNGaussianPolicyDiag(nn.Module):
     def forward_diag(self, *args, train=True) -> Tuple[torch.Tensor, torch.Tensor]:
         self.train(train)
         B = args[0].shape[0]
+        if self.post_fc:
+            # gnn_gaussian_policy_diag.py:65-83 with post_fc=True (the default of abstract_gnn_gaussian_policy.py:37; config 1's
+            # transformer actor): the GNN hands over ``hidden`` only and BOTH heads are Linear layers on it.  The GNN of this branch
+            # is a stock torch module (geometry_rl_amd.transformer), so the two small heads stay torch ops under the same autograd.
+            graph, u = self.hyper_data.build_data(*args, train=train)
+            hidden = self.gnn.one_step(graph, u)
+            mean = self._mean(hidden)
+            shift = self._pre_activation_shift.to(hidden.device)
+            sigma = torch.nn.functional.softplus(self._pre_std(hidden) + shift) + self.minimal_std.to(hidden.device)
+            return mean.reshape(B, -1), sigma.reshape(B, -1)
         if train and not self._calib_checked:
             self._maybe_calibrate(args)
         graph, u = self.hyper_data.build_data(*args, train=train)

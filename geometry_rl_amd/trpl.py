@@ -225,7 +225,7 @@ def _as_batch(td, in_features) -> Dict[str, torch.Tensor]:
     if isinstance(td, dict):
         return dict(td)
     out = {}
-    for k in tuple(in_features) + _TD_KEYS:
+    for k in tuple(dict.fromkeys(tuple(in_features))) + _TD_KEYS:
         try:
             v = td.get(k, None)
         except TypeError:
@@ -248,7 +248,8 @@ class TRPLLoss(_LossBase):
 
     def __init__(self, actor_network, critic_network, *, projection: KLProjectionLayer, clip_epsilon=0.2, entropy_bonus=True,
                  samples_mc_entropy=1, entropy_coef=0.01, critic_coef=1.0, trust_region_coef=1.0, loss_critic_type="l2",
-                 normalize_advantage=True, gamma=None, separate_losses=False, clip_value=None, in_features=None, group=None, **kwargs):
+                 normalize_advantage=True, gamma=None, separate_losses=False, clip_value=None, in_features=None, group=None,
+                 critic_in_features=None, **kwargs):
         super().__init__()
         if loss_critic_type != "l2":
             raise NotImplementedError("loss_critic_type is l2 in configs/algorithm/objective/trpl.yaml:12")
@@ -267,7 +268,11 @@ class TRPLLoss(_LossBase):
         self.trust_region_coef = trust_region_coef
         self.entropy_bonus, self.entropy_coef, self.critic_coef = entropy_bonus, float(entropy_coef), float(critic_coef)
         self.normalize_advantage, self.clip_value = normalize_advantage, clip_value
-        self.in_features = in_features or actor_network.hyper_data.spec.in_features
+        # tensordict keys handed POSITIONALLY to the actor / the critic (the in_keys of their TensorDictModules,
+        # utils_algo_graph.py:113-116,160-176).  They may differ: config 1 feeds its transformer actor the normalised vectors in the
+        # raw-vector slots (configs/rigid_insertion_multi_transformer_trpl_cfg.yaml:88-94) while the critic reads the raw ones.
+        self.in_features = list(in_features or actor_network.hyper_data.spec.in_features)
+        self.critic_in_features = list(critic_in_features or self.in_features)
         self.group = group
         self._global_steps = 0
 
@@ -289,12 +294,12 @@ class TRPLLoss(_LossBase):
                        "entropy_diff"]
 
     def forward(self, tensordict):
-        b = _as_batch(tensordict, self.in_features)
+        b = _as_batch(tensordict, self.in_features + self.critic_in_features)
         if "var" not in b:
             b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
         obs = [b[k] for k in self.in_features]
         loc, sigma = self.actor_network.forward_diag(*obs, train=True)
-        value = self.critic_network(*obs) if self.critic_coef else None
+        value = self.critic_network(*[b[k] for k in self.critic_in_features]) if self.critic_coef else None
         actor, critic, mt = _run_trpl(self, loc, sigma, value, b)
         out = {
             "loss_objective": actor - (mt["loss_trust_region"] + mt["loss_entropy"]),  # value = objective; gradient = d(actor loss)

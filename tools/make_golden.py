@@ -355,13 +355,79 @@ def tier2c():
         np.savez(os.path.join(OUT, f"tier2c_projection_{name}.npz"), **npd(rec))
 
 
+def tier2d():
+    """BASELINE config 1 (rigid_insertion_multi_transformer_trpl): the reference's TransformerVanilla (transformer_vanilla.py:10-92,
+    configs/algorithm/pyg_agent/model/transformer.yaml) inside the reference's GNNGaussianPolicyDiag with post_fc=True
+    (gnn_gaussian_policy_diag.py:26-87), forward and backward.  Stubs: PyG's ``MLP([64, 64], norm=None)`` -- one Linear layer stored as
+    ``lins.0`` [upstream PyG 2.5.2: plain_last=True, no norm, no activation for a two-entry channel list] -- and a graph object carrying
+    ``len()``, ``node_types`` and ``output_mask`` (what one_step reads, transformer_vanilla.py:59-66,88)."""
+    import torch_geometric.nn as tgnn
+
+    class MLP(nn.Module):   # PyG MLP restated for the only form the call site uses
+        def __init__(self, channel_list, norm=None, **kw):
+            super().__init__()
+            assert len(channel_list) == 2 and norm is None
+            self.lins = nn.ModuleList([nn.Linear(channel_list[0], channel_list[1])])
+
+        def forward(self, x):
+            return self.lins[0](x)
+
+    tgnn.MLP = MLP
+    sys.modules.pop("geometry_rl.modules.pyg_models.transformer_vanilla", None)
+    from geometry_rl.modules.pyg_models.transformer_vanilla import TransformerVanilla
+    from geometry_rl.algorithms.trust_region_projections.models.policy.gnn_gaussian_policy_diag import GNNGaussianPolicyDiag
+
+    B, P, G, d, A = 5, 32, 1, 15, 6
+    g = torch.Generator().manual_seed(17)
+
+    class Graph:
+        node_types = ["object_geometry", "grippers"]
+        output_mask = slice(P, P + G)
+
+        def __len__(self):
+            return B
+
+    class FakeData:
+        def build_data(self, *args, train=True):
+            return Graph(), self.payload
+
+    torch.manual_seed(7)
+    gnn = TransformerVanilla(input_dim_node=d, output_dim=64, num_layers=2, num_heads=2, hidden_dim=64, dropout=0.0, concat_global=False)
+    fd = FakeData()
+    policy = GNNGaussianPolicyDiag(gnn=gnn, hyper_data=fd, action_dim=A, num_actuators=G, init="orthogonal", hidden_sizes=(64, 64),
+                                   contextual_std=True, init_std=1.0, minimal_std=1e-5, share_action_dim=True, post_fc=True)
+    with torch.no_grad():   # the orthogonal(0.01) heads would hide the transformer behind a ~0 mean: make them visible
+        policy._mean.weight.mul_(30.0)
+        policy._pre_std.weight.mul_(30.0)
+    u_obj = torch.randn(B * P, d, generator=g)
+    u_grip = torch.randn(B * G, d, generator=g)
+    fd.payload = {"object_geometry": u_obj, "grippers": u_grip}
+    loc, cov = policy(torch.zeros(B, 1), train=True)
+    w_loc, w_cov = torch.randn(loc.shape, generator=g), torch.randn(B, A, generator=g)
+    (loc * w_loc).sum().add((cov.diagonal(dim1=-2, dim2=-1) * w_cov).sum()).backward()
+    rec = {"u_object_geometry": u_obj, "u_grippers": u_grip, "loc": loc, "cov": cov, "w_loc": w_loc, "w_cov": w_cov,
+           "B": np.int64(B), "P": np.int64(P), "G": np.int64(G)}
+    for k, v in policy.state_dict().items():
+        rec["param." + k] = v
+    for k, p_ in policy.named_parameters():
+        if p_.grad is not None:
+            rec["grad." + k] = p_.grad
+    np.savez(os.path.join(OUT, "tier2d_transformer_post_fc.npz"), **npd(rec))
+    print("tier2d: ", len(rec), "arrays;", sum(p_.numel() for p_ in policy.parameters()), "parameters; loc", tuple(loc.shape))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "tier2d":   # only the newest tier (the older fixtures stay byte-identical)
+        install_stubs()
+        tier2d()
+        sys.exit(0)
     tier1()
     install_stubs()
     tier2()
     tier2b()
     tier2c()
+    tier2d()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
