@@ -132,6 +132,11 @@ class PolicyUpdater:
         self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
         self._lr = float(lr)
         self.use_graph = use_graph
+        if use_graph and getattr(loss_module.actor_network, "post_fc", False):
+            # config 1's baseline actor is a stock torch.nn.TransformerEncoder: its launches are torch's own (rocBLAS / hipBLASLt
+            # workspaces are not capture-safe on this stack), so that step is issued eagerly -- it is the reference's CPU-sized
+            # plumbing case (64 envs x 32 steps), not a throughput path
+            self.use_graph, self.mode = False, "eager (stock-torch transformer actor: not recorded)"
         self._static = None
         self._program = None
         self._pending = []   # asynchronous collectives in flight

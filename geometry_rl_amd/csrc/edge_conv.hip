@@ -244,6 +244,11 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 // its (edge slot, orientation) row; after the last pass the two edge slots are folded with one cross-lane exchange
 // (lane r <-> r^16) and the rows leave with plain stores.  No LDS traffic besides the weights (LDS float atomics cost
 // ~200 LDS cycles per wave instruction on gfx950 -- measured, profiles/r01_*pmc* -- and made the first version LDS-bound).
+// GRL_FENCED_2W: the forward and the d x_src kernel run two waves per SIMD and therefore use the fenced MFMA groups (DESIGN.md finding 3).
+// -DGRL_FENCED_2W=false builds the hazard's in-situ reproducer (tools/det_check_all.py, tools/run_hazard_check.sh): never ship it.
+#ifndef GRL_FENCED_2W
+#define GRL_FENCED_2W true
+#endif
 #ifndef GRL_FWD_WAVES
 #define GRL_FWD_WAVES 4
 #endif
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
         const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
         const float wb = (cur.valid && cur.dst != d0) ? 1.f : 0.f;
         // message = K * x_src, summed into the accumulator of the edge's destination node as each K tile leaves the matrix pipe
-        edge_chain<false, true>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
+        edge_chain<false, GRL_FENCED_2W>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int t = 4 * nt + q;
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
         const float wb = (cur.valid && cur.src != s0) ? 1.f : 0.f;
         // d x_src row = dM * K, summed into the accumulator of the edge's source node as each K tile leaves the matrix pipe
         // (two waves share a SIMD: fenced MFMA groups, exactly like the forward kernel)
-        edge_chain<false, true>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
+        edge_chain<false, GRL_FENCED_2W>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int t = 4 * nt + q;

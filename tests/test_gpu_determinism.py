@@ -8,13 +8,25 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup():
+def _setup(shape="half"):
+    """``half``: 32 768 nodes / 98 304 random edges (the round-1 shape); ``internal``: the internal convolution of BASELINE's 4096-frame
+    rigid minibatch -- 65 536 nodes, 196 608 edges, three in-edges per node like the kNN graph; ``task``: its object -> gripper
+    convolution -- 65 536 sources, 4096 destinations with 16 in-edges each = 2048 destination tiles... at a 1024-frame shard 512 tiles,
+    i.e. the SPLIT forward (one workgroup per tile, edge_conv_fwd_kernel<true>)."""
     from geometry_rl_amd import ops, hepi
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    ns = nd = 32768
-    E = 98304
-    ei = torch.stack([torch.randint(0, ns, (E,), generator=g), torch.randint(0, nd, (E,), generator=g)])
+    if shape == "half":
+        ns = nd = 32768
+        E = 98304
+        ei = torch.stack([torch.randint(0, ns, (E,), generator=g), torch.randint(0, nd, (E,), generator=g)])
+    elif shape == "internal":
+        ns = nd = 65536
+        dst = torch.arange(nd).repeat_interleave(3)
+        ei = torch.stack([torch.randint(0, ns, (3 * nd,), generator=g), dst])
+    else:   # task, 1024-frame shard: 16384 sources -> 1024 destinations, 16 in-edges each (512 destination tiles: SPLIT path)
+        ns, nd = 16384, 1024
+        ei = torch.stack([torch.arange(ns), torch.arange(ns) // 16])
     es = ops.build_edge_set(ei.to(d), ns, nd)
     rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(d)
     t = dict(es=es, x=rnd(ns, 16, 64), ps=torch.rand(ns, 3, generator=g).to(d), pd=torch.rand(nd, 3, generator=g).to(d),
@@ -24,29 +36,34 @@ def _setup():
     return ops, t
 
 
-def _edge(ops, t):
+def _edge(ops, t, prec=""):
     xs = t["x"].clone().requires_grad_(True)
     ws = [w.clone().requires_grad_(True) for w in t["ew"]]
-    y = ops.EdgeConv.apply(xs, t["ps"], t["pd"], t["grid"], *ws, t["es"], 3)
+    y = ops.EdgeConv.apply(xs, t["ps"], t["pd"], t["grid"], *ws, t["es"], 3, None, prec)
     y.backward(t["dy"])
     return [y.detach(), xs.grad] + [w.grad for w in ws]
 
 
-def _mlp(ops, t):
-    x2 = t["x"].clone().requires_grad_(True)
+def _mlp(ops, t, prec=""):
+    x2 = t["x"][:t["xd"].shape[0]].clone().requires_grad_(True)
     ws = [w.clone().requires_grad_(True) for w in t["mw"]]
-    y = ops.NodeMLP.apply(x2, t["xd"], *ws, None)
+    y = ops.NodeMLP.apply(x2, t["xd"], *ws, None, None, prec)
     y.backward(t["dy"])
     return [y.detach(), x2.grad] + [w.grad for w in ws]
 
 
-@pytest.mark.parametrize("which", ["edge_conv", "node_mlp"])
-def test_bitwise_reproducible(which):
-    ops, t = _setup()
-    fn = _edge if which == "edge_conv" else _mlp
+@pytest.mark.parametrize("which,shape,prec", [("edge_conv", "half", ""), ("node_mlp", "half", ""),
+                                              ("edge_conv", "internal", ""), ("edge_conv", "task", ""), ("node_mlp", "internal", ""),
+                                              ("edge_conv", "internal", "_bf16"), ("node_mlp", "internal", "_bf16")])
+def test_bitwise_reproducible(which, shape, prec):
+    ops, t = _setup(shape)
+    if shape == "task":   # the launcher must have taken the one-workgroup-per-tile forward for this shape
+        assert (t["es"].n_dst + 1) // 2 <= 512
+    fn_ = _edge if which == "edge_conv" else _mlp
+    fn = lambda o, tt: fn_(o, tt, prec)
     ref = fn(ops, t)
     torch.cuda.synchronize()
-    for rep in range(8):
+    for rep in range(8 if shape == "half" else 5):
         cur = fn(ops, t)
         torch.cuda.synchronize()
         for k, (a, b) in enumerate(zip(ref, cur)):

@@ -106,6 +106,7 @@ def test_config1_rollout_pass_64_envs_x_32_steps(use_graph):
                 terminated=g["terminated"].reshape(N, T, 1).to(dev))
     buf = RolloutBuffer(data)
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=use_graph)
+    assert upd.mode.startswith("eager")   # asking for a recorded step with the stock-torch actor degrades loudly (mode says so), not silently
     drv = RolloutDriver(upd, spec, ppo_epochs=5, seed=0)
     p0 = upd.flat.clone()
     out = drv.run(buf, {k: frames[0][k].unsqueeze(1) for k in spec.in_features})
