@@ -15,7 +15,7 @@ before and after every collective and around the graph segments between them, fo
 Ranks sharing one GPU time-slice its CUs, so segment times are taken from rank 0 of a W = 1 run of the same shard (no contention)
 unless ``--segments-from-shared`` is given.
 
-  python tools/dp_collective_timing.py --world 2 --steps 20 > profiles/r02_dp_critical_path.json
+  python tools/dp_collective_timing.py --world 2 --steps 20 --out profiles/r02_dp_critical_path.json
 """
 import argparse
 import json
@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--shard", type=int, default=512)
+    ap.add_argument("--out", default=None, help="write the JSON here (stdout otherwise; c10d warnings may interleave with stdout)")
     ap.add_argument("--rccl-us", type=float, default=25.0, help="assumed latency of one small (<= 1 MB) RCCL all-reduce over xGMI, 8 ranks")
     args = ap.parse_args()
     import torch.multiprocessing as mp
@@ -125,7 +126,12 @@ def main():
                               "formula": "single-rank 512-frame step (device-bound, replayed) + (collectives the main lane waits for) x RCCL latency; "
                                          "the side lane's four statistic all-reduces hide behind the actor forward / backward if each stays below ~0.1 ms"},
     }
-    print(json.dumps({"summary": summary, "detail": out}, indent=1))
+    text = json.dumps({"summary": summary, "detail": out}, indent=1)
+    if args.out:
+        open(args.out, "w").write(text)
+        print(json.dumps(summary["prediction_8_gpus"]))
+    else:
+        print(text)
 
 
 if __name__ == "__main__":

@@ -24,10 +24,12 @@ struct Smem {
   float bias[3][64];
 };
 
-template <bool FENCED>
+// GATHER: like the production forward, every chain runs with eight 16-byte global loads of a gathered row in flight (issued in
+// front of the chain, consumed by a multiply behind it) and the next tile's index load issued under it.
+template <bool FENCED, bool GATHER>
 __global__ __launch_bounds__(256, 2) void chain_kernel(const float* __restrict__ W /*[3][64][64]*/, const float* __restrict__ bias,
                                                        const float* __restrict__ X /*[rows][64]*/, float* __restrict__ Y, int n_tiles,
-                                                       int inner) {
+                                                       int inner, const int* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   Smem& s = *reinterpret_cast<Smem*>(smem_raw);
   for (int l = 0; l < 3; ++l) stage_split<64, 64, 64, 256>(s.Wh[l], s.Wl[l], W + l * 4096, LDBW);
@@ -40,6 +42,13 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = xp[2 * t];
     for (int rep = 0; rep < inner; ++rep) {   // the same chain again on its own output: keeps the SIMD in the pattern for long
+      float4 gv[8];
+      if (GATHER) {
+        const int row = idx[(tile * 32 + r + rep * 7919) % (n_tiles * 32)];
+        const float4* gp = reinterpret_cast<const float4*>(X + (size_t)row * 64) + h;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) gv[t] = gp[2 * t];     // in flight behind the chain
+      }
 #pragma unroll
       for (int l = 0; l < 3; ++l) {
         bf16x8 xh[4], xl[4];
@@ -66,6 +75,11 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const float* __restrict__
           }
         }
       }
+      if (GATHER) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = make_float4(fmaf(x[t].x, 0.5f, 0.25f * gv[t].x), fmaf(x[t].y, 0.5f, 0.25f * gv[t].y),
+                                                       fmaf(x[t].z, 0.5f, 0.25f * gv[t].z), fmaf(x[t].w, 0.5f, 0.25f * gv[t].w));
+      }
     }
     float4* yp = reinterpret_cast<float4*>(Y + ((size_t)tile * 32 + r) * 64) + h;
 #pragma unroll
@@ -87,24 +101,35 @@ int main(int argc, char** argv) {
   hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice);
-  hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-  hipFuncSetAttribute((const void*)chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+  std::vector<int> hidx(rows);
+  for (auto& v : hidx) { seed = seed * 1664525u + 1013904223u; v = (int)((seed >> 4) % (unsigned)rows); }
+  int* idx;
+  hipMalloc(&idx, hidx.size() * 4);
+  hipMemcpy(idx, hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void*)chain_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+  hipFuncSetAttribute((const void*)chain_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+  hipFuncSetAttribute((const void*)chain_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
+  hipFuncSetAttribute((const void*)chain_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
   std::vector<float> ref(hX.size()), out(hX.size());
-  hipLaunchKernelGGL(chain_kernel<true>, dim3(256), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner);   // one wave per SIMD, fenced
+  int total_bad = 0;
+  for (int gather = 0; gather < 2; ++gather) {
+  if (gather) hipLaunchKernelGGL((chain_kernel<true, true>), dim3(256), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner, idx);
+  else hipLaunchKernelGGL((chain_kernel<true, false>), dim3(256), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner, idx);   // one wave per SIMD, fenced
   hipDeviceSynchronize();
   hipMemcpy(ref.data(), Y, ref.size() * 4, hipMemcpyDeviceToHost);
   double cs = 0;
   for (float v : ref) cs += v;
-  printf("reference (fenced, 1 wave/SIMD): checksum %.6f\n", cs);
-  int total_bad = 0;
+  printf("== %s: reference (fenced, 1 wave/SIMD): checksum %.6f\n", gather ? "chain with gathered rows in flight" : "bare chain", cs);
   for (int grid : {256, 512, 768, 1024}) {
     for (int fenced = 1; fenced >= 0; --fenced) {
       int bad_runs = 0;
       long long bad_tiles = 0;
       for (int it = 0; it < repeats; ++it) {
         hipMemset(Y, 0, hX.size() * 4);
-        if (fenced) hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner);
-        else hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner);
+        if (fenced && gather) hipLaunchKernelGGL((chain_kernel<true, true>), dim3(grid), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner, idx);
+        else if (fenced) hipLaunchKernelGGL((chain_kernel<true, false>), dim3(grid), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner, idx);
+        else if (gather) hipLaunchKernelGGL((chain_kernel<false, true>), dim3(grid), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner, idx);
+        else hipLaunchKernelGGL((chain_kernel<false, false>), dim3(grid), dim3(256), sizeof(Smem), 0, W, b, X, Y, n_tiles, inner, idx);
         hipDeviceSynchronize();
         hipMemcpy(out.data(), Y, out.size() * 4, hipMemcpyDeviceToHost);
         long long bt = 0;
@@ -115,9 +140,12 @@ int main(int argc, char** argv) {
       }
       printf("grid %3d (%d wave%s/SIMD) %-8s: %d of %d runs differ from the reference, %lld of %lld tiles\n", grid, grid / 256,
              grid == 256 ? "" : "s (up to)", fenced ? "fenced" : "unfenced", bad_runs, repeats, bad_tiles, (long long)repeats * n_tiles);
-      if (!fenced || grid == 256) total_bad += 0;
+      total_bad += bad_runs;
     }
   }
+  }
+  printf("runs with any difference: %d\n", total_bad);
+  hipFree(idx);
   hipFree(W); hipFree(b); hipFree(X); hipFree(Y);
   return 0;
 }
