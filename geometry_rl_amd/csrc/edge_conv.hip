@@ -26,7 +26,7 @@ constexpr int LDB = GRL_LDB(64); // 72   split-bf16 images (chain)
 constexpr int LDB1 = GRL_LDB(16);// 24
 
 struct EdgeParams {
-  const float* x_src;    // [Ns,16,64]
+  const st_t* x_src;     // [Ns,16,64] (storage type: grl_common.h)
   const float* pos_src;  // [Ns,3]
   const float* pos_dst;  // [Nd,3]
   const int* rowptr;     // [Na+1]  anchor-sorted CSR (anchor = dst in forward, src in backward)
@@ -264,7 +264,7 @@ constexpr int FWD_WAVES = GRL_FWD_WAVES;
 // four waves take every fourth pass and the four partial messages are added in wave order through LDS.
 template <bool SPLIT>
 __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
-(EdgeParams p, float* __restrict__ x1 /*[Nd,16,64]*/) {
+(EdgeParams p, st_t* __restrict__ x1 /*[Nd,16,64]*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
         PassMeta nxt;
         const bool more = e + ESTEP < e1;
         if (more) meta_indices(p, e + ESTEP + el, e1, nxt);                   // next pass: indices in flight
-        const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
+        const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
         float4 xv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) xv[t] = xs[2 * t];                         // this pass: x_src row in flight
+        for (int t = 0; t < 8; ++t) xv[t] = ld4(xs + 8 * t);                   // this pass: x_src row in flight
         float4 g1[8], gp1[8], g2[8], gp2[8];
         ChainFrags cf;
         const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
     }
     // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's
     const int node = d0 + el;
-    float4* dstp = reinterpret_cast<float4*>(x1 + ((size_t)node * O + o) * C) + h;
+    st_t* dstp = x1 + ((size_t)node * O + o) * C + 4 * h;
     float4* red = reinterpret_cast<float4*>(smem_raw + sizeof(ChainW) / 4);   // SPLIT only: [FWD_WAVES][8][64]
     if (SPLIT) __syncthreads();   // the previous tile's sums have been read
 #pragma unroll
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
       const bool is_a = el == 0;
       const float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
       if (SPLIT) red[(wave * 8 + t) * 64 + lane] = v;
-      else if (node < d1) dstp[2 * t] = v;
+      else if (node < d1) st4(dstp + 8 * t, v);
     }
     if (SPLIT) {
       __syncthreads();
@@ -337,11 +337,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
         float4 v = red[t * 64 + lane];
 #pragma unroll
         for (int w_ = 1; w_ < FWD_WAVES; ++w_) v = f4_add(v, red[(w_ * 8 + t) * 64 + lane]);
-        if (node < d1) dstp[2 * t] = v;
+        if (node < d1) st4(dstp + 8 * t, v);
       }
     }
   }
-  if (sink == 123456.789f) x1[0] = sink;   // never true
+  if (sink == 123456.789f) st1(x1, sink);   // never true
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -359,9 +359,9 @@ constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
 
 // p is the SOURCE-anchored view of the edge set (rowptr = rowptr_s, e_src / e_dst in source-sorted order, n_anchor = n_src).
-__global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                 float* __restrict__ dx_src /*[Ns,16,64]*/,
-                                                                 const float* __restrict__ dres /*[Ns,16,64] or null*/) {
+__global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, const st_t* __restrict__ dx1 /*[Nd,16,64]*/,
+                                                                 st_t* __restrict__ dx_src /*[Ns,16,64]*/,
+                                                                 const st_t* __restrict__ dres /*[Ns,16,64] or null*/) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
   load_chain_weights(s, p);
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
         PassMeta nxt;
         const bool more = e + 2 < e1;
         if (more) meta_indices(p, e + 2 + el, e1, nxt);
-        const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
+        const st_t* dm = dx1 + ((size_t)cur.dst * O + o) * C + 4 * h;
         float4 dv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) dv[t] = dm[2 * t];   // in flight behind the chain
+        for (int t = 0; t < 8; ++t) dv[t] = ld4(dm + 8 * t);   // in flight behind the chain
         float4 g1[8], gp1[8], g2[8], gp2[8];
         ChainFrags cf;
         const float wa = (cur.valid && cur.src == s0) ? 1.f : 0.f;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
     }
     // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's (see the forward kernel)
     const int node = s0 + el;
-    float4* dstp = reinterpret_cast<float4*>(dx_src + ((size_t)node * O + o) * C) + h;
+    st_t* dstp = dx_src + ((size_t)node * O + o) * C + 4 * h;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float4 a = accA[t], b = accB[t];
@@ -421,15 +421,15 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
       const bool is_a = el == 0;
       float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
       if (node < s1) {
-        if (dres) v = f4_add(v, (reinterpret_cast<const float4*>(dres + ((size_t)node * O + o) * C) + h)[2 * t]);  // + residual branch
-        dstp[2 * t] = v;
+        if (dres) v = f4_add(v, ld4(dres + ((size_t)node * O + o) * C + 4 * h + 8 * t));  // + residual branch
+        st4(dstp + 8 * t, v);
       }
     }
   }
-  if (sink == 123456.789f) dx_src[0] = sink;   // never true
+  if (sink == 123456.789f) st1(dx_src, sink);   // never true
 }
 
-__global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, const float* __restrict__ dx1 /*[Nd,16,64]*/,
+__global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, const st_t* __restrict__ dx1 /*[Nd,16,64]*/,
                                                                   float* __restrict__ partial, int n_edges) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
@@ -466,11 +466,11 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
     PassMeta nxt;
     const bool more = ps + stride < n_pass;
     if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
-    const float4* xs = reinterpret_cast<const float4*>(p.x_src + ((size_t)cur.src * O + o) * C) + h;
-    const float4* dm = reinterpret_cast<const float4*>(dx1 + ((size_t)cur.dst * O + o) * C) + h;
+    const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
+    const st_t* dm = dx1 + ((size_t)cur.dst * O + o) * C + 4 * h;
     float4 xv[8], dv[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { xv[t] = xs[2 * t]; dv[t] = dm[2 * t]; }   // in flight behind the chain
+    for (int t = 0; t < 8; ++t) { xv[t] = ld4(xs + 8 * t); dv[t] = ld4(dm + 8 * t); }   // in flight behind the chain
     float4 g1[8], gp1[8], g2[8], gp2[8];
     ChainFrags cf;
     edge_chain<true, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, NoK{});
@@ -624,9 +624,9 @@ int grl_edge_bwd_blocks(int n_edges) {
 int grl_edge_bwd_blocks(int n_edges);
 #endif
 
-int GRL_ENTRY(grl_edge_conv_fwd)(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
-                      const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream) {
+                      const float* W2, const float* b2, const float* Wk, st_t* x1, hipStream_t stream) {
   if (n_dst <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int n_tiles = (n_dst + TD - 1) / TD;
@@ -647,14 +647,14 @@ int GRL_ENTRY(grl_edge_conv_fwd)(const float* x_src, const float* pos_src, const
 // source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten:
 // dx_src = (dres ? dres : 0) + sum over out-edges; dres [n_src,16,64] = gradient of another use of x_src (the residual branch), or NULL.
 // partial must hold grl_edge_bwd_blocks(n_edges) rows of grl_edge_partial_size() floats.
-int GRL_ENTRY(grl_edge_conv_bwd)(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                      const float* Wk, const float* dx1, const float* dres, float* dx_src, float* partial, hipStream_t stream) {
+                      const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, hipStream_t stream) {
   if (n_edges <= 0) {
     if (n_src > 0) {
-      if (dres) hipMemcpyAsync(dx_src, dres, sizeof(float) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
-      else hipMemsetAsync(dx_src, 0, sizeof(float) * (size_t)n_src * O * C, stream);
+      if (dres) hipMemcpyAsync(dx_src, dres, sizeof(st_t) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
+      else hipMemsetAsync(dx_src, 0, sizeof(st_t) * (size_t)n_src * O * C, stream);
     }
     return 0;
   }

@@ -257,6 +257,37 @@ GRL_DEVINL void split_frags(const float4 (&x)[K / 8], bf16x8 (&hi)[K / 16], bf16
   for (int s = 0; s < K / 16; ++s) split_pair(x[2 * s], x[2 * s + 1], hi[s], lo[s]);
 }
 
+// ---- storage type of the node latents ([N,16,64] tensors x, x1, x2 and their gradients) -----------------------------------------
+// GRL_PREC = 0: float.  GRL_PREC = 1 (BASELINE config 5, "bf16 storage / MFMA, fp32 accumulate"): bf16 in HBM, widened to fp32 in
+// registers; every accumulation stays fp32 and the rounding to nearest bf16 happens once, at the store.  Weights, positions, weight-
+// gradient partial slabs and everything at the loss stay fp32.
+#if GRL_PREC
+typedef unsigned short st_t;   // bf16 bits
+GRL_DEVINL float ld1(const st_t* p) { return __uint_as_float((unsigned)(*p) << 16); }
+GRL_DEVINL void st1(st_t* p, float v) { *p = (unsigned short)(pack_rn(v, 0.f) & 0xFFFFu); }
+GRL_DEVINL float4 ld4(const st_t* p) {   // 4 consecutive elements, 8-byte aligned
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+GRL_DEVINL void st4(st_t* p, const float4& v) {
+  uint2 u;
+  u.x = pack_rn(v.x, v.y);
+  u.y = pack_rn(v.z, v.w);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+GRL_DEVINL float4 ld4_nt(const st_t* p) { return ld4(p); }
+GRL_DEVINL void st4_nt(st_t* p, const float4& v) { st4(p, v); }
+#else
+typedef float st_t;
+GRL_DEVINL float ld1(const st_t* p) { return *p; }
+GRL_DEVINL void st1(st_t* p, float v) { *p = v; }
+GRL_DEVINL float4 ld4(const st_t* p) { return *reinterpret_cast<const float4*>(p); }
+GRL_DEVINL void st4(st_t* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+GRL_DEVINL float4 ld4_nt(const st_t* p) { return load_nt4(p); }
+GRL_DEVINL void st4_nt(st_t* p, const float4& v) { store_nt4(p, v); }
+#endif
+
 // LDS leading dimension (in bf16 elements) of a [rows][K] split-weight image: +8 elements (16 B) keeps ds_read_b128 conflict-free
 #define GRL_LDB(K) ((K) + 8)
 

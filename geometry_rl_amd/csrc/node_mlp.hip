@@ -28,15 +28,15 @@ struct MlpSmemBf {
 GRL_DEVINL float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // loads this lane's 8 fragments of row `row` (64 floats)
-GRL_DEVINL void load_row(const float* base, size_t row, int h, float4 (&f)[8]) {
-  const float4* p = reinterpret_cast<const float4*>(base + row * C) + h;
+GRL_DEVINL void load_row(const st_t* base, size_t row, int h, float4 (&f)[8]) {
+  const st_t* p = base + row * C + 4 * h;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) f[t] = p[2 * t];
+  for (int t = 0; t < 8; ++t) f[t] = ld4(p + 8 * t);
 }
-GRL_DEVINL void store_row(float* base, size_t row, int h, const float4 (&f)[8]) {
-  float4* p = reinterpret_cast<float4*>(base + row * C) + h;
+GRL_DEVINL void store_row(st_t* base, size_t row, int h, const float4 (&f)[8]) {
+  st_t* p = base + row * C + 4 * h;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) p[2 * t] = f[t];
+  for (int t = 0; t < 8; ++t) st4(p + 8 * t, f[t]);
 }
 
 GRL_DEVINL f32x16 bias_acc(const float* bias, int n0, int h) {
@@ -52,9 +52,9 @@ GRL_DEVINL f32x16 bias_acc(const float* bias, int n0, int h) {
 // ------------------------------------------------------------------------------------------------ forward
 // Both GEMMs run on the bf16 matrix pipe with split operands (grl_common.h): per 32-row tile 2 x 96 bf16 MFMAs of 32 cycles
 // instead of 2 x 256 fp32 MFMAs of 64 cycles.
-__global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const float* __restrict__ x2, const float* __restrict__ x_dst,
+__global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restrict__ x2, const st_t* __restrict__ x_dst,
                                                            const float* W3, const float* b3, const float* W4, const float* b4,
-                                                           const float* gam, const float* bet, float* __restrict__ out,
+                                                           const float* gam, const float* bet, st_t* __restrict__ out,
                                                            int n_rows, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   MlpSmemBf& s = *reinterpret_cast<MlpSmemBf*>(smem_raw);
@@ -189,10 +189,10 @@ GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
   sink += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, acc[0]), 0xE4, 0xF, 0xF, false));
 }
 
-__global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __restrict__ x2, const float* __restrict__ dout,
+__global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __restrict__ x2, const st_t* __restrict__ dout,
                                                                   const float* __restrict__ W3, const float* __restrict__ b3,
                                                                   const float* __restrict__ W4, const float* __restrict__ gam,
-                                                                  const float* __restrict__ bet, float* __restrict__ dx2,
+                                                                  const float* __restrict__ bet, st_t* __restrict__ dx2,
                                                                   float* __restrict__ partial, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   MlpBwdSmem& s = *reinterpret_cast<MlpBwdSmem*>(smem_raw);
@@ -237,12 +237,12 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
     const bool ok = row < n_rows;
     const size_t g = (size_t)(ok ? row : 0) * C + 4 * cq;
 #if GRL_MLP_NT   // streamed once: keep these lines from displacing the workgroup's W3 fragment slab in L2 (profiles/r01_pmc_table_v12:
-                 // the launch fetched 2.9x its algorithmic bytes from the fabric)
-    px = load_nt4(x2 + g);
-    pd = load_nt4(dout + g);
+                 // the launch fetched 2.9x its algorithmic bytes from the fabric; with nt loads 2.4x: profiles/r02_node_mlp_bwd_nt_fetch.txt)
+    px = ld4_nt(x2 + g);
+    pd = ld4_nt(dout + g);
 #else
-    px = *reinterpret_cast<const float4*>(x2 + g);
-    pd = *reinterpret_cast<const float4*>(dout + g);
+    px = ld4(x2 + g);
+    pd = ld4(dout + g);
 #endif
     if (!ok) pd = make_float4(0.f, 0.f, 0.f, 0.f);
   };
@@ -463,9 +463,9 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const float* __
       const float4 dx = make_float4(rstd * (g.x - mg - xh.x * mgx), rstd * (g.y - mg - xh.y * mgx), rstd * (g.z - mg - xh.z * mgx),
                                     rstd * (g.w - mg - xh.w * mgx));
 #if GRL_MLP_NT
-      if (row < n_rows) store_nt4(dx2 + (size_t)row * C + 4 * cq, dx);
+      if (row < n_rows) st4_nt(dx2 + (size_t)row * C + 4 * cq, dx);
 #else
-      if (row < n_rows) *reinterpret_cast<float4*>(dx2 + (size_t)row * C + 4 * cq) = dx;
+      if (row < n_rows) st4(dx2 + (size_t)row * C + 4 * cq, dx);
 #endif
       dgam = make_float4(fmaf(da.x, xh.x, dgam.x), fmaf(da.y, xh.y, dgam.y), fmaf(da.z, xh.z, dgam.z), fmaf(da.w, xh.w, dgam.w));
       dbet = f4_add(dbet, da);
@@ -528,8 +528,8 @@ int grl_node_mlp_bwd_blocks(int n_rows);
 #endif
 
 // rows = n_nodes*16.  out = (accumulate ? out : 0) + x_dst + MLP(LN(x2))
-int GRL_ENTRY(grl_node_mlp_fwd)(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
-                     const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream) {
+int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, st_t* out, int n_rows, int accumulate, hipStream_t stream) {
   if (n_rows <= 0) return 0;
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
   hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
@@ -539,8 +539,8 @@ int GRL_ENTRY(grl_node_mlp_fwd)(const float* x2, const float* x_dst, const float
 }
 
 // partial [grl_node_mlp_bwd_blocks(n_rows)][grl_node_mlp_partial_size()].  d x_dst is simply dout (residual), not produced here.
-int GRL_ENTRY(grl_node_mlp_bwd)(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
-                     const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream) {
+int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, hipStream_t stream) {
   (void)b4;
   if (n_rows <= 0) return 0;
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem)));

@@ -19,7 +19,7 @@ struct FiberDfks { const float* p[4]; };
 // i.e. 3 multiply-adds per output instead of S+V (the kernel was VALU-bound at ~2x its HBM time); A and Bv cost 3+3V per (n,c).
 __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const float* __restrict__ Wenc,
-                                                              float* __restrict__ x, int N, int S, int V) {
+                                                              st_t* __restrict__ x, int N, int S, int V) {
   __shared__ float gs[O * 3];
   const int KF = S + V;
   for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
         for (int j = 0; j < 4; ++j) { Bx[j] = fmaf(vx, w[j][k], Bx[j]); By[j] = fmaf(vy, w[j][k], By[j]); Bz[j] = fmaf(vz, w[j][k], Bz[j]); }
       }
     }
-    float4* out = reinterpret_cast<float4*>(x) + n * (O * 16) + c4;
+    st_t* out = x + n * (O * C) + 4 * c4;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
       const float gx = gs[3 * o], gy = gs[3 * o + 1], gz = gs[3 * o + 2];
       float r[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) r[j] = fmaf(gz, Bz[j], fmaf(gy, By[j], fmaf(gx, Bx[j], A[j])));
-      out[o * 16] = make_float4(r[0], r[1], r[2], r[3]);
+      st4(out + o * C, make_float4(r[0], r[1], r[2], r[3]));
     }
   }
 }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
 // dW[c,s] = sum_n scal[n,s] D0,  dW[c,S+v] = sum_n vec[n,v,:] . D[n,c,:]  -- 4 multiply-adds per dx element instead of S+V.
 // Thread (c, part): channel c, nodes part, part+4, ...; a node's 16 rows of dx are 16 coalesced loads in flight.
 __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
-                                                              const float* __restrict__ grid, const float* __restrict__ dx,
+                                                              const float* __restrict__ grid, const st_t* __restrict__ dx,
                                                               float* __restrict__ partial, int N, int S, int V) {
   __shared__ float gs[O * 3];
   __shared__ float red[4 * C * KF_MAX];
@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __res
 #pragma unroll
   for (int k = 0; k < KF_MAX; ++k) dw[k] = 0.f;
   for (size_t n = (size_t)blockIdx.x * 4 + part; n < (size_t)N; n += (size_t)gridDim.x * 4) {
-    const float* dp = dx + n * (O * C) + c;
+    const st_t* dp = dx + n * (O * C) + c;
     float dv[O];
 #pragma unroll
-    for (int o = 0; o < O; ++o) dv[o] = dp[o * C];
+    for (int o = 0; o < O; ++o) dv[o] = ld1(dp + o * C);
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------------ fiber conv
 // thread (c, q): owns channel c and the output-orientation quad p = 4q..4q+3; fk[o][p][c] slice lives in registers.
-__global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ fk,
-                                                             const float* __restrict__ bias, float* __restrict__ x2, int N) {
+__global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
+                                                             const float* __restrict__ bias, st_t* __restrict__ x2, int N) {
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   float k[O][4];
 #pragma unroll
@@ -122,24 +122,24 @@ __global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) k[o][j] = fk[(o * O + 4 * q + j) * C + c] * (1.f / O);
   const float b = bias[c];
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const float* xin = x1 + (size_t)n * O * C + c;
+    const st_t* xin = x1 + (size_t)n * O * C + c;
     float acc[4] = {b, b, b, b};
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-      const float v = xin[o * C];
+      const float v = ld1(xin + o * C);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += v * k[o][j];
     }
-    float* xo = x2 + (size_t)n * O * C + c;
+    st_t* xo = x2 + (size_t)n * O * C + c;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xo[(4 * q + j) * C] = acc[j];
+    for (int j = 0; j < 4; ++j) st1(xo + (4 * q + j) * C, acc[j]);
   }
 }
 
 // partial[block] = [dfk 16*16*64 | dbias 64]
 constexpr int FIBER_PARTIAL = O * O * C + C;
-__global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ fk,
-                                                             const float* __restrict__ dx2, float* __restrict__ dx1,
+__global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
+                                                             const st_t* __restrict__ dx2, st_t* __restrict__ dx1,
                                                              float* __restrict__ partial, int N) {
   __shared__ float red[4 * C];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -155,18 +155,18 @@ __global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) dk[o][j] = 0.f;
   float db = 0.f;
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const float* xin = x1 + (size_t)n * O * C + c;
-    const float* din = dx2 + (size_t)n * O * C + c;
+    const st_t* xin = x1 + (size_t)n * O * C + c;
+    const st_t* din = dx2 + (size_t)n * O * C + c;
     float xv[O], dv[O];
 #pragma unroll
-    for (int o = 0; o < O; ++o) { xv[o] = xin[o * C]; dv[o] = din[o * C]; }
-    float* dxo = dx1 + (size_t)n * O * C + c;
+    for (int o = 0; o < O; ++o) { xv[o] = ld1(xin + o * C); dv[o] = ld1(din + o * C); }
+    st_t* dxo = dx1 + (size_t)n * O * C + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float acc = 0.f;
 #pragma unroll
       for (int p = 0; p < O; ++p) acc += dv[p] * kq[j][p];
-      dxo[(4 * q + j) * C] = acc;
+      st1(dxo + (4 * q + j) * C, acc);
       db += dv[4 * q + j];
     }
 #pragma unroll
@@ -478,11 +478,16 @@ int cap_blocks(long long work, int per_block, int cap) {
 
 extern "C" {
 
+#if !GRL_PREC   // shape queries: shared by both precision builds
 int grl_fiber_partial_size() { return FIBER_PARTIAL; }
 int grl_fiber_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
 int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
+#else
+int grl_fiber_bwd_blocks(int n_nodes);
+int grl_lift_bwd_blocks(int n_nodes);
+#endif
 
-int grl_lift_encode_fwd(const float* scal, const float* vec, const float* grid, const float* Wenc, float* x, int n_nodes,
+int GRL_ENTRY(grl_lift_encode_fwd)(const float* scal, const float* vec, const float* grid, const float* Wenc, st_t* x, int n_nodes,
                         int n_scal, int n_vec, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   if (n_scal + n_vec > KF_MAX) return -2;
@@ -494,7 +499,7 @@ int grl_lift_encode_fwd(const float* scal, const float* vec, const float* grid, 
 }
 
 // partial: [grl_lift_bwd_blocks(n_nodes)][64*(n_scal+n_vec)]
-int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, const float* dx, float* partial, int n_nodes,
+int GRL_ENTRY(grl_lift_encode_bwd)(const float* scal, const float* vec, const float* grid, const st_t* dx, float* partial, int n_nodes,
                         int n_scal, int n_vec, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   if (n_scal + n_vec > KF_MAX) return -2;
@@ -504,7 +509,7 @@ int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, 
   return 0;
 }
 
-int grl_fiber_conv_fwd(const float* x1, const float* fk, const float* bias, float* x2, int n_nodes, hipStream_t stream) {
+int GRL_ENTRY(grl_fiber_conv_fwd)(const st_t* x1, const float* fk, const float* bias, st_t* x2, int n_nodes, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   hipLaunchKernelGGL(fiber_conv_fwd_kernel, dim3(cap_blocks(n_nodes, 4, 2048)), dim3(256), 0, stream, x1, fk, bias, x2,
                      n_nodes);
@@ -513,7 +518,7 @@ int grl_fiber_conv_fwd(const float* x1, const float* fk, const float* bias, floa
 }
 
 // partial: [grl_fiber_bwd_blocks(n_nodes)][grl_fiber_partial_size()]
-int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float* dx1, float* partial, int n_nodes,
+int GRL_ENTRY(grl_fiber_conv_bwd)(const st_t* x1, const float* fk, const st_t* dx2, st_t* dx1, float* partial, int n_nodes,
                        hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   hipLaunchKernelGGL(fiber_conv_bwd_kernel, dim3(grl_fiber_bwd_blocks(n_nodes)), dim3(256), 0, stream, x1, fk, dx2, dx1,
@@ -522,6 +527,7 @@ int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float
   return 0;
 }
 
+#if !GRL_PREC   // parameter-only and reduction entry points exist once (fp32)
 // poly [256,3]; W1 [64,3]; W2 [64,64]; wf: HOST array of n_conv <= 4 device pointers to fiber_kernel weights [64 channels, 64];
 // fk: HOST array of n_conv device pointers to outputs [256,64]; saved: scratch [4,256,64] kept for the backward
 int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, const float* W2, const float* b2, const float* const* wf,
@@ -615,5 +621,6 @@ int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int*
   GRL_CHECK_LAUNCH();
   return 0;
 }
+#endif   // !GRL_PREC
 
 }  // extern "C"

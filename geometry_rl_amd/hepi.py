@@ -69,7 +69,7 @@ def global_std(t: torch.Tensor, group=None) -> torch.Tensor:
     summed over the ranks first, so every data-parallel replica computes the calibration factors of the WHOLE minibatch -- the same
     numbers a single device would (no rank-local re-initialisation, no divergence between replicas)."""
     if group is None:
-        return t.std()
+        return t.float().std()   # (bf16 latents: statistics in fp32)
     import torch.distributed as dist
     td = t.double()
     m = torch.stack([td.sum(), (td * td).sum(), torch.tensor(float(t.numel()), dtype=torch.float64, device=t.device)])
@@ -177,7 +177,7 @@ class HEPi(nn.Module):
         x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
                                 conv.kernel.weight, es, self.dim, res, self._prec)
         fk = fks[id(conv)]
-        x2 = ops.FiberConv.apply(x1, fk, conv.bias)
+        x2 = ops.FiberConv.apply(x1, fk, conv.bias, self._prec)
         m = conv.node_mlp
         return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res,
                                  self._prec), x1, fk
@@ -187,7 +187,7 @@ class HEPi(nn.Module):
         """hepi.py:125-173: lift/encode, message-passing rounds; returns the actuator latents [B*G, 16, 64]."""
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight)
+        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight, self._prec)
              for t in self._needed_types(graph)}
         fks = self._fiber_kernels(graph)
         for rnd in self.processor:
@@ -198,7 +198,8 @@ class HEPi(nn.Module):
                 s, _, d = et
                 outs[d], _, _ = self._conv(conv, x[s], x[d], graph, et, grid3, fks, outs.get(d))
             x.update(outs)
-        return x[graph.output_mask_key]
+        lat = x[graph.output_mask_key]
+        return lat.float() if lat.dtype != torch.float32 else lat   # the read-out of the few actuator nodes runs in fp32
 
     def one_step(self, graph: GraphBatch, u_dict, u=None, u_properties=None):
         """Reference contract: -> (out [B*G*out_vec, 3], hidden [B*G, 64])."""
@@ -217,7 +218,8 @@ class HEPi(nn.Module):
         ``group``: data-parallel process group -- the statistics are then those of the whole (sharded) minibatch."""
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight) for t in graph_full.node_types}
+        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight, self._prec)
+             for t in graph_full.node_types}
         fks = self._fiber_kernels(graph_full)
         for rnd in self.processor:
             outs = {}
@@ -227,7 +229,7 @@ class HEPi(nn.Module):
                 s, _, d = et
                 out, x1, fk = self._conv(conv, x[s], x[d], graph_full, et, grid3, fks, outs.get(d))
                 if not bool(conv.callibrated):
-                    x2 = ops.FiberConv.apply(x1, fk, torch.zeros_like(conv.bias))
+                    x2 = ops.FiberConv.apply(x1, fk, torch.zeros_like(conv.bias), self._prec)
                     s_in, s_1, s_2 = global_std(x[d], group), global_std(x1, group), global_std(x2, group)
                     conv.kernel.weight.mul_(s_in / s_1)
                     conv.fiber_kernel.weight.mul_(s_1 / s_2)

@@ -18,7 +18,8 @@ ABI_VERSION = 200   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
-VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16")]
+VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"),
+            ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16")]
 
 
 def build(verbose: bool = True, force: bool = False) -> str:
@@ -149,3 +150,15 @@ def check_f32(*tensors: torch.Tensor):
     for t in tensors:
         if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
             raise TypeError(f"expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
+
+
+def storage_dtype(prec: str) -> torch.dtype:
+    """Storage type of the node latents for an entry-point suffix: "" -> float32, "_bf16" -> bfloat16 (csrc/grl_common.h st_t)."""
+    return torch.bfloat16 if prec == "_bf16" else torch.float32
+
+
+def check_latent(prec: str, *tensors: torch.Tensor):
+    want = storage_dtype(prec)
+    for t in tensors:
+        if t is not None and (t.dtype != want or not t.is_cuda):
+            raise TypeError(f"expected a CUDA {want} latent tensor for the '{prec or 'fp32'}' kernels, got {t.dtype} on {t.device}")

@@ -105,15 +105,15 @@ class LiftEncode(torch.autograd.Function):
     """x[n,o,:] = [scalars | vectors . grid_o] W_enc^T   (reference hepi.py:136-143)."""
 
     @staticmethod
-    def forward(ctx, scal, vec, grid3, w_enc):
+    def forward(ctx, scal, vec, grid3, w_enc, prec: str = ""):
         hip.check_f32(scal, vec, grid3, w_enc)
         n, s = scal.shape
         v = vec.shape[1]
-        x = torch.empty(n, 16, 64, device=scal.device, dtype=torch.float32)
-        hip.call("grl_lift_encode_fwd", scal, vec, grid3, w_enc.contiguous(), x, n, s, v)
+        x = torch.empty(n, 16, 64, device=scal.device, dtype=hip.storage_dtype(prec))
+        hip.call("grl_lift_encode_fwd" + prec, scal, vec, grid3, w_enc.contiguous(), x, n, s, v)
         ctx.save_for_backward(scal, vec, grid3)
         ctx.kf = s + v
-        ctx.w_enc = w_enc
+        ctx.w_enc, ctx.prec = w_enc, prec
         return x
 
     @staticmethod
@@ -123,9 +123,10 @@ class LiftEncode(torch.autograd.Function):
         v = vec.shape[1]
         blocks = hip.query("grl_lift_bwd_blocks", n)
         partial = torch.empty(blocks, 64 * ctx.kf, device=dx.device, dtype=torch.float32)
-        hip.call("grl_lift_encode_bwd", scal, vec, grid3, dx.contiguous(), partial, n, s, v)
+        hip.check_latent(ctx.prec, dx)
+        hip.call("grl_lift_encode_bwd" + ctx.prec, scal, vec, grid3, dx.contiguous(), partial, n, s, v)
         (dw,) = _emit_grads(partial, [(0, 64 * ctx.kf, (64, ctx.kf), ctx.w_enc)])
-        return None, None, None, dw
+        return None, None, None, dw, None
 
 
 class EdgeConv(torch.autograd.Function):
@@ -135,8 +136,9 @@ class EdgeConv(torch.autograd.Function):
     def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int, residual=None, prec: str = ""):
         """``residual``: optional dict shared with the NodeMLP of the same layer when x_src is also that block's residual input:
         NodeMLP.backward leaves d(out)/d(x_dst) there and this backward adds it inside the d x_src kernel (no separate add pass)."""
-        hip.check_f32(x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
-        x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=torch.float32)  # every row is written by the kernel
+        hip.check_f32(pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
+        hip.check_latent(prec, x_src)
+        x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=x_src.dtype)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
         hip.call("grl_edge_conv_fwd" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
                  dim, *args, x1, rows=edges.n_edges * 16)
@@ -167,13 +169,14 @@ class FiberConv(torch.autograd.Function):
     """x2[n,p,c] = 1/16 sum_o x1[n,o,c] fk[o,p,c] + bias[c]   (reference conv.py:88-90,108-109)."""
 
     @staticmethod
-    def forward(ctx, x1, fk, bias):
-        hip.check_f32(x1, fk, bias)
+    def forward(ctx, x1, fk, bias, prec: str = ""):
+        hip.check_f32(fk, bias)
+        hip.check_latent(prec, x1)
         x2 = torch.empty_like(x1)
         fk = fk.contiguous()
-        hip.call("grl_fiber_conv_fwd", x1, fk, bias.contiguous(), x2, x1.shape[0])
+        hip.call("grl_fiber_conv_fwd" + prec, x1, fk, bias.contiguous(), x2, x1.shape[0])
         ctx.save_for_backward(x1, fk)
-        ctx.bias = bias
+        ctx.bias, ctx.prec = bias, prec
         return x2
 
     @staticmethod
@@ -184,9 +187,10 @@ class FiberConv(torch.autograd.Function):
         psize = hip.query("grl_fiber_partial_size")
         partial = torch.empty(blocks, psize, device=dx2.device, dtype=torch.float32)
         dx1 = torch.empty_like(x1)
-        hip.call("grl_fiber_conv_bwd", x1, fk, dx2.contiguous(), dx1, partial, n)
+        hip.check_latent(ctx.prec, dx2)
+        hip.call("grl_fiber_conv_bwd" + ctx.prec, x1, fk, dx2.contiguous(), dx1, partial, n)
         dfk, dbias = _emit_grads(partial, [(0, 16 * 16 * 64, (16, 16, 64), None), (16 * 16 * 64, 64, (64,), ctx.bias)])
-        return dx1, dfk, dbias
+        return dx1, dfk, dbias, None
 
 
 class FiberKernels(torch.autograd.Function):
@@ -246,7 +250,8 @@ class NodeMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor], residual=None, prec: str = ""):
-        hip.check_f32(x2, x_dst, gamma, beta, w3, b3, w4, b4)
+        hip.check_f32(gamma, beta, w3, b3, w4, b4)
+        hip.check_latent(prec, x2, x_dst, prev)
         ws = [a.contiguous() for a in (w3, b3, w4, b4, gamma, beta)]
         n_rows = x2.shape[0] * 16
         out = prev.clone() if prev is not None else torch.empty_like(x2)
@@ -285,7 +290,7 @@ class Readout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lat, grid3, wd, bd, ws, bs, shift: float, min_std: float, od: int, ov: int):
-        hip.check_f32(lat, grid3, wd, bd, ws, bs)
+        hip.check_f32(lat, grid3, wd, bd, ws, bs)   # (bf16 latents of the few actuator nodes are widened by the caller)
         n = lat.shape[0]
         dev = lat.device
         mean = torch.empty(n, ov, 3, device=dev, dtype=torch.float32)

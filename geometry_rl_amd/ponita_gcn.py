@@ -110,7 +110,7 @@ class PonitaGCN(nn.Module):
             x1t = x1.get(t)
             if x1t is None:
                 x1t = torch.zeros_like(xt)
-            x2 = ops.FiberConv.apply(x1t, fk, layer.conv.bias)
+            x2 = ops.FiberConv.apply(x1t, fk, layer.conv.bias, self._prec)
             out[t] = ops.NodeMLP.apply(x2, xt, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
                                        layer.linear_2.weight, layer.linear_2.bias, None, None, self._prec)
             if collect is not None:
@@ -120,11 +120,13 @@ class PonitaGCN(nn.Module):
     def latent_step(self, graph: GraphBatch, u_dict):
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight) for t in graph.node_types}
+        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight, self._prec)
+             for t in graph.node_types}
         fks = self._fiber_kernels()
         for layer in self.ponita.interaction_layers:
             x = self._layer(layer, x, graph, grid3, fks)
-        return x[graph.output_mask_key]
+        lat = x[graph.output_mask_key]
+        return lat.float() if lat.dtype != torch.float32 else lat
 
     def one_step(self, graph: GraphBatch, u_dict, **ignored):
         lat = self.latent_step(graph, u_dict)
@@ -138,7 +140,7 @@ class PonitaGCN(nn.Module):
         """ponita.py:178-180,187-192: statistics over ALL nodes of the homogeneous graph (all node types, padding included)."""
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight)
+        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight, self._prec)
              for t in graph_full.node_types}
         fks = self._fiber_kernels()
         cat = lambda d: torch.cat([d[t].reshape(-1) for t in graph_full.node_types])
@@ -147,7 +149,7 @@ class PonitaGCN(nn.Module):
             out = self._layer(layer, x, graph_full, grid3, fks, collect=col)
             if not bool(layer.conv.callibrated):
                 x1 = {t: col[t][0] for t in col}
-                x2 = {t: ops.FiberConv.apply(col[t][0], col[t][1], torch.zeros_like(layer.conv.bias)) for t in col}
+                x2 = {t: ops.FiberConv.apply(col[t][0], col[t][1], torch.zeros_like(layer.conv.bias), self._prec) for t in col}
                 s_in, s_1, s_2 = global_std(cat(x), group), global_std(cat(x1), group), global_std(cat(x2), group)
                 layer.conv.kernel.weight.mul_(s_in / s_1)
                 layer.conv.fiber_kernel.weight.mul_(s_1 / s_2)

@@ -51,17 +51,32 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
                       const float* b2, const float* Wk, const float* dx1, const float* dres /* optional [n_src,16,64] added to dx_src */,
                       float* dx_src, float* partial, hipStream_t stream);
 
-/* Reduced-precision twins of the four MFMA entry points (BASELINE config 5: rope_shaping_hepi_trpl, bf16): identical signatures and
- * fp32 buffers, but every dense product is ONE bf16 MFMA (operands rounded to nearest bf16, fp32 accumulation) instead of the
- * split-bf16 triple.  Tolerance: tests/test_gpu_bf16_rope.py (<= 2e-2 relative on the loss entries). */
-int grl_edge_conv_fwd_bf16(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+/* ---- reduced-precision twins (BASELINE config 5: rope_shaping_hepi_trpl, "bf16 storage / MFMA, fp32 accumulate") --------------------
+ * Same argument lists as the fp32 entry points above / below, with two differences: (1) every dense product is ONE bf16 MFMA (operands
+ * rounded to nearest bf16, fp32 accumulation) instead of the split-bf16 triple, (2) the node latents -- x, x1, x2, out and their
+ * gradients, i.e. every [N,16,64] tensor -- are stored as bf16 (`grl_bf16` = raw bits) and widened to fp32 in registers.  Weights,
+ * positions, partial slabs and everything at the loss stay fp32.  Tolerance: tests/test_gpu_bf16_rope.py (<= 2e-2 relative on the
+ * loss entries). */
+typedef unsigned short grl_bf16;
+int grl_lift_encode_fwd_bf16(const float* scal, const float* vec, const float* grid, const float* Wenc, grl_bf16* x, int n_nodes,
+                             int n_scal, int n_vec, hipStream_t stream);
+int grl_lift_encode_bwd_bf16(const float* scal, const float* vec, const float* grid, const grl_bf16* dx, float* partial, int n_nodes,
+                             int n_scal, int n_vec, hipStream_t stream);
+int grl_edge_conv_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                            const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
-                           const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
-int grl_edge_conv_bwd_bf16(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                           const float* W2, const float* b2, const float* Wk, grl_bf16* x1, hipStream_t stream);
+int grl_edge_conv_bwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                            const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
                            int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
-                           const float* b2, const float* Wk, const float* dx1, const float* dres, float* dx_src, float* partial,
-                           hipStream_t stream);
+                           const float* b2, const float* Wk, const grl_bf16* dx1, const grl_bf16* dres, grl_bf16* dx_src,
+                           float* partial, hipStream_t stream);
+int grl_fiber_conv_fwd_bf16(const grl_bf16* x1, const float* fk, const float* bias, grl_bf16* x2, int n_nodes, hipStream_t stream);
+int grl_fiber_conv_bwd_bf16(const grl_bf16* x1, const float* fk, const grl_bf16* dx2, grl_bf16* dx1, float* partial, int n_nodes,
+                            hipStream_t stream);
+int grl_node_mlp_fwd_bf16(const grl_bf16* x2, const grl_bf16* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                          const float* gamma, const float* beta, grl_bf16* out, int n_rows, int accumulate, hipStream_t stream);
+int grl_node_mlp_bwd_bf16(const grl_bf16* x2, const grl_bf16* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                          const float* gamma, const float* beta, grl_bf16* dx2, float* partial, int n_rows, hipStream_t stream);
 
 /* ---- fiber kernel basis (parameter-only, 256 rows): hepi.py:109-123,157 / ponita.py:246-268 + conv.py:62 ------------------------
  * Phi = GELU(W2 GELU(W1 poly + b1) + b2), fk_i = Phi Wf_i^T for n_conv <= 4 convolutions, one launch each way.
@@ -92,11 +107,6 @@ int grl_node_mlp_partial_size(void);
 int grl_node_mlp_bwd_blocks(int n_rows);
 int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream);
-
-int grl_node_mlp_fwd_bf16(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
-                          const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream);
-int grl_node_mlp_bwd_bf16(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
-                          const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream);
 
 /* ---- read-out + contextual std head: hepi.py:173-190 (ponita_gcn.py:129-146),
  *      algorithms/trust_region_projections/models/policy/gnn_gaussian_policy_diag.py:65-87 ------------------------------------

@@ -37,18 +37,22 @@ def _setup(shape="half"):
 
 
 def _edge(ops, t, prec=""):
-    xs = t["x"].clone().requires_grad_(True)
+    from geometry_rl_amd import hip
+    dt = hip.storage_dtype(prec)   # the "_bf16" kernels keep the node latents in bf16
+    xs = t["x"].to(dt).requires_grad_(True)
     ws = [w.clone().requires_grad_(True) for w in t["ew"]]
     y = ops.EdgeConv.apply(xs, t["ps"], t["pd"], t["grid"], *ws, t["es"], 3, None, prec)
-    y.backward(t["dy"])
+    y.backward(t["dy"].to(dt))
     return [y.detach(), xs.grad] + [w.grad for w in ws]
 
 
 def _mlp(ops, t, prec=""):
-    x2 = t["x"][:t["xd"].shape[0]].clone().requires_grad_(True)
+    from geometry_rl_amd import hip
+    dt = hip.storage_dtype(prec)
+    x2 = t["x"][:t["xd"].shape[0]].to(dt).requires_grad_(True)
     ws = [w.clone().requires_grad_(True) for w in t["mw"]]
-    y = ops.NodeMLP.apply(x2, t["xd"], *ws, None, None, prec)
-    y.backward(t["dy"])
+    y = ops.NodeMLP.apply(x2, t["xd"].to(dt), *ws, None, None, prec)
+    y.backward(t["dy"].to(dt))
     return [y.detach(), x2.grad] + [w.grad for w in ws]
 
 
