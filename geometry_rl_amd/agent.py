@@ -38,6 +38,7 @@ class AgentConfig:
     lr: float = 3e-4
     clip_grad_norm: bool = False
     max_grad_norm: float = 1.0
+    aggr: str = "add"         # "AttentionalAggregation": configs/algorithm/pyg_agent/model/hepi_attention.yaml
     precision: str = "fp32"   # "bf16": one bf16 MFMA per dense product in the actor (BASELINE config 5), fp32 storage / accumulation
 
 
@@ -47,7 +48,7 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
     if cfg.model == "hepi":
         mp = []  # utils_algo_graph.py:29-47: one fresh conv per (level, active round)
         for lvl in range(len(spec.edge_levels)):
-            mp.append([FiberBundleConv(64, 64, 64, groups=64, separable=True, widening_factor=4) if cfg.codes[lvl][k] else None
+            mp.append([FiberBundleConv(64, 64, 64, groups=64, separable=True, widening_factor=4, aggr=cfg.aggr) if cfg.codes[lvl][k] else None
                        for k in range(len(cfg.codes[lvl]))])
         gnn = HEPi(input_dim_node=n_in, input_dim_edge=len(spec.edge_types) + 4, hidden_dim=64, latent_dim=64,
                    output_dim=cfg.output_dim, output_dim_vec=cfg.output_dim_vec, node_type_mapping=spec.node_types,

@@ -40,6 +40,11 @@ struct EdgeParams {
   const float* Wk;       // [64,64]
   int n_anchor;
   int dim;
+  // Attention aggregation (conv.py:21-26,58-61,138-139): the gradient that reaches the messages is PER EDGE ([E,16,64], rows in
+  // destination-sorted edge order) instead of per destination node.  per_edge != 0: the backward kernels read row erow[i] of that
+  // tensor for the i-th edge of THEIR order (erow == nullptr: row i, i.e. the kernel walks the destination-sorted order itself).
+  const int* erow = nullptr;
+  int per_edge = 0;
 };
 
 // Polynomial features of (a, b) in the reference order (ponita.py:233-244):
@@ -219,6 +224,7 @@ GRL_DEVINL void load_chain_weights(ChainW& s, const EdgeParams& p) {
 // ------------------------------------------------------------------------------------------------ per-pass metadata
 struct PassMeta {
   int src, dst;   // node ids of this lane's edge
+  int grow;       // row of the incoming-gradient tensor for this edge: its destination node, or its per-edge row (attention)
   float a, b;     // spatial invariants for this lane's (edge, orientation)
   bool valid;
 };
@@ -228,6 +234,7 @@ GRL_DEVINL void meta_indices(const EdgeParams& p, int e, int e_end, PassMeta& m)
   const int ee = m.valid ? e : e_end - 1;
   m.src = p.e_src[ee];
   m.dst = p.e_dst[ee];
+  m.grow = p.per_edge ? (p.erow ? p.erow[ee] : ee) : m.dst;
 }
 GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o, PassMeta& m) {
   float rx = p.pos_src[3 * m.src] - p.pos_dst[3 * m.dst];
@@ -344,6 +351,54 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
   if (sink == 123456.789f) st1(x1, sink);   // never true
 }
 
+// ------------------------------------------------------------------------------------------------ messages (attention aggregation)
+// FiberBundleConv(aggr="AttentionalAggregation") (conv.py:21-26,58-61,138-139; configs/algorithm/pyg_agent/model/hepi_attention.yaml)
+// gates every message before it is summed, so the messages m_e = K_e * x_src[src(e)] have to exist per edge: this kernel is the forward
+// chain with a store in place of the per-destination sum -- flat passes of two edges in destination-sorted order, row e of
+// msg [E,16,64] = edge e of that order.  The gate, the per-destination softmax and the weighted sum follow in grl_softmax_aggregate_*.
+__global__ __launch_bounds__(256, 2) void edge_msg_fwd_kernel(EdgeParams p, st_t* __restrict__ msg /*[E,16,64]*/, int n_edges) {
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
+  load_chain_weights(s, p);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int o = r & 15, el = r >> 4;
+  float sink = 0.f;
+  const int n_pass = (n_edges + 1) >> 1;
+  const int stride = gridDim.x * 4;
+  int ps = blockIdx.x * 4 + wave;
+  PassMeta cur;
+  if (ps < n_pass) {
+    meta_indices(p, 2 * ps + el, n_edges, cur);
+    meta_invariants(p, s.grid_s, o, cur);
+  }
+#pragma unroll 1
+  for (; ps < n_pass; ps += stride) {
+    PassMeta nxt;
+    const bool more = ps + stride < n_pass;
+    if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
+    const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
+    float4 xv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xv[t] = ld4(xs + 8 * t);
+    float4 g1[8], gp1[8], g2[8], gp2[8];
+    ChainFrags cf;
+    st_t* mrow = msg + ((size_t)(2 * ps + el) * O + o) * C + 4 * h;
+    const bool ok = cur.valid;
+    edge_chain<false, GRL_FENCED_2W>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = 4 * nt + q;
+        const float4 m = f4_mul(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), xv[t]);
+        if (ok) st4(mrow + 8 * t, m);
+      }
+    }, &sink);
+    if (more) meta_invariants(p, s.grid_s, o, nxt);
+    cur = nxt;
+  }
+  if (sink == 123456.789f) st1(msg, sink);   // never true
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // Two launches, each recomputing the cheap split-bf16 chain, so that the register file holds one launch's accumulators without
 // spilling (everything in one kernel: 224 accumulator registers + the chain state, 170-220 spilled VGPRs, 30 % slower):
@@ -387,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
         PassMeta nxt;
         const bool more = e + 2 < e1;
         if (more) meta_indices(p, e + 2 + el, e1, nxt);
-        const st_t* dm = dx1 + ((size_t)cur.dst * O + o) * C + 4 * h;
+        const st_t* dm = dx1 + ((size_t)cur.grow * O + o) * C + 4 * h;
         float4 dv[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) dv[t] = ld4(dm + 8 * t);   // in flight behind the chain
@@ -467,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
     const bool more = ps + stride < n_pass;
     if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
     const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
-    const st_t* dm = dx1 + ((size_t)cur.dst * O + o) * C + 4 * h;
+    const st_t* dm = dx1 + ((size_t)cur.grow * O + o) * C + 4 * h;
     float4 xv[8], dv[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { xv[t] = ld4(xs + 8 * t); dv[t] = ld4(dm + 8 * t); }   // in flight behind the chain
@@ -677,6 +732,55 @@ int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const 
   grl_prof_begin("edge_conv_bwd_w_kernel", stream);
   hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dx1, partial, n_edges);
   grl_prof_end(stream);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- attention aggregation, edge side: messages per edge (rows in destination-sorted edge order) and the backward for a per-edge
+//      incoming gradient.  s2d [E]: for the i-th edge of the SOURCE-sorted order, its row in the destination-sorted order.
+int GRL_ENTRY(grl_edge_messages_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                                     const int* e_dst, int n_dst, int n_edges, const float* grid, int dim, const float* W1,
+                                     const float* b1, const float* W2, const float* b2, const float* Wk, st_t* msg,
+                                     hipStream_t stream) {
+  if (n_edges <= 0) return 0;
+  EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+  const size_t smem = sizeof(ChainW);
+  GRL_ONCE(hipFuncSetAttribute((const void*)edge_msg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW)));
+  int blocks = ((n_edges + 1) / 2 + 3) / 4;
+  if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
+  hipLaunchKernelGGL(edge_msg_fwd_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), smem, stream, p, msg, n_edges);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                                     const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
+                                     const int* s2d, int n_src, const float* grid, int dim, const float* W1, const float* b1,
+                                     const float* W2, const float* b2, const float* Wk, const st_t* dmsg, const st_t* dres,
+                                     st_t* dx_src, float* partial, hipStream_t stream) {
+  if (n_edges <= 0) {
+    if (n_src > 0) {
+      if (dres) hipMemcpyAsync(dx_src, dres, sizeof(st_t) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
+      else hipMemsetAsync(dx_src, 0, sizeof(st_t) * (size_t)n_src * O * C, stream);
+    }
+    return 0;
+  }
+  EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+  EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
+  pd.per_edge = 1;            // the weight kernel walks the destination-sorted order: row = edge position
+  ps.per_edge = 1;
+  ps.erow = s2d;              // the d x_src kernel walks the source-sorted order
+  const int blocks = grl_edge_bwd_blocks(n_edges);
+  const size_t smem_x = sizeof(ChainW);
+  size_t smem_w = smem_x + sizeof(BwdW);
+  if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;
+  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
+  const int n_tiles_s = (n_src + TD - 1) / TD;
+  int xblocks = (n_tiles_s + 3) / 4;
+  if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
+  hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
+  GRL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dmsg, partial, n_edges);
   GRL_CHECK_LAUNCH();
   return 0;
 }

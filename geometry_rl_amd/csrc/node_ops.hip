@@ -184,6 +184,55 @@ __global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const st_t* __restr
   if (q == 0) out[O * O * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
 }
 
+// ------------------------------------------------------------------------------------------------ attention aggregation
+// PyG AttentionalAggregation (gate_nn = Linear + ReLU, no nn) as FiberBundleConv uses it (conv.py:21-26,58-61,138-139), vmapped over the
+// orientations: per destination node d, orientation o and channel c
+//     alpha_e = softmax over the in-edges e of d of gate[e,o,c]      (exp(g - max) / (sum + 1e-16): PyG 2.5.2 utils.softmax [upstream])
+//     x1[d,o,c] = sum_e alpha_e msg[e,o,c]
+// gate / msg rows are in destination-sorted edge order, so a destination's edges are the contiguous rows rowptr[d] .. rowptr[d+1].
+// One wave per (d, o) row, lane = channel; the few edges of a destination are walked twice (max, then sums).  HBM-bound streaming.
+// Backward (closed form): d msg_e = alpha_e dx1,  d gate_e = alpha_e dx1 (msg_e - x1).
+__global__ __launch_bounds__(256) void softmax_agg_fwd_kernel(const float* __restrict__ gate, const st_t* __restrict__ msg,
+                                                              const int* __restrict__ rowptr, int n_dst, st_t* __restrict__ x1) {
+  const int c = threadIdx.x & 63;
+  const long long n_rows = (long long)n_dst * O;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (long long)gridDim.x * 4) {
+    const int d = (int)(row >> 4), o = (int)(row & 15);
+    const int e0 = rowptr[d], e1 = rowptr[d + 1];
+    float mx = -3.0e38f;
+    for (int e = e0; e < e1; ++e) mx = fmaxf(mx, gate[((size_t)e * O + o) * C + c]);
+    float den = 0.f, num = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const size_t i = ((size_t)e * O + o) * C + c;
+      const float w = __expf(gate[i] - mx);
+      den += w;
+      num = fmaf(w, ld1(msg + i), num);
+    }
+    st1(x1 + (size_t)row * C + c, e1 > e0 ? num / (den + 1e-16f) : 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __restrict__ gate, const st_t* __restrict__ msg,
+                                                              const st_t* __restrict__ x1, const st_t* __restrict__ dx1,
+                                                              const int* __restrict__ rowptr, int n_dst, float* __restrict__ dgate,
+                                                              st_t* __restrict__ dmsg) {
+  const int c = threadIdx.x & 63;
+  const long long n_rows = (long long)n_dst * O;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (long long)gridDim.x * 4) {
+    const int d = (int)(row >> 4), o = (int)(row & 15);
+    const int e0 = rowptr[d], e1 = rowptr[d + 1];
+    float mx = -3.0e38f, den = 0.f;
+    for (int e = e0; e < e1; ++e) mx = fmaxf(mx, gate[((size_t)e * O + o) * C + c]);
+    for (int e = e0; e < e1; ++e) den += __expf(gate[((size_t)e * O + o) * C + c] - mx);
+    const float inv = 1.f / (den + 1e-16f), g = ld1(dx1 + (size_t)row * C + c), xo = ld1(x1 + (size_t)row * C + c);
+    for (int e = e0; e < e1; ++e) {
+      const size_t i = ((size_t)e * O + o) * C + c;
+      const float a = __expf(gate[i] - mx) * inv;
+      st1(dmsg + i, a * g);
+      dgate[i] = a * g * (ld1(msg + i) - xo);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ fiber kernel basis
 // Phi = GELU(W2 GELU(W1 poly + b1) + b2) over the 256 (orientation, orientation) pairs (reference hepi.py:109-123,157;
 // ponita.py:246-268: fiber_basis_fn on the degree-3 polynomial of o_i . o_j) and the fiber kernels fk_i = Phi Wf_i^T of up to
@@ -523,6 +572,24 @@ int GRL_ENTRY(grl_fiber_conv_bwd)(const st_t* x1, const float* fk, const st_t* d
   if (n_nodes <= 0) return 0;
   hipLaunchKernelGGL(fiber_conv_bwd_kernel, dim3(grl_fiber_bwd_blocks(n_nodes)), dim3(256), 0, stream, x1, fk, dx2, dx1,
                      partial, n_nodes);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// gate [E,16,64] fp32 (the gate network runs as a plain library GEMM), msg [E,16,64] and x1 [n_dst,16,64] in the latent storage type,
+// rowptr [n_dst+1] = destination CSR of the edge set; every row of x1 / dgate / dmsg is written
+int GRL_ENTRY(grl_softmax_aggregate_fwd)(const float* gate, const st_t* msg, const int* rowptr, int n_dst, st_t* x1, hipStream_t stream) {
+  if (n_dst <= 0) return 0;
+  hipLaunchKernelGGL(softmax_agg_fwd_kernel, dim3(cap_blocks((long long)n_dst * O, 4, 4096)), dim3(256), 0, stream, gate, msg, rowptr,
+                     n_dst, x1);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+int GRL_ENTRY(grl_softmax_aggregate_bwd)(const float* gate, const st_t* msg, const st_t* x1, const st_t* dx1, const int* rowptr, int n_dst,
+                                         float* dgate, st_t* dmsg, hipStream_t stream) {
+  if (n_dst <= 0) return 0;
+  hipLaunchKernelGGL(softmax_agg_bwd_kernel, dim3(cap_blocks((long long)n_dst * O, 4, 4096)), dim3(256), 0, stream, gate, msg, x1, dx1,
+                     rowptr, n_dst, dgate, dmsg);
   GRL_CHECK_LAUNCH();
   return 0;
 }

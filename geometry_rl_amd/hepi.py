@@ -54,8 +54,12 @@ class FiberBundleConv(nn.Module):
         if not (separable and groups == in_channels == out_channels == 64 and attr_dim == 64 and widening_factor == 4 and bias):
             raise NotImplementedError("the HIP path implements the separable depth-wise 64-channel configuration of every "
                                       "reference config (configs/algorithm/pyg_agent/model/hepi.yaml:19-48)")
-        if aggr != "add":
-            raise NotImplementedError("AttentionalAggregation is outside the hot path (SURVEY.md section 8f.4)")
+        if aggr not in ("add", "AttentionalAggregation"):
+            raise NotImplementedError("aggr: 'add' (hepi.yaml) or 'AttentionalAggregation' (hepi_attention.yaml)")
+        self.attention = aggr == "AttentionalAggregation"
+        if self.attention:   # conv.py:21-26: PyG registers the aggregation as ``aggr_module`` with gate_nn = Sequential(Linear, ReLU)
+            self.aggr_module = nn.Module()
+            self.aggr_module.gate_nn = nn.Sequential(nn.Linear(in_channels, in_channels), nn.ReLU())
         self.kernel = nn.Linear(attr_dim, in_channels, bias=False)
         self.fiber_kernel = nn.Linear(attr_dim, in_channels, bias=False)
         self.bias = nn.Parameter(torch.zeros(out_channels))
@@ -174,8 +178,15 @@ class HEPi(nn.Module):
         b = self.basis_fn
         # x feeds the convolution AND the residual of its own node block: the two gradients are summed inside the d x_src kernel
         res = {} if (x_src is x_dst and prev is None and torch.is_grad_enabled() and x_src.requires_grad) else None
-        x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
-                                conv.kernel.weight, es, self.dim, res, self._prec)
+        if getattr(conv, "attention", False):
+            # messages per edge -> gate network (a plain library GEMM + ReLU, autograd) -> per-destination softmax-weighted sum
+            msg = ops.EdgeMessages.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
+                                         conv.kernel.weight, es, self.dim, res, self._prec)
+            gate = conv.aggr_module.gate_nn(msg if msg.dtype == torch.float32 else msg.float())
+            x1 = ops.SoftmaxAggregate.apply(gate, msg, es, self._prec)
+        else:
+            x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
+                                    conv.kernel.weight, es, self.dim, res, self._prec)
         fk = fks[id(conv)]
         x2 = ops.FiberConv.apply(x1, fk, conv.bias, self._prec)
         m = conv.node_mlp

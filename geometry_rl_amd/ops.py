@@ -25,6 +25,7 @@ class EdgeSet:
     rowptr_s: torch.Tensor  # the same edges as a source-sorted CSR (the backward sums d x_src per source node in registers)
     src_s: torch.Tensor
     dst_s: torch.Tensor
+    s2d: Optional[torch.Tensor] = None  # row of the i-th source-sorted edge in the destination-sorted order (attention aggregation)
 
 
 def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
@@ -37,11 +38,14 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         a, o = anchor[order], other[order]
         rowptr = torch.zeros(n_anchor + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(torch.bincount(a, minlength=n_anchor), 0)
-        return rowptr.int().contiguous(), a.int().contiguous(), o.int().contiguous()
+        return rowptr.int().contiguous(), a.int().contiguous(), o.int().contiguous(), order
 
-    rp_d, dst_d, src_d = csr(dst, src, n_dst)
-    rp_s, src_s, dst_s = csr(src, dst, n_src)
-    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s, src_s, dst_s)
+    rp_d, dst_d, src_d, order_d = csr(dst, src, n_dst)
+    rp_s, src_s, dst_s, order_s = csr(src, dst, n_src)
+    pos_d = torch.empty_like(order_d)
+    pos_d[order_d] = torch.arange(order_d.numel(), device=dev)      # original edge id -> destination-sorted position
+    s2d = pos_d[order_s].int().contiguous()                         # source-sorted position -> destination-sorted position
+    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s, src_s, dst_s, s2d)
 
 
 def _reduce(partial: torch.Tensor, out: torch.Tensor):
@@ -163,6 +167,65 @@ class EdgeConv(torch.autograd.Function):
         dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
                                                          (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])
         return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None, None, None)
+
+
+class EdgeMessages(torch.autograd.Function):
+    """msg[e] = Wk(basis_mlp(invariants_e)) * x_src[src(e)] per edge, rows in destination-sorted edge order (conv.py:79,115-117) --
+    the un-aggregated form FiberBundleConv(aggr="AttentionalAggregation") needs.  Backward: the fused d x_src / weight-gradient
+    kernels of EdgeConv, fed with the per-edge gradient."""
+
+    @staticmethod
+    def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int, residual=None, prec: str = ""):
+        hip.check_f32(pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
+        hip.check_latent(prec, x_src)
+        msg = torch.empty(edges.n_edges, 16, 64, device=x_src.device, dtype=x_src.dtype)
+        args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
+        hip.call("grl_edge_messages_fwd" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst,
+                 edges.n_edges, grid3, dim, *args, msg, rows=edges.n_edges * 16)
+        ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
+        ctx.edges, ctx.dim, ctx.residual, ctx.prec = edges, dim, residual, prec
+        ctx.params = (w1, b1, w2, b2, wk)
+        return msg
+
+    @staticmethod
+    def backward(ctx, dmsg):
+        x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk = ctx.saved_tensors
+        e = ctx.edges
+        partial = torch.empty(hip.query("grl_edge_bwd_blocks", e.n_edges), hip.query("grl_edge_partial_size"), device=dmsg.device,
+                              dtype=torch.float32)
+        dx_src = torch.empty_like(x_src)
+        dres = ctx.residual.pop("dres", None) if ctx.residual is not None else None
+        hip.call("grl_edge_messages_bwd" + ctx.prec, x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges,
+                 e.rowptr_s, e.src_s, e.dst_s, e.s2d, e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dmsg.contiguous(), dres, dx_src,
+                 partial, rows=e.n_edges * 16)
+        pw1, pb1, pw2, pb2, pwk = ctx.params
+        dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
+                                                         (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])
+        return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None, None, None)
+
+
+class SoftmaxAggregate(torch.autograd.Function):
+    """x1[d] = sum over the in-edges e of d of softmax_e(gate[e]) * msg[e], per orientation and channel (PyG AttentionalAggregation as
+    conv.py:58-61,138-139 vmaps it; gate = gate_nn(msg) is computed by the caller)."""
+
+    @staticmethod
+    def forward(ctx, gate, msg, edges: EdgeSet, prec: str = ""):
+        hip.check_f32(gate)
+        hip.check_latent(prec, msg)
+        x1 = torch.empty(edges.n_dst, 16, 64, device=msg.device, dtype=msg.dtype)
+        gate = gate.contiguous()
+        hip.call("grl_softmax_aggregate_fwd" + prec, gate, msg, edges.rowptr_d, edges.n_dst, x1)
+        ctx.save_for_backward(gate, msg, x1)
+        ctx.edges, ctx.prec = edges, prec
+        return x1
+
+    @staticmethod
+    def backward(ctx, dx1):
+        gate, msg, x1 = ctx.saved_tensors
+        dgate, dmsg = torch.empty_like(gate), torch.empty_like(msg)
+        hip.call("grl_softmax_aggregate_bwd" + ctx.prec, gate, msg, x1, dx1.contiguous(), ctx.edges.rowptr_d, ctx.edges.n_dst, dgate,
+                 dmsg)
+        return dgate, dmsg, None, None
 
 
 class FiberConv(torch.autograd.Function):

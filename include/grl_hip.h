@@ -51,6 +51,25 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
                       const float* b2, const float* Wk, const float* dx1, const float* dres /* optional [n_src,16,64] added to dx_src */,
                       float* dx_src, float* partial, hipStream_t stream);
 
+/* ---- attention aggregation: FiberBundleConv(aggr="AttentionalAggregation"), ponita/conv.py:21-26,58-61,138-139;
+ *      configs/algorithm/pyg_agent/model/hepi_attention.yaml; PyG 2.5.2 AttentionalAggregation / utils.softmax [upstream] ---------------
+ * The messages m_e = K_e * x_src[src(e)] are materialised per edge (msg [E,16,64], rows in DESTINATION-sorted edge order), gated by
+ * gate = ReLU(Linear(msg)) (a plain library GEMM on the caller's side), and summed per destination with softmax weights:
+ * x1[d,o,c] = sum_e softmax_e(gate[e,o,c]) msg[e,o,c].  Backward: grl_softmax_aggregate_bwd hands back d gate and the direct part of
+ * d msg; grl_edge_messages_bwd takes the complete per-edge d msg (s2d [E]: row of the i-th SOURCE-sorted edge in the destination-sorted
+ * order) and produces d x_src and the five weight-gradient partial rows exactly like grl_edge_conv_bwd. */
+int grl_edge_messages_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                          const int* e_dst, int n_dst, int n_edges, const float* grid, int dim, const float* W1, const float* b1,
+                          const float* W2, const float* b2, const float* Wk, float* msg, hipStream_t stream);
+int grl_edge_messages_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                          const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
+                          const int* s2d, int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
+                          const float* b2, const float* Wk, const float* dmsg, const float* dres, float* dx_src, float* partial,
+                          hipStream_t stream);
+int grl_softmax_aggregate_fwd(const float* gate, const float* msg, const int* rowptr, int n_dst, float* x1, hipStream_t stream);
+int grl_softmax_aggregate_bwd(const float* gate, const float* msg, const float* x1, const float* dx1, const int* rowptr, int n_dst,
+                              float* dgate, float* dmsg, hipStream_t stream);
+
 /* ---- reduced-precision twins (BASELINE config 5: rope_shaping_hepi_trpl, "bf16 storage / MFMA, fp32 accumulate") --------------------
  * Same argument lists as the fp32 entry points above / below, with two differences: (1) every dense product is ONE bf16 MFMA (operands
  * rounded to nearest bf16, fp32 accumulation) instead of the split-bf16 triple, (2) the node latents -- x, x1, x2, out and their
@@ -70,6 +89,18 @@ int grl_edge_conv_bwd_bf16(const grl_bf16* x_src, const float* pos_src, const fl
                            int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
                            const float* b2, const float* Wk, const grl_bf16* dx1, const grl_bf16* dres, grl_bf16* dx_src,
                            float* partial, hipStream_t stream);
+int grl_edge_messages_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                               const int* e_dst, int n_dst, int n_edges, const float* grid, int dim, const float* W1,
+                               const float* b1, const float* W2, const float* b2, const float* Wk, grl_bf16* msg, hipStream_t stream);
+int grl_edge_messages_bwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                               const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
+                               const int* s2d, int n_src, const float* grid, int dim, const float* W1, const float* b1,
+                               const float* W2, const float* b2, const float* Wk, const grl_bf16* dmsg, const grl_bf16* dres,
+                               grl_bf16* dx_src, float* partial, hipStream_t stream);
+int grl_softmax_aggregate_fwd_bf16(const float* gate, const grl_bf16* msg, const int* rowptr, int n_dst, grl_bf16* x1,
+                                   hipStream_t stream);
+int grl_softmax_aggregate_bwd_bf16(const float* gate, const grl_bf16* msg, const grl_bf16* x1, const grl_bf16* dx1, const int* rowptr,
+                                   int n_dst, float* dgate, grl_bf16* dmsg, hipStream_t stream);
 int grl_fiber_conv_fwd_bf16(const grl_bf16* x1, const float* fk, const float* bias, grl_bf16* x2, int n_nodes, hipStream_t stream);
 int grl_fiber_conv_bwd_bf16(const grl_bf16* x1, const float* fk, const grl_bf16* dx2, grl_bf16* dx1, float* partial, int n_nodes,
                             hipStream_t stream);

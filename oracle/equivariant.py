@@ -100,6 +100,19 @@ def scatter_sum(msg: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.
     return out.index_add_(0, index, msg)
 
 
+def attentional_aggregation(msg: torch.Tensor, index: torch.Tensor, dim_size: int, w_gate: torch.Tensor, b_gate: torch.Tensor):
+    """PyG 2.5.2 AttentionalAggregation(gate_nn=Sequential(Linear, ReLU)) [upstream; PARITY UNPINNED beyond the call site], vmapped over
+    the orientation axis at conv.py:58-61 (the gate network acts on the channel axis, so the vmap is a plain broadcast):
+    gate = ReLU(Linear(msg)); alpha = utils.softmax(gate, index) = exp(gate - max_group) / (sum_group + 1e-16) with the max detached;
+    out = scatter_sum(alpha * msg)."""
+    gate = F.relu(F.linear(msg, w_gate, b_gate))
+    mx = torch.full((dim_size,) + tuple(gate.shape[1:]), -float("inf"), dtype=gate.dtype)
+    mx = mx.scatter_reduce(0, index.reshape(-1, *([1] * (gate.dim() - 1))).expand_as(gate), gate.detach(), "amax", include_self=True)
+    ex = (gate - mx[index]).exp()
+    den = scatter_sum(ex, index, dim_size) + 1e-16
+    return scatter_sum(ex / den[index] * msg, index, dim_size)
+
+
 def fiber_bundle_conv(
     x_src: torch.Tensor,
     x_dst: torch.Tensor,
@@ -118,7 +131,11 @@ def fiber_bundle_conv(
     """
     kernel = F.linear(kernel_basis, P[f"{prefix}.kernel.weight"])  # conv.py:79
     msg = kernel * x_src[edge_index[0]]  # conv.py:115-117
-    x_1 = scatter_sum(msg, edge_index[1].long(), x_dst.shape[0])  # conv.py:141-147
+    if f"{prefix}.aggr_module.gate_nn.0.weight" in P:  # aggr="AttentionalAggregation" (conv.py:21-26,58-61,138-139)
+        x_1 = attentional_aggregation(msg, edge_index[1].long(), x_dst.shape[0], P[f"{prefix}.aggr_module.gate_nn.0.weight"],
+                                      P[f"{prefix}.aggr_module.gate_nn.0.bias"])
+    else:
+        x_1 = scatter_sum(msg, edge_index[1].long(), x_dst.shape[0])  # conv.py:141-147
     fiber_kernel = F.linear(fiber_basis, P[f"{prefix}.fiber_kernel.weight"])  # conv.py:88
     x_2 = torch.einsum("boc,opc->bpc", x_1, fiber_kernel) / fiber_kernel.shape[-2]  # conv.py:90
     x_2b = x_2 + P[f"{prefix}.bias"]  # conv.py:108-109

@@ -35,6 +35,7 @@ class AgentConfig:
     lr: float = 3e-4
     clip_grad_norm: bool = False
     max_grad_norm: float = 1.0
+    aggr: str = "add"  # "AttentionalAggregation": configs/algorithm/pyg_agent/model/hepi_attention.yaml
 
 
 class OracleAgent:
@@ -143,6 +144,12 @@ def init_agent_params(spec: gr.TaskSpec, cfg: AgentConfig, seed=0):
         g = eq.init_empn_params(n_in, dim=cfg.dim, num_ori=cfg.num_ori,
                                 only_upper_hemisphere=cfg.only_upper_hemisphere, num_layers=cfg.num_layers,
                                 output_dim=cfg.output_dim, output_dim_vec=cfg.output_dim_vec, seed=seed)
+    if cfg.aggr == "AttentionalAggregation" and cfg.model == "hepi":  # conv.py:21-26: gate_nn = Sequential(Linear(C, C), ReLU())
+        gen_g = torch.Generator().manual_seed(seed + 555)
+        for k, r in enumerate(rounds):
+            for et in r:
+                pre = f"processor.{k}.convs.{eq.conv_key(et)}.aggr_module.gate_nn.0"
+                g[pre + ".weight"], g[pre + ".bias"] = eq.init_linear(64, 64, True, gen_g)
     actor = {"gnn." + k: v for k, v in g.items()}
     a_per = cfg.output_dim_vec * 3
     gen = torch.Generator().manual_seed(seed + 100)

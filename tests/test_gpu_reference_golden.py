@@ -15,6 +15,9 @@ CASES = {
     "rigid_g2": dict(spec=lambda g: g.rigid_spec(P=8, G=2, E_mesh=4, angular_velocity=False, object_velocity=False),
                      dim=3, upper=False, od=1, ov=1),
     "rope_dim2": dict(spec=lambda g: g.rope_spec(n_links=7, G=2), dim=2, upper=False, od=1, ov=1),
+    # hepi_attention.yaml: FiberBundleConv(aggr="AttentionalAggregation") -- per-edge messages, gate network, per-destination softmax
+    "rigid_g2_attention": dict(spec=lambda g: g.rigid_spec(P=8, G=2, E_mesh=4, angular_velocity=False, object_velocity=False),
+                               dim=3, upper=False, od=1, ov=1, aggr="AttentionalAggregation"),
 }
 
 
@@ -31,7 +34,8 @@ def test_hepi_matches_reference_fixture(golden_dir, name):
     c = CASES[name]
     spec = c["spec"](graph)
     z = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, f"tier2b_hepi_{name}.npz")).items()}
-    cfg = agent.AgentConfig(dim=c["dim"], only_upper_hemisphere=c["upper"], output_dim=c["od"], output_dim_vec=c["ov"])
+    cfg = agent.AgentConfig(dim=c["dim"], only_upper_hemisphere=c["upper"], output_dim=c["od"], output_dim_vec=c["ov"],
+                            aggr=c.get("aggr", "add"))
     actor, _, _, _ = agent.build_agent(spec, cfg, device=dev)
     gnn = actor.gnn
 

@@ -56,6 +56,11 @@ def make_case(name, B):
         spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
         kw = dict(model="empn")
         obs = syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=8)
+    elif name == "rigid_attn":   # FiberBundleConv(aggr="AttentionalAggregation") in every round (hepi_attention.yaml)
+        o_spec = ogr.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+        spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
+        kw = dict(aggr="AttentionalAggregation")
+        obs = syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=14)
     elif name in ("rigid_frob", "rigid_w2"):   # the other two projection layers (frob_projection_layer.py, w2_projection_layer.py)
         o_spec = ogr.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
         spec = graph.rigid_spec(G=2, angular_velocity=False, object_velocity=False)
@@ -83,7 +88,7 @@ def load_params(module, params, dev):
 
 
 @pytest.mark.parametrize("name,B", [("rigid_g1", 24), ("rigid_g2", 16), ("cloth", 8), ("rope", 8), ("empn_g2", 12),
-                                    ("rigid_tiny", 6), ("rigid_one", 1), ("rigid_frob", 12), ("rigid_w2", 12)])
+                                    ("rigid_tiny", 6), ("rigid_one", 1), ("rigid_frob", 12), ("rigid_w2", 12), ("rigid_attn", 12)])
 def test_policy_update_step(name, B):
     from geometry_rl_amd import agent
     dev = torch.device("cuda:0")

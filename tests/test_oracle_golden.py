@@ -66,6 +66,10 @@ CASES = {
     "rigid_g2": dict(spec=lambda: gr.rigid_spec(P=8, G=2, E_mesh=4, angular_velocity=False, object_velocity=False),
                      dim=3, od=1, ov=1),
     "rope_dim2": dict(spec=lambda: gr.rope_spec(n_links=7, G=2), dim=2, od=1, ov=1),
+    # FiberBundleConv(aggr="AttentionalAggregation") in every round (hepi_attention.yaml): reference conv.py / hepi.py under the PyG stubs,
+    # the aggregation module itself restated from PyG 2.5.2 inside the stub (tools/make_golden.py)
+    "rigid_g2_attention": dict(spec=lambda: gr.rigid_spec(P=8, G=2, E_mesh=4, angular_velocity=False, object_velocity=False),
+                               dim=3, od=1, ov=1),
 }
 
 

@@ -53,9 +53,28 @@ def install_stubs():
     mod("stable_baselines3.common.vec_env", VecEnvWrapper=object, VecNormalize=object)
 
     # --- PyG containers (tier 2b) -------------------------------------------------------------
+    class AttentionalAggregation(nn.Module):
+        """PyG 2.5.2 nn/aggr/attention.py (gate_nn only) + utils.softmax, restated with dense one-hot products so that the reference's
+        torch.vmap over the orientation axis (conv.py:58-61) can trace it: gate = gate_nn(x); alpha = exp(gate - max_group) /
+        (sum_group + 1e-16), max detached; out = sum_group(alpha * x)."""
+
+        def __init__(self, gate_nn, nn=None):
+            super().__init__()
+            self.gate_nn = gate_nn
+
+        def forward(self, x, index, ptr=None, dim_size=None, dim=-2):
+            gate = self.gate_nn(x)
+            M = torch.nn.functional.one_hot(index, dim_size).to(x.dtype)                   # [E, Nd]
+            mx = (gate.detach()[:, None, :] + (M[:, :, None] - 1.0) * 1e30).amax(0)        # [Nd, C]
+            ex = (gate - M @ mx).exp()
+            den = M.t() @ ex + 1e-16
+            return M.t() @ (ex / (M @ den) * x)
+
     class MessagePassing(nn.Module):
         def __init__(self, node_dim=0, aggr="add", aggr_kwargs=None, **kw):
             super().__init__()
+            if aggr == "AttentionalAggregation":
+                self.aggr_module = AttentionalAggregation(**(aggr_kwargs or {}))
 
         def propagate(self, edge_index, size=None, x=None, kernel=None, dim_size=None, **kw):
             x_src, x_dst = x
@@ -228,7 +247,9 @@ def tier2():
 
 
 # ----------------------------------------------------------------------------------------------- tier 2b
-def tier2b():
+def tier2b(attention=False):
+    """``attention``: one more case, FiberBundleConv(aggr="AttentionalAggregation") in every round (hepi_attention.yaml), written to
+    tier2b_hepi_rigid_g2_attention.npz; the other fixtures are not touched."""
     from geometry_rl.modules.pyg_models.hepi import HEPi
     from geometry_rl.modules.pyg_models.ponita.conv import FiberBundleConv
     from oracle import graph as gr
@@ -245,6 +266,10 @@ def tier2b():
                           dim=2, upper=False, od=1, ov=1),
     }
     codes = [[1, 0], [0, 1], [0, 1]]
+    aggr = "add"
+    if attention:
+        cases = {"rigid_g2_attention": cases["rigid_g2"]}
+        aggr = "AttentionalAggregation"
     for name, c in cases.items():
         spec = c["spec"]
         obs = c["obs"](21)
@@ -255,7 +280,7 @@ def tier2b():
         torch.manual_seed(77)
         mp = []
         for lvl in range(3):
-            mp.append([FiberBundleConv(64, 64, 64, groups=64, separable=True, widening_factor=4) if codes[lvl][k] else None
+            mp.append([FiberBundleConv(64, 64, 64, groups=64, separable=True, widening_factor=4, aggr=aggr) if codes[lvl][k] else None
                        for k in range(2)])
         n_in = len(spec.node_types) + spec.n_vec
         net = HEPi(input_dim_node=n_in, input_dim_edge=0, hidden_dim=64, latent_dim=64, output_dim=c["od"],
@@ -423,11 +448,16 @@ if __name__ == "__main__":
         install_stubs()
         tier2d()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "attention":
+        install_stubs()
+        tier2b(attention=True)
+        sys.exit(0)
     tier1()
     install_stubs()
     tier2()
     tier2b()
     tier2c()
     tier2d()
+    tier2b(attention=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
