@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void softmax_agg_fwd_kernel(const float* __res
     float den = 0.f, num = 0.f;
     for (int e = e0; e < e1; ++e) {
       const size_t i = ((size_t)e * O + o) * C + c;
-      const float w = __expf(gate[i] - mx);
+      const float w = expf(gate[i] - mx);
       den += w;
       num = fmaf(w, ld1(msg + i), num);
     }
@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void softmax_agg_bwd_kernel(const float* __res
     const int e0 = rowptr[d], e1 = rowptr[d + 1];
     float mx = -3.0e38f, den = 0.f;
     for (int e = e0; e < e1; ++e) mx = fmaxf(mx, gate[((size_t)e * O + o) * C + c]);
-    for (int e = e0; e < e1; ++e) den += __expf(gate[((size_t)e * O + o) * C + c] - mx);
+    for (int e = e0; e < e1; ++e) den += expf(gate[((size_t)e * O + o) * C + c] - mx);
     const float inv = 1.f / (den + 1e-16f), g = ld1(dx1 + (size_t)row * C + c), xo = ld1(x1 + (size_t)row * C + c);
     for (int e = e0; e < e1; ++e) {
       const size_t i = ((size_t)e * O + o) * C + c;
-      const float a = __expf(gate[i] - mx) * inv;
+      const float a = expf(gate[i] - mx) * inv;
       st1(dmsg + i, a * g);
       dgate[i] = a * g * (ld1(msg + i) - xo);
     }
