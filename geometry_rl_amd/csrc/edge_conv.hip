@@ -95,6 +95,25 @@ GRL_DEVINL f32x16 bias_frag(const float* bias_s, int n0, int h) {
 // One pass of the chain for this lane's row.  BWD keeps the activation derivatives; FENCED selects the two-waves-per-SIMD-safe
 // MFMA grouping (grl_common.h); k_epilogue(nt, acc) receives the two 32-column tiles of the kernel layer K = Wk g2 (pass
 // nullptr_t-like NoK to skip that layer).
+// ---- in-kernel phase timing (diagnostic build only: -DGRL_PHASE_PROF; tools/edge_phase.py reads the totals) ----------------------------
+// s_memtime stamps between the stages of the chain and of the kernels around it, accumulated by ONE wave per workgroup into a
+// __device__ table [kernel][phase].  The stamps cost ~10 % of the wave's cycles and serialise nothing else; shares, not absolutes.
+#ifdef GRL_PHASE_PROF
+__device__ unsigned long long g_ephase[3][24];
+struct PhaseClock {
+  unsigned long long ph[24], last;
+  GRL_DEVINL void start() { for (int i = 0; i < 24; ++i) ph[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+  GRL_DEVINL void stamp(int i) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph[i] += t - last; last = t; }
+  GRL_DEVINL void flush(int kernel) {
+    if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 1)
+      for (int i = 0; i < 24; ++i) atomicAdd(&g_ephase[kernel][i], ph[i]);
+  }
+};
+#define PHS(i) pc.stamp(i)
+#else
+struct PhaseClock { GRL_DEVINL void start() {} GRL_DEVINL void stamp(int) {} GRL_DEVINL void flush(int) {} };
+#define PHS(i)
+#endif
 struct NoK {};
 // GRL_CHAIN_PIPED (build switch, off): in the fenced (two waves per SIMD) form every MFMA group's weight fragments are requested
 // while the previous group's activation epilogue runs (mma_wx_bf_piped) instead of in front of the group.  Measured round 2: no
@@ -102,14 +121,19 @@ struct NoK {};
 #ifndef GRL_CHAIN_PIPED
 #define GRL_CHAIN_PIPED 0
 #endif
-template <bool BWD, bool FENCED, class KEpi>
+#ifndef GRL_POS_EARLY
+#define GRL_POS_EARLY 1
+#endif
+struct NoMid { GRL_DEVINL void operator()() const {} };
+template <bool BWD, bool FENCED, class KEpi, class Mid = NoMid>
 GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&g1)[8], float4 (&gp1)[8], float4 (&g2)[8], float4 (&gp2)[8],
-                           ChainFrags& f, KEpi&& k_epilogue, float* sink_p = nullptr) {
+                           ChainFrags& f, KEpi&& k_epilogue, float* sink_p, PhaseClock& pc, Mid&& mid = NoMid{}) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   float4 phi[2];
   poly_frags(a, b, h, phi[0], phi[1]);
   bf16x8 (&ph)[1] = f.ph, (&pl)[1] = f.pl;
   split_frags<16>(phi, ph, pl);
+  PHS(2);   // (a, b) available (positions of this pass arrived) + polynomial features + split
 #if GRL_CHAIN_PIPED
   if constexpr (FENCED && !BWD && !std::is_same<typename std::decay<KEpi>::type, NoK>::value) {
     float& sink = *sink_p;
@@ -163,9 +187,12 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&g1)[8], f
       act(acc);
     }
   }
+  mid();    // the caller's early requests for the NEXT pass (positions): their latency hides behind layers 2 and 3
+  PHS(3);   // layer 1: two tiles (fragment loads, 3 MFMAs, GELU each)
   bf16x8 (&g1h)[4] = f.g1h, (&g1l)[4] = f.g1l;
   split_frags<64>(g1, g1h, g1l);
   GRL_SCHED_BARRIER();
+  PHS(4);   // split of g1
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     auto act = [&](const f32x16& acc) {
@@ -185,9 +212,11 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&g1)[8], f
       act(acc);
     }
   }
+  PHS(5);   // layer 2: two tiles (fragment loads, 12 MFMAs, GELU each)
   bf16x8 (&g2h)[4] = f.g2h, (&g2l)[4] = f.g2l;
   split_frags<64>(g2, g2h, g2l);
   GRL_SCHED_BARRIER();
+  PHS(6);   // split of g2
   if constexpr (!std::is_same<typename std::decay<KEpi>::type, NoK>::value) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -201,6 +230,7 @@ GRL_DEVINL void edge_chain(const ChainW& w, float a, float b, float4 (&g1)[8], f
       }
     }
     GRL_SCHED_BARRIER();
+    PHS(7);   // kernel layer: two tiles (fragment loads, 12 MFMAs, message epilogue each)
   }
 }
 
@@ -226,6 +256,7 @@ struct PassMeta {
   int src, dst;   // node ids of this lane's edge
   int grow;       // row of the incoming-gradient tensor for this edge: its destination node, or its per-edge row (attention)
   float a, b;     // spatial invariants for this lane's (edge, orientation)
+  float rx, ry, rz, qx, qy, qz;   // pos_src / pos_dst of the edge (requested early, consumed by meta_invariants_compute)
   bool valid;
 };
 
@@ -235,6 +266,20 @@ GRL_DEVINL void meta_indices(const EdgeParams& p, int e, int e_end, PassMeta& m)
   m.src = p.e_src[ee];
   m.dst = p.e_dst[ee];
   m.grow = p.per_edge ? (p.erow ? p.erow[ee] : ee) : m.dst;
+}
+// The positions of a pass are requested as soon as its indices have arrived -- in the MIDDLE of the previous pass's chain (edge_chain's
+// ``mid`` hook, behind layer 1) -- and turned into (a, b) at its end: the dependent index -> position round trip used to sit exposed
+// at the end of every pass (phase timing, tools/edge_phase.py: 12 % of the forward, 14 % of the weights kernel).
+GRL_DEVINL void meta_pos_load(const EdgeParams& p, PassMeta& m) {   // loads only: nothing here may wait for them
+  m.rx = p.pos_src[3 * m.src]; m.ry = p.pos_src[3 * m.src + 1]; m.rz = p.pos_src[3 * m.src + 2];
+  m.qx = p.pos_dst[3 * m.dst]; m.qy = p.pos_dst[3 * m.dst + 1]; m.qz = p.pos_dst[3 * m.dst + 2];
+}
+GRL_DEVINL void meta_invariants_compute(const EdgeParams& p, const float* grid_s, int o, PassMeta& m) {
+  float rx = m.rx - m.qx, ry = m.ry - m.qy, rz = (p.dim == 2) ? 0.f : m.rz - m.qz;
+  const float gx = grid_s[3 * o], gy = grid_s[3 * o + 1], gz = grid_s[3 * o + 2];
+  m.a = rx * gx + ry * gy + rz * gz;                      // hepi.py:115
+  rx -= m.a * gx; ry -= m.a * gy; rz -= m.a * gz;
+  m.b = sqrtf(rx * rx + ry * ry + rz * rz);               // hepi.py:117
 }
 GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o, PassMeta& m) {
   float rx = p.pos_src[3 * m.src] - p.pos_dst[3 * m.dst];
@@ -281,6 +326,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
   const int n_tiles = (p.n_anchor + TD - 1) / TD;
   constexpr int ESTEP = SPLIT ? 2 * FWD_WAVES : 2;
   float sink = 0.f;   // keeps the accumulator fences of the pipelined chain alive (never stored, see the end of the kernel)
+  PhaseClock pc;
+  pc.start();
   for (int tl = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * FWD_WAVES + wave; tl < n_tiles;
        tl += SPLIT ? (int)gridDim.x : (int)gridDim.x * FWD_WAVES) {
     const int d0 = tl * TD, d1 = min(d0 + TD, p.n_anchor);
@@ -292,15 +339,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
       PassMeta cur;
       meta_indices(p, e0 + el, e1, cur);
       meta_invariants(p, s.grid_s, o, cur);
+      PHS(0);   // tile head: rowptr, first indices + positions (dependent loads, exposed)
 #pragma unroll 1
       for (int e = e0; e < e1; e += ESTEP) {
         PassMeta nxt;
         const bool more = e + ESTEP < e1;
-        if (more) meta_indices(p, e + ESTEP + el, e1, nxt);                   // next pass: indices in flight
+        // next pass: indices in flight (requested unconditionally -- meta_indices clamps past the end -- so that nothing downstream
+        // hangs on a branch: a guarded load's result is merged by register copies that wait for it on the spot)
+        meta_indices(p, e + ESTEP + el, e1, nxt);
         const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
         float4 xv[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) xv[t] = ld4(xs + 8 * t);                   // this pass: x_src row in flight
+        PHS(1);   // pass top: next indices + this pass's rows requested
         float4 g1[8], gp1[8], g2[8], gp2[8];
         ChainFrags cf;
         const float wa = (cur.valid && cur.dst == d0) ? 1.f : 0.f;
@@ -314,9 +365,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
             accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
             accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
           }
-        }, &sink);
-        if (more) meta_invariants(p, s.grid_s, o, nxt);                       // next pass: positions -> (a, b)
+        }, &sink, pc, [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });   // next pass: positions requested mid-chain
+        if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);         // next pass: positions -> (a, b)
+        else if (more) meta_invariants(p, s.grid_s, o, nxt);
         cur = nxt;
+        PHS(8);   // (a, b) of the next pass
       }
     }
     // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's
@@ -336,6 +389,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
       if (SPLIT) red[(wave * 8 + t) * 64 + lane] = v;
       else if (node < d1) st4(dstp + 8 * t, v);
     }
+    PHS(9);   // tile tail: cross-lane fold + stores
     if (SPLIT) {
       __syncthreads();
 #pragma unroll
@@ -349,6 +403,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
     }
   }
   if (sink == 123456.789f) st1(x1, sink);   // never true
+  pc.flush(0);
 }
 
 // ------------------------------------------------------------------------------------------------ messages (attention aggregation)
@@ -364,6 +419,8 @@ __global__ __launch_bounds__(256, 2) void edge_msg_fwd_kernel(EdgeParams p, st_t
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
   float sink = 0.f;
+  PhaseClock pc;
+  pc.start();
   const int n_pass = (n_edges + 1) >> 1;
   const int stride = gridDim.x * 4;
   int ps = blockIdx.x * 4 + wave;
@@ -376,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void edge_msg_fwd_kernel(EdgeParams p, st_t
   for (; ps < n_pass; ps += stride) {
     PassMeta nxt;
     const bool more = ps + stride < n_pass;
-    if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
+    meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
     const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
     float4 xv[8];
 #pragma unroll
@@ -392,8 +449,9 @@ __global__ __launch_bounds__(256, 2) void edge_msg_fwd_kernel(EdgeParams p, st_t
         const float4 m = f4_mul(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), xv[t]);
         if (ok) st4(mrow + 8 * t, m);
       }
-    }, &sink);
-    if (more) meta_invariants(p, s.grid_s, o, nxt);
+    }, &sink, pc, [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });
+    if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);
+    else if (more) meta_invariants(p, s.grid_s, o, nxt);
     cur = nxt;
   }
   if (sink == 123456.789f) st1(msg, sink);   // never true
@@ -424,6 +482,8 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int o = r & 15, el = r >> 4;
   float sink = 0.f;
+  PhaseClock pc;
+  pc.start();
 
   const int n_tiles = (p.n_anchor + TD - 1) / TD;
 #pragma unroll 1
@@ -441,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
       for (int e = e0; e < e1; e += 2) {
         PassMeta nxt;
         const bool more = e + 2 < e1;
-        if (more) meta_indices(p, e + 2 + el, e1, nxt);
+        meta_indices(p, e + 2 + el, e1, nxt);
         const st_t* dm = dx1 + ((size_t)cur.grow * O + o) * C + 4 * h;
         float4 dv[8];
 #pragma unroll
@@ -460,9 +520,11 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
             accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
             accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
           }
-        }, &sink);
-        if (more) meta_invariants(p, s.grid_s, o, nxt);
+        }, &sink, pc, [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });
+        if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);
+        else if (more) meta_invariants(p, s.grid_s, o, nxt);
         cur = nxt;
+        PHS(8);
       }
     }
     // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's (see the forward kernel)
@@ -482,6 +544,7 @@ __global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, c
     }
   }
   if (sink == 123456.789f) st1(dx_src, sink);   // never true
+  pc.flush(1);
 }
 
 __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, const st_t* __restrict__ dx1 /*[Nd,16,64]*/,
@@ -499,6 +562,8 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
   bf16x8 sel0, sel1;
   make_selectors(sel0, sel1);
 
+  PhaseClock pc;
+  pc.start();
   f32x16 accA[2][2], accB[2], accK[2][2];  // accA = dW2, accB = dW1, accK = dWk
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_) {
@@ -520,16 +585,20 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
   for (; ps < n_pass; ps += stride) {
     PassMeta nxt;
     const bool more = ps + stride < n_pass;
-    if (more) meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
+    meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
     const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
     const st_t* dm = dx1 + ((size_t)cur.grow * O + o) * C + 4 * h;
     float4 xv[8], dv[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { xv[t] = ld4(xs + 8 * t); dv[t] = ld4(dm + 8 * t); }   // in flight behind the chain
+    PHS(1);
     float4 g1[8], gp1[8], g2[8], gp2[8];
     ChainFrags cf;
-    edge_chain<true, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, NoK{});
-    if (more) meta_invariants(p, s.grid_s, o, nxt);
+    edge_chain<true, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, NoK{}, nullptr, pc,
+                            [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });
+    if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);
+    else if (more) meta_invariants(p, s.grid_s, o, nxt);
+    PHS(8);
 
     float4 dK[8];
 #pragma unroll
@@ -555,6 +624,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
           }
         }
         GRL_SCHED_BARRIER();
+        PHS(10);  // dK, its split, dWk: 4 transposed tiles (g2 x2, dK x2) + 4 x 6 MFMAs
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           f32x16 acc = zero16();
@@ -568,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
         }
       }
       GRL_SCHED_BARRIER();
+      PHS(11);  // dZ2 = (dK Wk) * gelu'(z2): 24 MFMAs from LDS fragments
       bf16x8 zh[4], zl[4];
       split_frags<64>(dz2, zh, zl);
       // ---- dW2 += dZ2^T g1, db2 += column sums of dZ2      (register-level transposes, split-bf16 products)
@@ -582,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
         }
       }
       GRL_SCHED_BARRIER();
+      PHS(12);  // split dZ2, dW2: 4 transposed tiles + 24 MFMAs
       // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
       float4 dz1[8];
 #pragma unroll
@@ -596,6 +668,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
         dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
       }
       GRL_SCHED_BARRIER();
+      PHS(13);  // dZ1: 24 MFMAs
       // ---- dW1 += dZ1^T phi, db1 += column sums of dZ1      (phi: one 16-column fragment, columns 16..31 of its tile are zero)
       {
         bf16x8 yh[4], yl[4];
@@ -610,9 +683,11 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
         }
       }
       GRL_SCHED_BARRIER();
+      PHS(14);  // split dZ1, dW1: 3 transposed tiles + 12 MFMAs
     }
     cur = nxt;
   }
+  pc.flush(2);
 
   // ---- fold the four waves' accumulators through LDS (the weight images are dead): pairs (1 -> 0, 3 -> 2), then 2 -> 0; every
   //      lane reads back exactly the slots its partner lane wrote ([register][lane]: conflict-free, no address arithmetic), so
@@ -785,4 +860,12 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
   return 0;
 }
 
+#if defined(GRL_PHASE_PROF) && !GRL_PREC
+// diagnostic build only: out [3][24] = accumulated phase ticks of (forward, d x_src, weights) kernels; reset != 0 clears them
+int grl_edge_phase_read(unsigned long long* out72, int reset) {
+  hipMemcpyFromSymbol(out72, HIP_SYMBOL(g_ephase), sizeof(unsigned long long) * 72);
+  if (reset) { unsigned long long z[72] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ephase), z, sizeof(z)); }
+  return 0;
+}
+#endif
 }  // extern "C"
