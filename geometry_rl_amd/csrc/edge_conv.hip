@@ -754,6 +754,15 @@ int grl_edge_bwd_blocks(int n_edges) {
 int grl_edge_bwd_blocks(int n_edges);
 #endif
 
+// 16-row-tile kernels (edge_conv16.hip): forward, d x_src and messages; the weight-gradient kernel and the few-tile SPLIT forward stay here
+#ifndef GRL_EDGE16
+#define GRL_EDGE16 1
+#endif
+int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                                 const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
+                                 const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                                 const float* Wk, st_t* out, const st_t* dres, hipStream_t stream);
+
 int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, st_t* x1, hipStream_t stream) {
@@ -764,6 +773,9 @@ int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const 
   GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split));
   if (n_tiles <= GRL_FWD_SPLIT_TILES) {   // fewer tiles than SIMD groups: spread each tile's passes over a workgroup
     hipLaunchKernelGGL(edge_conv_fwd_kernel<true>, dim3(n_tiles), dim3(64 * FWD_WAVES), smem_split, stream, p, x1);
+  } else if (GRL_EDGE16) {
+    return GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2,
+                                        b2, Wk, x1, nullptr, stream);
   } else {
     int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
     if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
@@ -796,7 +808,10 @@ int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const 
   if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
   GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
   grl_prof_begin("edge_conv_bwd_x_kernel", stream);
-  {
+  if (GRL_EDGE16) {
+    GRL_ENTRY(grl_edge16_launch)(1, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2,
+                                 Wk, dx_src, dres, stream);
+  } else {
     const int n_tiles_s = (n_src + TD - 1) / TD;
     int xblocks = (n_tiles_s + 3) / 4;
     if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;   // two 4-wave workgroups per CU, like the forward
@@ -821,6 +836,9 @@ int GRL_ENTRY(grl_edge_messages_fwd)(const st_t* x_src, const float* pos_src, co
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const size_t smem = sizeof(ChainW);
   GRL_ONCE(hipFuncSetAttribute((const void*)edge_msg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW)));
+  if (GRL_EDGE16)
+    return GRL_ENTRY(grl_edge16_launch)(2, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, n_edges, 1, grid, dim, W1, b1,
+                                        W2, b2, Wk, msg, nullptr, stream);
   int blocks = ((n_edges + 1) / 2 + 3) / 4;
   if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
   hipLaunchKernelGGL(edge_msg_fwd_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), smem, stream, p, msg, n_edges);
@@ -853,7 +871,11 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
   const int n_tiles_s = (n_src + TD - 1) / TD;
   int xblocks = (n_tiles_s + 3) / 4;
   if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
-  hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
+  if (GRL_EDGE16)
+    GRL_ENTRY(grl_edge16_launch)(1, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2, Wk,
+                                 dx_src, dres, stream);
+  else
+    hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
   GRL_CHECK_LAUNCH();
   hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dmsg, partial, n_edges);
   GRL_CHECK_LAUNCH();
