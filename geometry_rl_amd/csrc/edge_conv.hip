@@ -763,6 +763,15 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                                  const float* Wk, st_t* out, const st_t* dres, hipStream_t stream);
 
+// fused 16-row backward (edge_conv16.hip edge_bwd16_kernel): d x_src and the weight gradients in one launch, one chain recompute
+#ifndef GRL_EDGE_BWD16
+#define GRL_EDGE_BWD16 1
+#endif
+int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const float* pos_src, const float* pos_dst, const int* rowptr_s,
+                                     const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
+                                     const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                                     const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, hipStream_t stream);
+
 int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, st_t* x1, hipStream_t stream) {
@@ -803,6 +812,13 @@ int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const 
   EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
   const int blocks = grl_edge_bwd_blocks(n_edges);
+  if (GRL_EDGE_BWD16) {
+    grl_prof_begin("edge_bwd16_kernel", stream);
+    const int rc = GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, grid, dim,
+                                                    W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, stream);
+    grl_prof_end(stream);
+    return rc;
+  }
   const size_t smem_x = sizeof(ChainW);
   size_t smem_w = smem_x + sizeof(BwdW);
   if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
@@ -864,6 +880,9 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
   ps.per_edge = 1;
   ps.erow = s2d;              // the d x_src kernel walks the source-sorted order
   const int blocks = grl_edge_bwd_blocks(n_edges);
+  if (GRL_EDGE_BWD16)
+    return GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, grid, dim, W1, b1,
+                                            W2, b2, Wk, dres, dx_src, partial, blocks, stream);
   const size_t smem_x = sizeof(ChainW);
   size_t smem_w = smem_x + sizeof(BwdW);
   if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;

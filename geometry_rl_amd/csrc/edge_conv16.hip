@@ -33,7 +33,7 @@ GRL_DEVINL f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn
 #endif
 constexpr int E16_WAVES = GRL_E16_WAVES, E16_THREADS = 64 * E16_WAVES;
 constexpr int LD1 = 32 + 8;   // bf16 elements per image row, layer 1 (K = 14 padded to one 32-deep step)
-constexpr int LD2 = 64 + 8;   // layers 2 and 3
+constexpr int LD2 = 64 + 16;  // layers 2 and 3: 160-B rows put the 16 lanes of every ds_read_b128 group on disjoint banks (72: 2-way)
 struct ChainW16 {
   unsigned short W1h[64 * LD1], W1l[64 * LD1];
   unsigned short W2h[64 * LD2], W2l[64 * LD2];
@@ -43,7 +43,8 @@ struct ChainW16 {
 
 // image[n][32 s + 8 g + j] = W[n][32 s + 16 (j >> 2) + 4 g + (j & 3)]   (zero beyond KSRC); one (n, s, g) item per thread and step:
 // two 16-byte global loads (when aligned), one 16-byte LDS store per image
-template <int KSRC, int KPAD, int NT>
+//   TRANS: the image of W^T (row n of the image = column n of W [64,64]): the backward chain's dg = dZ W products
+template <int KSRC, int KPAD, int NT, bool TRANS = false>
 GRL_DEVINL void stage16(unsigned short* hi, unsigned short* lo, const float* __restrict__ W, int ld) {
   constexpr int ITEMS = 64 * (KPAD / 32) * 4;
   for (int idx = threadIdx.x; idx < ITEMS; idx += NT) {
@@ -52,7 +53,7 @@ GRL_DEVINL void stage16(unsigned short* hi, unsigned short* lo, const float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int f = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
-      v[j] = f < KSRC ? W[n * KSRC + f] : 0.f;
+      v[j] = f < KSRC ? (TRANS ? W[f * 64 + n] : W[n * KSRC + f]) : 0.f;
     }
     bf16x8 h, l;
     split_pair(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, l);
@@ -88,7 +89,7 @@ GRL_DEVINL void load_w16(ChainW16& s, const Edge16Params& p) {
 }
 
 // one fenced group: acc(16 features of n-tile nt x 16 rows) = init + sum over KS K-steps of W-tile . X, split-bf16
-template <int KS, class Epi>
+template <int KS, bool FENCED = true, class Epi>
 GRL_DEVINL void group16(const unsigned short* whi, const unsigned short* wlo, const bf16x8 (&xh)[KS], const bf16x8 (&xl)[KS], f32x4v acc,
                         Epi&& epi) {
   bf16x8 wh[KS], wl[KS];
@@ -105,7 +106,7 @@ GRL_DEVINL void group16(const unsigned short* whi, const unsigned short* wlo, co
     asm volatile("" ::"v"(wh[s]), "v"(wl[s]));
 #endif
   }
-  __builtin_amdgcn_sched_barrier(0);
+  if (FENCED) __builtin_amdgcn_sched_barrier(0);
 #if !defined(GRL_E16_NOMFMA) && !defined(GRL_E16_LDSONLY)
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -115,7 +116,7 @@ GRL_DEVINL void group16(const unsigned short* whi, const unsigned short* wlo, co
   }
 #endif
   epi(acc);
-  __builtin_amdgcn_sched_barrier(0);
+  if (FENCED) __builtin_amdgcn_sched_barrier(0);
 }
 
 GRL_DEVINL float4 v4(const f32x4v& a) { return make_float4(a[0], a[1], a[2], a[3]); }
@@ -262,6 +263,452 @@ __global__ __launch_bounds__(E16_THREADS, GRL_E16_WGS) void edge16_kernel(Edge16
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- fused backward
+// ONE kernel for the whole edge backward (round 1 needed two, each rebuilding the basis-MLP chain; as one 32-row kernel it spilled
+// 170-220 registers, DESIGN.md "what comes next" 1).  On 16-row tiles the chain state is half as wide and it fits:
+//   walk: SOURCE-sorted edges, one edge per pass, a chunk of source nodes per wave (exactly the d x_src kernel above), one wave per SIMD
+//   per pass: chain with derivatives (g1, g1', g2, g2'), K = Wk g2;  d x_src[src] += K * dM (registers, stored once per node);
+//             dK = dM * x_src;  dWk += dK^T g2;  dZ2 = (Wk^T dK) * g2';  dW2 += dZ2^T g1;  db2;  dZ1 = (W2^T dZ2) * g1';  dW1 += dZ1^T phi;  db1
+//   the products along the chain (contraction over features) are 16x16x32 MFMAs with the edge's 16 rows on the N side;
+//   the weight-gradient products contract over the ROWS: v_mfma_f32_32x32x16_bf16 with K = the edge's 16 rows.  Their operands
+//   need the rows in the registers and the feature on the lane -- the transpose of what the chain leaves -- so each operand is written
+//   once to a wave-private LDS image [row][feature] (bf16 hi / lo, ds_write_b64) and read back with ds_read_b64_tr_b16 (the
+//   hardware transpose read: cdna_hip_programming.md T10); no register transposes on the matrix pipe, no barrier (same wave).
+//   Weight-gradient accumulators: 160 registers per wave for the whole launch (dWk 64, dW2 64, dW1 | db1 32), one partial row per
+//   workgroup at the end in the layout of the 32-row kernel (edge_conv.hip EDGE_PARTIAL).
+// A staging image holds 16 rows x 64 features of bf16 in 4-row x 16-feature blocks of 128 B (the unit ds_read_b64_tr_b16 fetches per
+// 16-lane group), block (row >> 2, feature >> 4) at ((row >> 2) * 4 + (feature >> 4)) * 128 B, row (row & 3) of a block at 32 B, and the
+// four 8-byte feature quads of a row rotated by the block row (quad ^ (row >> 2)): the 16 lanes of a ds_write_b64 group (16 rows, one
+// quad) and the 32 lanes of a transposed read (two adjacent blocks) then both touch every bank once.  2 KB per image, no padding.
+constexpr int STG = 16 * 64;   // bf16 elements per image
+GRL_DEVINL int stg_off(int row, int feat_quad /* feature >> 2, 0..15 */) {
+  return (((row >> 2) * 4 + (feat_quad >> 2)) * 64) + (row & 3) * 16 + (((feat_quad & 3) ^ (row >> 2)) << 2);
+}
+struct Stage16 {
+  unsigned short Ah[STG], Al[STG];   // A side: dK / dZ2 / dZ1
+  unsigned short Bh[STG], Bl[STG];   // B side: g2 / g1 / phi
+};
+struct Bwd16Smem {
+  ChainW16 w;
+  unsigned short WkTh[64 * LD2], WkTl[64 * LD2];
+  unsigned short W2Th[64 * LD2], W2Tl[64 * LD2];
+  Stage16 st[4];
+};
+constexpr int BWD16_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;   // = EDGE_PARTIAL of edge_conv.hip
+
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s16 lds_v4s16;
+// fragment (8 rows x this lane's feature) of a staging image for a 32x32x16 operand: tile t = 32 features, lane (m = l & 31, h = l >> 5)
+// gets rows 8 h + j of feature 32 t + m.  Two transposed block reads (4 rows x 16 features per 16-lane group each).
+GRL_DEVINL bf16x8 tr_frag(const unsigned short* img, int t, int lane) {
+  const int h = lane >> 5, half16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  // block row 2 h (rows 8 h .. 8 h + 3) and 2 h + 1, feature block 2 t + half16; this lane supplies row q, quad p of the block
+  const unsigned short* base = img + ((2 * h) * 4 + 2 * t + half16) * 64 + q * 16 + ((p ^ (2 * h)) << 2);
+  const unsigned short* base1 = img + ((2 * h + 1) * 4 + 2 * t + half16) * 64 + q * 16 + ((p ^ (2 * h + 1)) << 2);
+  const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16*)base);
+  const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16*)base1);
+  typedef short v8s16 __attribute__((ext_vector_type(8)));
+  const v8s16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// this lane's chain-layout fragments (row r, features 32 s + {4 g .. 4 g + 3} and 32 s + 16 + {4 g .. 4 g + 3}) -> image[row][feature]
+template <int KS>
+GRL_DEVINL void stage_put(unsigned short* ih, unsigned short* il, const bf16x8 (&fh)[KS], const bf16x8 (&fl)[KS], int r, int g) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int o0 = stg_off(r, 8 * s + g), o1 = stg_off(r, 8 * s + 4 + g);   // features 32 s + 4 g .. and 32 s + 16 + 4 g ..
+    const u32x4 h = __builtin_bit_cast(u32x4, fh[s]);
+    *reinterpret_cast<uint2*>(ih + o0) = make_uint2(h[0], h[1]);
+    *reinterpret_cast<uint2*>(ih + o1) = make_uint2(h[2], h[3]);
+#if !GRL_PREC
+    const u32x4 l = __builtin_bit_cast(u32x4, fl[s]);
+    *reinterpret_cast<uint2*>(il + o0) = make_uint2(l[0], l[1]);
+    *reinterpret_cast<uint2*>(il + o1) = make_uint2(l[2], l[3]);
+#endif
+  }
+}
+// Weight-gradient accumulators are pinned to the accumulator half of the register file: the MFMA is an asm statement with the tile as
+// a read-write "a" operand (updated in place, never copied), while this file is compiled with -mllvm -amdgpu-mfma-vgpr-form so that
+// the chain's builtin MFMAs keep their results in ordinary VGPRs, where the GELU reads them (with the default selection a
+// 512-register kernel puts EVERY MFMA result into AGPRs: 450 v_accvgpr moves per pass, a third of the vector issue slots).
+// asm is opaque to the hazard recognizer: s_nop 1 covers an operand the compiler may have just copied with a VALU move; the operands
+// themselves come from LDS (counted loads: the compiler waits for them); acc_drain() before the accumulators are read at the end.
+GRL_DEVINL void mfma32_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+GRL_DEVINL void acc_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+template <int NTK>
+struct RFrags {
+  bf16x8 ah[2], al[2], bh[NTK], bl[NTK];
+};
+// the transposed operand fragments of one weight-gradient product: requested here, consumed by rowred_mma a chain step later
+template <int NTK>
+GRL_DEVINL void rowred_load(const Stage16& st, int lane, RFrags<NTK>& f) {
+#ifdef GRL_B16_NOROWMMA
+  return;
+#endif
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f.ah[t] = tr_frag(st.Ah, t, lane);
+    GRL_LO(f.al[t] = tr_frag(st.Al, t, lane);)
+  }
+#pragma unroll
+  for (int t = 0; t < NTK; ++t) {
+    f.bh[t] = tr_frag(st.Bh, t, lane);
+    GRL_LO(f.bl[t] = tr_frag(st.Bl, t, lane);)
+  }
+}
+// acc[tn][tk] (32 x 32: output feature n on the registers, input feature k on the lane) += A^T B over the 16 staged rows
+template <int NTK>
+GRL_DEVINL void rowred_mma(const RFrags<NTK>& f, f32x16 (&acc)[2][NTK]) {
+#ifdef GRL_B16_NOROWMMA
+  return;
+#endif
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int tk = 0; tk < NTK; ++tk) {
+      mfma32_acc(f.ah[tn], f.bh[tk], acc[tn][tk]);
+      GRL_LO(mfma32_acc(f.al[tn], f.bh[tk], acc[tn][tk]);)
+      GRL_LO(mfma32_acc(f.ah[tn], f.bl[tk], acc[tn][tk]);)
+    }
+}
+// weight fragments of one chain group (n-tile nt of a 64 x 64 image), requested one group ahead of their MFMAs
+struct WF2 {
+  bf16x8 h[2], l[2];
+};
+GRL_DEVINL void wf_load(WF2& f, const unsigned short* whi, const unsigned short* wlo) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    f.h[s] = *reinterpret_cast<const bf16x8*>(whi + 32 * s);
+    GRL_LO(f.l[s] = *reinterpret_cast<const bf16x8*>(wlo + 32 * s);)
+  }
+}
+GRL_DEVINL f32x4v wf_mma(const WF2& f, const bf16x8 (&xh)[2], const bf16x8 (&xl)[2], f32x4v acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    acc = mfma16(f.h[s], xh[s], acc);
+    GRL_LO(acc = mfma16(f.l[s], xh[s], acc);)
+    GRL_LO(acc = mfma16(f.h[s], xl[s], acc);)
+  }
+  return acc;
+}
+
+#ifdef GRL_B16_NOGELU
+#define B16_GELU(x, gv, gpv) ((gv) = (x), (gpv) = (x))
+#else
+#define B16_GELU(x, gv, gpv) gelu_both4((x), (gv), (gpv))
+#endif
+#ifdef GRL_B16_NOGATHER
+#define B16_LD(p) make_float4(0.5f, 0.25f, -0.5f, 1.f)
+#else
+#define B16_LD(p) ld4(p)
+#endif
+struct Bwd16Params {
+  Edge16Params e;         // the SOURCE-anchored view; e.x_in = dM rows (d x1 [Nd,16,64] or per-edge rows)
+  const st_t* x_src;      // [Ns,16,64]
+  const st_t* dres;       // optional [Ns,16,64]: gradient of the other use of x_src, added into d x_src
+  st_t* dx_src;           // [Ns,16,64], fully written
+  float* partial;         // [gridDim.x][BWD16_PARTIAL]
+};
+
+__global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  Bwd16Smem& sm = *reinterpret_cast<Bwd16Smem*>(smem_raw);
+  const Edge16Params& p = bp.e;
+  stage16<14, 32, 256>(sm.w.W1h, sm.w.W1l, p.W1, LD1);
+  stage16<64, 64, 256>(sm.w.W2h, sm.w.W2l, p.W2, LD2);
+  stage16<64, 64, 256>(sm.w.Wkh, sm.w.Wkl, p.Wk, LD2);
+  stage16<64, 64, 256, true>(sm.WkTh, sm.WkTl, p.Wk, LD2);
+  stage16<64, 64, 256, true>(sm.W2Th, sm.W2Tl, p.W2, LD2);
+  for (int i = threadIdx.x; i < 64; i += 256) {
+    sm.w.b1s[i] = p.b1[i];
+    sm.w.b2s[i] = p.b2[i];
+    sm.w.grid_s[i] = i < 48 ? p.grid[i] : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  Stage16& st = sm.st[wave];
+  for (int i = lane; i < STG / 2; i += 64) {
+    reinterpret_cast<unsigned*>(st.Ah)[i] = 0u; reinterpret_cast<unsigned*>(st.Al)[i] = 0u;
+    reinterpret_cast<unsigned*>(st.Bh)[i] = 0u; reinterpret_cast<unsigned*>(st.Bl)[i] = 0u;
+  }
+  __syncthreads();
+  const ChainW16& w = sm.w;
+  const float gx = w.grid_s[3 * r], gy = w.grid_s[3 * r + 1], gz = w.grid_s[3 * r + 2];
+
+  f32x16 accK[2][2], accA[2][2], accB[2][1];   // dWk, dW2, dW1 (| db1 in column 14)
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_) {
+    accB[a_][0] = zero16();
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_) { accK[a_][b_] = zero16(); accA[a_][b_] = zero16(); }
+  }
+  float4 db2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) db2[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int NPW = p.npw;
+  const int n_chunks = (p.n_anchor + NPW - 1) / NPW;
+#pragma unroll 1
+  for (int chunk = blockIdx.x * 4 + wave; chunk < n_chunks; chunk += gridDim.x * 4) {
+    const int n0 = chunk * NPW, nn = min(NPW, p.n_anchor - n0);
+    const int rp = p.rowptr[n0 + min(lane, nn)];
+    const int an = n0 + min(lane, nn - 1);
+    const float pax = p.pos_src[3 * an], pay = p.pos_src[3 * an + 1], paz = p.pos_src[3 * an + 2];
+    const int E0 = __builtin_amdgcn_readlane(rp, 0), E1 = __builtin_amdgcn_readlane(rp, nn);
+    int node = 0;
+    int node_end = __builtin_amdgcn_readlane(rp, 1);
+    float4 acc[4], xv[4];
+    auto node_begin = [&](int j) {   // the source node's own row: the same for all of its edges
+      const st_t* xs = bp.x_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {   // the accumulator starts from the other branch's gradient row (dres), long before it is needed
+        xv[t] = B16_LD(xs + 16 * t);
+        acc[t] = bp.dres ? B16_LD(bp.dres + ((size_t)(n0 + j) * O + r) * C + 4 * g + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto flush = [&](int j) {
+      st_t* o = bp.dx_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st4(o + 16 * t, acc[t]);
+    };
+    node_begin(0);
+    for (int eb = E0; eb < E1; eb += 64) {
+      const int ee = min(eb + lane, E1 - 1);
+      const int oth = p.e_dst[ee];
+      const int xrow = p.per_edge ? (p.erow ? p.erow[ee] : ee) : oth;
+      const float pox = p.pos_dst[3 * oth], poy = p.pos_dst[3 * oth + 1], poz = p.pos_dst[3 * oth + 2];
+      const int nb = min(64, E1 - eb);
+      // dM rows are gathered ONE EDGE AHEAD (a single wave per SIMD cannot hide an HBM round trip behind another wave)
+      float4 dvn[4];
+      auto dv_issue = [&](int kk) {
+        const int row_in = __builtin_amdgcn_readlane(xrow, kk);
+        const st_t* dm = p.x_in + ((size_t)row_in * O + r) * C + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dvn[t] = B16_LD(dm + 16 * t);
+      };
+      dv_issue(0);
+#pragma unroll 1
+      for (int k = 0; k < nb; ++k) {
+        const int e = eb + k;
+        while (e >= node_end) {
+          flush(node);
+          ++node;
+          node_end = __builtin_amdgcn_readlane(rp, node + 1);
+          node_begin(node);
+        }
+        float4 dv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dv[t] = dvn[t];
+        dv_issue(min(k + 1, nb - 1));
+        // rel = pos_src - pos_dst (hepi.py:109-117); the source is the anchor here
+        float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pax), node)) -
+                   __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pox), k));
+        float dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pay), node)) -
+                   __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, poy), k));
+        float dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, paz), node)) -
+                   __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, poz), k));
+        if (p.dim == 2) dz = 0.f;
+        const float a = dx * gx + dy * gy + dz * gz;
+        dx -= a * gx; dy -= a * gy; dz -= a * gz;
+        const float b = sqrtf(dx * dx + dy * dy + dz * dz);
+        // ---- chain with derivatives
+        const float aa = a * a, ab = a * b, bb = b * b;
+        float4 phi;   // column 14 carries a one: the dW1 product then leaves db1 in column 14 (W1's image has zeros there)
+        if (g == 0) phi = make_float4(a, b, aa, ab);
+        else if (g == 1) phi = make_float4(ab, bb, aa * a, aa * b);
+        else if (g == 2) phi = make_float4(ab * a, ab * b, ab * a, ab * b);
+        else phi = make_float4(bb * a, bb * b, 1.f, 0.f);
+        bf16x8 ph[1], pl[1];
+        split_pair(phi, make_float4(0.f, 0.f, 0.f, 0.f), ph[0], pl[0]);
+        float4 gp1[4], gp2[4];
+        bf16x8 xh[2], xl[2], yh[2], yl[2];
+        // One wave per SIMD: nobody else hides an LDS round trip, and the compiler places a fragment load next to its MFMA.  The
+        // pass is therefore cut into scheduling regions (BAR) by hand: region k issues the weight fragments of group k + 2, runs the
+        // MFMAs of group k + 1 and the epilogue (GELU / products) of group k -- loads a group ahead, matrix pipe beside the vector work.
+        // The sixteen 64-deep groups, in order: W2 (4), Wk (4), Wk^T (4), W2^T (4).
+#define BAR() __builtin_amdgcn_sched_barrier(0)
+        WF2 wf[2];
+        auto wptr_h = [&](int i) { const unsigned short* m = i < 4 ? w.W2h : i < 8 ? w.Wkh : i < 12 ? sm.WkTh : sm.W2Th; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
+        auto wptr_l = [&](int i) { const unsigned short* m = i < 4 ? w.W2l : i < 8 ? w.Wkl : i < 12 ? sm.WkTl : sm.W2Tl; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
+        // a 64-deep layer: groups base .. base + 3 (wf[base & 1] already requested); epi(nt, c) consumes tile nt one region later
+        auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], const float* bias, auto&& epi, auto&& tail) {
+          f32x4v c[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            if (base + nt + 1 < 16) wf_load(wf[(nt + 1) & 1], wptr_h(base + nt + 1), wptr_l(base + nt + 1));
+            BAR();
+            f32x4v init = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+              const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * nt + 4 * g);
+              init = f32x4v{bq.x, bq.y, bq.z, bq.w};
+            }
+            c[nt] = wf_mma(wf[nt & 1], ih, il, init);
+            if (nt > 0) epi(nt - 1, c[nt - 1]);
+            BAR();
+          }
+          epi(3, c[3]);
+          tail();
+          BAR();
+        };
+        {
+          float4 g1[4];
+          bf16x8 w1h[4], w1l[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            w1h[nt] = *reinterpret_cast<const bf16x8*>(w.W1h + (16 * nt + r) * LD1 + 8 * g);
+            GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
+          }
+          wf_load(wf[0], wptr_h(0), wptr_l(0));
+          BAR();
+          f32x4v c[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float4 bq = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
+            c[nt] = f32x4v{bq.x, bq.y, bq.z, bq.w};
+            c[nt] = mfma16(w1h[nt], ph[0], c[nt]);
+            GRL_LO(c[nt] = mfma16(w1l[nt], ph[0], c[nt]);)
+            GRL_LO(c[nt] = mfma16(w1h[nt], pl[0], c[nt]);)
+            if (nt > 0) B16_GELU(v4(c[nt - 1]), g1[nt - 1], gp1[nt - 1]);
+            BAR();
+          }
+          B16_GELU(v4(c[3]), g1[3], gp1[3]);
+          split_pair(g1[0], g1[1], xh[0], xl[0]);
+          split_pair(g1[2], g1[3], xh[1], xl[1]);
+          BAR();
+        }
+        {
+          float4 g2[4];
+          layer64(0, xh, xl, w.b2s, [&](int nt, const f32x4v& c) { B16_GELU(v4(c), g2[nt], gp2[nt]); },
+                  [&]() {
+                    split_pair(g2[0], g2[1], yh[0], yl[0]);
+                    split_pair(g2[2], g2[3], yh[1], yl[1]);
+                  });
+        }
+        // ---- K = Wk g2: d x_src row += K * dM;  dK = dM * x_src, staged with g2 for dWk += dK^T g2 (consumed after the dZ2 groups)
+        bf16x8 kh[2], kl[2];
+        RFrags<2> rf;
+        layer64(4, yh, yl, nullptr, [&](int nt, const f32x4v& c) { acc[nt] = f4_add(acc[nt], f4_mul(v4(c), dv[nt])); },
+                [&]() {
+                  split_pair(f4_mul(dv[0], xv[0]), f4_mul(dv[1], xv[1]), kh[0], kl[0]);
+                  split_pair(f4_mul(dv[2], xv[2]), f4_mul(dv[3], xv[3]), kh[1], kl[1]);
+                  stage_put<2>(st.Ah, st.Al, kh, kl, r, g);
+                  stage_put<2>(st.Bh, st.Bl, yh, yl, r, g);
+                  rowred_load<2>(st, lane, rf);
+                });
+        // ---- dZ2 = (Wk^T dK) * gelu'(z2);  db2;  then dWk's MFMAs beside the split of dZ2
+        bf16x8 zh[2], zl[2];
+        {
+          float4 dz2[4];
+          layer64(8, kh, kl, nullptr,
+                  [&](int nt, const f32x4v& c) {
+                    dz2[nt] = f4_mul(v4(c), gp2[nt]);
+                    db2[nt] = f4_add(db2[nt], dz2[nt]);
+                  },
+                  [&]() {
+                    rowred_mma<2>(rf, accK);
+                    split_pair(dz2[0], dz2[1], zh[0], zl[0]);
+                    split_pair(dz2[2], dz2[3], zh[1], zl[1]);
+                  });
+        }
+        // ---- dW2 += dZ2^T g1 (fragments requested now, product after the dZ1 groups)
+        stage_put<2>(st.Ah, st.Al, zh, zl, r, g);
+        stage_put<2>(st.Bh, st.Bl, xh, xl, r, g);
+        rowred_load<2>(st, lane, rf);
+        // ---- dZ1 = (W2^T dZ2) * gelu'(z1)
+        bf16x8 uh[2], ul[2];
+        {
+          float4 dz1[4];
+          layer64(12, zh, zl, nullptr, [&](int nt, const f32x4v& c) { dz1[nt] = f4_mul(v4(c), gp1[nt]); },
+                  [&]() {
+                    rowred_mma<2>(rf, accA);
+                    split_pair(dz1[0], dz1[1], uh[0], ul[0]);
+                    split_pair(dz1[2], dz1[3], uh[1], ul[1]);
+                  });
+        }
+        // ---- dW1 (| db1) += dZ1^T (phi | 1)
+        stage_put<2>(st.Ah, st.Al, uh, ul, r, g);
+        {   // phi image: features 4 g .. 4 g + 3 of columns 0..15; columns 16..31 of the tile are zeroed (g1 was there)
+          const u32x4 h4 = __builtin_bit_cast(u32x4, ph[0]);
+          *reinterpret_cast<uint2*>(st.Bh + stg_off(r, g)) = make_uint2(h4[0], h4[1]);
+          *reinterpret_cast<uint2*>(st.Bh + stg_off(r, 4 + g)) = make_uint2(0u, 0u);
+#if !GRL_PREC
+          const u32x4 l4 = __builtin_bit_cast(u32x4, pl[0]);
+          *reinterpret_cast<uint2*>(st.Bl + stg_off(r, g)) = make_uint2(l4[0], l4[1]);
+          *reinterpret_cast<uint2*>(st.Bl + stg_off(r, 4 + g)) = make_uint2(0u, 0u);
+#endif
+        }
+        RFrags<1> rf1;
+        rowred_load<1>(st, lane, rf1);
+        rowred_mma<1>(rf1, accB);
+#undef BAR
+      }
+    }
+    for (; node < nn; ++node) {   // the last node with edges and every trailing node without
+      flush(node);
+      if (node + 1 < nn) node_begin(node + 1);
+    }
+  }
+
+  // ---- fold the four waves through LDS (images dead): 1 -> 0 and 3 -> 2, then 2 -> 0; fixed order, one partial row per workgroup
+  constexpr int NACC = 10 * 16 + 16;
+  float* fold = smem_raw;
+  acc_drain();   // the last asm MFMAs have written the accumulators before they are read
+  auto visit = [&](auto&& f) {
+    int k = 0;
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accB[a_][0][i] = f(accB[a_][0][i], k++);
+#pragma unroll
+      for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accA[a_][b_][i] = f(accA[a_][b_][i], k++); accK[a_][b_][i] = f(accK[a_][b_][i], k++); }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      db2[t].x = f(db2[t].x, k++); db2[t].y = f(db2[t].y, k++); db2[t].z = f(db2[t].z, k++); db2[t].w = f(db2[t].w, k++);
+    }
+  };
+  __syncthreads();
+  if (wave & 1) visit([&](float v_, int k) { fold[((wave >> 1) * NACC + k) * 64 + lane] = v_; return v_; });
+  __syncthreads();
+  if (!(wave & 1)) visit([&](float v_, int k) { return v_ + fold[((wave >> 1) * NACC + k) * 64 + lane]; });
+  __syncthreads();
+  if (wave == 2) visit([&](float v_, int k) { fold[k * 64 + lane] = v_; return v_; });
+  __syncthreads();
+  if (wave != 0) return;
+  visit([&](float v_, int k) { return v_ + fold[k * 64 + lane]; });
+  // 32x32 accumulator element rho of lane (column j = lane & 31, h = lane >> 5): D[n = 8 (rho >> 2) + 4 h + (rho & 3)][j]
+  const int j = lane & 31, hh = lane >> 5;
+  float* out = bp.partial + (size_t)blockIdx.x * BWD16_PARTIAL;
+  float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64, *oWk = ob2 + 64;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int rho = 0; rho < 16; ++rho) {
+      const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * hh;
+      if (j < 14) oW1[n * 14 + j] = accB[nt][0][rho];
+      if (j == 14) ob1[n] = accB[nt][0][rho];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        oW2[n * 64 + 32 * kt + j] = accA[nt][kt][rho];
+        oWk[n * 64 + 32 * kt + j] = accK[nt][kt][rho];
+      }
+    }
+  // db2: this lane's row sums of features 16 t + 4 g + u -> over the 16 rows (lanes sharing g)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float v[4] = {db2[t].x, db2[t].y, db2[t].z, db2[t].w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float x = v[u];
+      x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+      if (r == 0) ob2[16 * t + 4 * g + u] = x;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -297,6 +744,22 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
   if (mode == 0) hipLaunchKernelGGL(edge16_kernel<0>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
   else if (mode == 1) hipLaunchKernelGGL(edge16_kernel<1>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
   else hipLaunchKernelGGL(edge16_kernel<2>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// The whole edge backward in one launch (edge_bwd16_kernel).  The arrays are the SOURCE-sorted view of the edge set; partial must
+// hold `blocks` rows of grl_edge_partial_size() floats and exactly `blocks` workgroups are launched (every row is written).
+int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const float* pos_src, const float* pos_dst, const int* rowptr_s,
+                                     const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
+                                     const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                                     const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, hipStream_t stream) {
+  int npw = n_src / (4 * 1024);            // ~4 chunks per wave (256 CUs x 4 waves)
+  npw = npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
+  Bwd16Params bp{{dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, erow, grid, W1, b1, W2, b2, Wk, n_src, n_edges, dim, 0, per_edge, npw},
+                 x_src, dres, dx_src, partial};
+  GRL_ONCE(hipFuncSetAttribute((const void*)edge_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Bwd16Smem)));
+  hipLaunchKernelGGL(edge_bwd16_kernel, dim3(blocks), dim3(256), sizeof(Bwd16Smem), stream, bp);
   GRL_CHECK_LAUNCH();
   return 0;
 }

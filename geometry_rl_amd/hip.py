@@ -18,6 +18,9 @@ ABI_VERSION = 200   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
+# per-source compiler flags.  edge_conv16.hip: its 512-register backward kernel keeps the chain's MFMA results in VGPRs (the default
+# selection would put every MFMA result of such a kernel into AGPRs) and pins the weight-gradient tiles to AGPRs itself (asm)
+FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16")]
@@ -40,7 +43,8 @@ def build(verbose: bool = True, force: bool = False) -> str:
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d)
                                                     for d in [s, os.path.join(CSRC, "grl_common.h"), os.path.abspath(__file__)]):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + flags + ["-c", s, "-o", o]
+        cmd = ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + FILE_FLAGS.get(os.path.basename(s), [])
+               + flags + ["-c", s, "-o", o])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -1,7 +1,7 @@
 // Micro-benchmark (gfx950): do one wave's MFMAs run beside ANOTHER wave's vector instructions on the same SIMD?
 // 512-thread workgroups, one per CU: waves 0-3 and 4-7 land on SIMDs 0-3 pairwise.  Role of a wave by (wave >> 2): role A runs a chain of
 // dependent v_mfma_f32_16x16x32_bf16 (or 32x32x16), role B a stream of independent v_fma_f32 / v_exp_f32 / ds_read_b128.
-// Three launches per pair: A alone (B waves exit), B alone, both.  If the pipes overlap, T(both) ~ max(T(A), T(B)); if the SIMD serialises
+// Every pair is run twice: plain, and with the B wave at s_setprio 3.  Three launches per pair: A alone (B waves exit), B alone, both.  If the pipes overlap, T(both) ~ max(T(A), T(B)); if the SIMD serialises
 // them, T(both) ~ T(A) + T(B).  Prints s_memtime ticks (100 MHz) per loop for each role.
 //   hipcc --offload-arch=gfx950 -O3 mfma_valu_overlap.hip -o mfma_valu_overlap && ./mfma_valu_overlap
 #include <hip/hip_runtime.h>
@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // AKIND: 0 = 16x16x32 one dependent chain, 1 = 32x32x16 one chain, 2 = 16x16x32 four independent chains
 // BKIND: 0 = v_fma_f32 independent, 1 = v_exp_f32, 2 = ds_read_b128 (conflict-free), 3 = v_pk_fma_f32
 template <int AKIND, int BKIND>
-__global__ __launch_bounds__(512) void k(float* out, unsigned long long* ticks, int iters, int run_a, int run_b) {
+__global__ __launch_bounds__(512) void k(float* out, unsigned long long* ticks, int iters, int run_a, int run_b, int prio_b) {
   __shared__ __attribute__((aligned(16))) float lds[64 * 4 * 8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, role = wave >> 2;
   for (int i = threadIdx.x; i < 64 * 4 * 8; i += 512) lds[i] = 0.001f * i;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* ticks, 
     t1 = __builtin_amdgcn_s_memtime();
     sink = c0[0] + c1[1] + c2[2] + c3[3] + d[0];
   } else {
+    if (prio_b) __builtin_amdgcn_s_setprio(3);   // the vector-work wave asks for issue priority over the MFMA wave
     float v[16];
     typedef float v2 __attribute__((ext_vector_type(2)));
     v2 p[8];
@@ -92,14 +93,14 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* ticks, 
 }
 
 template <int AKIND, int BKIND>
-void run(const char* an, const char* bn, int a_per_loop, float* out, unsigned long long* ticks) {
+void run(const char* an, const char* bn, int prio_b, float* out, unsigned long long* ticks) {
   const int iters = 2000, blocks = 256;
   std::vector<unsigned long long> h(blocks * 8);
   double res[3][2];
   for (int mode = 0; mode < 3; ++mode) {
     const int ra = mode != 1, rb = mode != 0;
     hipMemset(ticks, 0, sizeof(unsigned long long) * blocks * 8);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<AKIND, BKIND>), dim3(blocks), dim3(512), 0, 0, out, ticks, iters, ra, rb);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<AKIND, BKIND>), dim3(blocks), dim3(512), 0, 0, out, ticks, iters, ra, rb, prio_b);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), ticks, sizeof(unsigned long long) * blocks * 8, hipMemcpyDeviceToHost);
     double sa = 0, sb = 0;
@@ -108,9 +109,8 @@ void run(const char* an, const char* bn, int a_per_loop, float* out, unsigned lo
     res[mode][0] = sa / (blocks * 4) / iters;
     res[mode][1] = sb / (blocks * 4) / iters;
   }
-  printf("A = %-28s B = %-22s | ticks/loop  A alone %7.3f  B alone %7.3f | together: A %7.3f  B %7.3f | (A slows %.2fx, B slows %.2fx)\n", an, bn,
+  printf("A = %-24s B = %-14s%s | ticks/loop  A alone %7.3f  B alone %7.3f | together: A %7.3f  B %7.3f | (A slows %.2fx, B slows %.2fx)\n", an, bn,
          res[0][0], res[1][1], res[2][0], res[2][1], res[2][0] / res[0][0], res[2][1] / res[1][1]);
-  (void)a_per_loop;
 }
 
 int main() {
@@ -119,15 +119,24 @@ int main() {
   hipMalloc(&out, 4096);
   hipMalloc(&ticks, sizeof(unsigned long long) * 256 * 8);
   printf("per loop: A = 64 x 16x16x32 (or 32 x 32x32x16) MFMAs, B = 64 instructions; s_memtime ticks at 100 MHz\n");
-  run<0, 0>("16x16x32 one chain", "v_fma_f32", 64, out, ticks);
-  run<0, 1>("16x16x32 one chain", "v_exp_f32", 64, out, ticks);
-  run<0, 2>("16x16x32 one chain", "ds_read_b128", 64, out, ticks);
-  run<0, 3>("16x16x32 one chain", "v_pk_fma_f32", 64, out, ticks);
-  run<2, 0>("16x16x32 four chains", "v_fma_f32", 64, out, ticks);
-  run<1, 0>("32x32x16 one chain", "v_fma_f32", 32, out, ticks);
-  run<1, 1>("32x32x16 one chain", "v_exp_f32", 32, out, ticks);
-  run<1, 2>("32x32x16 one chain", "ds_read_b128", 32, out, ticks);
-  run<1, 3>("32x32x16 one chain", "v_pk_fma_f32", 32, out, ticks);
+run<0, 0>("16x16x32 one chain", "v_fma_f32", 0, out, ticks);
+  run<0, 1>("16x16x32 one chain", "v_exp_f32", 0, out, ticks);
+  run<0, 2>("16x16x32 one chain", "ds_read_b128", 0, out, ticks);
+  run<0, 3>("16x16x32 one chain", "v_pk_fma_f32", 0, out, ticks);
+  run<2, 0>("16x16x32 four chains", "v_fma_f32", 0, out, ticks);
+  run<1, 0>("32x32x16 one chain", "v_fma_f32", 0, out, ticks);
+  run<1, 1>("32x32x16 one chain", "v_exp_f32", 0, out, ticks);
+  run<1, 2>("32x32x16 one chain", "ds_read_b128", 0, out, ticks);
+  run<1, 3>("32x32x16 one chain", "v_pk_fma_f32", 0, out, ticks);
+run<0, 0>("16x16x32 one chain", "v_fma_f32", 1, out, ticks);
+  run<0, 1>("16x16x32 one chain", "v_exp_f32", 1, out, ticks);
+  run<0, 2>("16x16x32 one chain", "ds_read_b128", 1, out, ticks);
+  run<0, 3>("16x16x32 one chain", "v_pk_fma_f32", 1, out, ticks);
+  run<2, 0>("16x16x32 four chains", "v_fma_f32", 1, out, ticks);
+  run<1, 0>("32x32x16 one chain", "v_fma_f32", 1, out, ticks);
+  run<1, 1>("32x32x16 one chain", "v_exp_f32", 1, out, ticks);
+  run<1, 2>("32x32x16 one chain", "ds_read_b128", 1, out, ticks);
+  run<1, 3>("32x32x16 one chain", "v_pk_fma_f32", 1, out, ticks);
   hipFree(out);
   hipFree(ticks);
   return 0;
