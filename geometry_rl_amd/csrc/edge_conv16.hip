@@ -376,8 +376,11 @@ GRL_DEVINL void rowred_mma(const RFrags<NTK>& f, f32x16 (&acc)[2][NTK]) {
 // weight fragments of one chain group (n-tile nt of a 64 x 64 image), requested one group ahead of their MFMAs
 struct WF2 {
   bf16x8 h[2], l[2];
+  float4 bias;   // the group's accumulator start (requested with the fragments: a read issued inside the group's own region would make
+                 // its wait cover the next group's fragment reads as well -- LDS returns in order)
 };
-GRL_DEVINL void wf_load(WF2& f, const unsigned short* whi, const unsigned short* wlo) {
+GRL_DEVINL void wf_load(WF2& f, const unsigned short* whi, const unsigned short* wlo, const float* bias = nullptr) {
+  f.bias = bias ? *reinterpret_cast<const float4*>(bias) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     f.h[s] = *reinterpret_cast<const bf16x8*>(whi + 32 * s);
@@ -396,6 +399,15 @@ GRL_DEVINL f32x4v wf_mma(const WF2& f, const bf16x8 (&xh)[2], const bf16x8 (&xl)
 
 #ifdef GRL_B16_NOGELU
 #define B16_GELU(x, gv, gpv) ((gv) = (x), (gpv) = (x))
+#elif !defined(GRL_B16_SCALAR_GELU)   // packed pairs: one wave per SIMD issues a v_pk_* in the time of a scalar op (A/B: -5 %)
+GRL_DEVINL void gelu_both4_pk(const float4& x, float4& gv, float4& gpv) {
+  v2f g0, g1, d0, d1;
+  gelu_pair<true>(v2f{x.x, x.y}, g0, d0);
+  gelu_pair<true>(v2f{x.z, x.w}, g1, d1);
+  gv = make_float4(g0.x, g0.y, g1.x, g1.y);
+  gpv = make_float4(d0.x, d0.y, d1.x, d1.y);
+}
+#define B16_GELU(x, gv, gpv) gelu_both4_pk((x), (gv), (gpv))
 #else
 #define B16_GELU(x, gv, gpv) gelu_both4((x), (gv), (gpv))
 #endif
@@ -403,6 +415,12 @@ GRL_DEVINL f32x4v wf_mma(const WF2& f, const bf16x8 (&xh)[2], const bf16x8 (&xl)
 #define B16_LD(p) make_float4(0.5f, 0.25f, -0.5f, 1.f)
 #else
 #define B16_LD(p) ld4(p)
+#endif
+#ifdef GRL_B16_PHASE   // diagnostic build: s_memtime ticks per stage of the pass, wave 0 of every workgroup (tools/edge_phase.py --bwd16)
+__device__ unsigned long long g_b16phase[16];
+#define B16_PH(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[i] += t_ - tl_; tl_ = t_; } while (0)
+#else
+#define B16_PH(i)
 #endif
 struct Bwd16Params {
   Edge16Params e;         // the SOURCE-anchored view; e.x_in = dM rows (d x1 [Nd,16,64] or per-edge rows)
@@ -435,6 +453,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   __syncthreads();
   const ChainW16& w = sm.w;
   const float gx = w.grid_s[3 * r], gy = w.grid_s[3 * r + 1], gz = w.grid_s[3 * r + 2];
+  const bool g0 = g == 0, g1_ = g == 1, g2_ = g == 2;
 
   f32x16 accK[2][2], accA[2][2], accB[2][1];   // dWk, dW2, dW1 (| db1 in column 14)
 #pragma unroll
@@ -447,6 +466,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) db2[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+#ifdef GRL_B16_PHASE
+  unsigned long long ph_[8] = {0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   const int NPW = p.npw;
   const int n_chunks = (p.n_anchor + NPW - 1) / NPW;
 #pragma unroll 1
@@ -472,6 +494,26 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) st4(o + 16 * t, acc[t]);
     };
+    // nodes [from, to) have no out-edges (padded points come in runs): their rows are dres or zero.  Four nodes per round trip --
+    // a load -> store per node would expose an HBM latency each (indices are clamped, not branched on: duplicates are harmless)
+    auto skip_empty_run = [&](int from, int to) {
+#pragma unroll 1
+      for (int j = from; j < to; j += 4) {
+        float4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t row = ((size_t)(n0 + min(j + u, to - 1)) * O + r) * C + 4 * g;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[u][t] = bp.dres ? B16_LD(bp.dres + row + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t row = ((size_t)(n0 + min(j + u, to - 1)) * O + r) * C + 4 * g;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) st4(bp.dx_src + row + 16 * t, v[u][t]);
+        }
+      }
+    };
     node_begin(0);
     for (int eb = E0; eb < E1; eb += 64) {
       const int ee = min(eb + lane, E1 - 1);
@@ -491,16 +533,31 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #pragma unroll 1
       for (int k = 0; k < nb; ++k) {
         const int e = eb + k;
-        while (e >= node_end) {
+        if (e >= node_end) {            // the edge belongs to a later node of the chunk
           flush(node);
-          ++node;
-          node_end = __builtin_amdgcn_readlane(rp, node + 1);
-          node_begin(node);
+          int m = node + 1;
+          while (__builtin_amdgcn_readlane(rp, m + 1) <= e) ++m;
+          skip_empty_run(node + 1, m);
+          node = m;
+          node_end = __builtin_amdgcn_readlane(rp, m + 1);
+          node_begin(m);
         }
         float4 dv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) dv[t] = dvn[t];
         dv_issue(min(k + 1, nb - 1));
+        // layer 1's weight fragments and biases, and the first 64-deep group: requested before the invariants are computed
+        bf16x8 w1h[4], w1l[4];
+        float4 b1q[4];
+        WF2 wf[2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          w1h[nt] = *reinterpret_cast<const bf16x8*>(w.W1h + (16 * nt + r) * LD1 + 8 * g);
+          GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
+          b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
+        }
+        wf_load(wf[0], w.W2h + r * LD2 + 8 * g, w.W2l + r * LD2 + 8 * g, w.b2s + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
         // rel = pos_src - pos_dst (hepi.py:109-117); the source is the anchor here
         float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pax), node)) -
                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pox), k));
@@ -511,16 +568,19 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         if (p.dim == 2) dz = 0.f;
         const float a = dx * gx + dy * gy + dz * gz;
         dx -= a * gx; dy -= a * gy; dz -= a * gz;
-        const float b = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float b = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);   // 1 ulp; the IEEE expansion costs 15 instructions
         // ---- chain with derivatives
-        const float aa = a * a, ab = a * b, bb = b * b;
-        float4 phi;   // column 14 carries a one: the dW1 product then leaves db1 in column 14 (W1's image has zeros there)
-        if (g == 0) phi = make_float4(a, b, aa, ab);
-        else if (g == 1) phi = make_float4(ab, bb, aa * a, aa * b);
-        else if (g == 2) phi = make_float4(ab * a, ab * b, ab * a, ab * b);
-        else phi = make_float4(bb * a, bb * b, 1.f, 0.f);
+        // polynomial features 4 g .. 4 g + 3 of this lane (ponita.py:233-244), by selects; column 14 carries a one: the dW1 product then
+        // leaves db1 in column 14 (W1's image has zeros there)
+        const float aa = a * a, ab = a * b, bb = b * b, aba = ab * a, abb = ab * b;   // (products grouped as the reference's outer products)
+        float4 phi;
+        phi.x = g0 ? a : g1_ ? ab : g2_ ? aba : bb * a;
+        phi.y = g0 ? b : g1_ ? bb : g2_ ? abb : bb * b;
+        phi.z = g0 ? aa : g1_ ? aa * a : g2_ ? aba : 1.f;
+        phi.w = g0 ? ab : g1_ ? aa * b : g2_ ? abb : 0.f;
         bf16x8 ph[1], pl[1];
         split_pair(phi, make_float4(0.f, 0.f, 0.f, 0.f), ph[0], pl[0]);
+        B16_PH(0);   // pass top: node change, gathers issued, invariants, phi
         float4 gp1[4], gp2[4];
         bf16x8 xh[2], xl[2], yh[2], yl[2];
         // One wave per SIMD: nobody else hides an LDS round trip, and the compiler places a fragment load next to its MFMA.  The
@@ -528,22 +588,18 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         // MFMAs of group k + 1 and the epilogue (GELU / products) of group k -- loads a group ahead, matrix pipe beside the vector work.
         // The sixteen 64-deep groups, in order: W2 (4), Wk (4), Wk^T (4), W2^T (4).
 #define BAR() __builtin_amdgcn_sched_barrier(0)
-        WF2 wf[2];
         auto wptr_h = [&](int i) { const unsigned short* m = i < 4 ? w.W2h : i < 8 ? w.Wkh : i < 12 ? sm.WkTh : sm.W2Th; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
         auto wptr_l = [&](int i) { const unsigned short* m = i < 4 ? w.W2l : i < 8 ? w.Wkl : i < 12 ? sm.WkTl : sm.W2Tl; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
         // a 64-deep layer: groups base .. base + 3 (wf[base & 1] already requested); epi(nt, c) consumes tile nt one region later
-        auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], const float* bias, auto&& epi, auto&& tail) {
+        auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
           f32x4v c[4];
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            if (base + nt + 1 < 16) wf_load(wf[(nt + 1) & 1], wptr_h(base + nt + 1), wptr_l(base + nt + 1));
+            if (base + nt + 1 < 16)
+              wf_load(wf[(nt + 1) & 1], wptr_h(base + nt + 1), wptr_l(base + nt + 1), base + nt + 1 < 4 ? w.b2s + 16 * (nt + 1) + 4 * g : nullptr);
             BAR();
-            f32x4v init = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-              const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * nt + 4 * g);
-              init = f32x4v{bq.x, bq.y, bq.z, bq.w};
-            }
-            c[nt] = wf_mma(wf[nt & 1], ih, il, init);
+            const float4 bq = wf[nt & 1].bias;
+            c[nt] = wf_mma(wf[nt & 1], ih, il, f32x4v{bq.x, bq.y, bq.z, bq.w});
             if (nt > 0) epi(nt - 1, c[nt - 1]);
             BAR();
           }
@@ -553,19 +609,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         };
         {
           float4 g1[4];
-          bf16x8 w1h[4], w1l[4];
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            w1h[nt] = *reinterpret_cast<const bf16x8*>(w.W1h + (16 * nt + r) * LD1 + 8 * g);
-            GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
-          }
-          wf_load(wf[0], wptr_h(0), wptr_l(0));
           BAR();
           f32x4v c[4];
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
-            const float4 bq = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
-            c[nt] = f32x4v{bq.x, bq.y, bq.z, bq.w};
+            c[nt] = f32x4v{b1q[nt].x, b1q[nt].y, b1q[nt].z, b1q[nt].w};
             c[nt] = mfma16(w1h[nt], ph[0], c[nt]);
             GRL_LO(c[nt] = mfma16(w1l[nt], ph[0], c[nt]);)
             GRL_LO(c[nt] = mfma16(w1h[nt], pl[0], c[nt]);)
@@ -577,18 +625,20 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           split_pair(g1[2], g1[3], xh[1], xl[1]);
           BAR();
         }
+        B16_PH(1);   // layer 1 (12 MFMA, GELU + derivative, split)
         {
           float4 g2[4];
-          layer64(0, xh, xl, w.b2s, [&](int nt, const f32x4v& c) { B16_GELU(v4(c), g2[nt], gp2[nt]); },
+          layer64(0, xh, xl, [&](int nt, const f32x4v& c) { B16_GELU(v4(c), g2[nt], gp2[nt]); },
                   [&]() {
                     split_pair(g2[0], g2[1], yh[0], yl[0]);
                     split_pair(g2[2], g2[3], yh[1], yl[1]);
                   });
         }
+        B16_PH(2);   // layer 2 (24 MFMA, GELU + derivative, split)
         // ---- K = Wk g2: d x_src row += K * dM;  dK = dM * x_src, staged with g2 for dWk += dK^T g2 (consumed after the dZ2 groups)
         bf16x8 kh[2], kl[2];
         RFrags<2> rf;
-        layer64(4, yh, yl, nullptr, [&](int nt, const f32x4v& c) { acc[nt] = f4_add(acc[nt], f4_mul(v4(c), dv[nt])); },
+        layer64(4, yh, yl, [&](int nt, const f32x4v& c) { acc[nt] = f4_add(acc[nt], f4_mul(v4(c), dv[nt])); },
                 [&]() {
                   split_pair(f4_mul(dv[0], xv[0]), f4_mul(dv[1], xv[1]), kh[0], kl[0]);
                   split_pair(f4_mul(dv[2], xv[2]), f4_mul(dv[3], xv[3]), kh[1], kl[1]);
@@ -596,11 +646,12 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
                   stage_put<2>(st.Bh, st.Bl, yh, yl, r, g);
                   rowred_load<2>(st, lane, rf);
                 });
+        B16_PH(3);   // K (24 MFMA), d x_src, dK, staging dK | g2, transposed reads issued
         // ---- dZ2 = (Wk^T dK) * gelu'(z2);  db2;  then dWk's MFMAs beside the split of dZ2
         bf16x8 zh[2], zl[2];
         {
           float4 dz2[4];
-          layer64(8, kh, kl, nullptr,
+          layer64(8, kh, kl,
                   [&](int nt, const f32x4v& c) {
                     dz2[nt] = f4_mul(v4(c), gp2[nt]);
                     db2[nt] = f4_add(db2[nt], dz2[nt]);
@@ -611,6 +662,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
                     split_pair(dz2[2], dz2[3], zh[1], zl[1]);
                   });
         }
+        B16_PH(4);   // dZ2 (24 MFMA), dWk (12 MFMA 32x32), split dZ2
         // ---- dW2 += dZ2^T g1 (fragments requested now, product after the dZ1 groups)
         stage_put<2>(st.Ah, st.Al, zh, zl, r, g);
         stage_put<2>(st.Bh, st.Bl, xh, xl, r, g);
@@ -619,13 +671,14 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         bf16x8 uh[2], ul[2];
         {
           float4 dz1[4];
-          layer64(12, zh, zl, nullptr, [&](int nt, const f32x4v& c) { dz1[nt] = f4_mul(v4(c), gp1[nt]); },
+          layer64(12, zh, zl, [&](int nt, const f32x4v& c) { dz1[nt] = f4_mul(v4(c), gp1[nt]); },
                   [&]() {
                     rowred_mma<2>(rf, accA);
                     split_pair(dz1[0], dz1[1], uh[0], ul[0]);
                     split_pair(dz1[2], dz1[3], uh[1], ul[1]);
                   });
         }
+        B16_PH(5);   // staging dZ2 | g1, dZ1 (24 MFMA), dW2 (12 MFMA 32x32), split dZ1
         // ---- dW1 (| db1) += dZ1^T (phi | 1)
         stage_put<2>(st.Ah, st.Al, uh, ul, r, g);
         {   // phi image: features 4 g .. 4 g + 3 of columns 0..15; columns 16..31 of the tile are zeroed (g1 was there)
@@ -641,15 +694,18 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         RFrags<1> rf1;
         rowred_load<1>(st, lane, rf1);
         rowred_mma<1>(rf1, accB);
+        B16_PH(6);   // staging dZ1 | phi, dW1 (6 MFMA 32x32)
 #undef BAR
       }
     }
-    for (; node < nn; ++node) {   // the last node with edges and every trailing node without
-      flush(node);
-      if (node + 1 < nn) node_begin(node + 1);
-    }
+    flush(node);                  // the last node with edges (or node 0 of a chunk without any), then the trailing nodes without
+    skip_empty_run(node + 1, nn);
   }
 
+#ifdef GRL_B16_PHASE
+  if (lane == 0 && wave == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_b16phase[i], ph_[i]);
+#endif
   // ---- fold the four waves through LDS (images dead): 1 -> 0 and 3 -> 2, then 2 -> 0; fixed order, one partial row per workgroup
   constexpr int NACC = 10 * 16 + 16;
   float* fold = smem_raw;
@@ -763,5 +819,13 @@ int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const 
   GRL_CHECK_LAUNCH();
   return 0;
 }
+
+#if defined(GRL_B16_PHASE) && !GRL_PREC
+int grl_edge_bwd16_phase_read(unsigned long long* out16, int reset) {
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_b16phase), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_b16phase), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 }  // extern "C"
