@@ -28,6 +28,8 @@ FLOPS_PER_ROW = {
     "edge_conv_bwd_x_kernel": _CHAIN + 2 * 64,                                      # recompute, d x_src row (+ sum)
     "edge_conv_bwd_w_kernel": (_CHAIN - 2 * 64 * 64) + 2 * 64 + 2 * 64 * 64 + 2 * (2 * 64 * 64) + 2 * 64 * 64 + 2 * 64 * 14,
     # ^ z1, z2 recompute, dK, dWk, dG2, dG1, dW2, dW1
+    # the fused backward (edge_conv16.hip, default since round 2): ONE chain recompute, d x_src row, dK, dWk, dG2, dW2, dG1, dW1
+    "edge_bwd16_kernel": _CHAIN + 2 * 64 + 2 * 64 + 4 * (2 * 64 * 64) + 2 * 64 * 14,
     "node_mlp_fwd_kernel": 4 * 64 * 256,
     "node_mlp_bwd_fused_kernel": 10 * 64 * 256,                                    # z recompute, dH, dA, dW3, dW4
 }
@@ -293,7 +295,8 @@ def main():
         med = lambda xs: sorted(xs)[len(xs) // 2]
         summ = {k: (per_step[0][k][0], med([s_[k][1] for s_ in per_step])) for k in per_step[0]}  # launches/step, ms/step
         rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_x_kernel": "grl_edge_conv_bwd",
-                   "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
+                   "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "edge_bwd16_kernel": "grl_edge_conv_bwd",
+                   "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
                    "node_mlp_bwd_fused_kernel": "grl_node_mlp_bwd"}
         rows_step = {k.replace("_bf16", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
         pipe_peak = 2500.0 if cfg.precision == "bf16" else PEAK_BF16X3

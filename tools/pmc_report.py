@@ -13,7 +13,7 @@ def load(d):
 A, nA = load("pmcA"); B, nB = load("pmcB"); C, nC = load("pmcC"); D, nD = load("pmcD")
 print("kernel | launches | wave-cycle shares: active / wait(waitcnt,barrier) / issue-stall | VALU active | MFMA busy/(4 wave cyc) | VALU per MFMA | LDS insts | LDS conflict | fetch MB (x2 corr.) | write MB")
 for k in A:
-    if not any(s in k for s in ("edge_conv", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
+    if not any(s in k for s in ("edge_conv", "edge16", "edge_bwd16", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
         continue
     a, b, n = A[k], B[k], nA[k]
     wc = a["SQ_WAVE_CYCLES"] or 1
@@ -28,7 +28,7 @@ if len(sys.argv) > 2:
                     "frames); per-launch averages over all launches of a kernel in that run; FETCH_SIZE doubled (gfx950 correction, "
                     "MI355X_MICROARCH.md HBM section), KB -> bytes", "kernels": {}}
     for k in A:
-        if not any(s in k for s in ("edge_conv", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
+        if not any(s in k for s in ("edge_conv", "edge16", "edge_bwd16", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
             continue
         a, b, n = A[k], B[k], nA[k]
         wc = a["SQ_WAVE_CYCLES"] or 1
