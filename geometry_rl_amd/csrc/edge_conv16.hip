@@ -119,6 +119,7 @@ GRL_DEVINL void group16(const unsigned short* whi, const unsigned short* wlo, co
   if (FENCED) __builtin_amdgcn_sched_barrier(0);
 }
 
+
 GRL_DEVINL float4 v4(const f32x4v& a) { return make_float4(a[0], a[1], a[2], a[3]); }
 // timing knock-outs (diagnostic builds only; results are wrong): -DGRL_E16_NOGELU, -DGRL_E16_NOMFMA, -DGRL_E16_NOGATHER
 #ifdef GRL_E16_NOGELU
@@ -133,6 +134,106 @@ GRL_DEVINL float4 gelu4s(float4 x) {
 #else
 #define GELU16(x) gelu4(x)
 #endif
+// weight fragments of one chain group (n-tile nt of a 64 x 64 image), requested one group ahead of their MFMAs
+struct WF2 {
+  bf16x8 h[2], l[2];
+  float4 bias;   // the group's accumulator start (requested with the fragments: a read issued inside the group's own region would make
+                 // its wait cover the next group's fragment reads as well -- LDS returns in order)
+};
+GRL_DEVINL void wf_load(WF2& f, const unsigned short* whi, const unsigned short* wlo, const float* bias = nullptr) {
+  f.bias = bias ? *reinterpret_cast<const float4*>(bias) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    f.h[s] = *reinterpret_cast<const bf16x8*>(whi + 32 * s);
+    GRL_LO(f.l[s] = *reinterpret_cast<const bf16x8*>(wlo + 32 * s);)
+  }
+}
+GRL_DEVINL f32x4v wf_mma(const WF2& f, const bf16x8 (&xh)[2], const bf16x8 (&xl)[2], f32x4v acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    acc = mfma16(f.h[s], xh[s], acc);
+    GRL_LO(acc = mfma16(f.l[s], xh[s], acc);)
+    GRL_LO(acc = mfma16(f.h[s], xl[s], acc);)
+  }
+  return acc;
+}
+
+// The same chain cut into scheduling regions like the fused backward's pass (GRL_E16_REGIONS): the fragments (and bias) of group k + 1
+// are requested before group k's MFMAs, and region k runs the MFMAs of group k + 1 beside the epilogue (GELU) of group k -- matrix and
+// vector work of the SAME wave, the only overlap a SIMD gives (DESIGN.md finding 18).  No LDS read sits between the MFMAs of a chain.
+#ifndef GRL_E16_REGIONS
+#define GRL_E16_REGIONS 1
+#endif
+template <class KEpi>
+GRL_DEVINL void chain16_regions(const ChainW16& w, float a, float b, int r, int g, KEpi&& k_epi) {
+#define BAR() __builtin_amdgcn_sched_barrier(0)
+  bf16x8 w1h[4], w1l[4];
+  float4 b1q[4];
+  WF2 wf[2];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    w1h[nt] = *reinterpret_cast<const bf16x8*>(w.W1h + (16 * nt + r) * LD1 + 8 * g);
+    GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
+    b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
+  }
+  wf_load(wf[0], w.W2h + r * LD2 + 8 * g, w.W2l + r * LD2 + 8 * g, w.b2s + 4 * g);
+  const float aa = a * a, ab = a * b, bb = b * b;
+  float4 phi;
+  if (g == 0) phi = make_float4(a, b, aa, ab);
+  else if (g == 1) phi = make_float4(ab, bb, aa * a, aa * b);
+  else if (g == 2) phi = make_float4(ab * a, ab * b, ab * a, ab * b);
+  else phi = make_float4(bb * a, bb * b, 0.f, 0.f);
+  bf16x8 ph, pl;
+  split_pair(phi, make_float4(0.f, 0.f, 0.f, 0.f), ph, pl);
+  BAR();
+  bf16x8 xh[2], xl[2], yh[2], yl[2];
+  {
+    float4 g1[4];
+    f32x4v c[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      c[nt] = f32x4v{b1q[nt].x, b1q[nt].y, b1q[nt].z, b1q[nt].w};
+      c[nt] = mfma16(w1h[nt], ph, c[nt]);
+      GRL_LO(c[nt] = mfma16(w1l[nt], ph, c[nt]);)
+      GRL_LO(c[nt] = mfma16(w1h[nt], pl, c[nt]);)
+      if (nt > 0) g1[nt - 1] = GELU16(v4(c[nt - 1]));
+      BAR();
+    }
+    g1[3] = GELU16(v4(c[3]));
+    split_pair(g1[0], g1[1], xh[0], xl[0]);
+    split_pair(g1[2], g1[3], xh[1], xl[1]);
+    BAR();
+  }
+  auto layer64 = [&](int base, const unsigned short* mh, const unsigned short* ml, const unsigned short* nh, const unsigned short* nl,
+                     const float* nbias, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
+    // groups of image (mh, ml); the group after the last one is tile 0 of (nh, nl) (nullptr: none)
+    f32x4v c[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (nt < 3) wf_load(wf[(base + nt + 1) & 1], mh + (16 * (nt + 1) + r) * LD2 + 8 * g, ml + (16 * (nt + 1) + r) * LD2 + 8 * g,
+                          base == 0 ? w.b2s + 16 * (nt + 1) + 4 * g : nullptr);
+      else if (nh) wf_load(wf[(base + nt + 1) & 1], nh + r * LD2 + 8 * g, nl + r * LD2 + 8 * g, nbias);
+      BAR();
+      const float4 bq = wf[(base + nt) & 1].bias;
+      c[nt] = wf_mma(wf[(base + nt) & 1], ih, il, f32x4v{bq.x, bq.y, bq.z, bq.w});
+      if (nt > 0) epi(nt - 1, c[nt - 1]);
+      BAR();
+    }
+    epi(3, c[3]);
+    tail();
+    BAR();
+  };
+  {
+    float4 g2[4];
+    layer64(0, w.W2h, w.W2l, w.Wkh, w.Wkl, nullptr, xh, xl, [&](int nt, const f32x4v& c) { g2[nt] = GELU16(v4(c)); },
+            [&]() {
+              split_pair(g2[0], g2[1], yh[0], yl[0]);
+              split_pair(g2[2], g2[3], yh[1], yl[1]);
+            });
+  }
+  layer64(4, w.Wkh, w.Wkl, nullptr, nullptr, nullptr, yh, yl, [&](int nt, const f32x4v& c) { k_epi(nt, v4(c)); }, [&]() {});
+#undef BAR
+}
 
 // The chain for this lane's row: (a, b) -> K tiles handed to k_epi(nt, float4 of features 16 nt + 4 g + 0..3)
 template <class KEpi>
@@ -173,6 +274,11 @@ GRL_DEVINL void chain16(const ChainW16& w, float a, float b, int r, int g, KEpi&
                [&](const f32x4v& acc) { k_epi(nt, v4(acc)); });
 }
 
+#if GRL_E16_REGIONS
+#define E16_CHAIN chain16_regions
+#else
+#define E16_CHAIN chain16
+#endif
 constexpr int NPW_MAX = 16;   // anchor nodes per wave chunk (their rowptr entries live on the lanes)
 
 // MODE 0: forward       out[anchor] = sum over its edges of K_e * x_in[other(e)]                    (anchor = destination)
@@ -252,7 +358,7 @@ __global__ __launch_bounds__(E16_THREADS, GRL_E16_WGS) void edge16_kernel(Edge16
         dx -= a * gx; dy -= a * gy; dz -= a * gz;
         const float b = sqrtf(dx * dx + dy * dy + dz * dz);
         st_t* mrow = MODE == 2 ? out + ((size_t)e * O + r) * C + 4 * g : nullptr;
-        chain16(s, a, b, r, g, [&](int nt, const float4& kq) {
+        E16_CHAIN(s, a, b, r, g, [&](int nt, const float4& kq) {
           const float4 m = f4_mul(kq, xv[nt]);
           if (MODE == 2) st4(mrow + 16 * nt, m);
           else acc[nt] = f4_add(acc[nt], m);
@@ -372,29 +478,6 @@ GRL_DEVINL void rowred_mma(const RFrags<NTK>& f, f32x16 (&acc)[2][NTK]) {
       GRL_LO(mfma32_acc(f.al[tn], f.bh[tk], acc[tn][tk]);)
       GRL_LO(mfma32_acc(f.ah[tn], f.bl[tk], acc[tn][tk]);)
     }
-}
-// weight fragments of one chain group (n-tile nt of a 64 x 64 image), requested one group ahead of their MFMAs
-struct WF2 {
-  bf16x8 h[2], l[2];
-  float4 bias;   // the group's accumulator start (requested with the fragments: a read issued inside the group's own region would make
-                 // its wait cover the next group's fragment reads as well -- LDS returns in order)
-};
-GRL_DEVINL void wf_load(WF2& f, const unsigned short* whi, const unsigned short* wlo, const float* bias = nullptr) {
-  f.bias = bias ? *reinterpret_cast<const float4*>(bias) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    f.h[s] = *reinterpret_cast<const bf16x8*>(whi + 32 * s);
-    GRL_LO(f.l[s] = *reinterpret_cast<const bf16x8*>(wlo + 32 * s);)
-  }
-}
-GRL_DEVINL f32x4v wf_mma(const WF2& f, const bf16x8 (&xh)[2], const bf16x8 (&xl)[2], f32x4v acc) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    acc = mfma16(f.h[s], xh[s], acc);
-    GRL_LO(acc = mfma16(f.l[s], xh[s], acc);)
-    GRL_LO(acc = mfma16(f.h[s], xl[s], acc);)
-  }
-  return acc;
 }
 
 #ifdef GRL_B16_NOGELU

@@ -223,7 +223,13 @@ void grl_prof_end(hipStream_t stream);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-GRL_DEVINL f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+GRL_DEVINL f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef GRL_KNOCK_MFMA   // timing knock-out (diagnostic builds of one file; results are wrong)
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 GRL_DEVINL unsigned pack_hi(float a, float b) {  // upper halves of a (low word) and b (high word)
   return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);

@@ -4,12 +4,23 @@
 // (see grl_common.h): LayerNorm by lane-pair shuffles, W3/W4 staged once per workgroup in LDS as MFMA A operands.
 //
 // Backward: ONE fused launch (node_mlp_bwd_fused_kernel below): dx2 and all six parameter gradients, nothing handed over through HBM.
+#ifdef GRL_MLPB_NOMFMA
+#define GRL_KNOCK_MFMA
+#endif
 #include "grl_common.h"
+#ifdef GRL_MLPB_NOBARRIER   // timing knock-out: the chunk loop of the fused backward without its barriers (results are wrong)
+#define MLPB_SYNC()
+#else
+#define MLPB_SYNC() __syncthreads()
+#endif
 
 namespace {
 
 #ifndef GRL_MLP_NT
 #define GRL_MLP_NT 1
+#endif
+#ifndef GRL_MLPF_PIPE
+#define GRL_MLPF_PIPE 1
 #endif
 constexpr int C = 64, O = 16, W = 256;
 constexpr float LN_EPS = 1e-5f;
@@ -49,6 +60,12 @@ GRL_DEVINL f32x16 bias_acc(const float* bias, int n0, int h) {
   return acc;
 }
 
+GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
+  // a compiler-visible VALU read of the accumulator: it cannot issue before the MFMA group that produced acc has finished
+  sink += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, acc[0]), 0xE4, 0xF, 0xF, false));
+}
+
+
 // ------------------------------------------------------------------------------------------------ forward
 // Both GEMMs run on the bf16 matrix pipe with split operands (grl_common.h): per 32-row tile 2 x 96 bf16 MFMAs of 32 cycles
 // instead of 2 x 256 fp32 MFMAs of 64 cycles.
@@ -65,6 +82,7 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int n_tiles = (n_rows + 31) >> 5;
+  float sink = 0.f;
   for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
     const int row = tile * 32 + r;
     const bool valid = row < n_rows;
@@ -95,6 +113,90 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
     bf16x8 ah[4], al[4];
     split_frags<64>(a, ah, al);
     f32x16 o0 = bias_acc(s.b4s, 0, h), o1 = bias_acc(s.b4s, 32, h);
+#if GRL_MLPF_PIPE
+    // Software pipeline over the eight 32-unit hidden tiles (round 2, DESIGN.md findings 18 / 20): one scheduling region holds the
+    // GELU + split of tile nt (vector work), the z chain of tile nt + 1 and the two output chains of tile nt - 1 (24 MFMAs) -- three
+    // independent streams of the SAME wave; every weight fragment is requested one region before its MFMAs, none between the MFMAs
+    // of a chain.  (Before: each of the 24 fragment reads of an iteration sat directly in front of its MFMA.)
+    struct F3 { bf16x8 h[4], l[4]; } f3;
+    struct F4 { bf16x8 h[2][2], l[2][2]; } f4;
+    auto load3 = [&](int nt) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f3.h[u] = *reinterpret_cast<const bf16x8*>(s.W3h + (32 * nt + r) * LB3 + 8 * h + 16 * u);
+        GRL_LO(f3.l[u] = *reinterpret_cast<const bf16x8*>(s.W3l + (32 * nt + r) * LB3 + 8 * h + 16 * u);)
+      }
+    };
+    auto load4 = [&](int nt) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f4.h[t2][u] = *reinterpret_cast<const bf16x8*>(s.W4h + (32 * t2 + r) * LB4 + 32 * nt + 8 * h + 16 * u);
+          GRL_LO(f4.l[t2][u] = *reinterpret_cast<const bf16x8*>(s.W4l + (32 * t2 + r) * LB4 + 32 * nt + 8 * h + 16 * u);)
+        }
+    };
+    auto zchain = [&](f32x16 acc) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = mfma_bf(f3.h[u], ah[u], acc);
+        GRL_LO(acc = mfma_bf(f3.l[u], ah[u], acc);)
+        GRL_LO(acc = mfma_bf(f3.h[u], al[u], acc);)
+      }
+      return acc;
+    };
+    load3(0);
+    f32x16 acc = bias_acc(s.b3s, 0, h);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = zchain(acc);
+    mfma_fence(acc, sink);
+    __builtin_amdgcn_sched_barrier(0);
+    load3(1);
+    bf16x8 ph[2], pl[2];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      f32x16 acc_next = acc;
+      if (nt < 7) acc_next = zchain(bias_acc(s.b3s, 32 * (nt + 1), h));
+      if (nt > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          o0 = mfma_bf(f4.h[0][u], ph[u], o0);
+          o1 = mfma_bf(f4.h[1][u], ph[u], o1);
+          GRL_LO(o0 = mfma_bf(f4.l[0][u], ph[u], o0);)
+          GRL_LO(o1 = mfma_bf(f4.l[1][u], ph[u], o1);)
+          GRL_LO(o0 = mfma_bf(f4.h[0][u], pl[u], o0);)
+          GRL_LO(o1 = mfma_bf(f4.h[1][u], pl[u], o1);)
+        }
+      }
+      float4 hq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        hq[q] = gelu4(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+      bf16x8 hh[2], hl[2];
+      split_frags<32>(hq, hh, hl);
+      // the fragment registers are re-loaded next: every MFMA that reads them must have finished, not merely issued (finding 3: with
+      // two waves per SIMD an MFMA can sit queued behind the partner's) -- a vector read of each chain's accumulator
+      mfma_fence(acc_next, sink);
+      if (nt > 0) { mfma_fence(o0, sink); mfma_fence(o1, sink); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (nt < 6) load3(nt + 2);
+      load4(nt);
+      ph[0] = hh[0]; ph[1] = hh[1];
+      GRL_LO(pl[0] = hl[0]; pl[1] = hl[1];)
+      acc = acc_next;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      o0 = mfma_bf(f4.h[0][u], ph[u], o0);
+      o1 = mfma_bf(f4.h[1][u], ph[u], o1);
+      GRL_LO(o0 = mfma_bf(f4.l[0][u], ph[u], o0);)
+      GRL_LO(o1 = mfma_bf(f4.l[1][u], ph[u], o1);)
+      GRL_LO(o0 = mfma_bf(f4.h[0][u], pl[u], o0);)
+      GRL_LO(o1 = mfma_bf(f4.h[1][u], pl[u], o1);)
+    }
+#else
 #pragma unroll 1
     for (int nt = 0; nt < 8; ++nt) {
       f32x16 acc = bias_acc(s.b3s, 32 * nt, h);
@@ -108,6 +210,7 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
       mma_wx_bf<32>(s.W4h + r * LB4 + 32 * nt + 8 * h, s.W4l + r * LB4 + 32 * nt + 8 * h, hh, hl, o0);
       mma_wx_bf<32>(s.W4h + (32 + r) * LB4 + 32 * nt + 8 * h, s.W4l + (32 + r) * LB4 + 32 * nt + 8 * h, hh, hl, o1);
     }
+#endif
     float4 res[8], y[8];
     load_row(x_dst, rr, h, res);
     if (accumulate) {
@@ -121,6 +224,7 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
     for (int t = 0; t < 8; ++t) y[t] = f4_add(y[t], res[t]);
     if (valid) store_row(out, rr, h, y);
   }
+  if (sink == 123456.789f) st1(out, sink);   // keeps the fences alive; never true
 }
 
 #ifdef GRL_MLP_PHASE_PROF
@@ -184,11 +288,6 @@ struct MlpBwdSmem {
   float DA[4][32 * LDD];      // dA partial rows: waves 0-3 write, waves 4-7 add (second round); reused for the final column sums
   u32x4 W4F[8][4][2][64];
 };
-GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
-  // a compiler-visible VALU read of the accumulator: it cannot issue before the MFMA group that produced acc has finished
-  sink += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, acc[0]), 0xE4, 0xF, 0xF, false));
-}
-
 __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __restrict__ x2, const st_t* __restrict__ dout,
                                                                   const float* __restrict__ W3, const float* __restrict__ b3,
                                                                   const float* __restrict__ W4, const float* __restrict__ gam,
@@ -278,7 +377,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __r
     const int ch_next = ch + gridDim.x;
     if (ch_next < n_chunks) fetch(ch_next);
     PH(1);
-    __syncthreads();
+    MLPB_SYNC();
     PH(2);
     // ------------------------------------------------------------ 2: the four shared transposed tiles (all eight waves)
     {  // tile = wave & 3 (a | a | dOut | dOut column halves); waves 0-3 transpose the hi parts, waves 4-7 the lo parts
@@ -355,7 +454,11 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // reads z and dh: fences both groups
       float4 gp;
+#ifdef GRL_MLPB_NOGELU
+      hv[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]); gp = hv[q];
+#else
       gelu_both4(make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]), hv[q], gp);
+#endif
       dz[q] = f4_mul(make_float4(dh[4 * q], dh[4 * q + 1], dh[4 * q + 2], dh[4 * q + 3]), gp);
       csum += (dz[q].x + dz[q].y) + (dz[q].z + dz[q].w);
     }
@@ -367,7 +470,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __r
     split_pair(dz[2], dz[3], zT.h1, zT.l1);
     __builtin_amdgcn_sched_barrier(0);
     PH(5);
-    __syncthreads();   // transposed shared tiles (stage 2) complete
+    MLPB_SYNC();   // transposed shared tiles (stage 2) complete
     PH(6);
 
     {
@@ -434,7 +537,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __r
 #pragma unroll
       for (int t = 4; t < 8; ++t) *reinterpret_cast<float4*>(drow + 8 * t) = daf[t];
     }
-    __syncthreads();
+    MLPB_SYNC();
     PH(9);
     if (wave < 4) {
 #pragma unroll
@@ -449,7 +552,7 @@ __global__ __launch_bounds__(512) void node_mlp_bwd_fused_kernel(const st_t* __r
         *p = f4_add(*p, daf[t]);
       }
     }
-    __syncthreads();
+    MLPB_SYNC();
     PH(10);
     // ------------------------------------------------------------ 4: LayerNorm backward
     {

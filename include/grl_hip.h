@@ -39,7 +39,10 @@ int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, 
  *           in registers per source node, like the forward sums per destination node: no scratch, no atomics);
  *           dx_src [n_src,16,64] fully overwritten;
  *           partial [grl_edge_bwd_blocks(n_edges)][grl_edge_partial_size()] = [dW1 64x14 | db1 64 | dW2 64x64 | db2 64 | dWk 64x64]
- *           (one row per workgroup: its four waves are folded through LDS at the end of the launch) */
+ *           (one row per workgroup: its four waves are folded through LDS at the end of the launch).
+ *           Since round 2 the backward is ONE launch (d x_src and the five weight gradients share one recompute of the basis MLP).
+ * libgrl_hip.so also exports grl_edge16_launch / grl_edge_bwd16_launch (and their _bf16 twins): cross-file entry points of the 16-row
+ * kernels used by the functions below -- internal, NOT part of this ABI. */
 int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
