@@ -161,8 +161,10 @@ GRL_DEVINL f32x4v wf_mma(const WF2& f, const bf16x8 (&xh)[2], const bf16x8 (&xl)
 // The same chain cut into scheduling regions like the fused backward's pass (GRL_E16_REGIONS): the fragments (and bias) of group k + 1
 // are requested before group k's MFMAs, and region k runs the MFMAs of group k + 1 beside the epilogue (GELU) of group k -- matrix and
 // vector work of the SAME wave, the only overlap a SIMD gives (DESIGN.md finding 18).  No LDS read sits between the MFMAs of a chain.
+// Measured (tools/run_variants.sh, one box): 0.46-0.51 ms against 0.48-0.52 for the fenced groups -- inside the noise at three waves per
+// SIMD; the default stays the fenced form (no fragment register is ever re-loaded while an MFMA that reads it may be queued).
 #ifndef GRL_E16_REGIONS
-#define GRL_E16_REGIONS 1
+#define GRL_E16_REGIONS 0
 #endif
 template <class KEpi>
 GRL_DEVINL void chain16_regions(const ChainW16& w, float a, float b, int r, int g, KEpi&& k_epi) {
