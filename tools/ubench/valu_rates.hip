@@ -1,4 +1,4 @@
-// Micro-benchmark (gfx950): what does one wave-instruction of each VALU class cost on a SIMD, alone and with a second wave on the
+// Micro-benchmark (gfx950): what does one wave-instruction of each VALU class cost on a SIMD, alone and with one to three more waves on the
 // SIMD?  Independent instructions on 16 registers, unrolled; every CU runs 1 or 2 waves per SIMD.  Prints cycles per
 // wave-instruction per SIMD (s_memtime ticks / instructions issued on that SIMD).
 //   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates && ./valu_rates
@@ -10,7 +10,7 @@
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int KIND>
-__global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, int iters) {
   float v[16];
   typedef float v2 __attribute__((ext_vector_type(2)));
   v2 p[8];
@@ -87,9 +87,9 @@ template <int KIND>
 void run(const char* name, int per_iter) {
   float* d;
   unsigned long long* c;
-  hipMalloc(&d, 256 * 512 * 4);
-  hipMalloc(&c, 256 * 8 * 8);
-  for (int threads : {256, 512}) {
+  hipMalloc(&d, 256 * 1024 * 4);
+  hipMalloc(&c, 256 * 16 * 8);
+  for (int threads : {256, 512, 768, 1024}) {
     const int iters = 2000;
     hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, d, c, 10);
     hipDeviceSynchronize();
