@@ -334,8 +334,9 @@ class NodeMLP(torch.autograd.Function):
         dx2 = torch.empty_like(x2)
         blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
         psize = hip.query("grl_node_mlp_partial_size")
-        partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
+        partial = torch.empty(blocks + 1, psize, device=dev, dtype=torch.float32)   # last row: scratch (shared W3 fragment image)
         hip.call("grl_node_mlp_bwd" + ctx.prec, x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows, rows=n_rows)
+        partial = partial[:blocks]
         pw3, pb3, pw4, pb4, pg, pbt = ctx.params
         dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
                                                                (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),

@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 200
+#define GRL_HIP_VERSION 201
 int grl_version(void);
 
 /* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
@@ -133,8 +133,9 @@ int grl_fiber_conv_bwd(const float* x1, const float* fk, const float* dx2, float
 
 /* ---- ConvNeXt node block: ponita/conv.py:64-69,112 (ponita.py:219-230); hetero sum hetero_fiber_conv.py:63-64 -------------
  * out = (accumulate ? out : 0) + x_dst + W4 GELU(W3 LN(x2) + b3) + b4 ; n_rows = n_nodes*16
- * bwd: one fused launch (dx2 + all six parameter gradients), no scratch;
- * partial [grl_node_mlp_bwd_blocks(n_rows)][grl_node_mlp_partial_size()] = [dW3 | db3 | dW4 | db4 | dgamma | dbeta] */
+ * bwd: one fused launch (dx2 + all six parameter gradients) behind a one-workgroup launch that images W3 as MFMA fragments;
+ * partial [grl_node_mlp_bwd_blocks(n_rows) + 1][grl_node_mlp_partial_size()]: rows 0 .. blocks-1 = [dW3 | db3 | dW4 | db4 | dgamma | dbeta]
+ * (sum THOSE), the last row is scratch for that fragment image (since ABI 201; 200 wanted `blocks` rows) */
 int grl_node_mlp_fwd(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* out, int n_rows, int accumulate, hipStream_t stream);
 int grl_node_mlp_partial_size(void);

@@ -10,7 +10,7 @@ x2, dout = mk(n, 64), mk(n, 64)
 W3, b3, W4, b4, gam, bet = mk(256, 64), mk(256), mk(64, 256), mk(64), mk(64) + 1, mk(64)
 dx2 = torch.empty_like(x2)
 blocks = hip.query("grl_node_mlp_bwd_blocks", n)
-partial = torch.empty(blocks, hip.query("grl_node_mlp_partial_size"), device=dev)
+partial = torch.empty(blocks + 1, hip.query("grl_node_mlp_partial_size"), device=dev)   # last row: scratch
 buf = (ctypes.c_ulonglong * 32)()
 for it in range(3):
     hip.call("grl_node_mlp_bwd", x2, dout, W3, b3, W4, b4, gam, bet, dx2, partial, n)
