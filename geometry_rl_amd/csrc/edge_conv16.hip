@@ -1,5 +1,9 @@
-// Edge pipeline on 16-row tiles (round 2): forward, d x_src and message kernels of the separable fiber-bundle convolution with ONE EDGE
-// (= its 16 orientation rows) per wave pass on v_mfma_f32_16x16x32_bf16, instead of two edges (32 rows) on 32x32x16.
+// Edge pipeline on 16-row tiles (round 2) of the separable fiber-bundle convolution (reference: hepi.py:76-82,109-123,145-157,
+// ponita/conv.py:79-86,115-149): ONE EDGE (= its 16 orientation rows) per wave pass on v_mfma_f32_16x16x32_bf16, instead of two edges
+// (32 rows) on 32x32x16.  Kernels of this file:
+//   edge16_kernel<0> forward (three waves per SIMD), <2> per-edge messages, <1> d x_src alone (not used by the library any more);
+//   edge_bwd16_kernel: the WHOLE backward (d x_src + the five weight gradients) in one launch, one wave per SIMD -- see its header.
+// Entry points: grl_edge16_launch / grl_edge_bwd16_launch (called by the C-ABI functions of edge_conv.hip; internal).
 //
 // Why (DESIGN.md findings 13, 17; profiles/r02_edge_phase_*.txt): the 32-row kernels need 218-232 registers, so only two waves share a
 // SIMD; a wave issues one vector instruction per ~5 cycles, the exact-erf GELU between the layers is ~190 dependent-ish instructions per
