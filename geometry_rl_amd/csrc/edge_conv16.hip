@@ -646,6 +646,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
         }
         wf_load(wf[0], w.W2h + r * LD2 + 8 * g, w.W2l + r * LD2 + 8 * g, w.b2s + 4 * g);
+        // dW1 (| db1) of the PREVIOUS pass: its operands were staged at that pass's end (zero tiles before a wave's first pass); the six
+        // MFMAs run beside this pass's first GELU instead of standing alone behind an exposed LDS round trip
+        RFrags<1> rf1;
+        rowred_load<1>(st, lane, rf1);
         __builtin_amdgcn_sched_barrier(0);
         // rel = pos_src - pos_dst (hepi.py:109-117); the source is the anchor here
         float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pax), node)) -
@@ -710,6 +714,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
             BAR();
           }
           B16_GELU(v4(c[3]), g1[3], gp1[3]);
+          rowred_mma<1>(rf1, accB);
           split_pair(g1[0], g1[1], xh[0], xl[0]);
           split_pair(g1[2], g1[3], xh[1], xl[1]);
           BAR();
@@ -780,10 +785,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           *reinterpret_cast<uint2*>(st.Bl + stg_off(r, 4 + g)) = make_uint2(0u, 0u);
 #endif
         }
-        RFrags<1> rf1;
-        rowred_load<1>(st, lane, rf1);
-        rowred_mma<1>(rf1, accB);
-        B16_PH(6);   // staging dZ1 | phi, dW1 (6 MFMA 32x32)
+        B16_PH(6);   // staging dZ1 | phi (their product runs in the next pass)
 #undef BAR
       }
     }
@@ -791,6 +793,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
     skip_empty_run(node + 1, nn);
   }
 
+  {   // dW1 of the wave's last pass
+    RFrags<1> rf1;
+    rowred_load<1>(st, lane, rf1);
+    rowred_mma<1>(rf1, accB);
+  }
 #ifdef GRL_B16_PHASE
   if (lane == 0 && wave == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_b16phase[i], ph_[i]);
