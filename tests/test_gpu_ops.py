@@ -72,6 +72,56 @@ def test_edge_conv(n_src, n_dst, n_edges, dim, upper):
         check(name, a.grad, b.grad, 2e-4)
 
 
+@pytest.mark.parametrize("kind", ["star_in", "star_out", "sparse_sources", "chain_of_hubs"])
+def test_edge_conv_ragged(kind):
+    """Ragged graphs for the 16-row kernels (edge_conv16.hip): a destination with more in-edges than one 64-edge metadata batch, a source
+    with more out-edges than one batch, long runs of nodes without edges (padded points) on either side, hubs that straddle the
+    per-wave node chunks.  Forward, d x_src and the five weight gradients against the oracle (ragged / empty inputs)."""
+    from geometry_rl_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(7)
+    if kind == "star_in":          # 1100 destinations (> 512 forward tiles), destination 3 has 300 in-edges, the others one or none
+        n_src, n_dst = 400, 1100
+        src = torch.cat([torch.randint(0, n_src, (300,), generator=g), torch.randint(0, n_src, (600,), generator=g)])
+        dst = torch.cat([torch.full((300,), 3), torch.randperm(n_dst, generator=g)[:600]])
+    elif kind == "star_out":       # source 17 feeds 200 destinations; most sources have no out-edge at all
+        n_src, n_dst = 1500, 1200
+        src = torch.cat([torch.full((200,), 17), torch.randint(0, 40, (300,), generator=g) * 37])
+        dst = torch.cat([torch.randperm(n_dst, generator=g)[:200], torch.randint(0, n_dst, (300,), generator=g)])
+    elif kind == "sparse_sources":  # edges only among every 29th node: runs of 28 nodes without edges on both sides
+        n_src = n_dst = 2900
+        idx = torch.arange(0, 2900, 29)
+        src = idx[torch.randint(0, 100, (700,), generator=g)]
+        dst = idx[torch.randint(0, 100, (700,), generator=g)]
+    else:                          # hubs of 70 / 130 / 65 in- and out-edges at nodes 15, 16, 31 (chunk boundaries for 16-node chunks)
+        n_src = n_dst = 1300
+        parts_s, parts_d = [], []
+        for hub, deg in ((15, 70), (16, 130), (31, 65)):
+            parts_s += [torch.full((deg,), hub), torch.randint(0, n_src, (deg,), generator=g)]
+            parts_d += [torch.randint(0, n_dst, (deg,), generator=g), torch.full((deg,), hub)]
+        src, dst = torch.cat(parts_s), torch.cat(parts_d)
+    ei = torch.stack([src, dst])
+    grid = eq.make_grid(3, 16, True)
+    grid3 = F.pad(grid, (0, 3 - grid.shape[1]))
+    x_src = torch.randn(n_src, 16, 64, generator=g)
+    pos_s, pos_d = torch.rand(n_src, 3, generator=g) * 2 - 1, torch.rand(n_dst, 3, generator=g) * 2 - 1
+    w1, b1, w2, b2, wk = params(g, [(64, 14), (64,), (64, 64), (64,), (64, 64)])
+    R = torch.randn(n_dst, 16, 64, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x_src, w1, b1, w2, b2, wk)]
+    xs, W1, B1, W2, B2, WK = leaves
+    P = {"b.1.weight": W1, "b.1.bias": B1, "b.3.weight": W2, "b.3.bias": B2}
+    kb = eq.basis_mlp(eq.spatial_invariants(grid, pos_s[ei[0]], pos_d[ei[1]]), P, "b")
+    x1_ref = eq.scatter_sum(F.linear(kb, WK) * xs[ei[0]], ei[1], n_dst)
+    (x1_ref * R).sum().backward()
+    es = ops.build_edge_set(ei.to(d), n_src, n_dst)
+    dl = [t.clone().to(d).requires_grad_(True) for t in (x_src, w1, b1, w2, b2, wk)]
+    x1 = ops.EdgeConv.apply(dl[0], pos_s.to(d), pos_d.to(d), grid3.to(d), dl[1], dl[2], dl[3], dl[4], dl[5], es, 3)
+    check("x1", x1, x1_ref)
+    (x1 * R.to(d)).sum().backward()
+    for name, a, b in zip(["dx_src", "dW1", "db1", "dW2", "db2", "dWk"], dl, leaves):
+        check(name, a.grad, b.grad, 2e-4)
+
+
 @pytest.mark.parametrize("n", [1, 7, 130])
 def test_node_mlp(n):
     from geometry_rl_amd import ops
