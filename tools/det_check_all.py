@@ -19,25 +19,31 @@ dy = torch.randn(nd, 16, 64, generator=g).to(d)
 xd = torch.randn(nd, 16, 64, generator=g).to(d)
 
 
-def edge():
-    xs = x.clone().requires_grad_(True)
+from geometry_rl_amd import hip
+
+
+def edge(prec=""):
+    dt = hip.storage_dtype(prec)
+    xs = x.to(dt).clone().detach().requires_grad_(True)
     ws = [w.clone().requires_grad_(True) for w in ew]
-    y = ops.EdgeConv.apply(xs, ps, pd, grid3, *ws, es, 3)
-    y.backward(dy)
+    y = ops.EdgeConv.apply(xs, ps, pd, grid3, *ws, es, 3, None, prec)
+    y.backward(dy.to(dt))
     return [y.detach(), xs.grad] + [w.grad for w in ws]
 
 
-def mlp():
-    x2 = x.clone().requires_grad_(True)
+def mlp(prec=""):
+    dt = hip.storage_dtype(prec)
+    x2 = x.to(dt).clone().detach().requires_grad_(True)
     ws = [w.clone().requires_grad_(True) for w in mw]
-    y = ops.NodeMLP.apply(x2, xd, *ws, None)
-    y.backward(dy)
+    y = ops.NodeMLP.apply(x2, xd.to(dt), *ws, None, None, prec)
+    y.backward(dy.to(dt))
     return [y.detach(), x2.grad] + [w.grad for w in ws]
 
 
 bad_total = 0
-for name, fn, labels in (("edge_conv", edge, ["x1", "dx_src", "dW1", "db1", "dW2", "db2", "dWk"]),
-                         ("node_mlp", mlp, ["out", "dx2", "dgamma", "dbeta", "dW3", "db3", "dW4", "db4"])):
+EL, ML = ["x1", "dx_src", "dW1", "db1", "dW2", "db2", "dWk"], ["out", "dx2", "dgamma", "dbeta", "dW3", "db3", "dW4", "db4"]
+for name, fn, labels in (("edge_conv", edge, EL), ("node_mlp", mlp, ML), ("edge_conv_bf16", lambda: edge("_bf16"), EL),
+                         ("node_mlp_bf16", lambda: mlp("_bf16"), ML)):
     ref = fn()
     torch.cuda.synchronize()
     for i in range(1, REPS):
