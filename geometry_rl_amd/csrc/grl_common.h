@@ -88,12 +88,54 @@ GRL_DEVINL void acc_to_frag(const f32x16& a, float4& f0, float4& f1, float4& f2,
 typedef float v2f __attribute__((ext_vector_type(2)));
 GRL_DEVINL v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 GRL_DEVINL v2f splat2(float a) { return v2f{a, a}; }
+// GRL_GELU_V2 (round 3, default): the same A&S 7.1.26 evaluation with fewer issue slots -- what the MFMA kernels are short of
+// (DESIGN.md finding 22).  Per PAIR of elements, value + derivative: 4 transcendental + 4 plain + 12 packed instructions (was 4 + 6 + 15):
+//   e2 = exp2(-x^2/2 log2 e + log2(1/sqrt(2 pi))) = pdf(x)            (the 1/sqrt(2 pi) rides in the exponent: an FMA instead of a multiply)
+//   hq = (b1 t + .. + b5 t^5) e2 = erfc(|x|/sqrt 2)/2 = Phi(-|x|)      (b_i = a_i sqrt(2 pi)/2)
+//   cdf = 1/2 + copysign(1/2 - hq, x);   gelu = x cdf;   gelu' = cdf + x e2
+// value only: gelu = max(x, 0) - |x| hq with hq = (a1/2 t + ..) exp(-x^2/2): 4 transcendental + 6 plain (|x| and the sign are operand
+// modifiers of v_fma_f32) + 8 packed (was 4 + 4 + 11).  Max |error| against erf-GELU in fp32: 4.7e-7 / 3.3e-7 (old form: 3.3e-7), derivative 3.0e-7.
+// A transcendental-free odd polynomial x P(x^2) for Phi - 1/2 was priced and dropped: 13 coefficients for 6e-7 on |x| <= 5 (26 packed-FMA
+// issue slots per pair against 17 for the rcp + exp it replaces) and a degree-25 Horner form cancels catastrophically in fp32.
+#ifndef GRL_GELU_V2
+#define GRL_GELU_V2 1
+#endif
 template <bool WITH_GRAD>
 GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
   const float kp = 0.3275911f * 0.70710678118654752440f;
   v2f t, e;
   t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), kp, 1.0f));
   t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), kp, 1.0f));
+#if GRL_GELU_V2
+  if (WITH_GRAD) {
+    const v2f arg = fma2(x * x, splat2(-0.72134752044448170368f), splat2(-1.32574806473615910f));   // log2 pdf(x)
+    e.x = __builtin_amdgcn_exp2f(arg.x);
+    e.y = __builtin_amdgcn_exp2f(arg.y);
+    v2f poly = fma2(t, splat2(1.33027442959f), splat2(-1.82125597911f));     // a_i * sqrt(2 pi) / 2
+    poly = fma2(poly, t, splat2(1.78147793657f));
+    poly = fma2(poly, t, splat2(-0.35656378125f));
+    poly = fma2(poly, t, splat2(0.31938153026f));
+    const v2f hq = (poly * t) * e;                                         // Phi(-|x|)
+    const v2f w = splat2(0.5f) - hq;
+    v2f ws;
+    ws.x = copysignf(w.x, x.x);
+    ws.y = copysignf(w.y, x.y);
+    const v2f cdf = ws + splat2(0.5f);
+    g = x * cdf;
+    gp = fma2(x, e, cdf);
+  } else {
+    const v2f arg = (x * x) * splat2(-0.72134752044448170368f);
+    e.x = __builtin_amdgcn_exp2f(arg.x);
+    e.y = __builtin_amdgcn_exp2f(arg.y);
+    v2f poly = fma2(t, splat2(0.5307027145f), splat2(-0.7265760135f));     // a_i / 2
+    poly = fma2(poly, t, splat2(0.7107068705f));
+    poly = fma2(poly, t, splat2(-0.142248368f));
+    poly = fma2(poly, t, splat2(0.127414796f));
+    const v2f hq = (poly * t) * e;
+    g.x = fmaf(-fabsf(x.x), hq.x, fmaxf(x.x, 0.f));
+    g.y = fmaf(-fabsf(x.y), hq.y, fmaxf(x.y, 0.f));
+  }
+#else
   const v2f arg = (x * x) * splat2(-0.72134752044448170368f);   // -x^2/2 * log2(e)
   e.x = __builtin_amdgcn_exp2f(arg.x);
   e.y = __builtin_amdgcn_exp2f(arg.y);
@@ -114,6 +156,7 @@ GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
     const v2f cdf = fma2(-cs, q, cs + splat2(0.5f));
     gp = fma2(x * e, splat2(0.39894228040143267794f), cdf);
   }
+#endif
 }
 GRL_DEVINL float4 gelu4(float4 x) {
   v2f g0, g1, d0, d1;

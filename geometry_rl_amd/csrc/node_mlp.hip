@@ -257,11 +257,28 @@ constexpr int MLP_PARTIAL = W * C + W + C * W + C + C + C;
 constexpr int LDF = GRL_LDB(64);  // 72 bf16: activation fragment images (same layout as the weight images)
 constexpr int LDD = C + 4;        // 68 fp32: partial dA rows
 
-GRL_DEVINL float row16_sum(float v) {  // sum over the 16 consecutive lanes that share a row
+// sum over the 16 consecutive lanes that share a row.  GRL_ROW_DPP (round 3, default): four DPP adds on the vector pipe (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror) instead of four dependent ds_bpermute round trips through the LDS (~4 x 100 cycles of latency
+// in front of every LayerNorm statistic, twice per stage, with all eight waves phase-locked in that stage).
+#ifndef GRL_ROW_DPP
+#define GRL_ROW_DPP 1
+#endif
+template <int CTRL>
+GRL_DEVINL float dpp_read(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+GRL_DEVINL float row16_sum(float v) {
+#if GRL_ROW_DPP
+  v += dpp_read<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_read<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_read<0x141>(v);   // row_half_mirror: the other quad of the 8-lane half
+  v += dpp_read<0x140>(v);   // row_mirror: the other half of the 16-lane row
+#else
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   v += __shfl_xor(v, 4, 64);
   v += __shfl_xor(v, 8, 64);
+#endif
   return v;
 }
 GRL_DEVINL void put_split4(unsigned short* hi, unsigned short* lo, const float4& v) {  // 4 consecutive image positions
