@@ -20,14 +20,12 @@
 // 32-block: position 8 g + j <-> feature 16 (j >> 2) + 4 g + (j & 3); the weight images are staged in that order), so the chain stays
 // in registers exactly as in the 32-row kernels.  Three waves per SIMD: every MFMA group is fenced (all fragment loads, then the
 // MFMAs, then a read of the accumulator: DESIGN.md finding 3).
-#include "grl_common.h"
+#include "grl_tile16.h"
 #include <cstdlib>
 
 namespace {
 
 constexpr int C = 64, O = 16;
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-GRL_DEVINL f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 #ifndef GRL_E16_WAVES
 #define GRL_E16_WAVES 4                  // waves per workgroup
@@ -124,7 +122,6 @@ GRL_DEVINL void group16(const unsigned short* whi, const unsigned short* wlo, co
 }
 
 
-GRL_DEVINL float4 v4(const f32x4v& a) { return make_float4(a[0], a[1], a[2], a[3]); }
 // timing knock-outs (diagnostic builds only; results are wrong): -DGRL_E16_NOGELU, -DGRL_E16_NOMFMA, -DGRL_E16_NOGATHER
 #ifdef GRL_E16_NOGELU
 #define GELU16(x) (x)
@@ -388,14 +385,7 @@ __global__ __launch_bounds__(E16_THREADS, GRL_E16_WGS) void edge16_kernel(Edge16
 //   hardware transpose read: cdna_hip_programming.md T10); no register transposes on the matrix pipe, no barrier (same wave).
 //   Weight-gradient accumulators: 160 registers per wave for the whole launch (dWk 64, dW2 64, dW1 | db1 32), one partial row per
 //   workgroup at the end in the layout of the 32-row kernel (edge_conv.hip EDGE_PARTIAL).
-// A staging image holds 16 rows x 64 features of bf16 in 4-row x 16-feature blocks of 128 B (the unit ds_read_b64_tr_b16 fetches per
-// 16-lane group), block (row >> 2, feature >> 4) at ((row >> 2) * 4 + (feature >> 4)) * 128 B, row (row & 3) of a block at 32 B, and the
-// four 8-byte feature quads of a row rotated by the block row (quad ^ (row >> 2)): the 16 lanes of a ds_write_b64 group (16 rows, one
-// quad) and the 32 lanes of a transposed read (two adjacent blocks) then both touch every bank once.  2 KB per image, no padding.
-constexpr int STG = 16 * 64;   // bf16 elements per image
-GRL_DEVINL int stg_off(int row, int feat_quad /* feature >> 2, 0..15 */) {
-  return (((row >> 2) * 4 + (feat_quad >> 2)) * 64) + (row & 3) * 16 + (((feat_quad & 3) ^ (row >> 2)) << 2);
-}
+// (staging image layout, transposed fragment reads, pinned accumulators: grl_tile16.h)
 struct Stage16 {
   unsigned short Ah[STG], Al[STG];   // A side: dK / dZ2 / dZ1
   unsigned short Bh[STG], Bl[STG];   // B side: g2 / g1 / phi
@@ -408,47 +398,6 @@ struct Bwd16Smem {
 };
 constexpr int BWD16_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;   // = EDGE_PARTIAL of edge_conv.hip
 
-typedef short v4s16 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4s16 lds_v4s16;
-// fragment (8 rows x this lane's feature) of a staging image for a 32x32x16 operand: tile t = 32 features, lane (m = l & 31, h = l >> 5)
-// gets rows 8 h + j of feature 32 t + m.  Two transposed block reads (4 rows x 16 features per 16-lane group each).
-GRL_DEVINL bf16x8 tr_frag(const unsigned short* img, int t, int lane) {
-  const int h = lane >> 5, half16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
-  // block row 2 h (rows 8 h .. 8 h + 3) and 2 h + 1, feature block 2 t + half16; this lane supplies row q, quad p of the block
-  const unsigned short* base = img + ((2 * h) * 4 + 2 * t + half16) * 64 + q * 16 + ((p ^ (2 * h)) << 2);
-  const unsigned short* base1 = img + ((2 * h + 1) * 4 + 2 * t + half16) * 64 + q * 16 + ((p ^ (2 * h + 1)) << 2);
-  const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16*)base);
-  const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16*)base1);
-  typedef short v8s16 __attribute__((ext_vector_type(8)));
-  const v8s16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-// this lane's chain-layout fragments (row r, features 32 s + {4 g .. 4 g + 3} and 32 s + 16 + {4 g .. 4 g + 3}) -> image[row][feature]
-template <int KS>
-GRL_DEVINL void stage_put(unsigned short* ih, unsigned short* il, const bf16x8 (&fh)[KS], const bf16x8 (&fl)[KS], int r, int g) {
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int o0 = stg_off(r, 8 * s + g), o1 = stg_off(r, 8 * s + 4 + g);   // features 32 s + 4 g .. and 32 s + 16 + 4 g ..
-    const u32x4 h = __builtin_bit_cast(u32x4, fh[s]);
-    *reinterpret_cast<uint2*>(ih + o0) = make_uint2(h[0], h[1]);
-    *reinterpret_cast<uint2*>(ih + o1) = make_uint2(h[2], h[3]);
-#if !GRL_PREC
-    const u32x4 l = __builtin_bit_cast(u32x4, fl[s]);
-    *reinterpret_cast<uint2*>(il + o0) = make_uint2(l[0], l[1]);
-    *reinterpret_cast<uint2*>(il + o1) = make_uint2(l[2], l[3]);
-#endif
-  }
-}
-// Weight-gradient accumulators are pinned to the accumulator half of the register file: the MFMA is an asm statement with the tile as
-// a read-write "a" operand (updated in place, never copied), while this file is compiled with -mllvm -amdgpu-mfma-vgpr-form so that
-// the chain's builtin MFMAs keep their results in ordinary VGPRs, where the GELU reads them (with the default selection a
-// 512-register kernel puts EVERY MFMA result into AGPRs: 450 v_accvgpr moves per pass, a third of the vector issue slots).
-// asm is opaque to the hazard recognizer: s_nop 1 covers an operand the compiler may have just copied with a VALU move; the operands
-// themselves come from LDS (counted loads: the compiler waits for them); acc_drain() before the accumulators are read at the end.
-GRL_DEVINL void mfma32_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-GRL_DEVINL void acc_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 template <int NTK>
 struct RFrags {
   bf16x8 ah[2], al[2], bh[NTK], bl[NTK];
@@ -805,7 +754,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   // ---- fold the four waves through LDS (images dead): 1 -> 0 and 3 -> 2, then 2 -> 0; fixed order, one partial row per workgroup
   constexpr int NACC = 10 * 16 + 16;
   float* fold = smem_raw;
-  acc_drain();   // the last asm MFMAs have written the accumulators before they are read
+  // the last asm MFMAs have written the accumulators before they are read (every tile is an operand of the drain: nothing moves above it)
+  acc_drain(accB[0][0], accB[1][0], accA[0][0], accA[0][1], accA[1][0], accA[1][1], accK[0][0], accK[0][1], accK[1][0], accK[1][1]);
   auto visit = [&](auto&& f) {
     int k = 0;
 #pragma unroll

@@ -671,10 +671,18 @@ int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* 
 
 // partial [grl_node_mlp_bwd_blocks(n_rows) + 1][grl_node_mlp_partial_size()]: one gradient row per workgroup, and the LAST row is scratch
 // (the shared W3 fragment image, 64 KB) -- sum rows 0 .. blocks-1 only.  d x_dst is simply dout (residual), not produced here.
+#ifndef GRL_MLP_BWD16
+#define GRL_MLP_BWD16 1   // round 3: the 16-row, one-barrier-per-chunk kernel of node_mlp16.hip; 0 = the 32-row kernel above
+#endif
+int GRL_ENTRY(grl_node_mlp_bwd16_launch)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4,
+                                         const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, int blocks,
+                                         hipStream_t stream);
 int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, hipStream_t stream) {
   (void)b4;
   if (n_rows <= 0) return 0;
+  if (GRL_MLP_BWD16 && n_rows % 16 == 0)
+    return GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), stream);
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem)));
   const int blocks = grl_node_mlp_bwd_blocks(n_rows);
   u32x4* slab = reinterpret_cast<u32x4*>(partial + (size_t)blocks * MLP_PARTIAL);

@@ -15,21 +15,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
 ABI_VERSION = 201   # include/grl_hip.h GRL_HIP_VERSION
-SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "head_ops.hip", "critic_ops.hip", "train_ops.hip"]
+SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "head_ops.hip", "critic_ops.hip",
+           "train_ops.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
 # per-source compiler flags.  edge_conv16.hip: its 512-register backward kernel keeps the chain's MFMA results in VGPRs (the default
 # selection would put every MFMA result of such a kernel into AGPRs) and pins the weight-gradient tiles to AGPRs itself (asm)
-FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "node_mlp16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
-            ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"),
+            ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16")]
 
 
 def build(verbose: bool = True, force: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libgrl_hip.so in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "grl_common.h"), os.path.abspath(__file__)]
+    deps = srcs + [os.path.join(CSRC, "grl_common.h"), os.path.join(CSRC, "grl_tile16.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -41,7 +42,8 @@ def build(verbose: bool = True, force: bool = False) -> str:
         o = os.path.join(CSRC, "build", os.path.basename(s) + sfx + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d)
-                                                    for d in [s, os.path.join(CSRC, "grl_common.h"), os.path.abspath(__file__)]):
+                                                    for d in [s, os.path.join(CSRC, "grl_common.h"), os.path.join(CSRC, "grl_tile16.h"),
+                                                              os.path.abspath(__file__)]):
             continue
         cmd = ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + FILE_FLAGS.get(os.path.basename(s), [])
                + flags + ["-c", s, "-o", o])

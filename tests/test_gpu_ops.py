@@ -122,7 +122,7 @@ def test_edge_conv_ragged(kind):
         check(name, a.grad, b.grad, 2e-4)
 
 
-@pytest.mark.parametrize("n", [1, 7, 130])
+@pytest.mark.parametrize("n", [1, 7, 130, 700, 1601])   # 700 / 1601 nodes: 2-3 / 6-7 chunks per workgroup of the pipelined backward
 def test_node_mlp(n):
     from geometry_rl_amd import ops
     d = dev()
