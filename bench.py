@@ -375,7 +375,7 @@ def main():
             "metric": "policy-update steps/sec, HEPi 4096 envs x 128 steps", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32 storage/accumulate, bf16 products (one bf16 MFMA per product)" if cfg.precision == "bf16" else
+            "dtype": ("bf16 latent storage and MFMA operands (one bf16 MFMA per product), f32 accumulate / weights / loss" if cfg.precision == "bf16" else
                       "f32 storage/accumulate, bf16x3 products (three bf16 MFMAs per f32 product)"), "data": "synthetic",
             "mode": upd.mode_timed, "host_cores": os.cpu_count(),
             "config": {"workload": f"{cfg_name}, 4096 synthetic envs x 128 steps, minibatch {args.minibatch} frames "

@@ -39,7 +39,7 @@ class AgentConfig:
     clip_grad_norm: bool = False
     max_grad_norm: float = 1.0
     aggr: str = "add"         # "AttentionalAggregation": configs/algorithm/pyg_agent/model/hepi_attention.yaml
-    precision: str = "fp32"   # "bf16": one bf16 MFMA per dense product in the actor (BASELINE config 5), fp32 storage / accumulation
+    precision: str = "fp32"   # "bf16": BASELINE config 5 -- node latents stored as bf16, one bf16 MFMA per dense product, fp32 accumulation
 
 
 def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):

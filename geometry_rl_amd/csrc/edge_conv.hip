@@ -406,6 +406,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
   pc.flush(0);
 }
 
+// GRL_LEGACY32 (build switch, default 0): the 32-row kernels that the 16-row kernels of edge_conv16.hip superseded in round 2 -- the flat
+// message kernel, the d x_src kernel and the weight-gradient kernel below, and the non-split instance of the forward above.  They are
+// the A/B baselines of DESIGN.md findings 19 / 20 (-DGRL_LEGACY32=1 -DGRL_EDGE16=0 -DGRL_EDGE_BWD16=0) and are NOT compiled into the
+// shipped library: nothing unreachable, nothing the parity / determinism suite does not cover.
+constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;   // partial row: [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64]
+#ifndef GRL_LEGACY32
+#define GRL_LEGACY32 0
+#endif
+#if GRL_LEGACY32
 // ------------------------------------------------------------------------------------------------ messages (attention aggregation)
 // FiberBundleConv(aggr="AttentionalAggregation") (conv.py:21-26,58-61,138-139; configs/algorithm/pyg_agent/model/hepi_attention.yaml)
 // gates every message before it is summed, so the messages m_e = K_e * x_src[src(e)] have to exist per edge: this kernel is the forward
@@ -468,7 +477,6 @@ __global__ __launch_bounds__(256, 2) void edge_msg_fwd_kernel(EdgeParams p, st_t
 //             dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
 // Weight-gradient accumulators live in registers for the whole launch and leave as one partial row per wave:
 //   partial[block][9216] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64]   (the four waves folded through LDS at the end).
-constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;
 
 
 // p is the SOURCE-anchored view of the edge set (rowptr = rowptr_s, e_src / e_dst in source-sorted order, n_anchor = n_src).
@@ -739,6 +747,7 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
     if (h == 0) { ob1[32 * nt + r] = v1; ob2[32 * nt + r] = v2; }
   }
 }
+#endif   // GRL_LEGACY32
 
 }  // namespace
 
@@ -779,19 +788,25 @@ int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const 
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int n_tiles = (n_dst + TD - 1) / TD;
   const size_t smem = sizeof(ChainW), smem_split = smem + sizeof(float4) * FWD_WAVES * 8 * 64;
-  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split));
+  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split));
   if (n_tiles <= GRL_FWD_SPLIT_TILES) {   // fewer tiles than SIMD groups: spread each tile's passes over a workgroup
     hipLaunchKernelGGL(edge_conv_fwd_kernel<true>, dim3(n_tiles), dim3(64 * FWD_WAVES), smem_split, stream, p, x1);
-  } else if (GRL_EDGE16) {
-    return GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2,
-                                        b2, Wk, x1, nullptr, stream);
-  } else {
+    GRL_CHECK_LAUNCH();
+    return 0;
+  }
+#if GRL_LEGACY32
+  if (!GRL_EDGE16) {
+    GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
     if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
     hipLaunchKernelGGL(edge_conv_fwd_kernel<false>, dim3(blocks), dim3(64 * FWD_WAVES), smem, stream, p, x1);
+    GRL_CHECK_LAUNCH();
+    return 0;
   }
-  GRL_CHECK_LAUNCH();
-  return 0;
+#endif
+  (void)smem;
+  return GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2, b2,
+                                      Wk, x1, nullptr, stream);
 }
 
 // The same edge set in both orders: destination-sorted (rowptr, e_src, e_dst: the forward's arrays) for the weight kernel and
@@ -802,44 +817,48 @@ int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const 
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, hipStream_t stream) {
-  if (n_edges <= 0) {
-    if (n_src > 0) {
+  if (n_edges <= 0) {   // an empty edge set: d x_src is the residual branch alone, the weight gradients are zero (the caller sums
+    if (n_src > 0) {    // grl_edge_bwd_blocks(n_edges) partial rows: they must hold zeros, not whatever the allocation held)
       if (dres) hipMemcpyAsync(dx_src, dres, sizeof(st_t) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
       else hipMemsetAsync(dx_src, 0, sizeof(st_t) * (size_t)n_src * O * C, stream);
     }
+    hipMemsetAsync(partial, 0, sizeof(float) * (size_t)grl_edge_bwd_blocks(n_edges) * EDGE_PARTIAL, stream);
     return 0;
   }
-  EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-  EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
   const int blocks = grl_edge_bwd_blocks(n_edges);
-  if (GRL_EDGE_BWD16) {
-    grl_prof_begin("edge_bwd16_kernel", stream);
-    const int rc = GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, grid, dim,
-                                                    W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, stream);
+#if GRL_LEGACY32
+  if (!GRL_EDGE_BWD16) {
+    EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+    EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
+    const size_t smem_x = sizeof(ChainW);
+    size_t smem_w = smem_x + sizeof(BwdW);
+    if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
+    GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
+    grl_prof_begin("edge_conv_bwd_x_kernel", stream);
+    if (GRL_EDGE16) {
+      GRL_ENTRY(grl_edge16_launch)(1, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2,
+                                   Wk, dx_src, dres, stream);
+    } else {
+      const int n_tiles_s = (n_src + TD - 1) / TD;
+      int xblocks = (n_tiles_s + 3) / 4;
+      if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;   // two 4-wave workgroups per CU, like the forward
+      hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dx1, dx_src, dres);
+    }
     grl_prof_end(stream);
-    return rc;
+    GRL_CHECK_LAUNCH();
+    grl_prof_begin("edge_conv_bwd_w_kernel", stream);
+    hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dx1, partial, n_edges);
+    grl_prof_end(stream);
+    GRL_CHECK_LAUNCH();
+    return 0;
   }
-  const size_t smem_x = sizeof(ChainW);
-  size_t smem_w = smem_x + sizeof(BwdW);
-  if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
-  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
-  grl_prof_begin("edge_conv_bwd_x_kernel", stream);
-  if (GRL_EDGE16) {
-    GRL_ENTRY(grl_edge16_launch)(1, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2,
-                                 Wk, dx_src, dres, stream);
-  } else {
-    const int n_tiles_s = (n_src + TD - 1) / TD;
-    int xblocks = (n_tiles_s + 3) / 4;
-    if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;   // two 4-wave workgroups per CU, like the forward
-    hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dx1, dx_src, dres);
-  }
+#endif
+  (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;   // the destination-sorted view is the legacy weight kernel's
+  grl_prof_begin("edge_bwd16_kernel", stream);
+  const int rc = GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, grid, dim,
+                                                  W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, stream);
   grl_prof_end(stream);
-  GRL_CHECK_LAUNCH();
-  grl_prof_begin("edge_conv_bwd_w_kernel", stream);
-  hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dx1, partial, n_edges);
-  grl_prof_end(stream);
-  GRL_CHECK_LAUNCH();
-  return 0;
+  return rc;
 }
 
 // ---- attention aggregation, edge side: messages per edge (rows in destination-sorted edge order) and the backward for a per-edge
@@ -849,17 +868,20 @@ int GRL_ENTRY(grl_edge_messages_fwd)(const st_t* x_src, const float* pos_src, co
                                      const float* b1, const float* W2, const float* b2, const float* Wk, st_t* msg,
                                      hipStream_t stream) {
   if (n_edges <= 0) return 0;
-  EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-  const size_t smem = sizeof(ChainW);
-  GRL_ONCE(hipFuncSetAttribute((const void*)edge_msg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW)));
-  if (GRL_EDGE16)
-    return GRL_ENTRY(grl_edge16_launch)(2, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, n_edges, 1, grid, dim, W1, b1,
-                                        W2, b2, Wk, msg, nullptr, stream);
-  int blocks = ((n_edges + 1) / 2 + 3) / 4;
-  if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
-  hipLaunchKernelGGL(edge_msg_fwd_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), smem, stream, p, msg, n_edges);
-  GRL_CHECK_LAUNCH();
-  return 0;
+#if GRL_LEGACY32
+  if (!GRL_EDGE16) {
+    EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+    const size_t smem = sizeof(ChainW);
+    GRL_ONCE(hipFuncSetAttribute((const void*)edge_msg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW)));
+    int blocks = ((n_edges + 1) / 2 + 3) / 4;
+    if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
+    hipLaunchKernelGGL(edge_msg_fwd_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), smem, stream, p, msg, n_edges);
+    GRL_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
+  return GRL_ENTRY(grl_edge16_launch)(2, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, n_edges, 1, grid, dim, W1, b1,
+                                      W2, b2, Wk, msg, nullptr, stream);
 }
 
 int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
@@ -867,38 +889,43 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
                                      const int* s2d, int n_src, const float* grid, int dim, const float* W1, const float* b1,
                                      const float* W2, const float* b2, const float* Wk, const st_t* dmsg, const st_t* dres,
                                      st_t* dx_src, float* partial, hipStream_t stream) {
-  if (n_edges <= 0) {
-    if (n_src > 0) {
+  if (n_edges <= 0) {   // an empty edge set: d x_src is the residual branch alone, the weight gradients are zero (the caller sums
+    if (n_src > 0) {    // grl_edge_bwd_blocks(n_edges) partial rows: they must hold zeros, not whatever the allocation held)
       if (dres) hipMemcpyAsync(dx_src, dres, sizeof(st_t) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
       else hipMemsetAsync(dx_src, 0, sizeof(st_t) * (size_t)n_src * O * C, stream);
     }
+    hipMemsetAsync(partial, 0, sizeof(float) * (size_t)grl_edge_bwd_blocks(n_edges) * EDGE_PARTIAL, stream);
     return 0;
   }
-  EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-  EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
-  pd.per_edge = 1;            // the weight kernel walks the destination-sorted order: row = edge position
-  ps.per_edge = 1;
-  ps.erow = s2d;              // the d x_src kernel walks the source-sorted order
   const int blocks = grl_edge_bwd_blocks(n_edges);
-  if (GRL_EDGE_BWD16)
-    return GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, grid, dim, W1, b1,
-                                            W2, b2, Wk, dres, dx_src, partial, blocks, stream);
-  const size_t smem_x = sizeof(ChainW);
-  size_t smem_w = smem_x + sizeof(BwdW);
-  if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;
-  GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
-  const int n_tiles_s = (n_src + TD - 1) / TD;
-  int xblocks = (n_tiles_s + 3) / 4;
-  if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
-  if (GRL_EDGE16)
-    GRL_ENTRY(grl_edge16_launch)(1, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2, Wk,
-                                 dx_src, dres, stream);
-  else
-    hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
-  GRL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dmsg, partial, n_edges);
-  GRL_CHECK_LAUNCH();
-  return 0;
+#if GRL_LEGACY32
+  if (!GRL_EDGE_BWD16) {
+    EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+    EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
+    pd.per_edge = 1;            // the weight kernel walks the destination-sorted order: row = edge position
+    ps.per_edge = 1;
+    ps.erow = s2d;              // the d x_src kernel walks the source-sorted order
+    const size_t smem_x = sizeof(ChainW);
+    size_t smem_w = smem_x + sizeof(BwdW);
+    if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;
+    GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
+    const int n_tiles_s = (n_src + TD - 1) / TD;
+    int xblocks = (n_tiles_s + 3) / 4;
+    if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
+    if (GRL_EDGE16)
+      GRL_ENTRY(grl_edge16_launch)(1, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2, Wk,
+                                   dx_src, dres, stream);
+    else
+      hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
+    GRL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dmsg, partial, n_edges);
+    GRL_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
+  (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;
+  return GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, grid, dim, W1, b1,
+                                          W2, b2, Wk, dres, dx_src, partial, blocks, stream);
 }
 
 #if defined(GRL_PHASE_PROF) && !GRL_PREC

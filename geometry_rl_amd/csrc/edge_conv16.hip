@@ -841,10 +841,16 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
   if (blocks < 1) blocks = 1;
   const size_t smem = sizeof(ChainW16);
   GRL_ONCE(hipFuncSetAttribute((const void*)edge16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16));
-           hipFuncSetAttribute((const void*)edge16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16));
            hipFuncSetAttribute((const void*)edge16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16)));
   if (mode == 0) hipLaunchKernelGGL(edge16_kernel<0>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
-  else if (mode == 1) hipLaunchKernelGGL(edge16_kernel<1>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
+#if defined(GRL_LEGACY32) && GRL_LEGACY32   // the d x_src-alone instance: only the two-launch backward of legacy builds reaches it
+  else if (mode == 1) {
+    GRL_ONCE(hipFuncSetAttribute((const void*)edge16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16)));
+    hipLaunchKernelGGL(edge16_kernel<1>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
+  }
+#else
+  else if (mode == 1) return -4;
+#endif
   else hipLaunchKernelGGL(edge16_kernel<2>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
   GRL_CHECK_LAUNCH();
   return 0;
@@ -860,6 +866,9 @@ int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const 
   npw = npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
   Bwd16Params bp{{dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, erow, grid, W1, b1, W2, b2, Wk, n_src, n_edges, dim, 0, per_edge, npw},
                  x_src, dres, dx_src, partial};
+  // one wave per SIMD is a precondition of the unfenced MFMA groups of this kernel (DESIGN.md finding 3): more than half the LDS per
+  // workgroup makes a second workgroup on the CU impossible, whatever the register allocation of a future compiler
+  static_assert(sizeof(Bwd16Smem) > 80 * 1024, "edge_bwd16_kernel must not share a CU with a second workgroup");
   GRL_ONCE(hipFuncSetAttribute((const void*)edge_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Bwd16Smem)));
   hipLaunchKernelGGL(edge_bwd16_kernel, dim3(blocks), dim3(256), sizeof(Bwd16Smem), stream, bp);
   GRL_CHECK_LAUNCH();

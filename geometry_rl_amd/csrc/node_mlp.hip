@@ -680,7 +680,10 @@ int GRL_ENTRY(grl_node_mlp_bwd16_launch)(const st_t* x2, const st_t* dout, const
 int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, hipStream_t stream) {
   (void)b4;
-  if (n_rows <= 0) return 0;
+  if (n_rows <= 0) {   // no rows: zero gradients (the caller sums grl_node_mlp_bwd_blocks(n_rows) = 1 partial row)
+    hipMemsetAsync(partial, 0, sizeof(float) * MLP_PARTIAL, stream);
+    return 0;
+  }
   if (GRL_MLP_BWD16 && n_rows % 16 == 0)
     return GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), stream);
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem)));

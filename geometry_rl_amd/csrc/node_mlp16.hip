@@ -68,7 +68,15 @@ GRL_DEVINL void split4(const float4& v, uint2& hi, uint2& lo) {
   lo.y = pack_rn(v.z - trunc_bf16(v.z), v.w - trunc_bf16(v.w));
 #endif
 }
+// GRL_M16_SCALAR (default): plain f32 vector instructions only in this kernel (scalar GELU, file compiled with -fno-slp-vectorize)
+#ifndef GRL_M16_SCALAR
+#define GRL_M16_SCALAR 1
+#endif
 GRL_DEVINL void gelu_both4_pk(const float4& x, float4& gv, float4& gpv) {
+#if GRL_M16_SCALAR
+  gelu_both4(x, gv, gpv);
+  return;
+#endif
   v2f g0, g1, d0, d1;
   gelu_pair<true>(v2f{x.x, x.y}, g0, d0);
   gelu_pair<true>(v2f{x.z, x.w}, g1, d1);
@@ -233,6 +241,48 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
     dbet = f4_add(dbet, s4_da);
   };
 
+  // ---- the same two stages as twelve micro-steps of ~6 vector instructions (k is a constant after unrolling)
+  // (volatile asm statements keep their order: an empty one that re-defines a step's input keeps the step behind the MFMA in front of it,
+  // one that re-defines its output keeps it in front of the next MFMA -- without them every step sinks below the twelve MFMAs)
+#define PIN(x) asm volatile("" : "+v"(x))
+  float4 m_t0, m_t1, m_dx;
+  float m_sa, m_sb;
+  auto s4_step = [&](int k, st_t* rows) {
+    const float4& xh = xh0;
+    switch (k) {
+      case 0: PIN(s4_p[0].x); m_t0 = f4_add(s4_p[0], s4_p[1]); PIN(m_t0.x); PIN(m_t0.w); break;
+      case 1: PIN(s4_p[2].x); m_t1 = f4_add(s4_p[2], s4_p[3]); PIN(m_t1.x); PIN(m_t1.w); break;
+      case 2: PIN(m_t0.y); s4_da = f4_add(m_t0, m_t1); PIN(s4_da.x); PIN(s4_da.w); break;
+      case 3: PIN(s4_da.y); s4_gg = f4_mul(s4_da, gq); PIN(s4_gg.x); PIN(s4_gg.w); break;
+      case 4: PIN(s4_gg.y); m_sa = (s4_gg.x + s4_gg.y) + (s4_gg.z + s4_gg.w); m_sb = s4_gg.x * xh.x + s4_gg.y * xh.y; PIN(m_sa); PIN(m_sb); break;
+      case 5: PIN(m_sb); m_sb = fmaf(s4_gg.z, xh.z, fmaf(s4_gg.w, xh.w, m_sb)); m_sa += dpp_read<0xB1>(m_sa); m_sb += dpp_read<0xB1>(m_sb); PIN(m_sa); PIN(m_sb); break;
+      case 6: PIN(m_sa); m_sa += dpp_read<0x4E>(m_sa); m_sb += dpp_read<0x4E>(m_sb); m_sa += dpp_read<0x141>(m_sa); m_sb += dpp_read<0x141>(m_sb); PIN(m_sa); PIN(m_sb); break;
+      case 7: PIN(m_sa); m_sa += dpp_read<0x140>(m_sa); m_sb += dpp_read<0x140>(m_sb); s4_s1 = m_sa * (1.f / C); s4_s2 = m_sb * (1.f / C); PIN(s4_s1); PIN(s4_s2); break;
+      case 8: PIN(s4_s1); m_dx.x = rs0 * (s4_gg.x - s4_s1 - xh.x * s4_s2); m_dx.y = rs0 * (s4_gg.y - s4_s1 - xh.y * s4_s2); PIN(m_dx.x); PIN(m_dx.y); break;
+      case 9: PIN(s4_s2); m_dx.z = rs0 * (s4_gg.z - s4_s1 - xh.z * s4_s2); m_dx.w = rs0 * (s4_gg.w - s4_s1 - xh.w * s4_s2); PIN(m_dx.z); PIN(m_dx.w); break;
+      case 10: st4_nt(rows + (size_t)srow * C + 4 * cq, m_dx); break;
+      default: PIN(s4_da.z); s4_d(xh); PIN(dgam.x); PIN(dbet.x); break;
+    }
+  };
+  float4 m_a;
+  auto s1_step = [&](int k, int buf, float valid) {
+    switch (k) {
+      case 0: PIN(px.x); m_sa = (px.x + px.y) + (px.z + px.w); m_sa += dpp_read<0xB1>(m_sa); m_sa += dpp_read<0x4E>(m_sa); PIN(m_sa); break;
+      case 1: PIN(m_sa); m_sa += dpp_read<0x141>(m_sa); m_sa += dpp_read<0x140>(m_sa); m_sa *= (1.f / C); PIN(m_sa); break;
+      case 2: PIN(m_sa); s1_xc = make_float4(px.x - m_sa, px.y - m_sa, px.z - m_sa, px.w - m_sa);
+              m_sb = (s1_xc.x * s1_xc.x + s1_xc.y * s1_xc.y) + (s1_xc.z * s1_xc.z + s1_xc.w * s1_xc.w); PIN(m_sb); break;
+      case 3: PIN(m_sb); m_sb += dpp_read<0xB1>(m_sb); m_sb += dpp_read<0x4E>(m_sb); m_sb += dpp_read<0x141>(m_sb); PIN(m_sb); break;
+      case 4: PIN(m_sb); m_sb += dpp_read<0x140>(m_sb); rs2 = rsqrtf(m_sb * (1.f / C) + LN_EPS); PIN(rs2); break;
+      case 5: PIN(rs2); xh2 = f4_scale(s1_xc, rs2); PIN(xh2.x); PIN(xh2.w); break;
+      case 6: PIN(xh2.y); m_a = make_float4(xh2.x * gq.x + bq.x, xh2.y * gq.y + bq.y, xh2.z * gq.z + bq.z, xh2.w * gq.w + bq.w); PIN(m_a.x); PIN(m_a.w); break;
+      case 7: PIN(m_a.y); split4(m_a, s1_ah, s1_al); PIN(s1_ah.x); PIN(s1_al.y); break;
+      case 8: PIN(pd.x); split4(pd, s1_dh, s1_dl); PIN(s1_dh.x); PIN(s1_dl.y); break;
+      case 9: PIN(pd.y); db4 = make_float4(fmaf(pd.x, valid, db4.x), fmaf(pd.y, valid, db4.y), fmaf(pd.z, valid, db4.z), fmaf(pd.w, valid, db4.w)); PIN(db4.x); PIN(db4.w); break;
+      case 10: s1_d_(buf); break;
+      default: break;
+    }
+  };
+
   // ---- prologue: stage 1 of chunk 0, loads of chunk 1; the "previous chunk" of the first iteration is all zeros (its store is skipped)
   for (int i = tid; i < 4 * 16 * LDDA; i += 256) (&sm.DA[1][0][0])[i] = 0.f;
   if (n_mine > 0) {
@@ -271,13 +321,18 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
     fetch(it + 2, pxn, pdn);
     BAR();
     M16_PH(1);   // fragment reads issued
-    // ---- z = W3 a + b3 (hidden on the registers, row on the lane), GELU with derivative one n-tile behind the MFMAs
+    // ---- z = W3 a + b3 (hidden on the registers, row on the lane), then dH = W4^T dOut.  GRL_M16_PAIRS (build switch, off: measured equal, profiles/r03_mlp16_log.txt): the n-tiles go in PAIRS --
+    // a region holds the twelve MFMAs of two tiles and the GELU (value + derivative) of the two tiles before: four independent packed
+    // chains for the vector pipe instead of two (a lone wave pays ~8 cycles per DEPENDENT instruction, 4 per independent one)
+#ifndef GRL_M16_PAIRS
+#define GRL_M16_PAIRS 0
+#endif
     float4 hv[4], gp[4];
     bf16x8 zh[2], zl[2], hh[2], hl[2];
     {
-      f32x4v c[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      f32x4v c[4], e[4];
+      float4 dz[4];
+      auto z_tile = [&](int nt) {
         c[nt] = f32x4v{b3q[nt].x, b3q[nt].y, b3q[nt].z, b3q[nt].w};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -285,34 +340,57 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
           GRL_LO(c[nt] = mfma16(w3f.l[nt][s], ah[s], c[nt]);)
           GRL_LO(c[nt] = mfma16(w3f.h[nt][s], al[s], c[nt]);)
         }
-        if (nt > 0) gelu_both4_pk(v4(c[nt - 1]), hv[nt - 1], gp[nt - 1]);
-        if (nt == 3) w4_load(0);
-        BAR();
-      }
-      M16_PH(2);   // z: 24 MFMA, three GELU tiles
-      // ---- dH = W4^T dOut; the last GELU beside its first group
-      f32x4v e[4];
-      float4 dz[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      };
+      auto dh_tile = [&](int nt) {
         e[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (nt < 3) w4_load(nt + 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           e[nt] = mfma16(w4h[nt & 1][s], dh_[s], e[nt]);
           GRL_LO(e[nt] = mfma16(w4l[nt & 1][s], dh_[s], e[nt]);)
           GRL_LO(e[nt] = mfma16(w4h[nt & 1][s], dl_[s], e[nt]);)
         }
+      };
+      auto dz_tile = [&](int nt) {
+        dz[nt] = f4_mul(v4(e[nt]), gp[nt]);
+        db3[nt] = f4_add(db3[nt], dz[nt]);
+      };
+#if GRL_M16_PAIRS
+      z_tile(0); z_tile(1); w4_load(0); w4_load(1);
+      BAR();
+      z_tile(2); z_tile(3);
+      gelu_both4_pk(v4(c[0]), hv[0], gp[0]); gelu_both4_pk(v4(c[1]), hv[1], gp[1]);
+      BAR();
+      M16_PH(2);   // z: 24 MFMA, two GELU tiles
+      dh_tile(0); dh_tile(1);
+      gelu_both4_pk(v4(c[2]), hv[2], gp[2]); gelu_both4_pk(v4(c[3]), hv[3], gp[3]);
+      BAR();
+      w4_load(2); w4_load(3);
+      BAR();
+      dh_tile(2); dh_tile(3);
+      dz_tile(0); dz_tile(1);
+      split_pair(dz[0], dz[1], zh[0], zl[0]);
+      BAR();
+      dz_tile(2); dz_tile(3);
+#else
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        z_tile(nt);
+        if (nt > 0) gelu_both4_pk(v4(c[nt - 1]), hv[nt - 1], gp[nt - 1]);
+        if (nt == 3) w4_load(0);
+        BAR();
+      }
+      M16_PH(2);   // z: 24 MFMA, three GELU tiles
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt < 3) w4_load(nt + 1);
+        dh_tile(nt);
         if (nt == 0) gelu_both4_pk(v4(c[3]), hv[3], gp[3]);
-        else {
-          dz[nt - 1] = f4_mul(v4(e[nt - 1]), gp[nt - 1]);
-          db3[nt - 1] = f4_add(db3[nt - 1], dz[nt - 1]);
-        }
+        else dz_tile(nt - 1);
         if (nt == 2) split_pair(dz[0], dz[1], zh[0], zl[0]);
         BAR();
       }
-      dz[3] = f4_mul(v4(e[3]), gp[3]);
-      db3[3] = f4_add(db3[3], dz[3]);
+      dz_tile(3);
+#endif
       M16_PH(3);   // dH: 24 MFMA, last GELU tile, dZ
       // ---- split dZ (B operand of dA, A operand of dW3); staged for the transposed reads, which are requested at once
       split_pair(dz[2], dz[3], zh[1], zl[1]);
@@ -342,10 +420,9 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
         }
         if (ct == 0) split_pair(hv[0], hv[1], hh[0], hl[0]);
         if (ct == 1) split_pair(hv[2], hv[3], hh[1], hl[1]);
-        if (ct == 2) s1_a(px, pd);
         BAR();
       }
-      M16_PH(5);   // dA: 24 MFMA, split of h, row means of the next chunk
+      M16_PH(5);   // dA: 24 MFMA, split of h
       // partial dA rows of this wave (row r, channels 16 ct + 4 g .. + 3); h over dZ in the staging image (whose transposed reads were
       // issued above: in-order LDS); the operands of dW4 and the previous chunk's partial dA rows requested
       float* drow = &sm.DA[cb][wave][0] + r * LDDA + 4 * g;
@@ -365,26 +442,38 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
     BAR();
     M16_PH(6);   // partial dA rows written, h staged, reads requested
     // ---- dW3 += dZ^T a (hidden x channel): K = the 16 rows; stage 4 of the previous chunk in the gaps of its twelve MFMAs
-    auto w3_group = [&](int tn, int tk) {
-      mfma32_acc(fzh[tn], fah[tk], aW3[tn][tk]);
-      GRL_LO(mfma32_acc(fzl[tn], fah[tk], aW3[tn][tk]);)
-      GRL_LO(mfma32_acc(fzh[tn], fal[tk], aW3[tn][tk]);)
-    };
-    auto w4_group = [&](int tn, int tk) {
-      mfma32_acc(fdh[tn], fhh[tk], aW4[tn][tk]);
-      GRL_LO(mfma32_acc(fdl[tn], fhh[tk], aW4[tn][tk]);)
-      GRL_LO(mfma32_acc(fdh[tn], fhl[tk], aW4[tn][tk]);)
-    };
-    w3_group(0, 0); s4_a(xh0);                               BAR();
-    w3_group(0, 1); s4_b();                                  BAR();
-    w3_group(1, 0); s4_c(it > 0 ? dx2 + (size_t)chunk_of(it - 1) * 16 * C : dump, xh0, rs0); BAR();
-    w3_group(1, 1); s4_d(xh0);                               BAR();
+    // One MFMA (32 matrix-pipe cycles, 8 of them holding the issue port) hides ~5-6 independent vector instructions of the same wave;
+    // asm MFMAs are opaque to the scheduler, so the stages are cut into twelve micro-steps each and placed by hand: MFMA, step, MFMA, ...
+    st_t* s4_rows = it > 0 ? dx2 + (size_t)chunk_of(it - 1) * 16 * C : dump;
+    const float s1_valid = it + 1 < n_mine ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      {
+        const int tn = k / 6, tk = (k / 3) & 1, term = k % 3;
+#if GRL_PREC
+        if (term == 0) mfma32_acc(fzh[tn], fah[tk], aW3[tn][tk]);
+#else
+        mfma32_acc(term == 1 ? fzl[tn] : fzh[tn], term == 2 ? fal[tk] : fah[tk], aW3[tn][tk]);
+#endif
+      }
+      s4_step(k, s4_rows);
+      BAR();
+    }
     M16_PH(7);   // dW3: 12 MFMA 32x32, stage 4 of the previous chunk
     // ---- dW4 += dOut^T h (channel x hidden); stage 1 of the next chunk in the gaps
-    w4_group(0, 0); s1_b(xh2, rs2);                          BAR();
-    w4_group(0, 1); s1_c(xh2, it + 1 < n_mine ? 1.f : 0.f);  BAR();
-    w4_group(1, 0); s1_d_(cb ^ 1);                           BAR();
-    w4_group(1, 1);                                          BAR();
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      {
+        const int tn = k / 6, tk = (k / 3) & 1, term = k % 3;
+#if GRL_PREC
+        if (term == 0) mfma32_acc(fdh[tn], fhh[tk], aW4[tn][tk]);
+#else
+        mfma32_acc(term == 1 ? fdl[tn] : fdh[tn], term == 2 ? fhl[tk] : fhh[tk], aW4[tn][tk]);
+#endif
+      }
+      s1_step(k, cb ^ 1, s1_valid);
+      BAR();
+    }
     M16_PH(8);   // dW4: 12 MFMA 32x32, stage 1 of the next chunk
     xh0 = xh1; rs0 = rs1; xh1 = xh2; rs1 = rs2;
     px = pxn; pd = pdn;

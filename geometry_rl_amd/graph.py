@@ -250,7 +250,10 @@ class HyperData:
         else:
             edges[et_agent] = None  # empty edge set: the conv is skipped (hetero_fiber_conv.py:48-49)
         # task edges: every valid point -> every actuator of its sample; with knn_to_actuators_k > 0 only the k valid points
-        # nearest to each actuator (rigid_tasks_data.py:303-311: torch_geometric.nn.knn(points[:n], actuator[None], k).flip(0))
+        # nearest to each actuator (rope_tasks_data.py / cloth_tasks_data.py: torch_geometric.nn.knn(points[:n], actuator[None], k).flip(0)).
+        # DELIBERATE DEVIATION for family "rigid": the reference's rigid builder computes the same kNN (rigid_tasks_data.py:303-311) but its
+        # edge_index assignment sits in the else branch (:319), so with k > 0 it never sets these edges; here all families follow the
+        # rope / cloth semantics.  No BASELINE config sets k > 0.
         kta = getattr(spec, "knn_to_actuators_k", -1)
         if need_edges and et_task[0] in self.node_type_list and kta > 0:
             pm, pg = posv[main].float(), posv["grippers"].float()                      # [B,P,3], [B,G,3]
@@ -258,7 +261,7 @@ class HyperData:
             d2 = d2.masked_fill(~valid[:, None, :], float("inf"))
             kk = min(kta, P)
             order = torch.argsort(d2, dim=-1, stable=True)[..., :kk]                    # ties: lower index first
-            ok = torch.gather(d2, -1, order) < float("inf")                             # fewer than k valid points: no edge
+            ok = torch.gather(d2, -1, order) < float("inf")                             # fewer than k valid points: the valid ones only (as PyG knn)
             src = (offset[:, None, None] + order)[ok]
             dst = (torch.arange(B, device=dev)[:, None, None] * G + torch.arange(G, device=dev)[None, :, None]).expand_as(order)[ok]
             edges[et_task] = ops.build_edge_set(torch.stack([src, dst]), n_main, B * G)

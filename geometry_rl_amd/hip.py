@@ -21,7 +21,11 @@ SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
 # per-source compiler flags.  edge_conv16.hip: its 512-register backward kernel keeps the chain's MFMA results in VGPRs (the default
 # selection would put every MFMA result of such a kernel into AGPRs) and pins the weight-gradient tiles to AGPRs itself (asm)
-FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "node_mlp16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# node_mlp16.hip additionally without SLP vectorisation: beside the MFMAs of its one wave per SIMD plain f32 instructions overlap with the matrix
+# pipe, packed ones (v_pk_*) do not (DESIGN.md finding 23)
+# (edge_conv16.hip the same, with the scalar GELU in its one-wave backward: +1 % on the step, profiles/r03_ab_edge16_noslp.txt)
+FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-DGRL_B16_SCALAR_GELU"],
+              "node_mlp16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16")]

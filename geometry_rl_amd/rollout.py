@@ -61,9 +61,14 @@ class RolloutDriver:
         self.mini_batch_size = mini_batch_size   # None: one frame per environment (= num_envs)
         if sampling not in ("env_aligned", "uniform"):
             raise ValueError(sampling)
-        if sampling == "uniform" and getattr(spec, "family", None) == "rigid" and not allow_stale_topology:
-            raise ValueError("uniform sampling pairs the topology cached per batch size with rows of other environments; rigid "
-                             "tasks have ragged point counts (pass allow_stale_topology=True to reproduce the reference quirk)")
+        # raggedness, not the task family, is what makes the cached topology wrong for rows of other environments: rigid tasks carry a
+        # per-sample object_num_points, variable-length ropes a per-sample links_num_points (padded nodes are dropped by the CACHED counts)
+        infos = (getattr(spec, "obs_names", None) or {}).get("infos", ())
+        ragged = any(n in infos for n in ("object_num_points", "links_num_points"))
+        if sampling == "uniform" and ragged and not allow_stale_topology:
+            raise ValueError("uniform sampling pairs the topology cached per batch size with rows of other environments; this task has "
+                             "ragged per-sample point counts (object_num_points / links_num_points): pass allow_stale_topology=True to "
+                             "reproduce the reference quirk")
         self.sampling = sampling
 
     # ---- train.py:134-140,249-251: critic over the T+1 frames of every environment, then the shifted GAE scan

@@ -1,0 +1,43 @@
+"""`bench.py --gpus 2` end to end, as the driver will launch it on an 8-GPU node -- here with both ranks on the one visible GPU and gloo
+(GRL_BENCH_ONE_GPU=1: the collectives are host-staged, the data-parallel program -- graph segments between the all-reduces, lock-step
+profiling leg on rank != 0, max-over-ranks timing, rank 0's JSON line -- is the one that runs over RCCL).  A fresh child process: nothing
+of this pytest process's GPU state is inherited."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]     # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_line():
+    two = _bench("--gpus", "2", "--minibatch", "1024", "--steps", "3", "--warmup", "1", "--pool", "4",
+                 env_extra={"GRL_BENCH_ONE_GPU": "1"})
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["warmup"] == 1
+    assert two["scaling"] == "strong" and two["config"]["parallelism"] == "dp2"
+    assert "segments" in two["mode"], two["mode"]                    # hipGraph segments between the collectives
+    assert two["cpu_baseline"] is None and two["parity_gate"] is None   # N = 1 only
+    assert two["roofline"] is not None and two["roofline"]["frac"] > 0     # the profiling leg ran in lock-step on both ranks
+    for k, v in two["loss"].items():
+        assert v == v and abs(v) < 1e6, (k, v)
+    one = _bench("--gpus", "1", "--minibatch", "512", "--steps", "20", "--warmup", "3", "--pool", "4", "--no-parity-gate", "--no-roofline")
+    assert one["n_gpus"] == 1 and "one hipGraph" in one["mode"]
+    # two 512-frame shards time-share ONE GPU here and the all-reduces are host-staged (gloo): the step must stay within a small
+    # multiple of two single-rank 512-frame steps -- a hang, a serialised collective per kernel or an eager fallback would not
+    assert two["ms_per_step"] < 2 * one["ms_per_step"] * 6, (two["ms_per_step"], one["ms_per_step"])
+    print("2 ranks x 512 frames on one GPU (gloo):", two["ms_per_step"], "ms/step; 1 rank x 512 frames:", one["ms_per_step"], "ms/step")

@@ -43,6 +43,11 @@ def test_uniform_sampling_is_the_reference_sampler_and_guarded_for_ragged_tasks(
     assert len(mbs) == (N * T) // 10 and all(m.numel() == 10 for m in mbs)          # short last minibatch dropped
     flat = torch.cat(mbs).tolist()
     assert len(set(flat)) == len(flat) and set(flat) <= set(range(N * T))            # without replacement
-    with pytest.raises(ValueError):
-        RolloutDriver(updater=None, spec=SimpleNamespace(family="rigid"), sampling="uniform")
-    RolloutDriver(updater=None, spec=SimpleNamespace(family="rigid"), sampling="uniform", allow_stale_topology=True)
+    # the guard follows RAGGEDNESS (a per-sample point count among the infos), not the task family: rigid tasks and variable-length ropes
+    from geometry_rl_amd import graph
+    for spec in (graph.rigid_spec(), graph.rope_spec(variable_length=True)):
+        with pytest.raises(ValueError):
+            RolloutDriver(updater=None, spec=spec, sampling="uniform")
+        RolloutDriver(updater=None, spec=spec, sampling="uniform", allow_stale_topology=True)
+    RolloutDriver(updater=None, spec=graph.rope_spec(), sampling="uniform")    # fixed-length ropes and cloth: every sample has the same graph
+    RolloutDriver(updater=None, spec=graph.cloth_spec(), sampling="uniform")
