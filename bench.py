@@ -31,10 +31,13 @@ FLOPS_PER_ROW = {
     # the fused backward (edge_conv16.hip, default since round 2): ONE chain recompute, d x_src row, dK, dWk, dG2, dW2, dG1, dW1
     "edge_bwd16_kernel": _CHAIN + 2 * 64 + 2 * 64 + 4 * (2 * 64 * 64) + 2 * 64 * 14,
     "node_mlp_fwd_kernel": 4 * 64 * 256,
-    "node_mlp_bwd_fused_kernel": 10 * 64 * 256,                                    # z recompute, dH, dA, dW3, dW4
+    "node_mlp_bwd16_kernel": 10 * 64 * 256,                                        # z recompute, dH, dA, dW3, dW4
 }
+# Algorithmic HBM bytes per row of the same kernels with fp32 latents (bf16 latents: half): the row gathers of the edge
+# kernels (x_src | x_src + dM; the per-node stores, 256 B / in-degree, are left out) and the row streams of the node kernels
+BYTES_PER_ROW = {"edge_conv_fwd_kernel": 256, "edge_bwd16_kernel": 512, "node_mlp_fwd_kernel": 768, "node_mlp_bwd16_kernel": 768}
 ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel", "grl_node_mlp_fwd": "node_mlp_fwd_kernel",
-                   "grl_node_mlp_bwd": "node_mlp_bwd_fused_kernel"}
+                   "grl_node_mlp_bwd": "node_mlp_bwd16_kernel"}
 PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md:42 (the path is specified and checked in f32)
 PEAK_BF16X3 = 2500.0 / 3.0     # TFLOP/s of f32-equivalent products when each is three dense bf16 MFMAs (guide: ~2.5 PF dense)
 
@@ -77,59 +80,89 @@ LOSS_KEYS = ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic
              "mean_constraint_max", "cov_constraint", "cov_constraint_max", "entropy", "entropy_diff")
 
 
-def cpu_baseline_and_parity(wl_name, minibatch, dev, sample=1024, steps=3, max_threads=32):
-    """(1) BASELINE.md section 3's parity gate: one update of a ``sample``-frame minibatch (config 2's size) through the HIP path and
-    through the oracle (CPU restatement of the reference path) from identical parameters and inputs -- loc, var, state_value and
-    every loss-dict entry within 1e-4 * max(1, |ref|), post-Adam parameters within 2e-5;
+# Oracle twin of every bench workload and the bounded sample its CPU leg runs on: frames per oracle update (sized so that the parity
+# update + the timed oracle updates stay within ~10-40 s of CPU work on the GPU box's host cores) and the tolerance BASELINE.md section 3
+# states for the workload (1e-4 for the fp32 builds; 2e-2 relative for config 5's bf16 build)
+ORACLE_CASES = {
+    "rigid_hepi":     dict(spec="rigid", spec_kw={}, sample=1024, tol=1e-4, ptol=2e-5),
+    "cloth_hepi":     dict(spec="cloth", spec_kw={}, sample=256, tol=1e-4, ptol=2e-5),
+    "rope_hepi":      dict(spec="rope", spec_kw={}, sample=128, tol=1e-4, ptol=2e-5),
+    "rope_hepi_var":  dict(spec="rope", spec_kw=dict(variable_length=True), sample=128, tol=1e-4, ptol=2e-5),
+    "rope_hepi_bf16": dict(spec="rope", spec_kw=dict(variable_length=True), sample=128, tol=2e-2, ptol=None),
+    "rigid2_empn":    dict(spec="rigid", spec_kw=dict(G=2), sample=512, tol=1e-4, ptol=2e-5),
+}
+
+
+def cpu_baseline_and_parity(wl_name, minibatch, dev, steps=3, max_threads=32):
+    """(1) BASELINE.md section 3's parity gate: one update of a bounded-size minibatch of THIS workload through the HIP path and through
+    the oracle (CPU restatement of the reference path) from identical parameters and inputs -- loc, var, state_value and every
+    loss-dict entry within tol * max(1, |ref|), post-Adam parameters within 2e-5 (fp32 builds; the bf16 build of config 5 is held
+    to its own 2e-2 bar and its parameters are not compared: the oracle is fp32);
     (2) the oracle timed on this box's host cores on that bounded sample (the reported cpu_baseline, kind "port")."""
+    import dataclasses
     from oracle import graph as ogr, step as ost
-    from geometry_rl_amd import agent, graph, synthetic as syn
-    assert wl_name == "rigid_hepi"
+    from geometry_rl_amd import agent
+    case = ORACLE_CASES[wl_name]
+    sample, tol, ptol = case["sample"], case["tol"], case["ptol"]
+    spec, cfg, make_obs, _ = workload(wl_name)
+    o_spec = getattr(ogr, case["spec"] + "_spec")(**case["spec_kw"])
+    o_fields = {f.name for f in dataclasses.fields(ost.AgentConfig)}
+    kw = {k: v for k, v in dataclasses.asdict(cfg).items() if k in o_fields and k != "precision"}
+    o_cfg = ost.AgentConfig(**kw)
     host_cores = os.cpu_count() or 1
     cores = min(host_cores, max_threads)  # more intra-op threads than this only slow the small CPU ops of the oracle down
     torch.set_num_threads(cores)
-    kw = dict(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
-    o_spec, spec = ogr.rigid_spec(), graph.rigid_spec()
-    a, c = ost.init_agent_params(o_spec, ost.AgentConfig(**kw), seed=0)
-    ag = ost.OracleAgent(o_spec, ost.AgentConfig(**kw), a, c)
-    batch = dict(syn.make_rigid_obs(sample, seed=1))
-    batch.update(syn.make_ppo_fields(sample, 6, seed=1))
+    A = spec.num_actuators * cfg.output_dim_vec * 3
+    a, c = ost.init_agent_params(o_spec, o_cfg, seed=0)
+    ag = ost.OracleAgent(o_spec, o_cfg, a, c)
+    batch = dict(make_obs(sample, 1, 0))
+    batch.update(syn_fields(sample, A))
     with torch.no_grad():
         ag.actor_forward({k: batch[k] for k in o_spec.in_features}, calibrate=True)
     # HIP twin from the oracle's calibrated parameters
-    actor, critic, proj, loss = agent.build_agent(spec, agent.AgentConfig(**kw), device=dev)
+    actor, critic, proj, loss = agent.build_agent(spec, cfg, device=dev)
     actor.load_state_dict({k: v.detach().to(dev) for k, v in ag.actor.items()}, strict=False)
     critic.load_state_dict({"_network1." + k: v.detach().to(dev) for k, v in ag.critic.items()}, strict=False)
-    for conv_round in actor.gnn.processor:
-        for _, conv in conv_round.items():
-            conv.callibrated.fill_(True)
+    for m in actor.modules():
+        if hasattr(m, "callibrated"):
+            m.callibrated.fill_(True)
     actor._calib_checked = True
-    upd = agent.PolicyUpdater(loss)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm)
     out = upd.step({k: v.to(dev) for k, v in batch.items()})
     ref, _ = ag.update(batch)      # also the warm-up of the timed loop below
     worst, worst_key, ok = 0.0, None, True
     pairs = [("loc", out["loc"], ref["loc"]), ("var", out["sigma"] ** 2, ref["var"]), ("state_value", out["state_value"], ref["state_value"])]
     pairs += [(k, out[k], ref[k]) for k in LOSS_KEYS]
+    floor = 1.0 if tol <= 1e-3 else 1e-2   # the 2e-2 bar of the bf16 build is relative down to 1e-2 (tests/test_gpu_bf16_rope.py)
     for k, g, r in pairs:
         r = torch.as_tensor(r).detach().double().cpu()
-        e = (torch.as_tensor(g).detach().double().cpu().reshape(r.shape) - r).abs().max().item() / max(1.0, r.abs().max().item())
-        if not (e <= 1e-4):
+        e = (torch.as_tensor(g).detach().double().cpu().reshape(r.shape) - r).abs().max().item() / max(floor if r.numel() == 1 else 1.0, r.abs().max().item())
+        if not (e <= tol):
             ok = False
         if e > worst or e != e:
             worst, worst_key = e, k
-    p_err = max(max((p.detach().cpu() - ag.actor[k]).abs().max().item() for k, p in actor.named_parameters()),
-                max((p.detach().cpu() - ag.critic[k[len("_network1."):]]).abs().max().item() for k, p in critic.named_parameters()))
-    ok = ok and p_err <= 2e-5
-    gate = {"passed": bool(ok), "frames": sample, "tolerance": "1e-4 * max(1, |ref|) on loc / var / state_value / 13 loss entries; 2e-5 on post-Adam parameters",
+    p_err = None
+    if ptol is not None:
+        p_err = max(max((p.detach().cpu() - ag.actor[k]).abs().max().item() for k, p in actor.named_parameters()),
+                    max((p.detach().cpu() - ag.critic[k[len("_network1."):]]).abs().max().item() for k, p in critic.named_parameters()))
+        ok = ok and p_err <= ptol
+    gate = {"passed": bool(ok), "workload": wl_name, "frames": sample,
+            "tolerance": f"{tol:g} * max(1, |ref|) on loc / var / state_value / 13 loss entries" + (f"; {ptol:g} on post-Adam parameters" if ptol else
+                         " (relative down to 1e-2 for the scalar entries; parameters not compared: bf16 build against the fp32 oracle)"),
             "worst_value_err_over_scale": worst, "worst_key": worst_key, "post_adam_param_err": p_err}
     t0 = time.perf_counter()
     for _ in range(steps):
         ag.update(batch)
     dt = (time.perf_counter() - t0) / steps
     cpu = {"value": (sample / minibatch) / dt, "unit": "policy-update steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
-           "sample": f"{steps} oracle updates of a {sample}-frame minibatch ({dt:.2f} s each), scaled linearly to {minibatch} frames",
+           "sample": f"{steps} oracle updates of a {sample}-frame minibatch of this workload ({dt:.2f} s each), scaled linearly to {minibatch} frames",
            "torch_threads": torch.get_num_threads()}
     return cpu, gate
+
+
+def syn_fields(B, A):
+    from geometry_rl_amd import synthetic as syn
+    return syn.make_ppo_fields(B, A, seed=1)
 
 
 def main():
@@ -215,11 +248,14 @@ def main():
     buf = RolloutBuffer(data)
     drv = RolloutDriver(upd, spec, ppo_epochs=5, seed=rank)
     next_last = {k: first_frame[k].unsqueeze(1) for k in spec.in_features}
-    torch.cuda.synchronize()
-    t_adv = time.perf_counter()
-    drv.compute_advantages(buf, next_last)
-    torch.cuda.synchronize()
-    adv_ms = 1e3 * (time.perf_counter() - t_adv)
+    adv_times = []
+    for _ in range(2):   # first call: cold (topology of the rollout-sized batch, lazy initialisation); second: what every later rollout pays
+        torch.cuda.synchronize()
+        t_adv = time.perf_counter()
+        drv.compute_advantages(buf, next_last)
+        torch.cuda.synchronize()
+        adv_times.append(1e3 * (time.perf_counter() - t_adv))
+    adv_ms_cold, adv_ms = adv_times
 
     def sampler():   # sampling without replacement, reshuffled every epoch
         while True:
@@ -297,7 +333,7 @@ def main():
         rows_of = {"edge_conv_fwd_kernel": "grl_edge_conv_fwd", "edge_conv_bwd_x_kernel": "grl_edge_conv_bwd",
                    "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "edge_bwd16_kernel": "grl_edge_conv_bwd",
                    "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
-                   "node_mlp_bwd_fused_kernel": "grl_node_mlp_bwd"}
+                   "node_mlp_bwd16_kernel": "grl_node_mlp_bwd"}
         rows_step = {k.replace("_bf16", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
         pipe_peak = 2500.0 if cfg.precision == "bf16" else PEAK_BF16X3
         kernels = {}
@@ -307,9 +343,10 @@ def main():
             launches, ms_step = summ[k]
             flops_step = fl * rows_step[rows_of[k]]
             ach = flops_step / (ms_step * 1e-3) / 1e12
+            gbs = BYTES_PER_ROW.get(k, 0) * (0.5 if cfg.precision == "bf16" else 1.0) * rows_step[rows_of[k]] / (ms_step * 1e-3) / 1e9
             kernels[k] = {"launches_per_step": launches, "avg_launch_ms": ms_step / launches, "ms_per_step": ms_step,
                           "rows_per_step": rows_step[rows_of[k]], "gflop_per_launch": flops_step / launches / 1e9, "achieved": ach,
-                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / pipe_peak}
+                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / pipe_peak, "alg_gbyte_per_s": gbs, "frac_of_hbm": gbs / 8000.0}
         name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         d = kernels[name]
         # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the committed
@@ -356,8 +393,12 @@ def main():
                         "note": "formulas of SURVEY.md 8(d) with the realised node / edge counts of this minibatch; time = the timed region"}
         except Exception as e:  # never let bookkeeping break the benchmark line
             step_fig = {"error": repr(e)}
-        roof = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": pipe_peak, "unit": "TFLOP/s",
-                "frac": d["frac_of_bf16x3"], "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
+        if cfg.precision == "bf16":   # config 5's bf16 build is priced against the HBM roof, not the matrix pipe
+            head = {"bound": "hbm", "kernel": name, "achieved": d["alg_gbyte_per_s"], "peak": 8000.0, "unit": "GB/s", "frac": d["frac_of_hbm"],
+                    "mfma_frac_of_bf16_pipe": d["frac_of_bf16x3"]}
+        else:
+            head = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": pipe_peak, "unit": "TFLOP/s", "frac": d["frac_of_bf16x3"]}
+        roof = {**head, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
                 "peak_note": "peak = the pipe the kernel runs on: every f32 product is three dense bf16 MFMAs (split-bf16, f32 "
@@ -367,7 +408,7 @@ def main():
                 "per_kernel_ms_per_step": {k: v[1] for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
 
     cpu, gate = None, None
-    if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.no_parity_gate) and args.workload == "rigid_hepi":   # N = 1 only
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline or args.no_parity_gate):   # N = 1 only
         cpu, gate = cpu_baseline_and_parity(args.workload, args.minibatch, dev)
 
     if rank == 0:
@@ -381,7 +422,9 @@ def main():
             "config": {"workload": f"{cfg_name}, 4096 synthetic envs x 128 steps, minibatch {args.minibatch} frames "
                                    f"({B} per GPU), 640 updates per rollout", "global_minibatch": args.minibatch,
                        "parallelism": f"dp{world}"},
-            "gae_ms_per_rollout_scan": gae_ms, "advantage_pass_ms": adv_ms,
+            "gae_ms_per_rollout_scan": gae_ms, "advantage_pass_ms": adv_ms, "advantage_pass_ms_cold": adv_ms_cold,
+            "advantage_pass": f"critic over the {T_roll} + 1 frames of all {B} environments per GPU + shifted GAE, once per rollout (train.py:249-251); "
+                              "warm = second call; single GPU: the time steps are groups of one launch set (per-step LayerNorm statistics)",
             "minibatches": f"sampled without replacement from a device-resident {B} x {T_roll}-frame rollout per GPU (one frame per env), "
                            "gathered into the static inputs of the recorded step by one launch",
             "loss": {k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")},

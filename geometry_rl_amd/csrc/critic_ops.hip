@@ -156,6 +156,10 @@ constexpr int ROW_WAVES = 16;
 __global__ __launch_bounds__(64 * ROW_WAVES) void ds_fwd1(const float* __restrict__ x, const float* __restrict__ W1,
                                                         const float* __restrict__ b1, float* __restrict__ h1,
                                                         double* __restrict__ slots, int B, int n, int d) {
+  {   // group blockIdx.y of a grouped launch (time steps of the rollout pass): its own frames and its own statistic slots
+    const size_t g = blockIdx.y;
+    x += g * (size_t)B * n * d; h1 += g * (size_t)B * n * H; slots += g * 2 * NSLOT;
+  }
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float w[DMAX];
 #pragma unroll
@@ -195,6 +199,10 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict
                                                         const float* __restrict__ W3, const float* __restrict__ b3,
                                                         float* __restrict__ z, float* __restrict__ u1, double* __restrict__ slots2,
                                                         int B, int n) {
+  {
+    const size_t g = blockIdx.y;
+    h1 += g * (size_t)B * n * H; slots1 += g * 2 * NSLOT; z += g * (size_t)B * H; u1 += g * (size_t)B * H; slots2 += g * 2 * NSLOT;
+  }
   __shared__ __attribute__((aligned(16))) float ys_all[DS_WAVES][2][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float (*ys)[H] = ys_all[wave];
@@ -239,6 +247,10 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd3(const float* __restrict
                                                         const float* __restrict__ W4, const float* __restrict__ b4,
                                                         const float* __restrict__ wv, const float* __restrict__ bv,
                                                         float* __restrict__ value, int B) {
+  {
+    const size_t g = blockIdx.y;
+    u1 += g * (size_t)B * H; slots2 += g * 2 * NSLOT; value += g * (size_t)B;
+  }
   __shared__ __attribute__((aligned(16))) float ys_all[DS_WAVES][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* ys = ys_all[wave];
@@ -509,31 +521,52 @@ int grl_deepsets_partial2() { return P2; }
 // Forward, stage k of 3.  slots1/slots2: fp64[grl_deepsets_stat_slots()][2], fully written by the producing stage (no
 // initialisation needed); in a data-parallel run the caller all-reduces them (sum) between the stages and passes the GLOBAL
 // element counts count1 = B_glob*n*64, count2 = B_glob*64.
-int grl_deepsets_fwd1(const float* x, const float* W1, const float* b1, float* h1, double* slots1, int batch, int n_nodes, int d,
-                      hipStream_t stream) {
+// The *_groups forms run `groups` independent batches in one launch each (grid.y = group): x [groups][batch][n_nodes][d], every group with
+// its own whole-tensor LayerNorm statistics (slot arrays [groups][slots][2]) -- the critic pass over the T + 1 frames of a rollout
+// (gnn_vf_net.py:72-80 loops over the time steps: statistics per time step).  The per-group grid is the single-batch grid, so each group's
+// result is bitwise the one a separate call gives.
+int grl_deepsets_fwd1_groups(const float* x, const float* W1, const float* b1, float* h1, double* slots1, int batch, int n_nodes, int d,
+                             int groups, hipStream_t stream) {
   if (d > DMAX) return -2;
+  if (groups < 1 || groups > 65535) return -5;
   const long long rows = (long long)batch * n_nodes;
   const long long wg = (rows + ROW_WAVES * ROWS_IN_FLIGHT - 1) / (ROW_WAVES * ROWS_IN_FLIGHT);
-  hipLaunchKernelGGL(ds_fwd1, dim3(wg < 1 ? 1 : (wg < NSLOT ? (int)wg : NSLOT)), dim3(64 * ROW_WAVES), 0, stream, x, W1, b1, h1,
+  hipLaunchKernelGGL(ds_fwd1, dim3(wg < 1 ? 1 : (wg < NSLOT ? (int)wg : NSLOT), groups), dim3(64 * ROW_WAVES), 0, stream, x, W1, b1, h1,
                      slots1, batch, n_nodes, d);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-int grl_deepsets_fwd2(const float* h1, const double* slots1, double count1, const float* g1, const float* be1, const float* W2,
-                      const float* b2, const float* W3, const float* b3, float* z, float* u1, double* slots2, int batch,
-                      int n_nodes, hipStream_t stream) {
-  hipLaunchKernelGGL(ds_fwd2, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, b2, W3, b3, z,
-                     u1, slots2, batch, n_nodes);
+int grl_deepsets_fwd2_groups(const float* h1, const double* slots1, double count1, const float* g1, const float* be1, const float* W2,
+                             const float* b2, const float* W3, const float* b3, float* z, float* u1, double* slots2, int batch,
+                             int n_nodes, int groups, hipStream_t stream) {
+  if (groups < 1 || groups > 65535) return -5;
+  hipLaunchKernelGGL(ds_fwd2, dim3(ds_blocks(batch), groups), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, b2, W3, b3,
+                     z, u1, slots2, batch, n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;
 }
-int grl_deepsets_fwd3(const float* u1, const double* slots2, double count2, const float* g2, const float* be2, const float* W4,
-                      const float* b4, const float* wv, const float* bv, float* value, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(ds_fwd3, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, u1, slots2, count2, g2, be2, W4, b4, wv, bv,
+int grl_deepsets_fwd3_groups(const float* u1, const double* slots2, double count2, const float* g2, const float* be2, const float* W4,
+                             const float* b4, const float* wv, const float* bv, float* value, int batch, int groups, hipStream_t stream) {
+  if (groups < 1 || groups > 65535) return -5;
+  hipLaunchKernelGGL(ds_fwd3, dim3(ds_blocks(batch), groups), dim3(64 * DS_WAVES), 0, stream, u1, slots2, count2, g2, be2, W4, b4, wv, bv,
                      value, batch);
   GRL_CHECK_LAUNCH();
   return 0;
 }
+int grl_deepsets_fwd1(const float* x, const float* W1, const float* b1, float* h1, double* slots1, int batch, int n_nodes, int d,
+                      hipStream_t stream) {
+  return grl_deepsets_fwd1_groups(x, W1, b1, h1, slots1, batch, n_nodes, d, 1, stream);
+}
+int grl_deepsets_fwd2(const float* h1, const double* slots1, double count1, const float* g1, const float* be1, const float* W2,
+                      const float* b2, const float* W3, const float* b3, float* z, float* u1, double* slots2, int batch,
+                      int n_nodes, hipStream_t stream) {
+  return grl_deepsets_fwd2_groups(h1, slots1, count1, g1, be1, W2, b2, W3, b3, z, u1, slots2, batch, n_nodes, 1, stream);
+}
+int grl_deepsets_fwd3(const float* u1, const double* slots2, double count2, const float* g2, const float* be2, const float* W4,
+                      const float* b4, const float* wv, const float* bv, float* value, int batch, hipStream_t stream) {
+  return grl_deepsets_fwd3_groups(u1, slots2, count2, g2, be2, W4, b4, wv, bv, value, batch, 1, stream);
+}
+
 // Backward stages (reverse order).  bslots1/bslots2: slot arrays like the forward's; all-reduced between stages when data
 // parallel.  Every partial slab has grl_deepsets_blocks(batch) rows.
 int grl_deepsets_bwd3(const float* u1, const double* slots2, double count2, const float* g2, const float* be2, const float* W4,

@@ -461,6 +461,30 @@ class DeepSetsPipeline:
         return (dw1, db1, dg1, dbe1, dw2, db2, dw3, db3, dg2, dbe2, dw4, db4, dwv, dbv)
 
 
+@torch.no_grad()
+def deepsets_values_groups(x: torch.Tensor, params, groups: int) -> torch.Tensor:
+    """No-grad critic pass over ``groups`` independent batches in three launches: x [groups * B, n, d] (group-major) -> V [groups, B].
+    Every group has its own whole-tensor LayerNorm statistics, exactly as if ``DeepSetsValue`` had been called once per group
+    (gnn_vf_net.py:72-80 loops over the time steps of a [N, T, .] input); the per-group launch grid is the single-batch grid, so the
+    values are bitwise those of the loop.  ``params``: the 14 tensors in DeepSetsPipeline.PARAM_ORDER."""
+    hip.check_f32(x, *params)
+    GB, n, d = x.shape
+    assert GB % groups == 0
+    B, dev = GB // groups, x.device
+    P = [t.contiguous() for t in params]
+    ns = 2 * hip.query("grl_deepsets_stat_slots")
+    slots = torch.empty(2, groups, ns, device=dev, dtype=torch.float64)
+    h1 = torch.empty(GB, n, 64, device=dev, dtype=torch.float32)
+    z = torch.empty(GB, 64, device=dev, dtype=torch.float32)
+    u1 = torch.empty(GB, 64, device=dev, dtype=torch.float32)
+    value = torch.empty(groups, B, device=dev, dtype=torch.float32)
+    w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = P
+    hip.call("grl_deepsets_fwd1_groups", x.contiguous(), w1, b1, h1, slots[0], B, n, d, groups)
+    hip.call("grl_deepsets_fwd2_groups", h1, slots[0], ctypes_double(float(B * n * 64)), g1, be1, w2, b2, w3, b3, z, u1, slots[1], B, n, groups)
+    hip.call("grl_deepsets_fwd3_groups", u1, slots[1], ctypes_double(float(B * 64)), g2, be2, w4, b4, wv, bv, value, B, groups)
+    return value
+
+
 class DeepSetsValue(torch.autograd.Function):
     """DeepSets critic + value head as one autograd node: x [B, n, d] -> V [B] (stages: DeepSetsPipeline).
 

@@ -183,9 +183,40 @@ class GNNVFNet(nn.Module):
                                        a.lins[1].bias, b.lins[0].weight, b.lins[0].bias, b.norms[0].weight, b.norms[0].bias,
                                        b.lins[1].weight, b.lins[1].bias, self.final.weight, self.final.bias, self.group)
 
+    # frames per grouped launch set: bounds the [frames, n, 64] fp32 intermediate of the first DeepSets stage to ~6 GB of the 288 GB
+    GROUPED_BYTES = 6 << 30
+
+    def _values_time_batched(self, args):
+        """[N, T, .] inputs without autograd (the once-per-rollout critic pass, examples/torchrl/train.py:249-251): the T time steps as
+        GROUPS of one launch set -- features of all frames from one ``grl_build_features`` launch, the three DeepSets stages once, with
+        LayerNorm statistic slots per time step (the reference loops over T, gnn_vf_net.py:72-80: statistics per step).  Bitwise the loop's
+        values; ~10 launches per chunk of time steps instead of ~10 per step."""
+        N, T = args[0].shape[:2]
+        g, (a, b) = self.gnn, (self.gnn.mlp_inner, self.gnn.mlp_outer)
+        params = (a.lins[0].weight, a.lins[0].bias, a.norms[0].weight, a.norms[0].bias, a.lins[1].weight, a.lins[1].bias, b.lins[0].weight,
+                  b.lins[0].bias, b.norms[0].weight, b.norms[0].bias, b.lins[1].weight, b.lins[1].bias, self.final.weight, self.final.bias)
+        n_nodes = None
+        out = torch.empty(N, T, device=args[0].device, dtype=torch.float32)
+        t0, step = 0, T
+        while t0 < T:
+            t1 = min(T, t0 + step)
+            tm = [x[:, t0:t1].transpose(0, 1).reshape((t1 - t0) * N, -1) for x in args]   # time-major frames of this chunk
+            _, xf = self.hyper_data.build_data(*tm, train=False)
+            if n_nodes is None:   # first chunk tells the node count: re-plan the chunk length if it was too long
+                n_nodes = xf.shape[1]
+                fit = max(1, int(self.GROUPED_BYTES // (N * n_nodes * 256)))
+                if fit < t1 - t0:
+                    step = fit
+                    continue
+            out[:, t0:t1] = ops.deepsets_values_groups(xf, params, t1 - t0).transpose(0, 1)
+            t0 = t1
+        return out
+
     def forward(self, *args, train=True):
         self.train(train)
         if args[0].dim() == 3:
+            if not torch.is_grad_enabled() and self.group is None:
+                return self._values_time_batched(args).unsqueeze(-1)
             T = args[0].shape[1]
             return torch.stack([self._values([a[:, i] for a in args], train) for i in range(T)], dim=1).unsqueeze(-1)
         return self._values(args, train).unsqueeze(-1)

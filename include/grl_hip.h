@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 201
+#define GRL_HIP_VERSION 202
 int grl_version(void);
 
 /* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
@@ -204,6 +204,16 @@ int grl_deepsets_fwd2(const float* h1, const double* stats1, double count1, cons
                       int n_nodes, hipStream_t stream);
 int grl_deepsets_fwd3(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
                       const float* b4, const float* wv, const float* bv, float* value, int batch, hipStream_t stream);
+/* grouped forward (ABI 202): `groups` independent batches per launch, x [groups][batch][n_nodes][d], slot arrays [groups][slots][2],
+ * value [groups][batch] -- the critic pass over the T+1 frames of a rollout (gnn_vf_net.py:72-80 loops over T: statistics per time step;
+ * examples/torchrl/train.py:249-251).  Each group's result is bitwise what the ungrouped call gives. */
+int grl_deepsets_fwd1_groups(const float* x, const float* W1, const float* b1, float* h1, double* stats1, int batch, int n_nodes, int d,
+                             int groups, hipStream_t stream);
+int grl_deepsets_fwd2_groups(const float* h1, const double* stats1, double count1, const float* g1, const float* be1, const float* W2,
+                             const float* b2, const float* W3, const float* b3, float* z, float* u1, double* stats2, int batch,
+                             int n_nodes, int groups, hipStream_t stream);
+int grl_deepsets_fwd3_groups(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
+                             const float* b4, const float* wv, const float* bv, float* value, int batch, int groups, hipStream_t stream);
 int grl_deepsets_bwd3(const float* u1, const double* stats2, double count2, const float* g2, const float* be2, const float* W4,
                       const float* b4, const float* wv, const float* dvalue, float* q2, double* bstats2, float* partial,
                       int batch, hipStream_t stream);

@@ -45,9 +45,9 @@ def test_100_repetitions_bitwise_and_cross_process(tmp_path):
     record = {"reps": REPS, "box": _box_identity(), "mismatches": []}
     labels = {"edge_conv": ["x1", "dx_src", "dW1", "db1", "dW2", "db2", "dWk"],
               "node_mlp": ["out", "dx2", "dgamma", "dbeta", "dW3", "db3", "dW4", "db4"]}
-    ops, t = td._setup("internal")
     for which, fn_ in (("edge_conv", td._edge), ("node_mlp", td._mlp)):
         for prec in ("", "_bf16"):
+            ops, t = td._setup("internal")   # fresh leaves per build (the helpers mark the inputs as requiring gradients in place)
             ref = fn_(ops, t, prec)
             torch.cuda.synchronize()
             for rep in range(1, REPS):

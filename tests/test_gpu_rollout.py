@@ -93,3 +93,24 @@ def test_collect_normalise_update_round_trip():
     out = RolloutDriver(upd, spec, ppo_epochs=1, seed=1).run(buf, next_last)
     assert all(torch.isfinite(out[k]).all() for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl"))
     assert float((upd.flat - p0).abs().max()) > 0
+
+
+@pytest.mark.parametrize("N,T,budget", [(8, 4, None), (96, 7, None), (96, 7, 3 * 96 * 33 * 256)])
+def test_time_batched_critic_pass_is_the_loop_bitwise(N, T, budget):
+    """The once-per-rollout critic pass (train.py:249-251): all time steps as groups of ONE launch set (per-step LayerNorm statistic
+    slots) must give bitwise the values of the reference's loop over T (gnn_vf_net.py:72-80) -- also when the byte budget cuts the
+    time axis into chunks (third case: three steps per chunk)."""
+    spec, cfg, loss, data, next_last = _make(N, T, seed=33)
+    critic = loss.critic_network
+    vf = critic._network1
+    obs = [data[k] for k in spec.in_features]
+    with torch.no_grad():
+        looped = torch.stack([vf._values([a[:, i].contiguous() for a in obs], False) for i in range(T)], dim=1)
+        if budget is not None:
+            vf.GROUPED_BYTES = budget
+        batched = critic(*obs, train=False)
+    assert batched.shape == (N, T, 1)
+    assert torch.equal(batched.reshape(N, T), looped), float((batched.reshape(N, T) - looped).abs().max())
+    # with autograd on, the 3-D call is still the differentiable loop
+    v = critic(*[a[:, :2] for a in obs], train=True)
+    assert v.requires_grad and v.shape == (N, 2, 1)

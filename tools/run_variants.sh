@@ -7,6 +7,6 @@ for round in 1 2; do
     GRL_LIB=$PWD/$lib python bench.py $ARGS 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); k=d['roofline']['per_kernel_ms_per_step']
-print('$lib'.split('lib_')[1][:-3].ljust(14), 'steps/s %7.2f' % d['value'], ' '.join('%s %.3f' % (n.replace('_kernel','').replace('edge_conv_','e_').replace('node_mlp_','m_').replace('edge_','e_'), k[n]) for n in ('edge_bwd16_kernel','edge_conv_bwd_w_kernel','node_mlp_bwd_fused_kernel','edge_conv_bwd_x_kernel','edge_conv_fwd_kernel','node_mlp_fwd_kernel') if n in k))"
+print('$lib'.split('lib_')[1][:-3].ljust(14), 'steps/s %7.2f' % d['value'], ' '.join('%s %.3f' % (n.replace('_kernel','').replace('edge_conv_','e_').replace('node_mlp_','m_').replace('edge_','e_'), k[n]) for n in ('edge_bwd16_kernel','edge_conv_bwd_w_kernel','node_mlp_bwd16_kernel','node_mlp_bwd_fused_kernel','edge_conv_bwd_x_kernel','edge_conv_fwd_kernel','node_mlp_fwd_kernel') if n in k))"
   done
 done
