@@ -5,6 +5,8 @@ replaces the inner loop of ``examples/torchrl/train.py:258-316``."""
 from dataclasses import dataclass
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -105,6 +107,9 @@ class PolicyUpdater:
                  group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False):
         self.loss_module, self.group = loss_module, group
         self.overlap_critic = overlap_critic   # one rank only: critic kernels on a second stream beside the actor's
+        self.overlap_folds = overlap_critic and os.environ.get("GRL_OVERLAP_FOLDS", "0") != "0"   # the leaf-gradient folds on a third
+        # stream, one launch per backward op (ops.FOLD_STREAM).  Measured round 3 and left OFF: 0.858 vs 0.783 ms per 512-frame step, 3.42 vs
+        # 3.38 ms at 4096 frames -- ten small launches with cross-stream edges in the graph cost more than the one 45 us launch they replace
         self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
         self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
         self._hyper = dict(eps=eps, betas=tuple(betas), clip=clip_grad_norm, max_norm=max_grad_norm)
@@ -254,7 +259,9 @@ class PolicyUpdater:
             with torch.no_grad():
                 self.step_dev.add_(1)
                 na, n = self.n_actor, self.flat.numel()
-                for i_, (lo, hi) in enumerate(((0, na), (na, n))):
+                # the two optimizers of train.py:120-127 have identical hyper-parameters and schedules: without per-network gradient
+                # clipping their two Adam steps are ONE launch over the flat buffer (element-wise: the same numbers)
+                for i_, (lo, hi) in enumerate(((0, na), (na, n)) if self.clip else ((0, n),)):
                     coef = None
                     if self.clip:  # train.py:308-310
                         sq = st["zw"][23 + i_:24 + i_]
@@ -263,7 +270,7 @@ class PolicyUpdater:
                     hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                              hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef,
                              1.0)
-                a_loss, c_loss, mt = loss_values(m, st["sums"], st["maxes"])
+                a_loss, c_loss, mt = st.pop("lv", None) or loss_values(m, st["sums"], st["maxes"])
                 out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": c_loss, "loc": st["loc"], "sigma": st["sigma"],
                        "state_value": st["value"].unsqueeze(-1)}
                 out.update(mt)
@@ -289,13 +296,16 @@ class PolicyUpdater:
                 pipe.fwd1()
                 pipe.fwd2()
                 value = pipe.fwd3()
-            with torch.no_grad():
+                # (the step's zeroed workspace and the advantage statistics: inputs of the fused loss kernel only -- off the actor's lane)
                 zw = st["zw"] = torch.zeros(26, device=self.flat.device, dtype=torch.float64)
                 st["adv"] = None
                 if m.normalize_advantage and st["obs"][0].shape[0] > 1:
                     st["adv"] = zw[8:10]
                     adv_stats_local(m, b, st["adv"])
             ops.DEFERRED = []
+            if self.overlap_folds:   # leaf-gradient folds beside the backward kernels, on a third stream (ops.FOLD_STREAM)
+                ops.FOLD_STREAM = self._fold_stream()
+                ops.FOLD_STREAM.wait_stream(cur)   # behind the zeroing of the flat gradient
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
             cur.wait_stream(cs)   # join: the fused loss kernel needs the values
             with torch.no_grad():
@@ -303,6 +313,7 @@ class PolicyUpdater:
                                                                 maxes=zw[22:23].view(torch.int32))
             cs.wait_stream(cur)   # fork: critic backward beside the actor backward
             with torch.cuda.stream(cs), torch.no_grad():
+                st["lv"] = loss_values(m, sums, maxes)   # reported values only: beside the backward pass, not behind Adam
                 pipe.bwd3(dvalue)
                 pipe.bwd2()
                 grads = pipe.bwd1(leaves)
@@ -311,6 +322,7 @@ class PolicyUpdater:
             cur.wait_stream(cs)   # join: every partial slab is complete
             ops.flush_deferred_grads()
             ops.DEFERRED = None
+            ops.FOLD_STREAM = None
             st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes)
 
         if world == 1 and self.overlap_critic:
@@ -390,6 +402,11 @@ class PolicyUpdater:
                 ("run", fold), ("sum", lambda: self.gflat)]
         plan += [("run", s5)]
         return plan
+
+    def _fold_stream(self):
+        if getattr(self, "_fstream", None) is None:
+            self._fstream = torch.cuda.Stream()
+        return self._fstream
 
     def _critic_stream(self):
         if getattr(self, "_cstream", None) is None:

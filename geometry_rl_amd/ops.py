@@ -55,6 +55,24 @@ def _reduce(partial: torch.Tensor, out: torch.Tensor):
 # Deferred folding: while a list is installed here (PolicyUpdater does, around the backward), folds whose destinations are all
 # existing leaf ``.grad`` buffers are queued and executed by ONE launch (flush_deferred_grads) instead of one launch each.
 DEFERRED = None
+# FOLD_STREAM (set by PolicyUpdater for one-rank steps): when not None, the queued folds of a backward op are launched at once on this side
+# stream, behind an event of the producing kernel, instead of waiting for the single launch at the end of the backward pass -- the
+# fold of a 34 MB partial slab then runs in the heads / tails of the following kernels (and beside the HBM-rate ones), and only the
+# last producer's fold is left on the critical path (the one launch at the end was a constant ~45 us per step at any batch size).
+# Folds into one destination are issued in program order on ONE stream: the summation order is fixed, the result reproducible.
+FOLD_STREAM = None
+_FOLD_KEEP = []   # partial slabs whose fold is in flight (kept alive until flush_deferred_grads joins the side stream)
+
+
+def _launch_folds(jobs):
+    import ctypes
+    for i in range(0, len(jobs), 64):
+        part = jobs[i:i + 64]
+        n = len(part)
+        hip.call("grl_reduce_partials_multi", n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part]),
+                 (ctypes.c_int * n)(*[j[0].shape[0] for j in part]), (ctypes.c_int * n)(*[j[0].shape[1] for j in part]),
+                 (ctypes.c_int * n)(*[j[1] for j in part]), (ctypes.c_int * n)(*[j[2] for j in part]),
+                 (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]))
 
 
 def flush_deferred_grads():
@@ -63,6 +81,12 @@ def flush_deferred_grads():
     jobs = DEFERRED or []
     if DEFERRED is not None:
         DEFERRED = []
+    if FOLD_STREAM is not None:
+        if jobs:
+            _launch_folds(jobs)
+        torch.cuda.current_stream().wait_stream(FOLD_STREAM)   # join: every fold has landed in the flat gradient
+        _FOLD_KEEP.clear()
+        return
     for i in range(0, len(jobs), 64):
         part = jobs[i:i + 64]
         n = len(part)
@@ -94,7 +118,14 @@ def _emit_grads(partial: torch.Tensor, segments):
         starts.append(start)
         lens.append(length)
     if DEFERRED is not None and not any(fresh_flags):
-        DEFERRED.extend((partial, st, ln, d) for st, ln, d in zip(starts, lens, dsts))   # keeps `partial` alive until the flush
+        jobs = [(partial, st, ln, d) for st, ln, d in zip(starts, lens, dsts)]
+        if FOLD_STREAM is not None:   # fold now, on the side stream, behind the kernel that has just been queued on this stream
+            FOLD_STREAM.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(FOLD_STREAM):
+                _launch_folds(jobs)
+            _FOLD_KEEP.append(partial)
+            return outs
+        DEFERRED.extend(jobs)   # keeps `partial` alive until the flush
         return outs
     for i in range(0, len(segments), 8):
         n = min(8, len(segments) - i)
