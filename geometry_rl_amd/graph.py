@@ -112,6 +112,12 @@ class GraphBatch:
     output_mask_key: Optional[str]
     nodes_per_sample: Dict[str, int]
     compact: bool  # True: padded points removed (actor graph)
+    # the per-type position / vector / one-hot tensors are views of ONE buffer each, node types in ``all_order`` (the read-out type last):
+    # a homogeneous model (EMPN: ponita_gcn.py:73-83 flattens the hetero batch into one graph) reads them without a concatenation
+    all_order: Optional[List[str]] = None
+    pos_all: Optional[torch.Tensor] = None      # [N_all, 3]
+    vec_all: Optional[torch.Tensor] = None      # [N_all, n_vec, 3]
+    scalar_all: Optional[torch.Tensor] = None   # [N_all, n_types] (one-hot node type)
 
     @property
     def edge_types(self):
@@ -345,13 +351,29 @@ class HyperData:
                 return xg.data_ptr(), stride, off, int(n_src == 1 and n_t > 1)
 
             row_off = 0
+            pos_all = vec_all = None
+            if not dense:   # one buffer per quantity, node types in all_order (read-out type last); the per-type tensors are views
+                order = topo.get("all_order")
+                if order is None:
+                    ro = self._output_mask_key
+                    order = topo["all_order"] = [t for t in self.node_type_list if t != ro] + ([ro] if ro in self.node_type_list else [])
+                    topo["scalar_all"] = torch.cat([topo["one_hot"][t] for t in order], 0).contiguous()
+                    o_, offs = 0, {}
+                    for t in order:
+                        offs[t] = o_
+                        o_ += topo["n_main"] if t == main else B * topo["n_per"][t]
+                        topo["one_hot"][t] = topo["scalar_all"][offs[t]:o_]
+                    topo["all_off"], topo["n_all"] = offs, o_
+                pos_all = torch.empty(topo["n_all"], 3, device=dev, dtype=torch.float32)
+                vec_all = torch.empty(topo["n_all"], n_vec, 3, device=dev, dtype=torch.float32)
             for t in self.node_type_list:
                 n_t = topo["n_per"][t]
                 gather = gm.data_ptr() if (t == main and not full) else 0
                 n_nodes = topo["n_main"] if t == main else B * n_t
                 if not dense:
-                    graph_pos[t] = torch.empty(n_nodes, 3, device=dev, dtype=torch.float32)
-                    vector_dict[t] = torch.empty(n_nodes, n_vec, 3, device=dev, dtype=torch.float32)
+                    o0 = topo["all_off"][t]
+                    graph_pos[t] = pos_all[o0:o0 + n_nodes]
+                    vector_dict[t] = vec_all[o0:o0 + n_nodes]
                     scalar_dict[t] = topo["one_hot"][t]
                     pa = term(("position_vectors", t), n_t)
                     words += [graph_pos[t].data_ptr(), pa[0], 0, gather, 3, 0, 0, 0, n_nodes, n_t, pa[1], pa[2], pa[3], 0, 0, 0, -1, 0]
@@ -372,7 +394,8 @@ class HyperData:
             self._keepalive = obs  # the launch reads these buffers asynchronously
             graph = GraphBatch(B, list(self.node_type_list), {t: (topo["n_main"] if t == main else B * topo["n_per"][t])
                                                               for t in self.node_type_list}, graph_pos,
-                               topo["edges"], self._output_mask_key, topo["n_per"], self.drop_padding)
+                               topo["edges"], self._output_mask_key, topo["n_per"], self.drop_padding,
+                               topo.get("all_order"), pos_all, vec_all, topo.get("scalar_all"))
             if dense:
                 return graph, x_dense
             return graph, (scalar_dict, vector_dict)

@@ -2,10 +2,15 @@
 ``geometry_rl/modules/pyg_models/ponita_gcn.py`` + ``ponita/ponita.py`` (Ponita, SeparableFiberBundleConvNext).
 
 The reference flattens the hetero batch into ONE homogeneous graph (ponita_gcn.py:73-83,102-126) and runs every layer over
-every edge.  Summation is linear, so the same result is obtained without materialising the flattened graph: per layer and
-destination node type, the spatial conv x1 is the sum of the per-edge-type fused edge kernels (all sharing that layer's
-weights), followed by the fiber conv and the ConvNeXt block of that layer.  Padded points have no edges and never reach the
-read-out, so they are dropped exactly as in the HEPi graph (geometry_rl_amd/graph.py)."""
+every edge (ponita.py:153-161).  So does this module (round 3): the node types share one latent array (read-out type last: the
+per-type feature tensors of ``build_data`` are views of one buffer, nothing is concatenated), the edge types are merged once per
+cached topology into ONE destination- / source-sorted edge set over that array, and a layer is one edge convolution, one fiber
+convolution and one ConvNeXt block -- three launches forward, three backward (round 2: one edge launch per edge type plus torch
+adds of the partial x1).  Padded points have no edges and never reach the read-out, so they are dropped exactly as in the HEPi
+graph (geometry_rl_amd/graph.py).  For the same reason the LAST layer only computes what the read-out can see: its edge set holds
+the edges into the read-out nodes, its fiber convolution and ConvNeXt block run on those nodes alone (the reference computes, and
+then never reads, the last layer's output at every other node; its gradient is identically zero) -- ``prune_last_layer=False``
+restores the full last layer."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -58,8 +63,10 @@ class Ponita(nn.Module):
 class PonitaGCN(nn.Module):
     def __init__(self, input_dim_node, output_dim, output_dim_vec, num_layers=2, hidden_dim=64, dropout=0.0, num_ori=16, degree=2,
                  widening_factor=4, attention=False, ponita_dim=3, only_upper_hemisphere=False, device="cuda", precision="fp32",
-                 **ignored):
+                 prune_last_layer=True, **ignored):
         super().__init__()
+        self.prune_last_layer = prune_last_layer
+        self._merged_cache = {}
         self.precision, self._prec = precision, ("_bf16" if precision == "bf16" else "")
         if hidden_dim != 64 or num_ori != 16 or degree != 2 or widening_factor != 4 or attention:
             raise NotImplementedError("HIP kernels are specialised for configs/algorithm/pyg_agent/model/ponita_gcn.yaml")
@@ -96,36 +103,58 @@ class PonitaGCN(nn.Module):
             poly = self._fiber_poly_cache = self.ponita.fiber_basis_fn[0](inv).detach().contiguous()
         return ops.fiber_kernels(poly, self.ponita.fiber_basis_fn, [l.conv for l in self.ponita.interaction_layers])
 
-    def _layer(self, layer, x, graph: GraphBatch, grid3, fks, collect=None):
+    def _merged(self, graph: GraphBatch):
+        """The homogeneous view of a cached topology: ONE edge set over the concatenated node array (ponita_gcn.py:73-83), and the
+        sub edge set of the edges INTO the read-out nodes for the pruned last layer.  Built once per topology (host syncs allowed)."""
+        hit = self._merged_cache.get(id(graph.edges))
+        if hit is not None and hit[0] is graph.edges:
+            return hit[1]
+        order, off, n = graph.all_order, {}, 0
+        for t in order:
+            off[t] = n
+            n += graph.num_nodes[t]
+        srcs, dsts = [], []
+        for (s_, _, d_), es in graph.edges.items():
+            srcs.append(es.src_d.long() + off[s_])
+            dsts.append(es.dst_d.long() + off[d_])
+        src, dst = torch.cat(srcs), torch.cat(dsts)
+        ro = graph.output_mask_key
+        lo, n_ro = off[ro], graph.num_nodes[ro]
+        assert order[-1] == ro and lo + n_ro == n
+        into_ro = dst >= lo
+        merged = dict(n=n, lo=lo, n_ro=n_ro, es_all=ops.build_edge_set(torch.stack([src, dst]), n, n),
+                      es_last=ops.build_edge_set(torch.stack([src[into_ro], dst[into_ro] - lo]), n, n_ro))
+        if len(self._merged_cache) >= 8:   # a handful of batch sizes / the padded calibration graph; never grows without bound
+            self._merged_cache.pop(next(iter(self._merged_cache)))
+        self._merged_cache[id(graph.edges)] = (graph.edges, merged)
+        return merged
+
+    def _layer_merged(self, layer, x, pos, es, grid3, fk, lo=0, collect=None):
+        """One interaction layer on the homogeneous graph: x [N,16,64] -> [N_dst,16,64]; destinations = nodes lo .. (all, or the read-out tail)."""
         b = self.ponita.basis_fn
-        x1 = {}
-        for et, es in graph.edges.items():  # spatial conv summed over all (merged) edge types: ponita.py:153,161
-            s, _, d = et
-            part = ops.EdgeConv.apply(x[s], graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
-                                      layer.conv.kernel.weight, es, self.dim, None, self._prec)
-            x1[d] = part if d not in x1 else x1[d] + part
-        fk = fks[id(layer.conv)]
-        out = {}
-        for t, xt in x.items():
-            x1t = x1.get(t)
-            if x1t is None:
-                x1t = torch.zeros_like(xt)
-            x2 = ops.FiberConv.apply(x1t, fk, layer.conv.bias, self._prec)
-            out[t] = ops.NodeMLP.apply(x2, xt, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
-                                       layer.linear_2.weight, layer.linear_2.bias, None, None, self._prec)
-            if collect is not None:
-                collect[t] = (x1t, fk)
-        return out
+        x_dst, pos_dst = (x, pos) if lo == 0 else (x[lo:], pos[lo:])
+        # x feeds the convolution AND the residual of its own node block: the two gradients are summed inside the fused edge backward
+        res = {} if (lo == 0 and torch.is_grad_enabled() and x.requires_grad) else None
+        x1 = ops.EdgeConv.apply(x, pos, pos_dst, grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias, layer.conv.kernel.weight, es,
+                                self.dim, res, self._prec)
+        x2 = ops.FiberConv.apply(x1, fk, layer.conv.bias, self._prec)
+        if collect is not None:
+            collect.update(x1=x1, fk=fk)
+        return ops.NodeMLP.apply(x2, x_dst, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
+                                 layer.linear_2.weight, layer.linear_2.bias, None, res, self._prec)
 
     def latent_step(self, graph: GraphBatch, u_dict):
-        scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight, self._prec)
-             for t in graph.node_types}
+        mg = self._merged(graph)
+        x = ops.LiftEncode.apply(graph.scalar_all, graph.vec_all, grid3, self.ponita.x_embedder.weight, self._prec)
         fks = self._fiber_kernels()
-        for layer in self.ponita.interaction_layers:
-            x = self._layer(layer, x, graph, grid3, fks)
-        lat = x[graph.output_mask_key]
+        layers = list(self.ponita.interaction_layers)
+        for i, layer in enumerate(layers):
+            if i == len(layers) - 1 and self.prune_last_layer:
+                x = self._layer_merged(layer, x, graph.pos_all, mg["es_last"], grid3, fks[id(layer.conv)], lo=mg["lo"])
+            else:
+                x = self._layer_merged(layer, x, graph.pos_all, mg["es_all"], grid3, fks[id(layer.conv)])
+        lat = x if x.shape[0] == mg["n_ro"] else x[mg["lo"]:]
         return lat.float() if lat.dtype != torch.float32 else lat
 
     def one_step(self, graph: GraphBatch, u_dict, **ignored):
@@ -137,20 +166,19 @@ class PonitaGCN(nn.Module):
 
     @torch.no_grad()
     def calibrate(self, graph_full: GraphBatch, u_dict, group=None) -> None:
-        """ponita.py:178-180,187-192: statistics over ALL nodes of the homogeneous graph (all node types, padding included)."""
-        scalar_dict, vector_dict = u_dict
+        """ponita.py:178-180,187-192: statistics over ALL nodes of the homogeneous graph (all node types, padding included; every layer
+        in full -- no pruning here)."""
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.ponita.x_embedder.weight, self._prec)
-             for t in graph_full.node_types}
+        mg = self._merged(graph_full)
+        x = ops.LiftEncode.apply(graph_full.scalar_all, graph_full.vec_all, grid3, self.ponita.x_embedder.weight, self._prec)
         fks = self._fiber_kernels()
-        cat = lambda d: torch.cat([d[t].reshape(-1) for t in graph_full.node_types])
         for layer in self.ponita.interaction_layers:
             col = {}
-            out = self._layer(layer, x, graph_full, grid3, fks, collect=col)
+            out = self._layer_merged(layer, x, graph_full.pos_all, mg["es_all"], grid3, fks[id(layer.conv)], collect=col)
             if not bool(layer.conv.callibrated):
-                x1 = {t: col[t][0] for t in col}
-                x2 = {t: ops.FiberConv.apply(col[t][0], col[t][1], torch.zeros_like(layer.conv.bias), self._prec) for t in col}
-                s_in, s_1, s_2 = global_std(cat(x), group), global_std(cat(x1), group), global_std(cat(x2), group)
+                x1 = col["x1"]
+                x2 = ops.FiberConv.apply(x1, col["fk"], torch.zeros_like(layer.conv.bias), self._prec)
+                s_in, s_1, s_2 = global_std(x, group), global_std(x1, group), global_std(x2, group)
                 layer.conv.kernel.weight.mul_(s_in / s_1)
                 layer.conv.fiber_kernel.weight.mul_(s_1 / s_2)
                 layer.conv.callibrated.fill_(True)
