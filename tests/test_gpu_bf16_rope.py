@@ -4,8 +4,9 @@
   mask: padded links have no edges and are dropped from the actor graph) -- one whole policy update against the fp32 oracle at the
   fp32 bar (1e-4 values, 2e-4 gradients, 2e-5 post-Adam parameters), toy size and the 80 / 40-link size.
 * ``test_bf16_products_within_tolerance``: the reduced-precision build of the MFMA kernels (ONE bf16 MFMA per product, operands
-  rounded to nearest bf16, fp32 accumulation and storage: entry points ``*_bf16``) against BOTH the fp32 oracle and the fp32 HIP
-  path.  Tolerance as BASELINE.md section 3 states it for this config: every loss-dict entry within 2e-2 relative
+  rounded to nearest bf16, bf16 latents, fp32 accumulation: entry points ``*_bf16``) against BOTH the fp32 oracle and the fp32 HIP
+  path; every actor gradient tensor against the fp32 HIP path (relative L2 error <= 4e-2, worst element <= 6e-2 of the tensor's
+  largest) and the parameters after one Adam step (mean distance <= 0.08 lr).  Tolerance as BASELINE.md section 3 states it for this config: every loss-dict entry within 2e-2 relative
   (|got - ref| <= 2e-2 * max(|ref|, floor)), loc / var / state_value within 2e-2 * max(1, max|ref|); 1e-4 is unattainable with
   8-bit mantissas.  Measured margins are printed.
 """
@@ -111,19 +112,33 @@ def test_bf16_products_within_tolerance():
             w = max(w, e)
             assert e <= 2e-2, (against, k, e)
         worst[against] = w
-    # gradients: direction and size of every actor gradient tensor (cosine >= 0.99, norm within 5 %) against the fp32 HIP path
+    # gradients, per tensor, against the fp32 HIP path: relative L2 error and worst element relative to the tensor's largest entry
     gb, g32 = outs["bf16"][1], outs["fp32"][1]
-    cos_min, ratio_worst = 1.0, 0.0
+    worst_l2, worst_max, worst_l2_name = 0.0, 0.0, None
     for k in g32:
         a, b = gb[k].flatten().double(), g32[k].flatten().double()
         if b.norm() < 1e-12:
             continue
-        cos = float(a @ b / (a.norm() * b.norm()))
-        cos_min = min(cos_min, cos)
-        ratio_worst = max(ratio_worst, abs(float(a.norm() / b.norm()) - 1.0))
-        assert cos >= 0.99 and abs(float(a.norm() / b.norm()) - 1.0) <= 5e-2, (k, cos, float(a.norm() / b.norm()))
-    print(f"bf16 products: worst relative loss/value error vs oracle {worst['oracle fp32']:.2e}, vs fp32 HIP {worst['HIP fp32']:.2e}; "
-          f"actor gradients: min cosine {cos_min:.5f}, worst norm ratio error {ratio_worst:.2e}")
+        l2 = float((a - b).norm() / b.norm())
+        mx = float((a - b).abs().max() / b.abs().max())
+        if l2 > worst_l2:
+            worst_l2, worst_l2_name = l2, k
+        worst_max = max(worst_max, mx)
+        assert l2 <= 4e-2 and mx <= 6e-2, (k, l2, mx)
+    # post-Adam parameters from identical starting points: Adam's first step moves every element by ~lr * sign(g), so the two builds may
+    # differ by up to 2 lr where a near-zero gradient changes sign; the MEAN distance in units of lr measures how often that happens
+    from geometry_rl_amd import agent
+    pa = {}
+    for name, (a_, c_, l_) in {"bf16": (actor, critic, loss), "fp32": (actor32, critic32, loss32)}.items():
+        upd = agent.PolicyUpdater(l_, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm)
+        upd.step(dbatch)
+        pa[name] = {k: p.detach().cpu().clone() for k, p in a_.named_parameters()}
+    d_all = torch.cat([(pa["bf16"][k] - pa["fp32"][k]).abs().flatten() for k in pa["fp32"]])
+    mean_lr, max_lr = float(d_all.mean()) / cfg.lr, float(d_all.max()) / cfg.lr
+    assert max_lr <= 2.05 and mean_lr <= 0.08, (mean_lr, max_lr)
+    print(f"bf16 build: worst relative loss/value error vs oracle {worst['oracle fp32']:.2e}, vs fp32 HIP {worst['HIP fp32']:.2e}; "
+          f"actor gradients vs fp32 HIP: worst relative L2 error {worst_l2:.2e} ({worst_l2_name}), worst element / max|g| {worst_max:.2e}; "
+          f"post-Adam parameters: mean |dp| = {mean_lr:.3f} lr, max {max_lr:.2f} lr")
     # and the fp32 build on the same inputs stays at the fp32 bar
     for k in LOSS_KEYS:
         assert abs(float(outs["fp32"][0][k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), k

@@ -1,5 +1,6 @@
-"""BASELINE.json's full size (rigid_insertion_multi HEPi, 4096-frame minibatch) through properties that hold at any size -- the CPU
-oracle needs minutes per update there, so it is not the checker:
+"""BASELINE.json's full size (4096-frame minibatches of configs 2 / 3 / 4 / 5: rigid HEPi, cloth HEPi, two-agent EMPN, variable-length rope
+HEPi in the fp32 and the bf16 build) through properties that hold at any size -- the CPU oracle needs minutes per update there, so it
+is not the checker:
 
 * the whole policy update is bitwise reproducible (loss dict, flat gradient, post-Adam parameters);
 * permuting the frames of the minibatch changes nothing but the summation order (every loss term is a sum over frames, the graphs
@@ -15,15 +16,21 @@ B = 4096
 KEYS = ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic", "kl", "ESS", "mean_constraint", "cov_constraint", "entropy")
 
 
-def _make(seed=0, group=None):
-    from geometry_rl_amd import agent, graph, synthetic as syn
+WORKLOADS = ["rigid_hepi", "cloth_hepi", "rigid2_empn", "rope_hepi_var", "rope_hepi_bf16"]
+
+
+def _make(seed=0, group=None, wl="rigid_hepi"):
+    import os
+    import sys
+    from geometry_rl_amd import agent, synthetic as syn
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench   # the workload table of the benchmark: the SAME specs / configs / synthetic inputs the reported numbers run on
     dev = torch.device("cuda:0")
-    spec = graph.rigid_spec()
-    cfg = agent.AgentConfig(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)   # configs/rigid_insertion_multi_hepi_trpl_cfg.yaml
+    spec, cfg, make_obs, _ = bench.workload(wl)
     torch.manual_seed(seed)
     actor, critic, proj, loss = agent.build_agent(spec, cfg, device=dev, group=group)
-    batch = dict(syn.make_rigid_obs(B, seed=3))
-    batch.update(syn.make_ppo_fields(B, 6, seed=3))
+    batch = dict(make_obs(B, 3, 0))
+    batch.update(syn.make_ppo_fields(B, spec.num_actuators * cfg.output_dim_vec * 3, seed=3))
     batch = {k: v.to(dev) for k, v in batch.items()}
     with torch.no_grad():
         actor.forward_diag(*[batch[k] for k in spec.in_features], train=True)   # calibration
@@ -31,7 +38,7 @@ def _make(seed=0, group=None):
 
 
 def _one_update(agent, loss, cfg, batch):
-    upd = agent.PolicyUpdater(loss, lr=cfg.lr)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm)
     p0 = upd.flat.clone()
     out = upd.step(batch)
     res = ({k: float(out[k]) for k in KEYS}, upd.gflat.clone(), upd.flat.clone())
@@ -39,8 +46,10 @@ def _one_update(agent, loss, cfg, batch):
     return res
 
 
-def test_full_size_update_is_reproducible_and_permutation_invariant():
-    agent, spec, cfg, actor, critic, loss, batch = _make()
+@pytest.mark.parametrize("wl", WORKLOADS)
+def test_full_size_update_is_reproducible_and_permutation_invariant(wl):
+    agent, spec, cfg, actor, critic, loss, batch = _make(wl=wl)
+    tol_l, tol_g = (2e-5, 1e-4) if cfg.precision == "fp32" else (2e-3, 2e-2)   # bf16 build: another summation order moves bf16 roundings
     l0, g0, p0 = _one_update(agent, loss, cfg, batch)
     l1, g1, p1 = _one_update(agent, loss, cfg, batch)
     assert l0 == l1, (l0, l1)
@@ -54,22 +63,23 @@ def test_full_size_update_is_reproducible_and_permutation_invariant():
     critic._network1.hyper_data._cache.clear()
     lp, gp, _ = _one_update(agent, loss, cfg, {k: v[perm].contiguous() for k, v in batch.items()})
     for k in KEYS:
-        assert abs(lp[k] - l0[k]) <= 2e-5 * max(1.0, abs(l0[k])), (k, lp[k], l0[k])
+        assert abs(lp[k] - l0[k]) <= tol_l * max(1.0, abs(l0[k])), (k, lp[k], l0[k])
     scale = float(g0.abs().max())
-    assert float((gp - g0).abs().max()) <= 1e-4 * scale, float((gp - g0).abs().max()) / scale
+    assert float((gp - g0).abs().max()) <= tol_g * scale, float((gp - g0).abs().max()) / scale
 
 
-def _dp_worker(rank, world, port, ret):
+def _dp_worker(rank, world, port, ret, wl):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    agent, spec, cfg, actor, critic, loss, batch = _make(group=dist.group.WORLD)   # same seed: identical replicas, calibrated on the full batch
+    agent, spec, cfg, actor, critic, loss, batch = _make(group=dist.group.WORLD, wl=wl)   # same seed: identical replicas, calibrated on the full batch
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = {k: v[lo:hi].contiguous() for k, v in batch.items()}
     actor.hyper_data._cache.clear()
     critic._network1.hyper_data._cache.clear()
-    upd = agent.PolicyUpdater(loss, lr=cfg.lr, group=dist.group.WORLD, use_graph=True)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=dist.group.WORLD,
+                              use_graph=True)
     for _ in range(2):   # step 1 eager (builds the shard's topology), step 2 replays the recorded segments
         p0 = upd.flat.clone()
         out = upd.step(shard)
@@ -79,16 +89,17 @@ def _dp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_full_size_four_shards_match_the_full_minibatch():
+@pytest.mark.parametrize("wl", ["rigid_hepi", "cloth_hepi", "rigid2_empn", "rope_hepi_var"])
+def test_full_size_four_shards_match_the_full_minibatch(wl):
     """4 ranks x 1024 frames (all on cuda:0, gloo; second step = hipGraph segments between the collectives) against the 4096-frame
     update: loss terms and the all-reduced flat gradient."""
     import socket
     import torch.multiprocessing as mp
-    agent, spec, cfg, actor, critic, loss, batch = _make()
+    agent, spec, cfg, actor, critic, loss, batch = _make(wl=wl)
     l0, g0, _ = _one_update(agent, loss, cfg, batch)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_dp_worker, args=(4, port, ret), nprocs=4, join=True)
+    mp.spawn(_dp_worker, args=(4, port, ret, wl), nprocs=4, join=True)
     scale = float(g0.abs().max())
     for r in range(4):
         lr_, gr = ret[r]
