@@ -34,7 +34,11 @@ constexpr int C = 64, O = 16;
 #define GRL_E16_WGS 3                    // workgroups per CU the register budget is cut for (and the grid is capped at)
 #endif
 constexpr int E16_WAVES = GRL_E16_WAVES, E16_THREADS = 64 * E16_WAVES;
-constexpr int LD1 = 32 + 8;   // bf16 elements per image row, layer 1 (K = 14 padded to one 32-deep step)
+#ifndef GRL_LD1
+#define GRL_LD1 40
+#endif
+constexpr int LD1 = GRL_LD1;  // bf16 elements per image row, layer 1 (K = 14 padded to one 32-deep step): 40 (80-B rows) is 2-way conflicted for
+                              // the ds_read_b128 lane groups, 48 (96-B rows) conflict-free (tools: the bank model of MI355X_MICROARCH.md)
 constexpr int LD2 = 64 + 16;  // layers 2 and 3: 160-B rows put the 16 lanes of every ds_read_b128 group on disjoint banks (72: 2-way)
 struct ChainW16 {
   unsigned short W1h[64 * LD1], W1l[64 * LD1];

@@ -158,7 +158,23 @@ GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
   }
 #endif
 }
+// value only, scalar form (plain f32 instructions; 12 + 2 transcendental per element): for forward kernels built without packed math
+GRL_DEVINL float gelu_val(float x) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
+  float poly = fmaf(t, 0.5307027145f, -0.7265760135f);     // a_i / 2
+  poly = fmaf(poly, t, 0.7107068705f);
+  poly = fmaf(poly, t, -0.142248368f);
+  poly = fmaf(poly, t, 0.127414796f);
+  return fmaf(-fabsf(x), (poly * t) * e, fmaxf(x, 0.f));
+}
+#ifndef GRL_GELU4_SCALAR
+#define GRL_GELU4_SCALAR 0
+#endif
 GRL_DEVINL float4 gelu4(float4 x) {
+#if GRL_GELU4_SCALAR
+  return make_float4(gelu_val(x.x), gelu_val(x.y), gelu_val(x.z), gelu_val(x.w));
+#endif
   v2f g0, g1, d0, d1;
   gelu_pair<false>(v2f{x.x, x.y}, g0, d0);
   gelu_pair<false>(v2f{x.z, x.w}, g1, d1);

@@ -25,7 +25,10 @@ SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "
 # pipe, packed ones (v_pk_*) do not (DESIGN.md finding 23)
 # (edge_conv16.hip the same, with the scalar GELU in its one-wave backward: +1 % on the step, profiles/r03_ab_edge16_noslp.txt)
 FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize", "-DGRL_B16_SCALAR_GELU"],
-              "node_mlp16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+              "node_mlp16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+              # the ConvNeXt forward: plain-f32 GELU as well (0.313 vs 0.330 ms per step; the 16-row edge forward, three waves per SIMD, is
+              # FASTER with its packed GELU: 0.48 vs 0.52 ms -- profiles/r03_ab_forward_gelu_ld1.txt)
+              "node_mlp.hip": ["-fno-slp-vectorize", "-DGRL_GELU4_SCALAR=1"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16")]
