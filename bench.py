@@ -160,6 +160,40 @@ def cpu_baseline_and_parity(wl_name, minibatch, dev, steps=3, max_threads=32):
     return cpu, gate
 
 
+def determinism_selfcheck(dev, prec=""):
+    """Two identical launches of each MFMA op (edge convolution and ConvNeXt block, forward + backward, 8192 nodes / 24576 edges) must agree
+    BITWISE (the one-wave kernels rely on unfenced MFMA groups; DESIGN.md finding 15 records one pool box that once failed this).
+    Run once per process before anything is timed; a failure voids the line."""
+    from geometry_rl_amd import hip, ops, hepi
+    g = torch.Generator().manual_seed(0)
+    n, E = 8192, 24576
+    ei = torch.stack([torch.randint(0, n, (E,), generator=g), torch.arange(n).repeat_interleave(3)])
+    es = ops.build_edge_set(ei.to(dev), n, n)
+    dt = hip.storage_dtype(prec)
+    rnd = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g) * sc).to(dev)
+    x, dy, xd = rnd(n, 16, 64).to(dt), rnd(n, 16, 64).to(dt), rnd(n, 16, 64).to(dt)
+    ps = torch.rand(n, 3, generator=g).to(dev)
+    grid = hepi.make_grid(3, 16).to(dev).contiguous()
+    ew = [rnd(64, 14, sc=0.25), rnd(64), rnd(64, 64, sc=0.125), rnd(64), rnd(64, 64, sc=0.125)]
+    mw = [1 + rnd(64, sc=0.1), rnd(64, sc=0.1), rnd(256, 64, sc=0.125), rnd(256, sc=0.1), rnd(64, 256, sc=0.06), rnd(64, sc=0.1)]
+
+    def run():
+        xs = x.clone().requires_grad_(True)
+        ws = [w.clone().requires_grad_(True) for w in ew]
+        y = ops.EdgeConv.apply(xs, ps, ps, grid, *ws, es, 3, None, prec)
+        y.backward(dy)
+        x2 = x.clone().requires_grad_(True)
+        ms = [w.clone().requires_grad_(True) for w in mw]
+        z = ops.NodeMLP.apply(x2, xd, *ms, None, None, prec)
+        z.backward(dy)
+        return [y.detach(), xs.grad, z.detach(), x2.grad] + [w.grad for w in ws + ms]
+
+    a, b = run(), run()
+    torch.cuda.synchronize()
+    bad = [i for i, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
+    return {"passed": not bad, "differing_outputs": bad, "shape": f"{n} nodes, {E} edges, edge conv + ConvNeXt block forward / backward twice"}
+
+
 def syn_fields(B, A):
     from geometry_rl_amd import synthetic as syn
     return syn.make_ppo_fields(B, A, seed=1)
@@ -218,6 +252,9 @@ def main():
 
     from geometry_rl_amd import agent, hip, synthetic as syn
     spec, cfg, make_obs, cfg_name = workload(args.workload)
+    det = None
+    if rank == 0 and not os.environ.get("GRL_BENCH_NO_SELFCHECK"):   # (the override is for timing knock-out builds, whose results are garbage)
+        det = determinism_selfcheck(dev, "_bf16" if cfg.precision == "bf16" else "")
     assert args.minibatch % world == 0
     B = args.minibatch // world
     torch.manual_seed(0)
@@ -428,8 +465,12 @@ def main():
             "minibatches": f"sampled without replacement from a device-resident {B} x {T_roll}-frame rollout per GPU (one frame per env), "
                            "gathered into the static inputs of the recorded step by one launch",
             "loss": {k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")},
-            "roofline": roof, "cpu_baseline": cpu, "parity_gate": gate,
+            "roofline": roof, "cpu_baseline": cpu, "parity_gate": gate, "determinism_selfcheck": det,
         }
+        if det is not None and not det["passed"]:   # a box (or a build) whose MFMA kernels are not reproducible reports no number
+            line["invalid_value"], line["value"] = line["value"], None
+            print(json.dumps(line))
+            raise SystemExit("determinism self-check failed: " + json.dumps(det))
         if gate is not None and not gate["passed"]:   # no speed number without parity
             line["invalid_value"], line["value"] = line["value"], None
             print(json.dumps(line))

@@ -84,6 +84,9 @@ struct Edge16Params {
 };
 
 GRL_DEVINL void load_w16(ChainW16& s, const Edge16Params& p) {
+#ifdef GRL_KNOCK_STAGE   // timing knock-out: no weight staging (results are wrong)
+  return;
+#endif
   stage16<14, 32, E16_THREADS>(s.W1h, s.W1l, p.W1, LD1);
   stage16<64, 64, E16_THREADS>(s.W2h, s.W2l, p.W2, LD2);
   stage16<64, 64, E16_THREADS>(s.Wkh, s.Wkl, p.Wk, LD2);
@@ -476,11 +479,13 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   Bwd16Smem& sm = *reinterpret_cast<Bwd16Smem*>(smem_raw);
   const Edge16Params& p = bp.e;
+#ifndef GRL_KNOCK_STAGE
   stage16<14, 32, 256>(sm.w.W1h, sm.w.W1l, p.W1, LD1);
   stage16<64, 64, 256>(sm.w.W2h, sm.w.W2l, p.W2, LD2);
   stage16<64, 64, 256>(sm.w.Wkh, sm.w.Wkl, p.Wk, LD2);
   stage16<64, 64, 256, true>(sm.WkTh, sm.WkTl, p.Wk, LD2);
   stage16<64, 64, 256, true>(sm.W2Th, sm.W2Tl, p.W2, LD2);
+#endif
   for (int i = threadIdx.x; i < 64; i += 256) {
     sm.w.b1s[i] = p.b1[i];
     sm.w.b2s[i] = p.b2[i];

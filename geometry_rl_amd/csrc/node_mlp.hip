@@ -75,8 +75,10 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
                                                            int n_rows, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   MlpSmemBf& s = *reinterpret_cast<MlpSmemBf*>(smem_raw);
+#ifndef GRL_KNOCK_STAGE   // (timing knock-out: no weight staging; results are wrong)
   stage_split<W, C, C, 512>(s.W3h, s.W3l, W3, LB3);
   stage_split<C, W, W, 512>(s.W4h, s.W4l, W4, LB4);
+#endif
   for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
   for (int i = threadIdx.x; i < C; i += blockDim.x) { s.b4s[i] = b4[i]; s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
   __syncthreads();

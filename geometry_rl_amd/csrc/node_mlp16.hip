@@ -111,6 +111,18 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
   const int j0 = 64 * wave;
   WFrag16 w3f, w3t;
   float4 b3q[4];
+#ifdef GRL_KNOCK_STAGE   // timing knock-out: constant fragments instead of the strided weight loads (results are wrong)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    b3q[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const u32x4 c = {0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+      w3f.h[nt][s] = w3f.l[nt][s] = w3t.h[nt][s] = w3t.l[nt][s] = __builtin_bit_cast(bf16x8, c);
+      sm.W4F[wave][nt][s][0][lane] = c; sm.W4F[wave][nt][s][1][lane] = c;
+    }
+  }
+#else
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     b3q[nt] = *reinterpret_cast<const float4*>(b3 + j0 + 16 * nt + 4 * g);
@@ -137,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
       }
     }
   }
+#endif
 #ifndef GRL_M16_PIN_STATIC
 #define GRL_M16_PIN_STATIC 1
 #endif
