@@ -391,7 +391,9 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_summary_*.json")))[-1]
+            # the committed PMC summary of THIS workload (rigid_hepi: r0N_pmc_summary_vK.json, the others r0N_pmc_summary_<workload>.json)
+            pat = "r0*_pmc_summary_v*.json" if args.workload == "rigid_hepi" else f"r0*_pmc_summary_{args.workload}*.json"
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]
             pk = json.load(open(f))["kernels"].get(name)
             if pk:
                 traffic = pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"]
