@@ -50,39 +50,23 @@ struct ChainW16 {
 // image[n][32 s + 8 g + j] = W[n][32 s + 16 (j >> 2) + 4 g + (j & 3)]   (zero beyond KSRC); one (n, s, g) item per thread and step:
 // two 16-byte global loads (when aligned), one 16-byte LDS store per image
 //   TRANS: the image of W^T (row n of the image = column n of W [64,64]): the backward chain's dg = dZ W products
-// Staging in two phases (round 3): EVERY image's global loads are issued before the first split / LDS store, so the prologue of a launch
-// costs one L2 round trip instead of one per image and loop iteration (five images, two iterations each in the backward: ~8 dependent
-// round trips at the head of every launch, ~40 us per step over the eight MFMA launches -- profiles/r03_sizes_and_workloads.txt).
 template <int KSRC, int KPAD, int NT, bool TRANS = false>
-struct WStage {
-  static constexpr int ITEMS = 64 * (KPAD / 32) * 4, IT = (ITEMS + NT - 1) / NT;
-  float v[IT][8];
-  GRL_DEVINL void load(const float* __restrict__ W) {
+GRL_DEVINL void stage16(unsigned short* hi, unsigned short* lo, const float* __restrict__ W, int ld) {
+  constexpr int ITEMS = 64 * (KPAD / 32) * 4;
+  for (int idx = threadIdx.x; idx < ITEMS; idx += NT) {
+    const int g = idx & 3, s = (idx >> 2) % (KPAD / 32), n = idx / (4 * (KPAD / 32));
+    float v[8];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int idx = threadIdx.x + it * NT;
-      const int g = idx & 3, s = (idx >> 2) % (KPAD / 32), n = idx / (4 * (KPAD / 32));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int f = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
-        v[it][j] = (idx < ITEMS && f < KSRC) ? (TRANS ? W[f * 64 + n] : W[n * KSRC + f]) : 0.f;
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int f = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+      v[j] = f < KSRC ? (TRANS ? W[f * 64 + n] : W[n * KSRC + f]) : 0.f;
     }
+    bf16x8 h, l;
+    split_pair(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, l);
+    *reinterpret_cast<bf16x8*>(hi + n * ld + 32 * s + 8 * g) = h;
+    GRL_LO(*reinterpret_cast<bf16x8*>(lo + n * ld + 32 * s + 8 * g) = l;)
   }
-  GRL_DEVINL void store(unsigned short* hi, unsigned short* lo, int ld) const {
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int idx = threadIdx.x + it * NT;
-      const int g = idx & 3, s = (idx >> 2) % (KPAD / 32), n = idx / (4 * (KPAD / 32));
-      bf16x8 h, l;
-      split_pair(make_float4(v[it][0], v[it][1], v[it][2], v[it][3]), make_float4(v[it][4], v[it][5], v[it][6], v[it][7]), h, l);
-      if (idx < ITEMS) {
-        *reinterpret_cast<bf16x8*>(hi + n * ld + 32 * s + 8 * g) = h;
-        GRL_LO(*reinterpret_cast<bf16x8*>(lo + n * ld + 32 * s + 8 * g) = l;)
-      }
-    }
-  }
-};
+}
 
 struct Edge16Params {
   const st_t* x_in;       // rows gathered per edge: x_src [Ns,16,64] (forward / messages) or dx1 [Nd or E,16,64] (d x_src kernel)
@@ -103,10 +87,9 @@ GRL_DEVINL void load_w16(ChainW16& s, const Edge16Params& p) {
 #ifdef GRL_KNOCK_STAGE   // timing knock-out: no weight staging (results are wrong)
   return;
 #endif
-  WStage<14, 32, E16_THREADS> i1;
-  WStage<64, 64, E16_THREADS> i2, ik;
-  i1.load(p.W1); i2.load(p.W2); ik.load(p.Wk);
-  i1.store(s.W1h, s.W1l, LD1); i2.store(s.W2h, s.W2l, LD2); ik.store(s.Wkh, s.Wkl, LD2);
+  stage16<14, 32, E16_THREADS>(s.W1h, s.W1l, p.W1, LD1);
+  stage16<64, 64, E16_THREADS>(s.W2h, s.W2l, p.W2, LD2);
+  stage16<64, 64, E16_THREADS>(s.Wkh, s.Wkl, p.Wk, LD2);
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     s.b1s[i] = p.b1[i];
     s.b2s[i] = p.b2[i];
@@ -497,14 +480,11 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   Bwd16Smem& sm = *reinterpret_cast<Bwd16Smem*>(smem_raw);
   const Edge16Params& p = bp.e;
 #ifndef GRL_KNOCK_STAGE
-  {
-    WStage<14, 32, 256> i1;
-    WStage<64, 64, 256> i2, ik;
-    WStage<64, 64, 256, true> ikt, i2t;
-    i1.load(p.W1); i2.load(p.W2); ik.load(p.Wk); ikt.load(p.Wk); i2t.load(p.W2);
-    i1.store(sm.w.W1h, sm.w.W1l, LD1); i2.store(sm.w.W2h, sm.w.W2l, LD2); ik.store(sm.w.Wkh, sm.w.Wkl, LD2);
-    ikt.store(sm.WkTh, sm.WkTl, LD2); i2t.store(sm.W2Th, sm.W2Tl, LD2);
-  }
+  stage16<14, 32, 256>(sm.w.W1h, sm.w.W1l, p.W1, LD1);
+  stage16<64, 64, 256>(sm.w.W2h, sm.w.W2l, p.W2, LD2);
+  stage16<64, 64, 256>(sm.w.Wkh, sm.w.Wkl, p.Wk, LD2);
+  stage16<64, 64, 256, true>(sm.WkTh, sm.WkTl, p.Wk, LD2);
+  stage16<64, 64, 256, true>(sm.W2Th, sm.W2Tl, p.W2, LD2);
 #endif
   for (int i = threadIdx.x; i < 64; i += 256) {
     sm.w.b1s[i] = p.b1[i];
