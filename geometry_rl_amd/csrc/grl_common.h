@@ -85,6 +85,27 @@ GRL_DEVINL void acc_to_frag(const f32x16& a, float4& f0, float4& f1, float4& f2,
 // with z = x/sqrt(2): exp(-z^2) = exp(-x^2/2) is also the Gaussian pdf factor the derivative needs, so one v_exp_f32 and one
 // v_rcp_f32 per element give both gelu(x) and gelu'(x).  (libm erff costs ~3x the instructions and diverges.)
 //   gelu(x)  = x/2 + |x|/2 (1 - q),  q = erfc(|z|)          gelu'(x) = 1/2 + sign(x)/2 (1 - q) + x pdf(x)
+#ifndef GRL_PREC
+#define GRL_PREC 0   // (documented below, at the split-bf16 section: 1 = the plain-bf16 build of BASELINE config 5)
+#endif
+// GRL_PREC = 1 only: GELU through the logistic approximation of the normal CDF, Phi(x) ~ sigma(1.5976 x + 0.07056 x^3) (|error| <= 1.4e-4,
+// far below the 4e-3 of a bf16 operand; the build's tolerance is 2e-2): value 5 plain + 2 transcendental
+// instructions per element instead of 12 + 2, value + derivative 10 + 2 instead of 14 + 2 -- GELU is two thirds of the vector instructions of
+// the bf16 kernels (profiles/r03_pmc_table_rope_hepi_bf16.txt).  The derivative is the exact derivative of the approximant.
+#ifndef GRL_GELU_LOGISTIC
+#define GRL_GELU_LOGISTIC GRL_PREC
+#endif
+GRL_DEVINL float gelu_logistic(float x) {
+  const float w = x * fmaf(x * x, -0.07056f * 1.44269504088896f, -1.5976f * 1.44269504088896f);   // -(u log2 e)
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(w));
+}
+GRL_DEVINL void gelu_logistic_both(float x, float& g, float& gp) {
+  const float x2 = x * x;
+  const float w = x * fmaf(x2, -0.07056f * 1.44269504088896f, -1.5976f * 1.44269504088896f);
+  const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(w));
+  g = x * s;
+  gp = fmaf(s * (1.f - s), x * fmaf(x2, 3.f * 0.07056f, 1.5976f), s);
+}
 typedef float v2f __attribute__((ext_vector_type(2)));
 GRL_DEVINL v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 GRL_DEVINL v2f splat2(float a) { return v2f{a, a}; }
@@ -102,6 +123,18 @@ GRL_DEVINL v2f splat2(float a) { return v2f{a, a}; }
 #endif
 template <bool WITH_GRAD>
 GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
+#if GRL_GELU_LOGISTIC
+  if (WITH_GRAD) {
+    float g0, g1, d0, d1;
+    gelu_logistic_both(x.x, g0, d0);
+    gelu_logistic_both(x.y, g1, d1);
+    g = v2f{g0, g1};
+    gp = v2f{d0, d1};
+  } else {
+    g = v2f{gelu_logistic(x.x), gelu_logistic(x.y)};
+  }
+  return;
+#endif
   const float kp = 0.3275911f * 0.70710678118654752440f;
   v2f t, e;
   t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), kp, 1.0f));
@@ -160,6 +193,9 @@ GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
 }
 // value only, scalar form (plain f32 instructions; 12 + 2 transcendental per element): for forward kernels built without packed math
 GRL_DEVINL float gelu_val(float x) {
+#if GRL_GELU_LOGISTIC
+  return gelu_logistic(x);
+#endif
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
   const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
   float poly = fmaf(t, 0.5307027145f, -0.7265760135f);     // a_i / 2
@@ -183,6 +219,10 @@ GRL_DEVINL float4 gelu4(float4 x) {
 // value + derivative, scalar form: plain (unpacked) vector instructions only -- the form for code that runs beside MFMAs of the same
 // wave (packed f32 operations do not overlap with the matrix pipe: MI355X_MICROARCH.md cycle constants; DESIGN.md finding 23)
 GRL_DEVINL void gelu_both(float x, float& g, float& gp) {
+#if GRL_GELU_LOGISTIC
+  gelu_logistic_both(x, g, gp);
+  return;
+#endif
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
 #if GRL_GELU_V2
   const float e = __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170368f, -1.32574806473615910f));   // pdf(x)

@@ -5,8 +5,9 @@
   fp32 bar (1e-4 values, 2e-4 gradients, 2e-5 post-Adam parameters), toy size and the 80 / 40-link size.
 * ``test_bf16_products_within_tolerance``: the reduced-precision build of the MFMA kernels (ONE bf16 MFMA per product, operands
   rounded to nearest bf16, bf16 latents, fp32 accumulation: entry points ``*_bf16``) against BOTH the fp32 oracle and the fp32 HIP
-  path; every actor gradient tensor against the fp32 HIP path (relative L2 error <= 4e-2, worst element <= 6e-2 of the tensor's
-  largest) and the parameters after one Adam step (mean distance <= 0.08 lr).  Tolerance as BASELINE.md section 3 states it for this config: every loss-dict entry within 2e-2 relative
+  path; every actor gradient tensor against the fp32 HIP path (relative L2 error <= 2e-2, worst element <= 3e-2 of the tensor's
+  largest) and the parameters after one Adam step (mean distance <= 0.02 lr).  The build's GELU is the logistic approximation of the
+  normal CDF (csrc/grl_common.h GRL_GELU_LOGISTIC; |error| 4e-4 on the value, 8e-4 on the derivative).  Tolerance as BASELINE.md section 3 states it for this config: every loss-dict entry within 2e-2 relative
   (|got - ref| <= 2e-2 * max(|ref|, floor)), loc / var / state_value within 2e-2 * max(1, max|ref|); 1e-4 is unattainable with
   8-bit mantissas.  Measured margins are printed.
 """
@@ -124,7 +125,7 @@ def test_bf16_products_within_tolerance():
         if l2 > worst_l2:
             worst_l2, worst_l2_name = l2, k
         worst_max = max(worst_max, mx)
-        assert l2 <= 4e-2 and mx <= 6e-2, (k, l2, mx)
+        assert l2 <= 2e-2 and mx <= 3e-2, (k, l2, mx)   # measured round 3: 5.9e-3 / 6.5e-3
     # post-Adam parameters from identical starting points: Adam's first step moves every element by ~lr * sign(g), so the two builds may
     # differ by up to 2 lr where a near-zero gradient changes sign; the MEAN distance in units of lr measures how often that happens
     from geometry_rl_amd import agent
@@ -135,7 +136,7 @@ def test_bf16_products_within_tolerance():
         pa[name] = {k: p.detach().cpu().clone() for k, p in a_.named_parameters()}
     d_all = torch.cat([(pa["bf16"][k] - pa["fp32"][k]).abs().flatten() for k in pa["fp32"]])
     mean_lr, max_lr = float(d_all.mean()) / cfg.lr, float(d_all.max()) / cfg.lr
-    assert max_lr <= 2.05 and mean_lr <= 0.08, (mean_lr, max_lr)
+    assert max_lr <= 2.05 and mean_lr <= 0.02, (mean_lr, max_lr)   # measured: mean 0.002 lr, max 1.5 lr
     print(f"bf16 build: worst relative loss/value error vs oracle {worst['oracle fp32']:.2e}, vs fp32 HIP {worst['HIP fp32']:.2e}; "
           f"actor gradients vs fp32 HIP: worst relative L2 error {worst_l2:.2e} ({worst_l2_name}), worst element / max|g| {worst_max:.2e}; "
           f"post-Adam parameters: mean |dp| = {mean_lr:.3f} lr, max {max_lr:.2f} lr")
