@@ -405,16 +405,21 @@ def main():
         try:
             topo_b = actor.hyper_data._cache[B]
             O_, C_, W_ = 16, 64, 256
-            F_ = O_ * C_ * 4
+            F_ = O_ * C_ * (2 if cfg.precision == "bf16" else 4)   # bytes of one node's latent block
             n_of = lambda t: topo_b["n_main"] if t == topo_b["main"] else B * topo_b["n_per"][t]
             if hasattr(actor.gnn, "processor"):   # HEPi: one conv per (round, edge type)
                 convs = [(et, topo_b["edges"][et].n_src, topo_b["edges"][et].n_dst, topo_b["edges"][et].n_edges)
                          for rnd in actor.gnn.processor for et, _c in rnd.items() if et in topo_b["edges"]]
-            else:                                 # EMPN: every layer runs over every (merged) edge type (ponita_gcn.py:102-126)
-                convs = [(et, es.n_src, es.n_dst, es.n_edges) for _l in actor.gnn.ponita.interaction_layers
-                         for et, es in topo_b["edges"].items()]
-            types_used = {t for et, _, _, _ in convs for t in (et[0], et[2])}
-            n_nodes = sum(n_of(t) for t in types_used)
+            else:   # EMPN: every layer runs over the merged edge set (ponita_gcn.py:102-126); the LAST layer is only evaluated where the
+                    # read-out reads it (edges into the actuators, node block on the actuators) -- the work counted here is the work needed
+                mg = next(v[1] for v in actor.gnn._merged_cache.values() if v[0] is topo_b["edges"])
+                main_et = next(iter(topo_b["edges"]))
+                L = len(actor.gnn.ponita.interaction_layers)
+                convs = [(main_et, mg["n"], mg["n"], mg["es_all"].n_edges)] * (L - 1 if actor.gnn.prune_last_layer else L)
+                if actor.gnn.prune_last_layer:
+                    convs.append((main_et, mg["n"], mg["n_ro"], mg["es_last"].n_edges))
+            types_used = {t for et, _, _, _ in convs for t in (et[0], et[2])} if hasattr(actor.gnn, "processor") else set(topo_b["n_per"])
+            n_nodes = sum(n_of(t) for t in types_used if t in topo_b["n_per"])
             c_in = len(spec.node_types) + spec.n_vec
             fwd = n_nodes * O_ * c_in * C_ * 2
             fwd += sum(E * O_ * 2 * (14 * C_ + C_ * C_) + O_ * O_ * 2 * (3 * C_ + C_ * C_) for _, _, _, E in convs)
