@@ -308,11 +308,12 @@ class PolicyUpdater:
                 ops.FOLD_STREAM.wait_stream(cur)   # behind the zeroing of the flat gradient
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
             cur.wait_stream(cs)   # join: the fused loss kernel needs the values
-            with torch.no_grad():
-                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],
-                                                                maxes=zw[22:23].view(torch.int32))
+            with torch.no_grad():   # (the fold of the per-workgroup loss sums is deferred: reported values only, off the actor's lane)
+                fold, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],
+                                                                maxes=zw[22:23].view(torch.int32), defer_fold=True)
             cs.wait_stream(cur)   # fork: critic backward beside the actor backward
             with torch.cuda.stream(cs), torch.no_grad():
+                sums, maxes = fold()
                 st["lv"] = loss_values(m, sums, maxes)   # reported values only: beside the backward pass, not behind Adam
                 pipe.bwd3(dvalue)
                 pipe.bwd2()

@@ -616,6 +616,15 @@ static int trpl_launch(const double* cfg9, int action_dim, const float* mean, co
   }
 #undef GRL_TRPL_LAUNCH
   GRL_CHECK_LAUNCH();
+  if (sums) {   // sums == NULL: the caller folds the slots later (grl_trpl_fold, on a stream of its choice: the sums are reported values only)
+    hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes);
+    GRL_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int grl_trpl_fold(const double* slots, int batch, double* sums, unsigned int* maxes, hipStream_t stream) {
+  if (!slots || !sums || !maxes || batch < 1) return -2;
   hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -565,9 +565,10 @@ TRPL_SUM_KEYS = ("loss_objective", "loss_trust_region", "entropy_dist", "loss_cr
 
 def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
                  global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False, sums=None, maxes=None,
-                 proj_type: int = 0):
+                 proj_type: int = 0, defer_fold: bool = False):
     """Launches the fused TRPL kernel (proj_type 0 KL | 1 Frobenius | 2 Wasserstein).  Returns (sums fp64[12], maxes u32[2], dloc,
-    dsigma, dvalue, proj_mean, proj_var)."""
+    dsigma, dvalue, proj_mean, proj_var).  ``defer_fold``: the per-workgroup slots are not folded into ``sums`` / ``maxes`` by this call;
+    the returned ``sums`` is then a callable that does it (on whatever stream is current when it is called) and returns (sums, maxes)."""
     import ctypes
     hip.check_f32(loc, sigma)
     B, A = loc.shape
@@ -588,7 +589,12 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
              value.reshape(B).contiguous() if value is not None else None,
              batch["state_value"].reshape(B).contiguous() if value is not None else None,
              batch["value_target"].reshape(B).contiguous() if value is not None else None,
-             dloc, dsigma, dvalue, pm, pv, adv_stats, sums, maxes, slots, B)
+             dloc, dsigma, dvalue, pm, pv, adv_stats, None if defer_fold else sums, maxes, slots, B)
+    if defer_fold:
+        def fold(sums=sums, maxes=maxes, slots=slots):
+            hip.call("grl_trpl_fold", slots, B, sums, maxes)
+            return sums, maxes
+        return fold, maxes, dloc, dsigma, dvalue, pm, pv
     return sums, maxes, dloc, dsigma, dvalue, pm, pv
 
 

@@ -168,9 +168,9 @@ def adv_stats_local(m, batch, out):
     hip.call("grl_adv_stats", adv, out, adv.numel())
 
 
-def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None):
+def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None, defer_fold=False):
     """One launch of the fused kernel on detached inputs: rank-local (sums, maxes) and the gradients of the (1/B_global-scaled)
-    losses with respect to loc, sigma and value."""
+    losses with respect to loc, sigma and value.  ``defer_fold``: see ops.trpl_fwd_bwd (``sums`` comes back as the folding callable)."""
     p = m.projection
     B = loc.shape[0]
     sums, maxes, dloc, dsigma, dvalue, _, _ = ops.trpl_fwd_bwd(
@@ -178,7 +178,7 @@ def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None):
         cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
         entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, critic_coef=m.critic_coef,
         clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats,
-        sums=sums, maxes=maxes, proj_type=getattr(p, "proj_code", 0))
+        sums=sums, maxes=maxes, proj_type=getattr(p, "proj_code", 0), defer_fold=defer_fold)
     return sums, maxes, dloc, dsigma, dvalue
 
 

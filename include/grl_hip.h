@@ -164,6 +164,9 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
  *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
 int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream);
+/* (ABI 202) sums == NULL in grl_trpl_fwd_bwd: the per-workgroup slots are left unfolded and the caller runs grl_trpl_fold later, e.g. on a
+ * side stream -- the sums / maxes are reported values (trpl.py:280-321), nothing on the gradient path reads them. */
+int grl_trpl_fold(const double* slots, int batch, double* sums /* [12] */, unsigned int* maxes /* [2] */, hipStream_t stream);
 int grl_trpl_slot_doubles(int batch);   /* size (in doubles) of the per-workgroup slot workspace `slots` below */
 int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
                      const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
