@@ -358,7 +358,7 @@ def main():
             entry = hip.kernel_time_summary()
             inner = hip.kernel_prof_summary()   # the kernels inside grl_edge_conv_bwd / grl_node_mlp_bwd, one by one
             hip.kernel_prof_enable(False)
-            entry = {k.replace("_bf16", ""): v for k, v in entry.items()}
+            entry = {k.replace("_bf16", "").replace("_balanced", ""): v for k, v in entry.items()}
             rec = {ENTRY_TO_KERNEL.get(k, k): v for k, v in entry.items() if k != "grl_edge_conv_bwd"}
             rec.update(inner)
             per_step.append(rec)
@@ -371,7 +371,7 @@ def main():
                    "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "edge_bwd16_kernel": "grl_edge_conv_bwd",
                    "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
                    "node_mlp_bwd16_kernel": "grl_node_mlp_bwd"}
-        rows_step = {k.replace("_bf16", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
+        rows_step = {k.replace("_bf16", "").replace("_balanced", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
         pipe_peak = 2500.0 if cfg.precision == "bf16" else PEAK_BF16X3
         kernels = {}
         for k, fl in FLOPS_PER_ROW.items():

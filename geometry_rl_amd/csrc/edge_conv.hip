@@ -779,7 +779,8 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
 int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const float* pos_src, const float* pos_dst, const int* rowptr_s,
                                      const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
                                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                                     const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, hipStream_t stream);
+                                     const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, const int* split,
+                                     hipStream_t stream);
 
 int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
@@ -813,10 +814,25 @@ int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const 
 // source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten:
 // dx_src = (dres ? dres : 0) + sum over out-edges; dres [n_src,16,64] = gradient of another use of x_src (the residual branch), or NULL.
 // partial must hold grl_edge_bwd_blocks(n_edges) rows of grl_edge_partial_size() floats.
+// grl_edge_conv_bwd_balanced: the same with ``split_s`` [4 * grl_edge_bwd_blocks(n_edges) + 1] -- node boundaries of an edge-balanced
+// partition of the source-sorted CSR over the launch's wave slots (split_s[0] = 0, split_s[last] = n_src, non-decreasing); NULL = none.
+int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
+                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                      const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, const int* split_s,
+                      hipStream_t stream);
 int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, hipStream_t stream) {
+  return GRL_ENTRY(grl_edge_conv_bwd_balanced)(x_src, pos_src, pos_dst, rowptr, e_src, e_dst, n_dst, n_edges, rowptr_s, src_s, dst_s, n_src,
+                                               grid, dim, W1, b1, W2, b2, Wk, dx1, dres, dx_src, partial, nullptr, stream);
+}
+int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                      const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
+                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                      const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, const int* split_s,
+                      hipStream_t stream) {
   if (n_edges <= 0) {   // an empty edge set: d x_src is the residual branch alone, the weight gradients are zero (the caller sums
     if (n_src > 0) {    // grl_edge_bwd_blocks(n_edges) partial rows: they must hold zeros, not whatever the allocation held)
       if (dres) hipMemcpyAsync(dx_src, dres, sizeof(st_t) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
@@ -856,7 +872,7 @@ int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const 
   (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;   // the destination-sorted view is the legacy weight kernel's
   grl_prof_begin("edge_bwd16_kernel", stream);
   const int rc = GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, grid, dim,
-                                                  W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, stream);
+                                                  W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, split_s, stream);
   grl_prof_end(stream);
   return rc;
 }
@@ -925,7 +941,7 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
 #endif
   (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;
   return GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, grid, dim, W1, b1,
-                                          W2, b2, Wk, dres, dx_src, partial, blocks, stream);
+                                          W2, b2, Wk, dres, dx_src, partial, blocks, nullptr, stream);
 }
 
 #if defined(GRL_PHASE_PROF) && !GRL_PREC

@@ -473,6 +473,8 @@ struct Bwd16Params {
   const st_t* dres;       // optional [Ns,16,64]: gradient of the other use of x_src, added into d x_src
   st_t* dx_src;           // [Ns,16,64], fully written
   float* partial;         // [gridDim.x][BWD16_PARTIAL]
+  const int* split;       // optional [4 gridDim.x + 1]: wave slot s walks the source nodes split[s] .. split[s + 1] (an edge-balanced partition
+                          // built once per topology: ops.build_edge_set); NULL: chunks of npw nodes dealt round-robin
 };
 
 __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
@@ -516,11 +518,28 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #ifdef GRL_B16_PHASE
   unsigned long long ph_[8] = {0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
-  const int NPW = p.npw;
+  // The chunks of this wave.  Round-robin chunks of npw nodes are balanced when every chunk carries the same number of edges (whole frames
+  // of a large minibatch); for small graphs the OUT-degrees of a kNN graph vary (mean 3, up to ~10) and a wave with a few more edges than
+  // the others sets the launch time (512-frame shard: 24 passes per wave on average, 37 for the slowest).  With bp.split every wave slot
+  // gets a contiguous node range holding ~E / slots edges instead -- a function of the topology alone, so the partial rows (and with them
+  // the weight gradients) stay bitwise reproducible, which a dynamic work queue would not.
+  const int NPW = bp.split ? NPW_MAX : p.npw;
+  const int slot = blockIdx.x * 4 + wave;
+  const int n_lo = bp.split ? bp.split[slot] : 0, n_hi = bp.split ? bp.split[slot + 1] : p.n_anchor;
   const int n_chunks = (p.n_anchor + NPW - 1) / NPW;
 #pragma unroll 1
-  for (int chunk = blockIdx.x * 4 + wave; chunk < n_chunks; chunk += gridDim.x * 4) {
-    const int n0 = chunk * NPW, nn = min(NPW, p.n_anchor - n0);
+  for (int it = 0;; ++it) {
+    int n0, nn;
+    if (bp.split) {
+      n0 = n_lo + it * NPW_MAX;
+      if (n0 >= n_hi) break;
+      nn = min(NPW_MAX, n_hi - n0);
+    } else {
+      const int chunk = slot + it * (int)gridDim.x * 4;
+      if (chunk >= n_chunks) break;
+      n0 = chunk * NPW;
+      nn = min(NPW, p.n_anchor - n0);
+    }
     const int rp = p.rowptr[n0 + min(lane, nn)];
     const int an = n0 + min(lane, nn - 1);
     const float pax = p.pos_src[3 * an], pay = p.pos_src[3 * an + 1], paz = p.pos_src[3 * an + 2];
@@ -870,11 +889,12 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
 int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const float* pos_src, const float* pos_dst, const int* rowptr_s,
                                      const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
                                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                                     const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, hipStream_t stream) {
+                                     const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, const int* split,
+                                     hipStream_t stream) {
   int npw = n_src / (4 * 1024);            // ~4 chunks per wave (256 CUs x 4 waves)
   npw = npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
   Bwd16Params bp{{dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, erow, grid, W1, b1, W2, b2, Wk, n_src, n_edges, dim, 0, per_edge, npw},
-                 x_src, dres, dx_src, partial};
+                 x_src, dres, dx_src, partial, split};
   // one wave per SIMD is a precondition of the unfenced MFMA groups of this kernel (DESIGN.md finding 3): more than half the LDS per
   // workgroup makes a second workgroup on the CU impossible, whatever the register allocation of a future compiler
   static_assert(sizeof(Bwd16Smem) > 80 * 1024, "edge_bwd16_kernel must not share a CU with a second workgroup");

@@ -7,6 +7,8 @@ forward/backward kernel pair into autograd so the modules in ``geometry_rl_amd.m
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from . import hip
@@ -26,6 +28,8 @@ class EdgeSet:
     src_s: torch.Tensor
     dst_s: torch.Tensor
     s2d: Optional[torch.Tensor] = None  # row of the i-th source-sorted edge in the destination-sorted order (attention aggregation)
+    split_s: Optional[torch.Tensor] = None  # [4 * grl_edge_bwd_blocks(E) + 1] node boundaries of an edge-balanced partition of the
+    #                                         source-sorted CSR over the backward's wave slots (small graphs only; None: round-robin chunks)
 
 
 def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
@@ -45,7 +49,28 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
     pos_d = torch.empty_like(order_d)
     pos_d[order_d] = torch.arange(order_d.numel(), device=dev)      # original edge id -> destination-sorted position
     s2d = pos_d[order_s].int().contiguous()                         # source-sorted position -> destination-sorted position
-    return EdgeSet(n_src, n_dst, int(src.numel()), rp_d, src_d, dst_d, rp_s, src_s, dst_s, s2d)
+    # Edge-balanced wave partition for the fused backward (csrc/edge_conv16.hip edge_bwd16_kernel): wave slot s walks the source nodes
+    # split_s[s] .. split_s[s + 1], which carry ~E / slots edges.  Built only where the kernel's round-robin deal of node chunks leaves
+    # the slowest wave > 4 % above the mean (the OUT-degrees of a kNN graph vary: rigid HEPi, every batch size; measured -2.5 % on the
+    # 4096-frame step, -5.5 % at 1024 frames).  A function of the topology alone: results stay reproducible.
+    split_s = None
+    E = int(src.numel())
+    if E > 0:
+        slots = 4 * hip.query("grl_edge_bwd_blocks", E)
+        # load of every wave slot under the kernel's round-robin deal (chunks of npw nodes, csrc/edge_conv16.hip grl_edge_bwd16_launch)
+        npw = max(1, min(16, n_src // 4096))
+        n_chunks = (n_src + npw - 1) // npw
+        cb = (torch.arange(n_chunks + 1, device=dev, dtype=torch.int64) * npw).clamp_(max=n_src)
+        chunk_edges = rp_s.long()[cb[1:]] - rp_s.long()[cb[:-1]]
+        load = torch.zeros(slots, device=dev, dtype=torch.int64).scatter_add_(0, torch.arange(n_chunks, device=dev) % slots, chunk_edges)
+        imbalance = float(load.max()) * slots / E
+        force = os.environ.get("GRL_EDGE_SPLIT_ALWAYS")
+        if imbalance > 1.04 or force:   # uniform-degree graphs (cloth hole boundary, task edges) are balanced as dealt: left alone
+            targets = (torch.arange(slots + 1, device=dev, dtype=torch.int64) * E) // slots
+            split_s = torch.searchsorted(rp_s.long(), targets).clamp_(max=n_src)
+            split_s[0], split_s[-1] = 0, n_src
+            split_s = split_s.int().contiguous()
+    return EdgeSet(n_src, n_dst, E, rp_d, src_d, dst_d, rp_s, src_s, dst_s, s2d, split_s)
 
 
 def _reduce(partial: torch.Tensor, out: torch.Tensor):
@@ -54,6 +79,7 @@ def _reduce(partial: torch.Tensor, out: torch.Tensor):
 
 # Deferred folding: while a list is installed here (PolicyUpdater does, around the backward), folds whose destinations are all
 # existing leaf ``.grad`` buffers are queued and executed by ONE launch (flush_deferred_grads) instead of one launch each.
+SPLIT_BACKWARD = os.environ.get("GRL_EDGE_SPLIT", "1") != "0"   # edge-balanced wave partition in the fused edge backward (EdgeSet.split_s)
 DEFERRED = None
 # FOLD_STREAM (set by PolicyUpdater for one-rank steps): when not None, the queued folds of a backward op are launched at once on this side
 # stream, behind an event of the producing kernel, instead of waiting for the single launch at the end of the backward pass -- the
@@ -192,8 +218,9 @@ class EdgeConv(torch.autograd.Function):
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
         dx_src = torch.empty_like(x_src)
         dres = ctx.residual.pop("dres", None) if ctx.residual is not None else None
-        hip.call("grl_edge_conv_bwd" + ctx.prec, x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s, e.src_s,
-                 e.dst_s, e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dres, dx_src, partial, rows=e.n_edges * 16)
+        hip.call("grl_edge_conv_bwd_balanced" + ctx.prec, x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s,
+                 e.src_s, e.dst_s, e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dres, dx_src, partial,
+                 e.split_s if SPLIT_BACKWARD else None, rows=e.n_edges * 16)
         pw1, pb1, pw2, pb2, pwk = ctx.params
         dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
                                                          (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])

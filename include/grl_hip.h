@@ -53,6 +53,15 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
                       int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
                       const float* b2, const float* Wk, const float* dx1, const float* dres /* optional [n_src,16,64] added to dx_src */,
                       float* dx_src, float* partial, hipStream_t stream);
+/* (ABI 202) the same with split_s [4 * grl_edge_bwd_blocks(n_edges) + 1], or NULL: node boundaries of an edge-balanced partition of the
+ * source-sorted CSR over the launch's wave slots (split_s[0] = 0, split_s[last] = n_src, non-decreasing; wave slot s walks the source
+ * nodes split_s[s] .. split_s[s+1]).  The reference has no counterpart (PyG scatter kernels balance per element); results do not depend
+ * on the partition beyond the summation order of the weight-gradient partial rows, and are reproducible for a given partition. */
+int grl_edge_conv_bwd_balanced(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                               const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
+                               int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* Wk, const float* dx1, const float* dres, float* dx_src, float* partial,
+                               const int* split_s, hipStream_t stream);
 
 /* ---- attention aggregation: FiberBundleConv(aggr="AttentionalAggregation"), ponita/conv.py:21-26,58-61,138-139;
  *      configs/algorithm/pyg_agent/model/hepi_attention.yaml; PyG 2.5.2 AttentionalAggregation / utils.softmax [upstream] ---------------
@@ -92,6 +101,11 @@ int grl_edge_conv_bwd_bf16(const grl_bf16* x_src, const float* pos_src, const fl
                            int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
                            const float* b2, const float* Wk, const grl_bf16* dx1, const grl_bf16* dres, grl_bf16* dx_src,
                            float* partial, hipStream_t stream);
+int grl_edge_conv_bwd_balanced_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                                    const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
+                                    int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
+                                    const float* b2, const float* Wk, const grl_bf16* dx1, const grl_bf16* dres, grl_bf16* dx_src,
+                                    float* partial, const int* split_s, hipStream_t stream);
 int grl_edge_messages_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                const int* e_dst, int n_dst, int n_edges, const float* grid, int dim, const float* W1,
                                const float* b1, const float* W2, const float* b2, const float* Wk, grl_bf16* msg, hipStream_t stream);
