@@ -36,7 +36,7 @@ FLOPS_PER_ROW = {
 # Algorithmic HBM bytes per row of the same kernels with fp32 latents (bf16 latents: half): the row gathers of the edge
 # kernels (x_src | x_src + dM; the per-node stores, 256 B / in-degree, are left out) and the row streams of the node kernels
 BYTES_PER_ROW = {"edge_conv_fwd_kernel": 256, "edge_bwd16_kernel": 512, "node_mlp_fwd_kernel": 768, "node_mlp_bwd16_kernel": 768}
-ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel", "grl_node_mlp_fwd": "node_mlp_fwd_kernel",
+ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel",   # (entry names are normalised: _bf16 / _balanced suffixes dropped) "grl_node_mlp_fwd": "node_mlp_fwd_kernel",
                    "grl_node_mlp_bwd": "node_mlp_bwd16_kernel"}
 PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md:42 (the path is specified and checked in f32)
 PEAK_BF16X3 = 2500.0 / 3.0     # TFLOP/s of f32-equivalent products when each is three dense bf16 MFMAs (guide: ~2.5 PF dense)

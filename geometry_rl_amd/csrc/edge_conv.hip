@@ -770,7 +770,7 @@ int grl_edge_bwd_blocks(int n_edges);
 int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                  const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                                 const float* Wk, st_t* out, const st_t* dres, hipStream_t stream);
+                                 const float* Wk, st_t* out, const st_t* dres, const int* split, int n_slots, hipStream_t stream);
 
 // fused 16-row backward (edge_conv16.hip edge_bwd16_kernel): d x_src and the weight gradients in one launch, one chain recompute
 #ifndef GRL_EDGE_BWD16
@@ -782,9 +782,20 @@ int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const 
                                      const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, const int* split,
                                      hipStream_t stream);
 
+// grl_edge_conv_fwd_balanced: the same with split_d [n_slots + 1] (n_slots = a multiple of 4, at most 3072): node boundaries of an
+// in-edge-balanced partition of the destination-sorted CSR over the launch's wave slots; NULL = round-robin chunks.
+int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                      const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
+                      const float* W2, const float* b2, const float* Wk, st_t* x1, const int* split_d, int n_slots, hipStream_t stream);
 int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, st_t* x1, hipStream_t stream) {
+  return GRL_ENTRY(grl_edge_conv_fwd_balanced)(x_src, pos_src, pos_dst, rowptr, e_src, e_dst, n_dst, grid, dim, W1, b1, W2, b2, Wk, x1, nullptr,
+                                               0, stream);
+}
+int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                      const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
+                      const float* W2, const float* b2, const float* Wk, st_t* x1, const int* split_d, int n_slots, hipStream_t stream) {
   if (n_dst <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
   const int n_tiles = (n_dst + TD - 1) / TD;
@@ -807,7 +818,7 @@ int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const 
 #endif
   (void)smem;
   return GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2, b2,
-                                      Wk, x1, nullptr, stream);
+                                      Wk, x1, nullptr, split_d, n_slots, stream);
 }
 
 // The same edge set in both orders: destination-sorted (rowptr, e_src, e_dst: the forward's arrays) for the weight kernel and
@@ -853,7 +864,7 @@ int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_sr
     grl_prof_begin("edge_conv_bwd_x_kernel", stream);
     if (GRL_EDGE16) {
       GRL_ENTRY(grl_edge16_launch)(1, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2,
-                                   Wk, dx_src, dres, stream);
+                                   Wk, dx_src, dres, nullptr, 0, stream);
     } else {
       const int n_tiles_s = (n_src + TD - 1) / TD;
       int xblocks = (n_tiles_s + 3) / 4;
@@ -897,7 +908,7 @@ int GRL_ENTRY(grl_edge_messages_fwd)(const st_t* x_src, const float* pos_src, co
   }
 #endif
   return GRL_ENTRY(grl_edge16_launch)(2, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, n_edges, 1, grid, dim, W1, b1,
-                                      W2, b2, Wk, msg, nullptr, stream);
+                                      W2, b2, Wk, msg, nullptr, nullptr, 0, stream);
 }
 
 int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
@@ -930,7 +941,7 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
     if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
     if (GRL_EDGE16)
       GRL_ENTRY(grl_edge16_launch)(1, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2, Wk,
-                                   dx_src, dres, stream);
+                                   dx_src, dres, nullptr, 0, stream);
     else
       hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
     GRL_CHECK_LAUNCH();

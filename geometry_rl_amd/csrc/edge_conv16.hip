@@ -81,6 +81,7 @@ struct Edge16Params {
   int anchor_is_dst;      // 1: forward order (gather by source, accumulate per destination); 0: source order (the reverse)
   int per_edge;           // 1: x_in rows are per edge (erow or the edge's own position)
   int npw;                // anchor nodes per wave chunk, 1..16 (host: as large as still leaves every wave slot several chunks)
+  const int* split;       // optional [4 gridDim.x + 1] (forward only): wave slot s walks the anchor nodes split[s] .. split[s + 1]
 };
 
 GRL_DEVINL void load_w16(ChainW16& s, const Edge16Params& p) {
@@ -305,10 +306,24 @@ __global__ __launch_bounds__(E16_THREADS, GRL_E16_WGS) void edge16_kernel(Edge16
   const int* e_other = p.anchor_is_dst ? p.e_src : p.e_dst;
   const float* pos_anchor = p.anchor_is_dst ? p.pos_dst : p.pos_src;
   const float* pos_other = p.anchor_is_dst ? p.pos_src : p.pos_dst;
-  const int NPW = p.npw;
+  // chunks of this wave: round-robin chunks of npw nodes, or (p.split) a contiguous node range with ~E / slots in-edges -- 13 108 chunks of
+  // five nodes over 3 072 wave slots leave some waves five chunks and others four (75 passes against 60: the launch takes the 75)
+  const int NPW = p.split ? NPW_MAX : p.npw;
   const int n_chunks = (p.n_anchor + NPW - 1) / NPW;
-  for (int chunk = blockIdx.x * E16_WAVES + wave; chunk < n_chunks; chunk += gridDim.x * E16_WAVES) {
-    const int n0 = chunk * NPW, nn = min(NPW, p.n_anchor - n0);
+  const int slot = blockIdx.x * E16_WAVES + wave;
+  const int n_lo = p.split ? p.split[slot] : 0, n_hi = p.split ? p.split[slot + 1] : p.n_anchor;
+  for (int it = 0;; ++it) {
+    int n0, nn;
+    if (p.split) {
+      n0 = n_lo + it * NPW_MAX;
+      if (n0 >= n_hi) break;
+      nn = min(NPW_MAX, n_hi - n0);
+    } else {
+      const int chunk = slot + it * (int)gridDim.x * E16_WAVES;
+      if (chunk >= n_chunks) break;
+      n0 = chunk * NPW;
+      nn = min(NPW, p.n_anchor - n0);
+    }
     // chunk metadata on the lanes: rowptr (lanes 0..nn) and the anchor nodes' positions (lanes 0..nn-1)
     const int rp = p.rowptr[n0 + min(lane, nn)];
     const int an = n0 + min(lane, nn - 1);
@@ -847,7 +862,7 @@ extern "C" {
 int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                  const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                                 const float* Wk, st_t* out, const st_t* dres, hipStream_t stream) {
+                                 const float* Wk, st_t* out, const st_t* dres, const int* split, int n_slots, hipStream_t stream) {
   if (n_anchor <= 0) return 0;
   // chunks: at least ~4 per wave slot of the chip (256 CUs x 12 waves) while the graph allows it
   int npw = n_anchor / (4 * 256 * E16_WAVES * GRL_E16_WGS);
@@ -857,15 +872,15 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
   if (env_npw > 0) npw = env_npw;
 #endif
   Edge16Params p{x_in, pos_src, pos_dst, rowptr, e_src, e_dst, erow, grid, W1, b1, W2, b2, Wk, n_anchor, n_edges, dim, anchor_is_dst,
-                 per_edge, npw};
+                 per_edge, npw, (mode == 0 && split && n_slots >= E16_WAVES && n_slots % E16_WAVES == 0) ? split : nullptr};
   const int n_chunks = (n_anchor + npw - 1) / npw;
-  int blocks = (n_chunks + E16_WAVES - 1) / E16_WAVES;
+  int blocks = p.split ? n_slots / E16_WAVES : (n_chunks + E16_WAVES - 1) / E16_WAVES;
   int cap = 256 * GRL_E16_WGS;
 #ifdef GRL_E16_TUNE                        // diagnostic builds: grid cap and chunk size from the environment
   static const int env_cap = getenv("GRL_E16_BLOCKS") ? atoi(getenv("GRL_E16_BLOCKS")) : 0;
   if (env_cap > 0) cap = env_cap;
 #endif
-  if (blocks > cap) blocks = cap;
+  if (blocks > cap && !p.split) blocks = cap;
   if (blocks < 1) blocks = 1;
   const size_t smem = sizeof(ChainW16);
   GRL_ONCE(hipFuncSetAttribute((const void*)edge16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16));

@@ -29,7 +29,8 @@ class EdgeSet:
     dst_s: torch.Tensor
     s2d: Optional[torch.Tensor] = None  # row of the i-th source-sorted edge in the destination-sorted order (attention aggregation)
     split_s: Optional[torch.Tensor] = None  # [4 * grl_edge_bwd_blocks(E) + 1] node boundaries of an edge-balanced partition of the
-    #                                         source-sorted CSR over the backward's wave slots (small graphs only; None: round-robin chunks)
+    #                                         source-sorted CSR over the backward's wave slots (None: the round-robin deal is balanced)
+    split_d: Optional[torch.Tensor] = None  # the same for the destination-sorted CSR and the forward's wave slots ([n_slots + 1])
 
 
 def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
@@ -49,28 +50,43 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
     pos_d = torch.empty_like(order_d)
     pos_d[order_d] = torch.arange(order_d.numel(), device=dev)      # original edge id -> destination-sorted position
     s2d = pos_d[order_s].int().contiguous()                         # source-sorted position -> destination-sorted position
-    # Edge-balanced wave partition for the fused backward (csrc/edge_conv16.hip edge_bwd16_kernel): wave slot s walks the source nodes
-    # split_s[s] .. split_s[s + 1], which carry ~E / slots edges.  Built only where the kernel's round-robin deal of node chunks leaves
-    # the slowest wave > 4 % above the mean (the OUT-degrees of a kNN graph vary: rigid HEPi, every batch size; measured -2.5 % on the
-    # 4096-frame step, -5.5 % at 1024 frames).  A function of the topology alone: results stay reproducible.
-    split_s = None
+    # Edge-balanced wave partitions for the 16-row edge kernels (csrc/edge_conv16.hip): wave slot s walks the anchor nodes split[s] ..
+    # split[s + 1], which carry ~E / slots edges.  Built only where the kernel's round-robin deal of node chunks leaves the slowest wave
+    # > 4 % above the mean: in the backward the OUT-degrees of a kNN graph vary (rigid HEPi, every batch size: -2.5 % on the 4096-frame
+    # step, -5.5 % at 1024 frames); in the forward 13 108 five-node chunks over 3 072 slots leave some waves five chunks, others four.
+    # Functions of the topology alone: results stay reproducible.
     E = int(src.numel())
+    force = os.environ.get("GRL_EDGE_SPLIT_ALWAYS")
+
+    def balanced_split(rowptr, n_anchor, slots, npw, tol):
+        """Node boundaries [slots + 1] with ~E / slots edges per slot, or None where the slowest wave slot of the kernel's round-robin deal
+        of npw-node chunks over ``slots`` slots carries at most ``tol`` x the mean load (uniform-degree edge sets, whole frames per chunk)."""
+        rp = rowptr.long()
+        n_chunks = (n_anchor + npw - 1) // npw
+        cb = (torch.arange(n_chunks + 1, device=dev, dtype=torch.int64) * npw).clamp_(max=n_anchor)
+        load = torch.zeros(slots, device=dev, dtype=torch.int64).scatter_add_(0, torch.arange(n_chunks, device=dev) % slots, rp[cb[1:]] - rp[cb[:-1]])
+        if float(load.max()) * slots / E <= tol and not force:
+            return None
+        targets = (torch.arange(slots + 1, device=dev, dtype=torch.int64) * E) // slots
+        split = torch.searchsorted(rp, targets).clamp_(max=n_anchor)
+        split[0], split[-1] = 0, n_anchor
+        return split.int().contiguous()
+
+    split_s = split_d = None
     if E > 0:
-        slots = 4 * hip.query("grl_edge_bwd_blocks", E)
-        # load of every wave slot under the kernel's round-robin deal (chunks of npw nodes, csrc/edge_conv16.hip grl_edge_bwd16_launch)
-        npw = max(1, min(16, n_src // 4096))
-        n_chunks = (n_src + npw - 1) // npw
-        cb = (torch.arange(n_chunks + 1, device=dev, dtype=torch.int64) * npw).clamp_(max=n_src)
-        chunk_edges = rp_s.long()[cb[1:]] - rp_s.long()[cb[:-1]]
-        load = torch.zeros(slots, device=dev, dtype=torch.int64).scatter_add_(0, torch.arange(n_chunks, device=dev) % slots, chunk_edges)
-        imbalance = float(load.max()) * slots / E
-        force = os.environ.get("GRL_EDGE_SPLIT_ALWAYS")
-        if imbalance > 1.04 or force:   # uniform-degree graphs (cloth hole boundary, task edges) are balanced as dealt: left alone
-            targets = (torch.arange(slots + 1, device=dev, dtype=torch.int64) * E) // slots
-            split_s = torch.searchsorted(rp_s.long(), targets).clamp_(max=n_src)
-            split_s[0], split_s[-1] = 0, n_src
-            split_s = split_s.int().contiguous()
-    return EdgeSet(n_src, n_dst, E, rp_d, src_d, dst_d, rp_s, src_s, dst_s, s2d, split_s)
+        # backward (csrc/edge_conv16.hip grl_edge_bwd16_launch): 4 waves x grl_edge_bwd_blocks(E) workgroups, npw = n_src / 4096 in [1, 16]
+        # (one wave per SIMD: a wave that finishes early leaves its SIMD idle -- every per cent of imbalance is a per cent of the launch)
+        split_s = balanced_split(rp_s, n_src, 4 * hip.query("grl_edge_bwd_blocks", E), max(1, min(16, n_src // 4096)), 1.04)
+        # forward (grl_edge16_launch): npw = n_dst / 12288 in [1, 16], up to 768 workgroups of 4 waves; launches of <= 512 32-row tiles take
+        # the one-workgroup-per-tile forward instead (edge_conv.hip GRL_FWD_SPLIT_TILES) and ignore the partition
+        npw_d = max(1, min(16, n_dst // 12288))
+        blocks_d = min(768, ((n_dst + npw_d - 1) // npw_d + 3) // 4)
+        if (n_dst + 1) // 2 > 512 and blocks_d >= 1:
+            # three waves share a SIMD here: the waves that are left when the others finish run faster, so a moderately uneven deal heals
+            # itself (rigid HEPi, 17 % uneven: the partition costs 0.9 % of the step) -- only grossly uneven graphs are partitioned (the
+            # merged EMPN graph: actuator nodes with 17 in-edges behind object nodes with 3: -2 %)
+            split_d = balanced_split(rp_d, n_dst, 4 * blocks_d, npw_d, 1.25)
+    return EdgeSet(n_src, n_dst, E, rp_d, src_d, dst_d, rp_s, src_s, dst_s, s2d, split_s, split_d)
 
 
 def _reduce(partial: torch.Tensor, out: torch.Tensor):
@@ -80,6 +96,7 @@ def _reduce(partial: torch.Tensor, out: torch.Tensor):
 # Deferred folding: while a list is installed here (PolicyUpdater does, around the backward), folds whose destinations are all
 # existing leaf ``.grad`` buffers are queued and executed by ONE launch (flush_deferred_grads) instead of one launch each.
 SPLIT_BACKWARD = os.environ.get("GRL_EDGE_SPLIT", "1") != "0"   # edge-balanced wave partition in the fused edge backward (EdgeSet.split_s)
+SPLIT_FORWARD = os.environ.get("GRL_EDGE_SPLIT_FWD", os.environ.get("GRL_EDGE_SPLIT", "1")) != "0"   # ... and in the forward (EdgeSet.split_d)
 DEFERRED = None
 # FOLD_STREAM (set by PolicyUpdater for one-rank steps): when not None, the queued folds of a backward op are launched at once on this side
 # stream, behind an event of the producing kernel, instead of waiting for the single launch at the end of the backward pass -- the
@@ -201,8 +218,9 @@ class EdgeConv(torch.autograd.Function):
         hip.check_latent(prec, x_src)
         x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=x_src.dtype)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
-        hip.call("grl_edge_conv_fwd" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
-                 dim, *args, x1, rows=edges.n_edges * 16)
+        sd = edges.split_d if SPLIT_FORWARD else None
+        hip.call("grl_edge_conv_fwd_balanced" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
+                 dim, *args, x1, sd, (sd.numel() - 1) if sd is not None else 0, rows=edges.n_edges * 16)
         ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
         ctx.edges, ctx.dim, ctx.residual, ctx.prec = edges, dim, residual, prec
         ctx.params = (w1, b1, w2, b2, wk)

@@ -46,6 +46,12 @@ int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, 
 int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
+/* (ABI 202) the same with split_d [n_slots + 1], n_slots a multiple of 4 (or NULL / 0): node boundaries of an in-edge-balanced partition of
+ * the destination-sorted CSR over n_slots wave slots (n_slots / 4 workgroups are launched); see grl_edge_conv_bwd_balanced. */
+int grl_edge_conv_fwd_balanced(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                               const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
+                               const float* W2, const float* b2, const float* Wk, float* x1, const int* split_d, int n_slots,
+                               hipStream_t stream);
 int grl_edge_partial_size(void);
 int grl_edge_bwd_blocks(int n_edges);
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
@@ -96,6 +102,10 @@ int grl_lift_encode_bwd_bf16(const float* scal, const float* vec, const float* g
 int grl_edge_conv_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                            const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                            const float* W2, const float* b2, const float* Wk, grl_bf16* x1, hipStream_t stream);
+int grl_edge_conv_fwd_balanced_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
+                                    const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
+                                    const float* W2, const float* b2, const float* Wk, grl_bf16* x1, const int* split_d, int n_slots,
+                                    hipStream_t stream);
 int grl_edge_conv_bwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                            const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
                            int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
