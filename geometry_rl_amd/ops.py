@@ -67,8 +67,11 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         load = torch.zeros(slots, device=dev, dtype=torch.int64).scatter_add_(0, torch.arange(n_chunks, device=dev) % slots, rp[cb[1:]] - rp[cb[:-1]])
         if float(load.max()) * slots / E <= tol and not force:
             return None
-        targets = (torch.arange(slots + 1, device=dev, dtype=torch.int64) * E) // slots
-        split = torch.searchsorted(rp, targets).clamp_(max=n_anchor)
+        # cost of a node = its edges (one pass each) + NODE_COST passes for its own row loads / stores (the per-node part of a wave's work)
+        nc = float(os.environ.get("GRL_SPLIT_NODE_COST", "0"))
+        cum = rp.double() + nc * torch.arange(n_anchor + 1, device=dev, dtype=torch.float64)
+        targets = torch.arange(slots + 1, device=dev, dtype=torch.float64) * (float(cum[-1]) / slots)
+        split = torch.searchsorted(cum, targets).clamp_(max=n_anchor)
         split[0], split[-1] = 0, n_anchor
         return split.int().contiguous()
 
