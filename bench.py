@@ -445,6 +445,9 @@ def main():
         roof = {**head, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
+                "avg_launch_note": "HIP events on the launch stream around the eagerly issued launches of the profiled steps behind the timed region; "
+                                   "the replayed (hipGraph) launches of the timed region run 5-8 % faster (rocprofv3 --kernel-trace of this command, "
+                                   "profiles/), so achieved / frac are on the conservative side",
                 "peak_note": "peak = the pipe the kernel runs on: every f32 product is three dense bf16 MFMAs (split-bf16, f32 "
                              f"accumulate), 2500 / 3 = {PEAK_BF16X3:.0f} TFLOP/s of f32-equivalent products (MI355X_MICROARCH.md: ~2.5 PF "
                              "dense bf16); achieved = algorithmic f32 FLOP per launch / HIP-event launch time",
