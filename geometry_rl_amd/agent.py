@@ -294,6 +294,8 @@ class PolicyUpdater:
                 _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
                 pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                 pipe.fwd1()
+                ev1 = torch.cuda.Event()
+                ev1.record(cs)
                 pipe.fwd2()
                 value = pipe.fwd3()
                 # (the step's zeroed workspace and the advantage statistics: inputs of the fused loss kernel only -- off the actor's lane)
@@ -306,7 +308,19 @@ class PolicyUpdater:
             if self.overlap_folds:   # leaf-gradient folds beside the backward kernels, on a third stream (ops.FOLD_STREAM)
                 ops.FOLD_STREAM = self._fold_stream()
                 ops.FOLD_STREAM.wait_stream(cur)   # behind the zeroing of the flat gradient
+            # The MFMA kernels size their grids to fill every CU exactly (all LDS, all VGPRs): a critic workgroup still resident when
+            # one of them starts displaces one of ITS workgroups, which then runs as a second round behind the others -- the first edge
+            # convolution of the EMPN step took 751 instead of 566 us that way (profiles/r03_corun_*.txt).  So when the critic's forward
+            # is short enough to hide behind the actor's prologue (gather, features, lift: streaming kernels that share CUs gracefully)
+            # the first edge convolution waits for it; a long critic forward (cloth: 239 rows per frame, 0.7 ms) keeps running beside
+            # the actor instead -- waiting would cost more than the displacement.
+            mode = os.environ.get("GRL_CRITIC_JOIN", "auto")
+            rows = int(x.shape[0]) * (int(x.shape[1]) if x.dim() == 3 else 1)
+            if mode != "0":
+                ops.PRE_EDGE_HOOK = lambda n_nodes: (cur.wait_stream(cs) if (mode == "1" or (mode == "auto" and rows <= 4 * n_nodes)) else
+                                                     cur.wait_event(ev1) if mode in ("fwd1", "auto") else None)
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
+            ops.PRE_EDGE_HOOK = None
             cur.wait_stream(cs)   # join: the fused loss kernel needs the values
             with torch.no_grad():   # (the fold of the per-workgroup loss sums is deferred: reported values only, off the actor's lane)
                 fold, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],

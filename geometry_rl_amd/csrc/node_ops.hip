@@ -16,104 +16,240 @@ struct FiberDfks { const float* p[4]; };
 // ------------------------------------------------------------------------------------------------ lift + encode
 // x[n,o,c] = sum_s scal[n,s] W[c,s] + sum_v (vec[n,v,:] . grid[o,:]) W[c,S+v]
 //          = A[n,c] + sum_d grid[o,d] Bv[n,c,d],   A = scal W_s^T,  Bv[.,.,d] = vec[.,.,d] W_v^T
-// i.e. 3 multiply-adds per output instead of S+V (the kernel was VALU-bound at ~2x its HBM time); A and Bv cost 3+3V per (n,c).
+// i.e. 3 multiply-adds per output instead of S+V; A and Bv cost 3+3V per (n,c).
+// One WAVE per node and iteration: lane = (o4, c4) owns orientations o4, o4+4, o4+8, o4+12 of the channel quad c4, so a store
+// instruction covers four whole consecutive rows of the node -- 1 KB contiguous -- and a node is four of them; the node index is
+// wave-uniform (its S + 3V inputs are scalar loads, those of the next node are fetched before this node's rows are computed) and
+// nodes are dealt to the resident waves one at a time (round 2: a thread per (node, channel quad), 2 688 workgroups' worth of
+// work on a 2 048-workgroup grid -- half the chip idled through a second, partial round: 2.3 TB/s of stores).
+// The inputs of a node are fetched by ONE vector load: lane i < 8 reads scalar feature min(i, S-1), lane 8 + 3v + d reads component d of
+// vector feature min(v, V-1) (clamped duplicates meet zero weights / are dropped), and the values are broadcast from that register with
+// v_readlane when they are used.  (Scalar loads of the same 32 values came out as seven s_waitcnt-separated groups per node: seven
+// serialised scalar-cache round trips per iteration.)  `scal` / `vec` stand in for each other when S / V is zero (any readable floats).
+struct LiftLane { const float* base; long long stride; int off; };
+GRL_DEVINL LiftLane lift_lane(const float* scal, const float* vec, int S, int V) {
+  const int i = threadIdx.x & 31;        // lanes 32..63 mirror 0..31
+  LiftLane L;
+  if (i < 8) {
+    L.base = S > 0 ? scal : vec; L.stride = S > 0 ? S : 0; L.off = i < S ? i : (S > 0 ? S - 1 : 0);
+  } else {
+    const int v = (i - 8) / 3, d = (i - 8) - 3 * v;
+    L.base = V > 0 ? vec : scal; L.stride = V > 0 ? 3 * V : 0; L.off = V > 0 ? 3 * (v < V ? v : V - 1) + d : 0;
+  }
+  return L;
+}
+GRL_DEVINL float lift_fetch(const LiftLane& L, int n) { return L.base[(long long)n * L.stride + L.off]; }
+#define LIFT_S(val, k) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), (k)))
+#define LIFT_V(val, v, d) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), 8 + 3 * (v) + (d)))
+
+constexpr int LIFT_CHUNK = 16;   // iterations per input refill (8 KB of LDS)
 __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const float* __restrict__ Wenc,
                                                               st_t* __restrict__ x, int N, int S, int V) {
-  __shared__ float gs[O * 3];
+  __shared__ float stage[LIFT_CHUNK * 4 * 32];
   const int KF = S + V;
-  for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
-  __syncthreads();
-  // thread = (node, channel quad); the grid stride is a multiple of 16, so a thread keeps its channel quad for the whole launch
-  // and its 4 x KF weights live in registers
-  const int c4 = threadIdx.x & 15;
-  float w[4][KF_MAX];
+  const int lane = threadIdx.x & 63, c4 = lane & 15, o4 = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = 4 * blockIdx.x + wv, n_waves = gridDim.x * 4;
+  // wa[.][k]: weight of scalar feature k (0 for k >= S), wb[.][v]: of vector feature v (0 for v >= V) -- every slot takes the same
+  // multiply-adds, no branch (a zero weight adds an exact zero for finite inputs; a non-finite input poisons its node either way)
+  float wa[4][KF_MAX], wb[4][KF_MAX], g[4][3];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int k = 0; k < KF_MAX; ++k) w[j][k] = k < KF ? Wenc[(4 * c4 + j) * KF + k] : 0.f;
-  const size_t total = (size_t)N * 16;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = idx >> 4;
-    float A[4] = {0.f, 0.f, 0.f, 0.f}, Bx[4] = {0.f, 0.f, 0.f, 0.f}, By[4] = {0.f, 0.f, 0.f, 0.f}, Bz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int k = 0; k < KF_MAX; ++k) {
-      if (k < S) {
-        const float sv = scal[n * S + k];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) A[j] = fmaf(sv, w[j][k], A[j]);
-      } else if (k < KF) {
-        const float* v = vec + (n * V + (k - S)) * 3;
-        const float vx = v[0], vy = v[1], vz = v[2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { Bx[j] = fmaf(vx, w[j][k], Bx[j]); By[j] = fmaf(vy, w[j][k], By[j]); Bz[j] = fmaf(vz, w[j][k], Bz[j]); }
-      }
+      wa[j][k] = k < S ? Wenc[(4 * c4 + j) * KF + k] : 0.f;
+      wb[j][k] = k < V ? Wenc[(4 * c4 + j) * KF + S + k] : 0.f;
     }
-    st_t* out = x + n * (O * C) + 4 * c4;
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-      const float gx = gs[3 * o], gy = gs[3 * o + 1], gz = gs[3 * o + 2];
-      float r[4];
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = fmaf(gz, Bz[j], fmaf(gy, By[j], fmaf(gx, Bx[j], A[j])));
-      st4(out + o * C, make_float4(r[0], r[1], r[2], r[3]));
+    for (int d = 0; d < 3; ++d) g[i][d] = grid[(4 * i + o4) * 3 + d];
+  // The inputs of the workgroup's next LIFT_CHUNK iterations are staged in LDS by one burst of loads, so the node loop itself has no
+  // vector-memory load: a load there would be waited for with vmcnt(0) -- the loop-carried count is merged conservatively -- which
+  // also waits for the four stores issued after it: a store drain per node.
+  const LiftLane L = lift_lane(scal, vec, S, V);
+  const int n_iter = (N + n_waves - 1) / n_waves;
+  for (int it0 = 0; it0 < n_iter; it0 += LIFT_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < LIFT_CHUNK * 4 * 32 / 256; ++m) {
+      const int idx = threadIdx.x + 256 * m, i = idx >> 7, w_ = (idx >> 5) & 3;
+      const long long node = (long long)(4 * blockIdx.x + w_) + (long long)(it0 + i) * n_waves;
+      stage[idx] = lift_fetch(L, node < N ? (int)node : N - 1);   // (clamped, not skipped: a branch per load would serialise them)
+    }
+    __syncthreads();
+    for (int i = 0; i < LIFT_CHUNK; ++i) {
+      const long long n = (long long)wave + (long long)(it0 + i) * n_waves;
+      if (n >= N) break;
+      const float cur = stage[(i * 4 + wv) * 32 + (lane & 31)];
+      float A[4] = {0.f, 0.f, 0.f, 0.f}, Bx[4] = {0.f, 0.f, 0.f, 0.f}, By[4] = {0.f, 0.f, 0.f, 0.f}, Bz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KF_MAX; ++k) {
+        const float sv = LIFT_S(cur, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[j] = fmaf(sv, wa[j][k], A[j]);
+      }
+#pragma unroll
+      for (int k = 0; k < KF_MAX; ++k) {
+        const float vx = LIFT_V(cur, k, 0), vy = LIFT_V(cur, k, 1), vz = LIFT_V(cur, k, 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Bx[j] = fmaf(vx, wb[j][k], Bx[j]); By[j] = fmaf(vy, wb[j][k], By[j]); Bz[j] = fmaf(vz, wb[j][k], Bz[j]); }
+      }
+      st_t* out = x + (size_t)n * (O * C) + o4 * C + 4 * c4;
+#pragma unroll
+      for (int r_ = 0; r_ < 4; ++r_) {
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = fmaf(g[r_][2], Bz[j], fmaf(g[r_][1], By[j], fmaf(g[r_][0], Bx[j], A[j])));
+        st4(out + 4 * r_ * C, make_float4(r[0], r[1], r[2], r[3]));
+      }
     }
   }
 }
 
 // dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF].  With D0[n,c] = sum_o dx and Dd[n,c] = sum_o grid[o,d] dx:
 // dW[c,s] = sum_n scal[n,s] D0,  dW[c,S+v] = sum_n vec[n,v,:] . D[n,c,:]  -- 4 multiply-adds per dx element instead of S+V.
-// Thread (c, part): channel c, nodes part, part+4, ...; a node's 16 rows of dx are 16 coalesced loads in flight.
+// Same wave-per-node layout as the forward: a node's dx is four 1 KB loads (those of the next node are in flight while this one is
+// folded); a lane folds ITS four orientations into D and straight on into its own dW partial -- dW is linear in D, so the sum over
+// the four orientation groups of lanes waits until the end of the launch (two shuffles per accumulator, once).
 __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
                                                               const float* __restrict__ grid, const st_t* __restrict__ dx,
                                                               float* __restrict__ partial, int N, int S, int V) {
-  __shared__ float gs[O * 3];
-  __shared__ float red[4 * C * KF_MAX];
+  __shared__ float red[4][C * KF_MAX];
   const int KF = S + V;
-  for (int i = threadIdx.x; i < O * 3; i += blockDim.x) gs[i] = grid[i];
-  __syncthreads();
-  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  float dw[KF_MAX];
+  const int lane = threadIdx.x & 63, c4 = lane & 15, o4 = lane >> 4, wv = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = gridDim.x * 4;
+  float g[4][3];
 #pragma unroll
-  for (int k = 0; k < KF_MAX; ++k) dw[k] = 0.f;
-  for (size_t n = (size_t)blockIdx.x * 4 + part; n < (size_t)N; n += (size_t)gridDim.x * 4) {
-    const st_t* dp = dx + n * (O * C) + c;
-    float dv[O];
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int o = 0; o < O; ++o) dv[o] = ld1(dp + o * C);
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (int d = 0; d < 3; ++d) g[i][d] = grid[(4 * i + o4) * 3 + d];
+  float dwa[4][KF_MAX], dwb[4][KF_MAX];   // scalar slots k / vector slots v (slots past S / V collect clamped duplicates and are dropped)
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-      d0 += dv[o];
-      d1 = fmaf(gs[3 * o], dv[o], d1);
-      d2 = fmaf(gs[3 * o + 1], dv[o], d2);
-      d3 = fmaf(gs[3 * o + 2], dv[o], d3);
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < KF_MAX; ++k) dwa[j][k] = dwb[j][k] = 0.f;
+  const LiftLane L = lift_lane(scal, vec, S, V);
+  float cur = 0.f, nxt;
+  float4 dcur[4], dnxt[4];
+  if (wave < N) {
+    cur = lift_fetch(L, wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dcur[i] = ld4_nt(dx + (size_t)wave * (O * C) + (4 * i + o4) * C + 4 * c4);
+  }
+  for (int n = wave; n < N; n += n_waves) {
+    const int nn = n + n_waves < N ? n + n_waves : n;      // (the last iteration re-reads its own node: no branch around the loads)
+    nxt = lift_fetch(L, nn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dnxt[i] = ld4_nt(dx + (size_t)nn * (O * C) + (4 * i + o4) * C + 4 * c4);
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f}, d3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dv[4] = {dcur[i].x, dcur[i].y, dcur[i].z, dcur[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d0[j] += dv[j];
+        d1[j] = fmaf(g[i][0], dv[j], d1[j]);
+        d2[j] = fmaf(g[i][1], dv[j], d2[j]);
+        d3[j] = fmaf(g[i][2], dv[j], d3[j]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < KF_MAX; ++k) {
-      if (k < S) dw[k] = fmaf(scal[n * S + k], d0, dw[k]);
-      else if (k < KF) {
-        const float* v = vec + (n * V + (k - S)) * 3;
-        dw[k] += v[0] * d1 + v[1] * d2 + v[2] * d3;
+      const float sv = LIFT_S(cur, k), vx = LIFT_V(cur, k, 0), vy = LIFT_V(cur, k, 1), vz = LIFT_V(cur, k, 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dwa[j][k] = fmaf(sv, d0[j], dwa[j][k]);
+        dwb[j][k] += vx * d1[j] + vy * d2[j] + vz * d3[j];
       }
     }
+    cur = nxt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dcur[i] = dnxt[i];
   }
 #pragma unroll
-  for (int k = 0; k < KF_MAX; ++k) red[(part * C + c) * KF_MAX + k] = dw[k];
-  __syncthreads();
-  if (part == 0) {
-    for (int k = 0; k < KF; ++k) {
-      const float v = red[c * KF_MAX + k] + red[(C + c) * KF_MAX + k] + red[(2 * C + c) * KF_MAX + k] +
-                      red[(3 * C + c) * KF_MAX + k];
-      partial[(size_t)blockIdx.x * C * KF + c * KF + k] = v;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < KF_MAX; ++k) {
+      float v = k < S ? dwa[j][k] : dwb[j][k - S < 0 ? 0 : k - S];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (o4 == 0) red[wv][(4 * c4 + j) * KF_MAX + k] = v;
     }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * KF; i += 256) {
+    const int c = i / KF, k = i - c * KF;
+    const int s_ = c * KF_MAX + k;
+    partial[(size_t)blockIdx.x * C * KF + i] = red[0][s_] + red[1][s_] + red[2][s_] + red[3][s_];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ fiber conv
-// thread (c, q): owns channel c and the output-orientation quad p = 4q..4q+3; fk[o][p][c] slice lives in registers.
+// HBM-bound: 2 (forward) / 3 (backward) passes over [N,16,64].  A workgroup streams batches of FB nodes through LDS: all four waves load
+// the batch with 16-byte accesses (every byte fetched once per workgroup, the loads of batch b+1 are in flight while batch b is computed
+// from LDS), then thread (c, q) -- channel c, orientation quad q -- reads the 16 orientation values of its channel from LDS (bank = c:
+// conflict-free) against its register slice of fk.  Round 2's kernels had each of the four waves load the node's 16 rows itself, one
+// dword per lane and one node at a time: ~20 KB of distinct bytes in flight per CU, 3.1 / 2.4 TB/s.
+#ifndef GRL_FIBER_FB
+#define GRL_FIBER_FB 4
+#endif
+#ifndef GRL_FIBER_NT
+#define GRL_FIBER_NT 0   // bit 0: non-temporal loads, bit 1: non-temporal stores
+#endif
+constexpr int FB = GRL_FIBER_FB;                  // nodes per batch
+constexpr int FB_E = FB * O * C;                  // elements per batch
+template <int NT> struct FiberRegs { float4 r[FB_E / 4 / NT]; };   // 16-byte pieces per thread and batch (NT threads per workgroup)
+// Full batches only (the main loops are free of guards and branches: a conditional store or load in there makes the compiler's vmcnt
+// bookkeeping assume the worst, and the wait for the prefetched loads becomes a wait for every store of the iteration as well).
+template <int NT> GRL_DEVINL void fiber_load(FiberRegs<NT>& R, const st_t* __restrict__ src, long long batch) {
+#pragma unroll
+  for (int i = 0; i < FB_E / 4 / NT; ++i) {
+    const st_t* p = src + batch * FB_E + 4 * (threadIdx.x + NT * i);
+    R.r[i] = (GRL_FIBER_NT & 1) ? ld4_nt(p) : ld4(p);
+  }
+}
+template <int NT> GRL_DEVINL void fiber_put(const FiberRegs<NT>& R, float* tile) {
+#pragma unroll
+  for (int i = 0; i < FB_E / 4 / NT; ++i) *reinterpret_cast<float4*>(tile + 4 * (threadIdx.x + NT * i)) = R.r[i];
+}
+template <int NT> GRL_DEVINL void fiber_store(st_t* __restrict__ dst, long long batch, const float* tile) {
+#pragma unroll
+  for (int i = 0; i < FB_E / 4 / NT; ++i) {
+    const int e = 4 * (threadIdx.x + NT * i);
+    if (GRL_FIBER_NT & 2) st4_nt(dst + batch * FB_E + e, *reinterpret_cast<const float4*>(tile + e));
+    else st4(dst + batch * FB_E + e, *reinterpret_cast<const float4*>(tile + e));
+  }
+}
+// the last, partial batch of a launch (N % FB nodes; one workgroup, once): guarded element-wise copies, rows past N are zero in LDS
+GRL_DEVINL void fiber_tail_in(const st_t* __restrict__ src, long long first, int N, float* tile) {
+  for (int e = threadIdx.x; e < FB_E; e += blockDim.x) tile[e] = first * (O * C) + e < (long long)N * (O * C) ? ld1(src + first * (O * C) + e) : 0.f;
+}
+GRL_DEVINL void fiber_tail_out(st_t* __restrict__ dst, long long first, int N, const float* tile) {
+  for (int e = threadIdx.x; e < FB_E; e += blockDim.x)
+    if (first * (O * C) + e < (long long)N * (O * C)) st1(dst + first * (O * C) + e, tile[e]);
+}
+
+// x2 rows of the FB nodes of an LDS batch into the LDS tile `to` (thread (c, q): channel c, output orientations 4q..4q+3)
+GRL_DEVINL void fiber_fwd_batch(const float* tin, float* to, const float (&k)[O][4], float b, int c, int q) {
+#pragma unroll
+  for (int i = 0; i < FB; ++i) {
+    float acc[4] = {b, b, b, b};
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float v = tin[(i * O + o) * C + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += v * k[o][j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) to[(i * O + 4 * q + j) * C + c] = acc[j];
+  }
+}
+
 __global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
                                                              const float* __restrict__ bias, st_t* __restrict__ x2, int N) {
+  __shared__ __attribute__((aligned(16))) float tin[FB_E];   // the next batch waits in registers
+  __shared__ __attribute__((aligned(16))) float to[FB_E];    // x2 of the batch: leaves as 16-byte stores
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   float k[O][4];
 #pragma unroll
@@ -121,67 +257,116 @@ __global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const st_t* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) k[o][j] = fk[(o * O + 4 * q + j) * C + c] * (1.f / O);
   const float b = bias[c];
-  for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const st_t* xin = x1 + (size_t)n * O * C + c;
-    float acc[4] = {b, b, b, b};
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-      const float v = ld1(xin + o * C);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += v * k[o][j];
-    }
-    st_t* xo = x2 + (size_t)n * O * C + c;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st1(xo + (4 * q + j) * C, acc[j]);
+  const long long nb = N / FB;               // full batches
+  FiberRegs<256> R;
+  long long batch = blockIdx.x;
+  if (batch < nb) { fiber_load(R, x1, batch); fiber_put(R, tin); }
+  __syncthreads();
+  for (; batch < nb; batch += gridDim.x) {
+    const long long next = batch + gridDim.x;
+    if (next < nb) fiber_load(R, x1, next);
+    fiber_fwd_batch(tin, to, k, b, c, q);
+    __syncthreads();
+    fiber_store<256>(x2, batch, to);
+    if (next < nb) fiber_put(R, tin);
+    __syncthreads();
+  }
+  if (N % FB != 0 && blockIdx.x == nb % gridDim.x) {
+    fiber_tail_in(x1, nb * FB, N, tin);
+    __syncthreads();
+    fiber_fwd_batch(tin, to, k, b, c, q);
+    __syncthreads();
+    fiber_tail_out(x2, nb * FB, N, to);
   }
 }
 
 // partial[block] = [dfk 16*16*64 | dbias 64]
 constexpr int FIBER_PARTIAL = O * O * C + C;
-__global__ __launch_bounds__(256) void fiber_conv_bwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
-                                                             const st_t* __restrict__ dx2, st_t* __restrict__ dx1,
-                                                             float* __restrict__ partial, int N) {
-  __shared__ float red[4 * C];
+// Backward: four waves, thread (c, q) owns channel c and the orientation quad 4q..4q+3: 64 registers of fk slice, 64 of dfk accumulators;
+// two workgroups per CU.  (An eight-wave form -- two orientations per thread, ~120 VGPRs, four waves per SIMD -- ran the same 120 us on
+// its own and cost 1-2 % of the step on every workload: sixteen resident waves per CU starve the critic's backward next to it.)
+constexpr int FBW = 4;                       // waves per workgroup
+constexpr int FBR = O / FBW;                 // orientations per thread
+GRL_DEVINL void fiber_bwd_batch(const float* tx, const float* td, float* to, const float (&kq)[FBR][O], float (&dk)[O][FBR], float& db,
+                                int c, int q) {
+#pragma unroll 1
+  for (int i = 0; i < FB; ++i) {
+    float dv[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) dv[o] = td[(i * O + o) * C + c];
+    float acc[FBR];
+#pragma unroll
+    for (int j = 0; j < FBR; ++j) {
+      acc[j] = 0.f;
+#pragma unroll
+      for (int p = 0; p < O; ++p) acc[j] += dv[p] * kq[j][p];
+      db += dv[FBR * q + j];
+    }
+#pragma unroll
+    for (int j = 0; j < FBR; ++j) to[(i * O + FBR * q + j) * C + c] = acc[j];
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float xv = tx[(i * O + o) * C + c];
+#pragma unroll
+      for (int j = 0; j < FBR; ++j) dk[o][j] += xv * dv[FBR * q + j];
+    }
+  }
+}
+__global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
+                                                                     const st_t* __restrict__ dx2, st_t* __restrict__ dx1,
+                                                                     float* __restrict__ partial, int N) {
+  constexpr int NT = 64 * FBW;
+  __shared__ __attribute__((aligned(16))) float tx[FB_E];   // single-buffered: the next batch waits in registers
+  __shared__ __attribute__((aligned(16))) float td[FB_E];
+  __shared__ __attribute__((aligned(16))) float to[FB_E];   // dx1 of the batch: leaves as 16-byte stores
+  __shared__ float red[FBW * C];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  float kq[4][O];   // fk[o = 4q+j][p][c] / 16   (rows this thread back-propagates to)
-  float dk[O][4];   // d fk[o][p = 4q+j][c]
+  float kq[FBR][O];   // fk[o = FBR q + j][p][c] / 16   (rows this thread back-propagates to)
+  float dk[O][FBR];   // d fk[o][p = FBR q + j][c]
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < FBR; ++j)
 #pragma unroll
-    for (int p = 0; p < O; ++p) kq[j][p] = fk[((4 * q + j) * O + p) * C + c] * (1.f / O);
+    for (int p = 0; p < O; ++p) kq[j][p] = fk[((FBR * q + j) * O + p) * C + c] * (1.f / O);
 #pragma unroll
   for (int o = 0; o < O; ++o)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dk[o][j] = 0.f;
+    for (int j = 0; j < FBR; ++j) dk[o][j] = 0.f;
   float db = 0.f;
-  for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const st_t* xin = x1 + (size_t)n * O * C + c;
-    const st_t* din = dx2 + (size_t)n * O * C + c;
-    float xv[O], dv[O];
-#pragma unroll
-    for (int o = 0; o < O; ++o) { xv[o] = ld1(xin + o * C); dv[o] = ld1(din + o * C); }
-    st_t* dxo = dx1 + (size_t)n * O * C + c;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float acc = 0.f;
-#pragma unroll
-      for (int p = 0; p < O; ++p) acc += dv[p] * kq[j][p];
-      st1(dxo + (4 * q + j) * C, acc);
-      db += dv[4 * q + j];
-    }
-#pragma unroll
-    for (int o = 0; o < O; ++o)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dk[o][j] += xv[o] * dv[4 * q + j];
+  const long long nb = N / FB;               // full batches
+  FiberRegs<NT> RX, RD;
+  long long batch = blockIdx.x;
+  if (batch < nb) { fiber_load(RX, x1, batch); fiber_load(RD, dx2, batch); fiber_put(RX, tx); fiber_put(RD, td); }
+  __syncthreads();
+  for (; batch < nb; batch += gridDim.x) {
+    const long long next = batch + gridDim.x;
+    if (next < nb) { fiber_load(RX, x1, next); fiber_load(RD, dx2, next); }
+    fiber_bwd_batch(tx, td, to, kq, dk, db, c, q);
+    __syncthreads();
+    fiber_store<NT>(dx1, batch, to);
+    if (next < nb) { fiber_put(RX, tx); fiber_put(RD, td); }
+    __syncthreads();
+  }
+  if (N % FB != 0 && blockIdx.x == nb % gridDim.x) {
+    fiber_tail_in(x1, nb * FB, N, tx);
+    fiber_tail_in(dx2, nb * FB, N, td);
+    __syncthreads();
+    fiber_bwd_batch(tx, td, to, kq, dk, db, c, q);
+    __syncthreads();
+    fiber_tail_out(dx1, nb * FB, N, to);
   }
   float* out = partial + (size_t)blockIdx.x * FIBER_PARTIAL;
 #pragma unroll
   for (int o = 0; o < O; ++o)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[(o * O + 4 * q + j) * C + c] = dk[o][j] * (1.f / O);
+    for (int j = 0; j < FBR; ++j) out[(o * O + FBR * q + j) * C + c] = dk[o][j] * (1.f / O);
   red[q * C + c] = db;
   __syncthreads();
-  if (q == 0) out[O * O * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
+  if (q == 0) {
+    float t = red[c];
+#pragma unroll
+    for (int g = 1; g < FBW; ++g) t += red[g * C + c];
+    out[O * O * C + c] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ attention aggregation
@@ -529,8 +714,10 @@ extern "C" {
 
 #if !GRL_PREC   // shape queries: shared by both precision builds
 int grl_fiber_partial_size() { return FIBER_PARTIAL; }
-int grl_fiber_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
-int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 4, 1024); }
+// two workgroups per CU (register budget), all resident; small graphs: at least four batches per workgroup -- every workgroup costs a
+// 66 KB partial row that the fold has to read back
+int grl_fiber_bwd_blocks(int n_nodes) { const int b = cap_blocks(n_nodes, 4 * FB, 512); return b < 256 ? cap_blocks(n_nodes, FB, 256) : b; }
+int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 16, 1024); }       // one node per wave and iteration, >= 4 nodes per wave
 #else
 int grl_fiber_bwd_blocks(int n_nodes);
 int grl_lift_bwd_blocks(int n_nodes);
@@ -540,7 +727,7 @@ int GRL_ENTRY(grl_lift_encode_fwd)(const float* scal, const float* vec, const fl
                         int n_scal, int n_vec, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   if (n_scal + n_vec > KF_MAX) return -2;
-  const int blocks = cap_blocks((long long)n_nodes * 16, 256, 2048);
+  const int blocks = cap_blocks(n_nodes, 16, 1024);   // one node per wave and iteration, >= 4 nodes per wave, <= 4 waves per SIMD
   hipLaunchKernelGGL(lift_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, scal, vec, grid, Wenc, x, n_nodes, n_scal,
                      n_vec);
   GRL_CHECK_LAUNCH();
@@ -560,7 +747,7 @@ int GRL_ENTRY(grl_lift_encode_bwd)(const float* scal, const float* vec, const fl
 
 int GRL_ENTRY(grl_fiber_conv_fwd)(const st_t* x1, const float* fk, const float* bias, st_t* x2, int n_nodes, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
-  hipLaunchKernelGGL(fiber_conv_fwd_kernel, dim3(cap_blocks(n_nodes, 4, 2048)), dim3(256), 0, stream, x1, fk, bias, x2,
+  hipLaunchKernelGGL(fiber_conv_fwd_kernel, dim3(cap_blocks(n_nodes, FB, 1024)), dim3(256), 0, stream, x1, fk, bias, x2,
                      n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;
@@ -570,7 +757,7 @@ int GRL_ENTRY(grl_fiber_conv_fwd)(const st_t* x1, const float* fk, const float* 
 int GRL_ENTRY(grl_fiber_conv_bwd)(const st_t* x1, const float* fk, const st_t* dx2, st_t* dx1, float* partial, int n_nodes,
                        hipStream_t stream) {
   if (n_nodes <= 0) return 0;
-  hipLaunchKernelGGL(fiber_conv_bwd_kernel, dim3(grl_fiber_bwd_blocks(n_nodes)), dim3(256), 0, stream, x1, fk, dx2, dx1,
+  hipLaunchKernelGGL(fiber_conv_bwd_kernel, dim3(grl_fiber_bwd_blocks(n_nodes)), dim3(64 * FBW), 0, stream, x1, fk, dx2, dx1,
                      partial, n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;

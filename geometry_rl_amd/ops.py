@@ -210,6 +210,10 @@ class LiftEncode(torch.autograd.Function):
         return None, None, None, dw, None
 
 
+# One-shot hook(n_source_nodes) run in front of the NEXT edge convolution's launch (PolicyUpdater: join the critic's forward there -- see agent.py).
+PRE_EDGE_HOOK = None
+
+
 class EdgeConv(torch.autograd.Function):
     """x1[d] = sum_{e->d} Wk(basis_mlp(invariants_e)) * x_src[src(e)]   (reference hepi.py:145-157, conv.py:79-86,115-149)."""
 
@@ -219,6 +223,10 @@ class EdgeConv(torch.autograd.Function):
         NodeMLP.backward leaves d(out)/d(x_dst) there and this backward adds it inside the d x_src kernel (no separate add pass)."""
         hip.check_f32(pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
         hip.check_latent(prec, x_src)
+        global PRE_EDGE_HOOK
+        if PRE_EDGE_HOOK is not None:
+            hook, PRE_EDGE_HOOK = PRE_EDGE_HOOK, None
+            hook(int(x_src.shape[0]))
         x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=x_src.dtype)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
         sd = edges.split_d if SPLIT_FORWARD else None

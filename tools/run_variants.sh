@@ -2,7 +2,7 @@
 # On the GPU box: bench every _variants/lib_*.so (alternating, two rounds) on this one box; prints steps/s and the five MFMA kernels' ms per step.
 cd $GRAFT_REPO_ROOT
 ARGS=${GRL_VARIANT_ARGS:---steps 30 --warmup 5 --pool 16 --no-parity-gate}
-for round in 1 2; do
+for round in ${GRL_VARIANT_ROUNDS:-1 2}; do
   for lib in _variants/lib_*.so; do
     GRL_LIB=$PWD/$lib python bench.py $ARGS 2>/dev/null | tail -1 | python -c "
 import sys,json
