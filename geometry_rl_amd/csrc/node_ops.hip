@@ -707,6 +707,9 @@ int cap_blocks(long long work, int per_block, int cap) {
   if (b < 1) b = 1;
   return (int)(b < cap ? b : cap);
 }
+// one node per wave and iteration, >= 4 nodes per wave: the prologue (weights, grid, staged inputs) is paid per workgroup -- one node per
+// wave on the step's small launches (a few thousand actuator nodes) took 17 instead of 11 us
+int lift_blocks(int n_nodes) { return cap_blocks(n_nodes, 16, 1024); }
 
 }  // namespace
 
@@ -717,7 +720,7 @@ int grl_fiber_partial_size() { return FIBER_PARTIAL; }
 // two workgroups per CU (register budget), all resident; small graphs: at least four batches per workgroup -- every workgroup costs a
 // 66 KB partial row that the fold has to read back
 int grl_fiber_bwd_blocks(int n_nodes) { const int b = cap_blocks(n_nodes, 4 * FB, 512); return b < 256 ? cap_blocks(n_nodes, FB, 256) : b; }
-int grl_lift_bwd_blocks(int n_nodes) { return cap_blocks(n_nodes, 16, 1024); }       // one node per wave and iteration, >= 4 nodes per wave
+int grl_lift_bwd_blocks(int n_nodes) { return lift_blocks(n_nodes); }
 #else
 int grl_fiber_bwd_blocks(int n_nodes);
 int grl_lift_bwd_blocks(int n_nodes);
@@ -727,7 +730,7 @@ int GRL_ENTRY(grl_lift_encode_fwd)(const float* scal, const float* vec, const fl
                         int n_scal, int n_vec, hipStream_t stream) {
   if (n_nodes <= 0) return 0;
   if (n_scal + n_vec > KF_MAX) return -2;
-  const int blocks = cap_blocks(n_nodes, 16, 1024);   // one node per wave and iteration, >= 4 nodes per wave, <= 4 waves per SIMD
+  const int blocks = lift_blocks(n_nodes);
   hipLaunchKernelGGL(lift_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, scal, vec, grid, Wenc, x, n_nodes, n_scal,
                      n_vec);
   GRL_CHECK_LAUNCH();
