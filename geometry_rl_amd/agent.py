@@ -106,7 +106,7 @@ class PolicyUpdater:
     def __init__(self, loss_module: TRPLLoss, lr=3e-4, eps=1e-5, betas=(0.9, 0.999), clip_grad_norm=False, max_grad_norm=1.0,
                  group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False):
         self.loss_module, self.group = loss_module, group
-        self.overlap_critic = overlap_critic   # one rank only: critic kernels on a second stream beside the actor's
+        self.overlap_critic = overlap_critic and os.environ.get("GRL_OVERLAP_CRITIC", "1") != "0"   # one rank only: critic kernels on a second stream beside the actor's
         self.overlap_folds = overlap_critic and os.environ.get("GRL_OVERLAP_FOLDS", "0") != "0"   # the leaf-gradient folds on a third
         # stream, one launch per backward op (ops.FOLD_STREAM).  Measured round 3 and left OFF: 0.858 vs 0.783 ms per 512-frame step, 3.42 vs
         # 3.38 ms at 4096 frames -- ten small launches with cross-stream edges in the graph cost more than the one 45 us launch they replace

@@ -216,7 +216,10 @@ def test_reduce_partials_multi_all_paths():
         assert err <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, err)
 
 
-@pytest.mark.parametrize("B,n,d", [(1, 3, 15), (7, 35, 15), (130, 241, 12), (1030, 9, 7)])
+@pytest.mark.parametrize("B,n,d", [(1, 3, 15), (7, 35, 15), (130, 241, 12), (1030, 9, 7),
+                                   # 64 or more rows per sample: the four-rows-per-access kernels (critic_ops.hip, QUAD_MIN_N) -- widest / narrowest
+                                   # input, row counts that are no multiple of four, fewer samples than waves, more workgroups than slots
+                                   (3, 64, 16), (5, 67, 1), (9, 130, 13), (1100, 65, 3), (2, 257, 15)])
 def test_deepsets_critic_shapes(B, n, d):
     """The six critic kernels (slot statistics, register-resident weights, 16-wave row kernels) against the oracle's DeepSets over
     batch / set / feature sizes around the kernels' tiling (fewer samples than waves, more workgroups than statistic slots ...)."""

@@ -41,4 +41,9 @@ for k in a[0]:
         line += f" {b[1][k]:8.1f}  {b[1][k] - a[1][k]:+7.1f}"
         tb += b[1][k]
     print(line)
+if b:
+    for k in b[0]:
+        if k not in a[1]:
+            print(f"{k[0]:42s} #{k[1]} {'':8s} {b[1][k]:8.1f}   (second trace only)")
+            tb += b[1][k]
 print(f"{'sum of launch durations':45s} {ta:8.1f}" + (f" {tb:8.1f}  {tb - ta:+7.1f}" if b else ""))
