@@ -310,7 +310,7 @@ class PolicyUpdater:
                 ops.FOLD_STREAM.wait_stream(cur)   # behind the zeroing of the flat gradient
             # The MFMA kernels size their grids to fill every CU exactly (all LDS, all VGPRs): a critic workgroup still resident when
             # one of them starts displaces one of ITS workgroups, which then runs as a second round behind the others -- the first edge
-            # convolution of the EMPN step took 751 instead of 566 us that way (profiles/r03_corun_*.txt).  So when the critic's forward
+            # convolution of the EMPN step took 751 instead of 566 us that way (profiles/r03_stream_kernels_ab.txt).  So when the critic's forward
             # is short enough to hide behind the actor's prologue (gather, features, lift: streaming kernels that share CUs gracefully)
             # the first edge convolution waits for it; a long critic forward (cloth: 239 rows per frame, 0.7 ms) keeps running beside
             # the actor instead -- waiting would cost more than the displacement.
