@@ -384,6 +384,32 @@ def main():
             kernels[k] = {"launches_per_step": launches, "avg_launch_ms": ms_step / launches, "ms_per_step": ms_step,
                           "rows_per_step": rows_step[rows_of[k]], "gflop_per_launch": flops_step / launches / 1e9, "achieved": ach,
                           "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / pipe_peak, "alg_gbyte_per_s": gbs, "frac_of_hbm": gbs / 8000.0}
+        # The same MFMA launches as the TIMED region runs them -- replayed from the recorded hipGraph: the step is recorded once more with
+        # wall-clock stamp kernels in front of and behind those launches (in-library, grl_prof_enable(2); ordinary kernel nodes, re-run by
+        # every replay) and the stamps of 8 replays are read back.  Reported beside the HIP-event figures, which stay the line's `frac`.
+        replayed = None
+        if world == 1 and not args.no_graph and upd.mode.startswith("graph"):
+            try:
+                hip.kernel_prof_enable(2)
+                upd.use_graph, upd._program, upd._static = True, None, None
+                upd.step_from(buf, next(mb))
+                reps = []
+                for i in range(8):
+                    upd.step_from(buf, next(mb))
+                    torch.cuda.synchronize()
+                    reps.append(hip.kernel_prof_summary())
+                replayed = {}
+                for k in reps[0]:
+                    if k in kernels:
+                        n_, t_ = reps[0][k][0], med([r_[k][1] for r_ in reps])
+                        fl_ = FLOPS_PER_ROW[k] * rows_step[rows_of[k]]
+                        replayed[k] = {"launches_per_step": n_, "avg_launch_ms": t_ / n_, "ms_per_step": t_,
+                                       "frac_of_bf16x3": fl_ / (t_ * 1e-3) / 1e12 / pipe_peak}
+            except Exception as e:   # bookkeeping must not break the line
+                replayed = {"error": repr(e)}
+            finally:
+                hip.kernel_prof_enable(False)
+                upd._program, upd._static = None, None
         name = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         d = kernels[name]
         # HBM traffic per launch: PMC counters cannot be collected from inside this process; the figure comes from the committed
@@ -446,12 +472,15 @@ def main():
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
                 "avg_launch_note": "HIP events on the launch stream around the eagerly issued launches of the profiled steps behind the timed region; "
-                                   "the replayed (hipGraph) launches of the timed region run 5-8 % faster (rocprofv3 --kernel-trace of this command, "
-                                   "profiles/), so achieved / frac are on the conservative side",
+                                   "the replayed (hipGraph) launches of the timed region run a few % faster (`replayed_launches`; rocprofv3 "
+                                   "--kernel-trace of this command, profiles/), so achieved / frac are on the conservative side",
                 "peak_note": "peak = the pipe the kernel runs on: every f32 product is three dense bf16 MFMAs (split-bf16, f32 "
                              f"accumulate), 2500 / 3 = {PEAK_BF16X3:.0f} TFLOP/s of f32-equivalent products (MI355X_MICROARCH.md: ~2.5 PF "
                              "dense bf16); achieved = algorithmic f32 FLOP per launch / HIP-event launch time",
                 "frac_of_f32_mfma_peak": d["frac"], "f32_mfma_peak": PEAK_F32_MFMA, "whole_step": step_fig, "mfma_kernels": kernels,
+                "replayed_launches": replayed,
+                "replayed_note": "the same launches replayed from the recorded hipGraph (as in the timed region), bracketed by device wall-clock "
+                                 "stamp kernels inside the graph (includes ~2-5 us of dispatch per launch); median of 8 replays",
                 "per_kernel_ms_per_step": {k: v[1] for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
 
     cpu, gate = None, None

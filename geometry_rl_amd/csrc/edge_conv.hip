@@ -802,7 +802,9 @@ int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_sr
   const size_t smem = sizeof(ChainW), smem_split = smem + sizeof(float4) * FWD_WAVES * 8 * 64;
   GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split));
   if (n_tiles <= GRL_FWD_SPLIT_TILES) {   // fewer tiles than SIMD groups: spread each tile's passes over a workgroup
+    grl_prof_begin_replay("edge_conv_fwd_kernel", stream);
     hipLaunchKernelGGL(edge_conv_fwd_kernel<true>, dim3(n_tiles), dim3(64 * FWD_WAVES), smem_split, stream, p, x1);
+    grl_prof_end_replay(stream);
     GRL_CHECK_LAUNCH();
     return 0;
   }
@@ -817,8 +819,11 @@ int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_sr
   }
 #endif
   (void)smem;
-  return GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2, b2,
-                                      Wk, x1, nullptr, split_d, n_slots, stream);
+  grl_prof_begin_replay("edge_conv_fwd_kernel", stream);
+  const int rc16 = GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2,
+                                                b2, Wk, x1, nullptr, split_d, n_slots, stream);
+  grl_prof_end_replay(stream);
+  return rc16;
 }
 
 // The same edge set in both orders: destination-sorted (rowptr, e_src, e_dst: the forward's arrays) for the weight kernel and

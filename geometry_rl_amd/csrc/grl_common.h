@@ -293,6 +293,8 @@ GRL_DEVINL void stage_matrix(float* dst, const float* __restrict__ src, int rows
 // Optional per-kernel HIP-event timing for entry points that launch more than one kernel (grl_prof_* in train_ops.hip).
 void grl_prof_begin(const char* name, hipStream_t stream);
 void grl_prof_end(hipStream_t stream);
+void grl_prof_begin_replay(const char* name, hipStream_t stream);   // (active in the stamp mode only: single-kernel entry points)
+void grl_prof_end_replay(hipStream_t stream);
 
 // One-time, thread-safe initialisation of per-process kernel attributes (max dynamic LDS): replaces the former `static bool`
 // latches.  One process drives one device, so "once per process" is "once per device".

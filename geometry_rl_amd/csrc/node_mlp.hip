@@ -665,8 +665,10 @@ int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* 
                      const float* gamma, const float* beta, st_t* out, int n_rows, int accumulate, hipStream_t stream) {
   if (n_rows <= 0) return 0;
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
+  grl_prof_begin_replay("node_mlp_fwd_kernel", stream);
   hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
                      W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate);
+  grl_prof_end_replay(stream);
   GRL_CHECK_LAUNCH();
   return 0;
 }
@@ -686,8 +688,12 @@ int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W
     hipMemsetAsync(partial, 0, sizeof(float) * MLP_PARTIAL, stream);
     return 0;
   }
-  if (GRL_MLP_BWD16 && n_rows % 16 == 0)
-    return GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), stream);
+  if (GRL_MLP_BWD16 && n_rows % 16 == 0) {
+    grl_prof_begin_replay("node_mlp_bwd16_kernel", stream);
+    const int rc = GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), stream);
+    grl_prof_end_replay(stream);
+    return rc;
+  }
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdSmem)));
   const int blocks = grl_node_mlp_bwd_blocks(n_rows);
   u32x4* slab = reinterpret_cast<u32x4*>(partial + (size_t)blocks * MLP_PARTIAL);

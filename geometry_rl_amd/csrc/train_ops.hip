@@ -285,30 +285,57 @@ __global__ __launch_bounds__(256) void vecnorm_apply_kernel(const float* __restr
   }
 }
 
-// ---- per-kernel event timing (off by default; bench.py's roofline leg switches it on for a few steps) ---------------------------
+// ---- per-kernel timing (off by default; bench.py's roofline leg switches it on for a few steps) ---------------------------------
+// mode 1: HIP events around the kernels inside multi-kernel entry points (eagerly issued launches).
+// mode 2: one-thread kernels that store the device's wall clock (wall_clock64, constant rate) in front of and behind a launch.  They are
+//         ordinary kernel nodes when the step is recorded into a hipGraph, so they are re-executed by every replay: the durations of
+//         REPLAYED launches (events cannot do that here: external event records are refused by the HIP runtime torch bundles, DESIGN
+//         finding 30).  The interval includes the dispatch of the launch behind the first stamp and of the second stamp: a few us.
 #include <string>
 #include <vector>
 namespace {
-struct ProfRec { const char* name; hipEvent_t e0, e1; };
-bool g_prof_on = false;
+struct ProfRec { const char* name; hipEvent_t e0, e1; int slot; };
+int g_prof_mode = 0;
 std::vector<ProfRec> g_prof;
 hipEvent_t g_prof_open = nullptr;
 const char* g_prof_open_name = nullptr;
+constexpr int PROF_STAMPS = 256;             // stamp pairs per recording
+unsigned long long* g_stamps = nullptr;      // device [PROF_STAMPS][2]
+int g_stamp_next = 0, g_stamp_open = -1;
+double g_wall_khz = 100000.0;
+__global__ void prof_stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
 }  // namespace
 void grl_prof_begin(const char* name, hipStream_t stream) {
-  if (!g_prof_on) return;
+  if (g_prof_mode == 0) return;
+  if (g_prof_mode == 2) {
+    if (g_stamp_next >= PROF_STAMPS) return;
+    g_stamp_open = g_stamp_next++;
+    hipLaunchKernelGGL(prof_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * g_stamp_open);
+    g_prof_open_name = name;
+    return;
+  }
   hipEventCreate(&g_prof_open);
   hipEventRecord(g_prof_open, stream);
   g_prof_open_name = name;
 }
 void grl_prof_end(hipStream_t stream) {
-  if (!g_prof_on || !g_prof_open) return;
+  if (g_prof_mode == 2) {
+    if (g_stamp_open < 0) return;
+    hipLaunchKernelGGL(prof_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * g_stamp_open + 1);
+    g_prof.push_back({g_prof_open_name, nullptr, nullptr, g_stamp_open});
+    g_stamp_open = -1;
+    return;
+  }
+  if (g_prof_mode == 0 || !g_prof_open) return;
   hipEvent_t e1;
   hipEventCreate(&e1);
   hipEventRecord(e1, stream);
-  g_prof.push_back({g_prof_open_name, g_prof_open, e1});
+  g_prof.push_back({g_prof_open_name, g_prof_open, e1, -1});
   g_prof_open = nullptr;
 }
+// wrappers of single-kernel entry points: only the replay mode needs them (eagerly, the caller's events around the entry point do)
+void grl_prof_begin_replay(const char* name, hipStream_t stream) { if (g_prof_mode == 2) grl_prof_begin(name, stream); }
+void grl_prof_end_replay(hipStream_t stream) { if (g_prof_mode == 2) grl_prof_end(stream); }
 
 extern "C" {
 
@@ -465,19 +492,34 @@ int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int bat
 }
 
 
-// Switch the per-kernel timing on (clears old records) or off.
+// Switch the per-kernel timing on (1: events around eagerly issued launches, 2: wall-clock stamp kernels, for recorded steps; clears old
+// records) or off (0).
 int grl_prof_enable(int on) {
-  for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto& r : g_prof) if (r.e0) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   g_prof.clear();
-  g_prof_on = on != 0;
+  g_prof_mode = on == 2 ? 2 : (on != 0 ? 1 : 0);
+  g_stamp_next = 0;
+  g_stamp_open = -1;
+  if (g_prof_mode == 2 && !g_stamps) {
+    if (hipMalloc(&g_stamps, sizeof(unsigned long long) * 2 * PROF_STAMPS) != hipSuccess) { g_prof_mode = 0; return 1; }
+    int dev = 0, khz = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) g_wall_khz = khz;
+  }
   return 0;
 }
 int grl_prof_count() { return (int)g_prof.size(); }
 // Record i -> kernel name (NUL-terminated, at most cap bytes) and its duration in ms; waits for the record's end event.
 int grl_prof_get(int i, char* name, int cap, float* ms) {
   if (i < 0 || i >= (int)g_prof.size() || cap < 1) return 1;
-  hipEventSynchronize(g_prof[i].e1);
-  if (hipEventElapsedTime(ms, g_prof[i].e0, g_prof[i].e1) != hipSuccess) return 2;
+  if (g_prof[i].slot >= 0) {   // stamp pair of the LATEST execution (eager or replayed) of that launch; the caller has synchronised
+    unsigned long long t[2];
+    if (hipMemcpy(t, g_stamps + 2 * g_prof[i].slot, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    *ms = (float)((double)(t[1] - t[0]) / g_wall_khz);
+  } else {
+    hipEventSynchronize(g_prof[i].e1);
+    if (hipEventElapsedTime(ms, g_prof[i].e0, g_prof[i].e1) != hipSuccess) return 2;
+  }
   int k = 0;
   for (; k < cap - 1 && g_prof[i].name[k]; ++k) name[k] = g_prof[i].name[k];
   name[k] = 0;
