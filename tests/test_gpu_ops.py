@@ -246,3 +246,47 @@ def test_deepsets_critic_shapes(B, n, d):
         gr = Pg[k].grad
         err = float((t.grad.cpu() - gr).abs().max())
         assert err <= 1e-4 * max(1.0, float(gr.abs().max())), (k, err, float(gr.abs().max()))
+
+
+def test_kernel_prof_stamp_mode_times_a_replayed_launch():
+    """grl_prof_enable(2): wall-clock stamp kernels around a launch are ordinary graph nodes, so the duration of a REPLAYED launch can
+    be read back (bench.py's `roofline.replayed_launches`).  Here: the node-MLP backward recorded into a hipGraph, replayed three
+    times; every replay yields a fresh, plausible duration that agrees with HIP events around the eager launch."""
+    from geometry_rl_amd import hip
+    dv = dev()
+    g = torch.Generator().manual_seed(3)
+    n = 4096
+    x2, dout = (torch.randn(n, 16, 64, generator=g).to(dv) for _ in range(2))
+    w3, b3, w4, b4 = (torch.randn(s, generator=g).mul(0.1).to(dv) for s in [(256, 64), (256,), (64, 256), (64,)])
+    gam, bet = torch.ones(64, device=dv), torch.zeros(64, device=dv)
+    rows = n * 16
+    blocks = hip.query("grl_node_mlp_bwd_blocks", rows)
+    partial = torch.empty(blocks + 1, hip.query("grl_node_mlp_partial_size"), device=dv)
+    dx2 = torch.empty_like(x2)
+    run = lambda: hip.call("grl_node_mlp_bwd", x2, dout, w3, b3, w4, b4, gam, bet, dx2, partial, rows)
+    for _ in range(2):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    eager_ms = e0.elapsed_time(e1)
+    hip.kernel_prof_enable(2)
+    try:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        seen = []
+        for _ in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            summ = hip.kernel_prof_summary()
+            assert list(summ) == ["node_mlp_bwd16_kernel"] and summ["node_mlp_bwd16_kernel"][0] == 1, summ
+            seen.append(summ["node_mlp_bwd16_kernel"][1])
+    finally:
+        hip.kernel_prof_enable(False)
+    print("eager (events)", eager_ms, "ms; replayed (stamps)", seen)
+    for ms in seen:
+        assert 0.3 * eager_ms < ms < 2.0 * eager_ms + 0.05, (ms, eager_ms)
+    assert hip.kernel_prof_summary() == {}
