@@ -150,7 +150,9 @@ def test_node_mlp(n):
             check(name, a.grad, b.grad, 2e-4)
 
 
-@pytest.mark.parametrize("n", [3, 77])
+# node counts around the kernels' batching: fewer nodes than one batch of four, exact batches, a partial last batch, several batches per
+# workgroup (9001), and more than 16 nodes per wave of the lift kernels' 4096 waves (70001: the staged inputs are refilled)
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 77, 9001, 70001])
 def test_fiber_conv_and_lift(n):
     from geometry_rl_amd import ops
     d = dev()
@@ -290,3 +292,28 @@ def test_kernel_prof_stamp_mode_times_a_replayed_launch():
     for ms in seen:
         assert 0.3 * eager_ms < ms < 2.0 * eager_ms + 0.05, (ms, eager_ms)
     assert hip.kernel_prof_summary() == {}
+
+
+@pytest.mark.parametrize("S,V", [(1, 7), (2, 1), (5, 3), (8, 0)])
+def test_lift_feature_splits(S, V):
+    """Lift + encoder with other scalar / vector feature counts than the bench configs' (the kernels fetch a node's S + 3 V inputs with one
+    load and clamp the unused slots: widest vector block, a single vector, S + V = 8 = the kernels' maximum, no vectors at all)."""
+    from geometry_rl_amd import ops
+    d = dev()
+    n = 301
+    g = torch.Generator().manual_seed(10 * S + V)
+    grid = eq.make_grid(3, 16)
+    scal = torch.randn(n, S, generator=g)
+    vec = torch.randn(n, V, 3, generator=g)
+    w = torch.randn(64, S + V, generator=g)
+    R = torch.randn(n, 16, 64, generator=g)
+    wl = w.clone().requires_grad_(True)
+    # x[n,o,c] = sum_s scal[n,s] W[c,s] + sum_v (vec[n,v,:] . grid[o,:]) W[c,S+v]     (hepi.py:136-143, to_from_sphere.py:4-9)
+    feat = torch.cat([scal[:, None, :].expand(n, 16, S), torch.einsum("nvd,od->nov", vec, grid)], -1)
+    ref = F.linear(feat, wl)
+    (ref * R).sum().backward()
+    wd = w.clone().to(d).requires_grad_(True)
+    out = ops.LiftEncode.apply(scal.to(d), vec.to(d), grid.to(d), wd)
+    check(f"lift S{S} V{V}", out, ref)
+    (out * R.to(d)).sum().backward()
+    check(f"lift dW S{S} V{V}", wd.grad, wl.grad, 2e-4)
