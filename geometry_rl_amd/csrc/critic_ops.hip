@@ -194,7 +194,8 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ds_fwd1(const float* __restric
 
 // ---- forward 2: y1 = relu(LNg(h1)); z = W2 sum_n y1 + n b2; u1 = z W3^T + b3; slot sums of (u1, u1^2)
 //      Thread j keeps row j of W2 and of W3 in registers; vectors are exchanged through wave-private LDS lines.
-__global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict__ h1, const double* __restrict__ slots1, double count1,
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ds_fwd2(const float* __restrict__ h1, const double* __restrict__ slots1, double count1,
                                                         const float* __restrict__ g1, const float* __restrict__ be1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
                                                         const float* __restrict__ W3, const float* __restrict__ b3,
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict
     const size_t g = blockIdx.y;
     h1 += g * (size_t)B * n * H; slots1 += g * 2 * NSLOT; z += g * (size_t)B * H; u1 += g * (size_t)B * H; slots2 += g * 2 * NSLOT;
   }
-  __shared__ __attribute__((aligned(16))) float ys_all[DS_WAVES][2][H];
+  __shared__ __attribute__((aligned(16))) float ys_all[WAVES][2][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float (*ys)[H] = ys_all[wave];
   float w2[H], w3[H];
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict
   const LnStat st = ln_stat(tot[0], count1);
   const float gj = g1[j], bj = be1[j], b2j = b2[j], b3j = b3[j];
   double s0 = 0, s1 = 0;
-  for (int b = blockIdx.x * DS_WAVES + wave; b < B; b += gridDim.x * DS_WAVES) {
+  for (int b = blockIdx.x * WAVES + wave; b < B; b += gridDim.x * WAVES) {
     const float* hrow = h1 + (size_t)b * n * H + j;
     float ysum = 0.f;
     for (int i0 = 0; i0 < n; i0 += 8) {   // eight rows in flight
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_fwd2(const float* __restrict
     s1 += (double)acc * acc;
     __builtin_amdgcn_wave_barrier();
   }
-  block_put_stats(s0, s1, slots2);
+  block_put_stats<WAVES>(s0, s1, slots2);
 }
 
 // ---- forward 3: y2 = relu(LNg(u1)); u2 = y2 W4^T + b4; V = u2 . wv + bv
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd3(const float* __restrict
 //      all rows) -> q1 = dy1 * relu'(.) * gamma1 written per row; slot sums of (q1, q1 xhat1).
 // partial row: [dW3 64x64 | db3 64 | dW2 64x64 | db2 64 | dg1 64 | dbe1 64]
 constexpr int P2 = H * H + H + H * H + H + H + H;
-__global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict__ h1, const double* __restrict__ slots1, double count1,
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ds_bwd2(const float* __restrict__ h1, const double* __restrict__ slots1, double count1,
                                                         const float* __restrict__ g1, const float* __restrict__ be1,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ z, const float* __restrict__ u1,
@@ -344,20 +346,21 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict
                                                         float* __restrict__ partial, int B, int n) {
   // the weight images (read by column) live in LDS and are shared by the four waves; their space is reused for the folds
   __shared__ __attribute__((aligned(16))) float W2s[H * (H + 1)], W3s[H * (H + 1)];
-  __shared__ __attribute__((aligned(16))) float sh_all[DS_WAVES][H], sy_all[DS_WAVES][H];
+  __shared__ __attribute__((aligned(16))) float sh_all[WAVES][H], sy_all[WAVES][H];
   const int j = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* sh = sh_all[wave];
   float* sy = sy_all[wave];
   {
-    float4 a[4], c[4];   // 1024 quads per matrix / 256 threads: all loads in flight before the first LDS store
+    constexpr int NT = 64 * WAVES, NQ = H * H / 4 / NT;   // quads per matrix and thread: all loads in flight before the first LDS store
+    float4 a[NQ], c[NQ];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = reinterpret_cast<const float4*>(W2)[threadIdx.x + 256 * u];
-      c[u] = reinterpret_cast<const float4*>(W3)[threadIdx.x + 256 * u];
+    for (int u = 0; u < NQ; ++u) {
+      a[u] = reinterpret_cast<const float4*>(W2)[threadIdx.x + NT * u];
+      c[u] = reinterpret_cast<const float4*>(W3)[threadIdx.x + NT * u];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = 4 * (threadIdx.x + 256 * u), r_ = i >> 6, k_ = i & 63;
+    for (int u = 0; u < NQ; ++u) {
+      const int i = 4 * (threadIdx.x + NT * u), r_ = i >> 6, k_ = i & 63;
       float* d2 = W2s + r_ * (H + 1) + k_;
       float* d3 = W3s + r_ * (H + 1) + k_;
       d2[0] = a[u].x; d2[1] = a[u].y; d2[2] = a[u].z; d2[3] = a[u].w;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict
   for (int k = 0; k < H; ++k) { dW3[k] = 0.f; dW2[k] = 0.f; }
   float db3 = 0.f, db2 = 0.f, dg = 0.f, dbe = 0.f;
   double s0 = 0, s1 = 0;
-  for (int b = blockIdx.x * DS_WAVES + wave; b < B; b += gridDim.x * DS_WAVES) {
+  for (int b = blockIdx.x * WAVES + wave; b < B; b += gridDim.x * WAVES) {
     // LNg2 backward: du1 = (q2 - mean(q2)) / s - xhat2 * sum(q2 xhat2) / (N sigma)
     const float xh2 = (u1[(size_t)b * H + j] - st2.mean) / st2.s;
     const float du1 = (q2[(size_t)b * H + j] - mq) / st2.s - xh2 * cq;
@@ -420,14 +423,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) void ds_bwd2(const float* __restrict
     axpy64(sy, dz, dW2);
     __builtin_amdgcn_wave_barrier();
   }
-  block_put_stats(s0, s1, bslots1);
+  block_put_stats<WAVES>(s0, s1, bslots1);
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * P2;
-  fold_rows64(dW3, W3s, out);
-  fold_rows64(dW2, W2s, out + H * H + H);
+  fold_rows64<WAVES>(dW3, W3s, out);
+  fold_rows64<WAVES>(dW2, W2s, out + H * H + H);
   const float sc[4] = {db3, db2, dg, dbe};
   float* const outs[4] = {out + H * H, out + 2 * H * H + H, out + 2 * H * H + 2 * H, out + 2 * H * H + 3 * H};
-  fold_scalars<4>(sc, W3s, outs);
+  fold_scalars<4, WAVES>(sc, W3s, outs);
 }
 
 // ---- backward 1: dh1 (LNg1 backward) -> dW1, db1.   partial row: [dW1 64 x d | db1 64]   (rows flattened, 16 waves per workgroup)
@@ -511,6 +514,7 @@ __global__ __launch_bounds__(64 * ROW_WAVES) void ds_bwd1(const float* __restric
 // microseconds of prologue and latency; with ~1 M rows they ran at 1.0-1.5 TB/s (cloth: forward 2 alone 0.56 ms inside the step).
 // ================================================================================================================================
 constexpr int QUAD_MIN_N = 64;
+constexpr int LANE8_MIN_BATCH = 8 * NSLOT;   // lane kernels of the per-sample passes: eight waves per workgroup from 2 048 samples up
 // ---- Row passes (forward 1 / 2, backward 2 / 1) walk [rows][64] fp32 arrays FOUR ROWS PER INSTRUCTION: lane = (r = lane >> 4, c4 = lane & 15)
 //      owns channels 4 c4 .. 4 c4 + 3 of row 4 q + r, so a load or store is 1 KB contiguous and a wave keeps 8-16 of them in flight.
 //      (Round 2: lane = channel, one 256-byte dword access per row, 4-8 rows in flight, and only 1 024 waves on the per-sample passes:
@@ -944,9 +948,12 @@ int grl_deepsets_fwd2_groups(const float* h1, const double* slots1, double count
   if (n_nodes >= QUAD_MIN_N)
     hipLaunchKernelGGL(ds_fwd2_quad, dim3(ds_blocks(batch), groups), dim3(64 * S_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, b2, W3,
                        b3, z, u1, slots2, batch, n_nodes);
-  else
-    hipLaunchKernelGGL(ds_fwd2, dim3(ds_blocks(batch), groups), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, b2, W3, b3,
+  else if (batch >= LANE8_MIN_BATCH)   // the workgroup count is capped (statistic slots): eight waves per workgroup, two samples per wave
+    hipLaunchKernelGGL(ds_fwd2<8>, dim3(ds_blocks(batch), groups), dim3(64 * 8), 0, stream, h1, slots1, count1, g1, be1, W2, b2, W3, b3,
                        z, u1, slots2, batch, n_nodes);
+  else
+    hipLaunchKernelGGL(ds_fwd2<DS_WAVES>, dim3(ds_blocks(batch), groups), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, b2,
+                       W3, b3, z, u1, slots2, batch, n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;
 }
@@ -989,8 +996,11 @@ int grl_deepsets_bwd2(const float* h1, const double* slots1, double count1, cons
   if (n_nodes >= QUAD_MIN_N)
     hipLaunchKernelGGL(ds_bwd2_quad, dim3(ds_blocks(batch)), dim3(64 * S_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, W3, z, u1,
                        slots2, count2, q2, bslots2, q1, bslots1, partial, batch, n_nodes);
+  else if (batch >= LANE8_MIN_BATCH)
+    hipLaunchKernelGGL(ds_bwd2<8>, dim3(ds_blocks(batch)), dim3(64 * 8), 0, stream, h1, slots1, count1, g1, be1, W2, W3, z, u1,
+                       slots2, count2, q2, bslots2, q1, bslots1, partial, batch, n_nodes);
   else
-    hipLaunchKernelGGL(ds_bwd2, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, W3, z, u1,
+    hipLaunchKernelGGL(ds_bwd2<DS_WAVES>, dim3(ds_blocks(batch)), dim3(64 * DS_WAVES), 0, stream, h1, slots1, count1, g1, be1, W2, W3, z, u1,
                        slots2, count2, q2, bslots2, q1, bslots1, partial, batch, n_nodes);
   GRL_CHECK_LAUNCH();
   return 0;
