@@ -257,7 +257,8 @@ class PolicyUpdater:
 
         def s5():  # optimizers + reported values (train.py:308-316, trpl.py:280-321)
             with torch.no_grad():
-                self.step_dev.add_(1)
+                if not st.pop("step_bumped", False):
+                    self.step_dev.add_(1)
                 na, n = self.n_actor, self.flat.numel()
                 # the two optimizers of train.py:120-127 have identical hyper-parameters and schedules: without per-network gradient
                 # clipping their two Adam steps are ONE launch over the flat buffer (element-wise: the same numbers)
@@ -332,6 +333,8 @@ class PolicyUpdater:
                 pipe.bwd3(dvalue)
                 pipe.bwd2()
                 grads = pipe.bwd1(leaves)
+                self.step_dev.add_(1)   # Adam's step counter: behind the critic's backward, long before the join -- not on the actor's lane
+                st["step_bumped"] = True
             assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
             torch.autograd.backward([loc, sigma], [dloc, dsigma])
             cur.wait_stream(cs)   # join: every partial slab is complete
