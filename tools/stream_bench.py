@@ -26,6 +26,16 @@ cases = {
     "lift_encode_fwd": (lambda: hip.call("grl_lift_encode_fwd", scal, vec, grid3, wenc, x2, n, S, V), NB, lambda: x2),
     "lift_encode_bwd": (lambda: hip.call("grl_lift_encode_bwd", scal, vec, grid3, d2, lpart, n, S, V), NB, lambda: lpart),
 }
+if os.environ.get("GRL_BF16"):   # the bf16-storage twins (config 5): latents stored as bf16, half the bytes
+    xb, db = x1.bfloat16(), d2.bfloat16()
+    x2b, dx1b = torch.empty_like(xb), torch.empty_like(xb)
+    NBh = NB // 2
+    cases = {
+        "fiber_conv_fwd_bf16": (lambda: hip.call("grl_fiber_conv_fwd_bf16", xb, fk, bias, x2b, n), 2 * NBh, lambda: x2b.float()),
+        "fiber_conv_bwd_bf16": (lambda: hip.call("grl_fiber_conv_bwd_bf16", xb, fk, db, dx1b, fpart, n), 3 * NBh, lambda: (dx1b.float(), fpart)),
+        "lift_encode_fwd_bf16": (lambda: hip.call("grl_lift_encode_fwd_bf16", scal, vec, grid3, wenc, x2b, n, S, V), NBh, lambda: x2b.float()),
+        "lift_encode_bwd_bf16": (lambda: hip.call("grl_lift_encode_bwd_bf16", scal, vec, grid3, db, lpart, n, S, V), NBh, lambda: lpart),
+    }
 only = os.environ.get("GRL_ONLY")
 for name, (run, nbytes, outs) in cases.items():
     if only and only not in name:
