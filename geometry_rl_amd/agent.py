@@ -320,8 +320,10 @@ class PolicyUpdater:
             if mode != "0":
                 ops.PRE_EDGE_HOOK = lambda n_nodes: (cur.wait_stream(cs) if (mode == "1" or (mode == "auto" and rows <= 4 * n_nodes)) else
                                                      cur.wait_event(ev1) if mode in ("fwd1", "auto") else None)
-            loc, sigma = actor.forward_diag(*st["obs"], train=True)
-            ops.PRE_EDGE_HOOK = None
+            try:
+                loc, sigma = actor.forward_diag(*st["obs"], train=True)
+            finally:
+                ops.PRE_EDGE_HOOK = None   # (one-shot; never left behind for another caller's edge convolution)
             cur.wait_stream(cs)   # join: the fused loss kernel needs the values
             with torch.no_grad():   # (the fold of the per-workgroup loss sums is deferred: reported values only, off the actor's lane)
                 fold, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],
