@@ -82,20 +82,25 @@ __global__ __launch_bounds__(64) void readout_fwd_kernel(const float* __restrict
 
 // partial row: [dWd JMAX*64 | dbd JMAX | dWs APER_MAX*64 | dbs APER_MAX]
 constexpr int RO_PARTIAL = JMAX * C + JMAX + APER_MAX * C + APER_MAX;
-__global__ __launch_bounds__(64) void readout_bwd_kernel(const float* __restrict__ lat, const float* __restrict__ grid,
+// Four waves per workgroup, one node per wave and iteration (round 3: one wave per workgroup, four nodes in a row per wave at 4096 frames --
+// a node is one long dependent chain of loads, ten wave reductions and the std head: 41 us of latency).  The waves' gradient accumulators are
+// summed in wave order through LDS: still one partial row per workgroup.
+constexpr int RO_WAVES = 4;
+__global__ __launch_bounds__(64 * RO_WAVES) void readout_bwd_kernel(const float* __restrict__ lat, const float* __restrict__ grid,
                                                         const float* __restrict__ Wd, const float* __restrict__ bd,
                                                         const float* __restrict__ Ws, const float* __restrict__ bs, float shift,
                                                         const float* __restrict__ dmean, const float* __restrict__ dsigma,
                                                         const float* __restrict__ dhidden_ext, float* __restrict__ dlat,
                                                         float* __restrict__ partial, int n_nodes, int od, int ov) {
-  const int c = threadIdx.x;
+  __shared__ float red[RO_WAVES][2 * (JMAX + APER_MAX)][C];
+  const int c = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int J = od + ov, aper = 3 * ov;
   float wd[JMAX], ws[APER_MAX], dwd[JMAX], dws[APER_MAX], dbd[JMAX], dbs[APER_MAX];
 #pragma unroll
   for (int j = 0; j < JMAX; ++j) { wd[j] = j < J ? Wd[j * C + c] : 0.f; dwd[j] = 0.f; dbd[j] = 0.f; }
 #pragma unroll
   for (int a = 0; a < APER_MAX; ++a) { ws[a] = a < aper ? Ws[a * C + c] : 0.f; dws[a] = 0.f; dbs[a] = 0.f; }
-  for (int n = blockIdx.x; n < n_nodes; n += gridDim.x) {
+  for (int n = blockIdx.x * RO_WAVES + wave; n < n_nodes; n += gridDim.x * RO_WAVES) {
     const float* l = lat + (size_t)n * O * C + c;
     float lv[O], hsum = 0.f, lgx = 0.f, lgy = 0.f, lgz = 0.f, sgx = 0.f, sgy = 0.f, sgz = 0.f;
 #pragma unroll
@@ -158,6 +163,19 @@ __global__ __launch_bounds__(64) void readout_bwd_kernel(const float* __restrict
       }
       dl[o * C] = g;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) { red[wave][j][c] = dwd[j]; red[wave][JMAX + j][c] = dbd[j]; }
+#pragma unroll
+  for (int a = 0; a < APER_MAX; ++a) { red[wave][2 * JMAX + a][c] = dws[a]; red[wave][2 * JMAX + APER_MAX + a][c] = dbs[a]; }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w_ = 1; w_ < RO_WAVES; ++w_) {
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) { dwd[j] += red[w_][j][c]; dbd[j] += red[w_][JMAX + j][c]; }
+#pragma unroll
+    for (int a = 0; a < APER_MAX; ++a) { dws[a] += red[w_][2 * JMAX + a][c]; dbs[a] += red[w_][2 * JMAX + APER_MAX + a][c]; }
   }
   float* out = partial + (size_t)blockIdx.x * RO_PARTIAL;
 #pragma unroll
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __res
 extern "C" {
 
 int grl_readout_partial_size() { return RO_PARTIAL; }
-int grl_readout_blocks(int n_nodes) { return n_nodes < 1024 ? (n_nodes < 1 ? 1 : n_nodes) : 1024; }
+int grl_readout_blocks(int n_nodes) { const int b = (n_nodes + RO_WAVES - 1) / RO_WAVES; return b < 1 ? 1 : (b < 1024 ? b : 1024); }
 
 int grl_readout_fwd(const float* lat, const float* grid, const float* Wd, const float* bd, const float* Ws, const float* bs,
                     float shift, float min_std, float* mean, float* sigma, float* hidden, int n_nodes, int output_dim,
@@ -570,7 +588,7 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
                     float shift, const float* dmean, const float* dsigma, const float* dhidden_ext, float* dlat, float* partial,
                     int n_nodes, int output_dim, int output_dim_vec, hipStream_t stream) {
   if (output_dim != output_dim_vec || output_dim + output_dim_vec > JMAX || 3 * output_dim_vec > APER_MAX) return -2;
-  hipLaunchKernelGGL(readout_bwd_kernel, dim3(grl_readout_blocks(n_nodes)), dim3(64), 0, stream, lat, grid, Wd, bd, Ws, bs, shift,
+  hipLaunchKernelGGL(readout_bwd_kernel, dim3(grl_readout_blocks(n_nodes)), dim3(64 * RO_WAVES), 0, stream, lat, grid, Wd, bd, Ws, bs, shift,
                      dmean, dsigma, dhidden_ext, dlat, partial, n_nodes, output_dim, output_dim_vec);
   GRL_CHECK_LAUNCH();
   return 0;
