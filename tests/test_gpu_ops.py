@@ -317,3 +317,34 @@ def test_lift_feature_splits(S, V):
     check(f"lift S{S} V{V}", out, ref)
     (out * R.to(d)).sum().backward()
     check(f"lift dW S{S} V{V}", wd.grad, wl.grad, 2e-4)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 130, 4099])
+def test_readout_head(n):
+    """Decoder + orientation pooling + contextual std head (ops.Readout) against the oracle's readout / std_head, forward and backward, over
+    node counts around the backward kernel's tiling (four waves per workgroup, one node per wave: fewer nodes than waves, a partial last
+    workgroup, more nodes than the 1024 x 4 resident waves)."""
+    from geometry_rl_amd import ops
+    from oracle import trpl as otr
+    d = dev()
+    od = ov = 2
+    g = torch.Generator().manual_seed(n)
+    grid = eq.make_grid(3, 16)
+    lat = torch.randn(n, 16, 64, generator=g)
+    wd, bd = torch.randn(od + ov, 64, generator=g) * 0.2, torch.randn(od + ov, generator=g) * 0.1
+    ws, bs = torch.randn(3 * ov, 64, generator=g) * 0.2, torch.randn(3 * ov, generator=g) * 0.1
+    Rm, Rs, Rh = torch.randn(n, ov, 3, generator=g), torch.randn(n, 3 * ov, generator=g), torch.randn(n, 64, generator=g)
+    init_std, min_std = 1.0, 1e-5
+    shift = float(otr.inverse_softplus(torch.tensor(init_std - min_std)))
+    ref_leaves = [t.clone().requires_grad_(True) for t in (lat, wd, bd, ws, bs)]
+    mean_r, hid_r = eq.readout(ref_leaves[0], ref_leaves[1], ref_leaves[2], grid, 3, od, ov)
+    sig_r = otr.std_head(hid_r, ref_leaves[3], ref_leaves[4], init_std, min_std, n)
+    ((mean_r.reshape(n, ov, 3) * Rm).sum() + (sig_r * Rs).sum() + (hid_r * Rh).sum()).backward()
+    dl = [t.clone().to(d).requires_grad_(True) for t in (lat, wd, bd, ws, bs)]
+    mean, sigma, hidden = ops.Readout.apply(dl[0], grid.to(d), dl[1], dl[2], dl[3], dl[4], shift, min_std, od, ov)
+    check("mean", mean.reshape(-1, 3), mean_r.reshape(-1, 3))
+    check("sigma", sigma, sig_r)
+    check("hidden", hidden, hid_r)
+    ((mean * Rm.to(d)).sum() + (sigma * Rs.to(d)).sum() + (hidden * Rh.to(d)).sum()).backward()
+    for name, a, b in zip(["dlat", "dWd", "dbd", "dWs", "dbs"], dl, ref_leaves):
+        check(name, a.grad, b.grad, 2e-4)
