@@ -213,9 +213,32 @@ __global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherJobs jobs, 
   const int k = blockIdx.y;
   const int wpr = jobs.words[k];
   const long long total = (long long)n_rows * wpr;
+  const unsigned int* __restrict__ src = jobs.src[k];
+  unsigned int* __restrict__ dst = jobs.dst[k];
+  if (total < (1ll << 31)) {   // the usual case: 32-bit index arithmetic, four independent (index, word) load pairs in flight per thread
+    const int tot = (int)total, stride = gridDim.x * blockDim.x;
+    for (int w0 = blockIdx.x * blockDim.x + threadIdx.x; w0 < tot; w0 += 4 * stride) {
+      long long row[4];
+      int c[4];
+      unsigned int v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w = w0 + u * stride < tot ? w0 + u * stride : tot - 1;   // clamped, not guarded
+        const int r = w / wpr;
+        c[u] = w - r * wpr;
+        row[u] = idx[r];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[row[u] * wpr + c[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (w0 + u * stride < tot) dst[w0 + u * stride] = v[u];
+    }
+    return;
+  }
   for (long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(w / wpr), c = (int)(w - (long long)r * wpr);
-    jobs.dst[k][w] = jobs.src[k][idx[r] * wpr + c];
+    dst[w] = src[idx[r] * wpr + c];
   }
 }
 
