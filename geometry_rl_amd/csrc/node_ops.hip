@@ -569,12 +569,15 @@ GRL_DEVINL float column_sum(const float* __restrict__ src /*column base*/, size_
 #pragma unroll
     for (int u = 0; u < RED_DEPTH; ++u) a[u] += v[u];
   }
-  {  // remainder: all of its (< RED_DEPTH) loads in flight together
+  {  // remainder: all of its (< RED_DEPTH) loads in flight together (clamped rows, dropped at the add: see column_sum4)
     float v[RED_DEPTH];
 #pragma unroll
-    for (int u = 0; u < RED_DEPTH; ++u) v[u] = w + u * RED_WAVES < n_rows ? src[(size_t)(w + u * RED_WAVES) * ld] : 0.f;
+    for (int u = 0; u < RED_DEPTH; ++u) {
+      const int row = w + u * RED_WAVES;
+      v[u] = src[(size_t)(row < n_rows ? row : n_rows - 1) * ld];
+    }
 #pragma unroll
-    for (int u = 0; u < RED_DEPTH; ++u) a[u] += v[u];
+    for (int u = 0; u < RED_DEPTH; ++u) a[u] = fmaf(w + u * RED_WAVES < n_rows ? 1.f : 0.f, v[u], a[u]);
   }
 #pragma unroll
   for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
@@ -650,13 +653,19 @@ GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_ro
 #pragma unroll
     for (int u = 0; u < RED_DEPTH; ++u) a[u] = f4_add(a[u], v[u]);
   }
-  {  // remainder: all of its (< RED_DEPTH) loads in flight together
+  {  // remainder: all of its (< RED_DEPTH) loads in flight together -- rows past the end are loaded CLAMPED and dropped at the add: a guard
+     // around the load is a branch per load with a wait at each join (finding 31a), and the 257-row slabs of the MLP backward are all remainder
     float4 v[RED_DEPTH];
 #pragma unroll
-    for (int u = 0; u < RED_DEPTH; ++u)
-      v[u] = w + u * STEP < n_rows ? *reinterpret_cast<const float4*>(src + (size_t)(w + u * STEP) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < RED_DEPTH; ++u) {
+      const int row = w + u * STEP;
+      v[u] = *reinterpret_cast<const float4*>(src + (size_t)(row < n_rows ? row : n_rows - 1) * ld);
+    }
 #pragma unroll
-    for (int u = 0; u < RED_DEPTH; ++u) a[u] = f4_add(a[u], v[u]);
+    for (int u = 0; u < RED_DEPTH; ++u) {
+      const float m = w + u * STEP < n_rows ? 1.f : 0.f;
+      a[u] = make_float4(fmaf(m, v[u].x, a[u].x), fmaf(m, v[u].y, a[u].y), fmaf(m, v[u].z, a[u].z), fmaf(m, v[u].w, a[u].w));
+    }
   }
 #pragma unroll
   for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
