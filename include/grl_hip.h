@@ -9,7 +9,7 @@
  *     process-wide state, all initialised once under std::call_once or guarded explicitly: (1) the per-kernel
  *     "max dynamic LDS" function attributes (set once per process), (2) the optional event-timing records of grl_prof_*
  *     (measurement aid: NOT thread-safe, keep it off in multi-threaded hosts), (3) nothing else -- there is no cached device
- *     memory, no allocator and no stream owned by the library;
+ *     memory (but the 4 KB stamp buffer of grl_prof_enable(2)), no allocator and no stream owned by the library;
  *   - "partial" buffers are per-workgroup weight-gradient rows [n_rows][partial_size]; sum them with grl_reduce_partials.
  * The reference has no native ABI for this path (it is Python on PyG / torch_scatter / ITPAL); each group below cites the
  * reference code it replaces (paths relative to the reference checkout).
@@ -289,8 +289,12 @@ int grl_vecnorm_scratch_bytes(int K);
 int grl_knn_topology(const float* pos, const int* n_valid, int* out_nbr, int batch, int n_points, int k, hipStream_t stream);
 
 
-/* ---- measurement aid (no reference counterpart): HIP-event timing of the individual kernels inside multi-kernel entry points
- * (grl_edge_conv_bwd, grl_node_mlp_bwd), recorded on the launch stream. Off by default. */
+/* ---- measurement aid (no reference counterpart): timing of the individual kernels inside the entry points, recorded on the launch
+ * stream.  Off by default.  grl_prof_enable(1): HIP events around the kernels of the multi-kernel entry points (grl_edge_conv_bwd,
+ * grl_node_mlp_bwd).  grl_prof_enable(2): one-thread kernels that store the device wall clock in front of and behind the MFMA launches
+ * (edge forward / backward, node-MLP forward / backward) -- ordinary kernel nodes when the caller records the launches into a hipGraph, so
+ * grl_prof_get returns the duration of the LATEST execution, replays included (the only state the library allocates: one 4 KB device
+ * buffer, kept for the life of the process).  grl_prof_enable(0) clears the records. */
 int grl_prof_enable(int on);
 int grl_prof_count(void);
 int grl_prof_get(int i, char* name, int cap, float* ms);
