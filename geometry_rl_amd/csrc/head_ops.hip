@@ -509,17 +509,28 @@ __global__ __launch_bounds__(64) void trpl_fold_kernel(const double* __restrict_
   }
 }
 
-// sum and sum of squares of the advantages (fp64) -> stats[0..1]
-__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, double* __restrict__ stats, int B) {
+// sum and sum of squares of the advantages (fp64) ADDED to stats[0..1] -- ONE workgroup, fixed summation order (thread-strided partial sums,
+// wave butterflies, the sixteen waves in order): bitwise reproducible.  (Until round 3 every wave of a multi-workgroup grid added its sums
+// with fp64 atomics: the order of 64 additions, hence the last bits of the normalised advantages, depended on the run.)
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict__ adv, double* __restrict__ stats, int B) {
+  __shared__ double red[16][2];
   double s0 = 0, s1 = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+  for (int i = threadIdx.x; i < B; i += 1024) {
     const double a = adv[i];
     s0 += a;
     s1 += a * a;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(stats, s0); atomicAdd(stats + 1, s1); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s0; red[threadIdx.x >> 6][1] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = red[0][0], t1 = red[0][1];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { t0 += red[w][0]; t1 += red[w][1]; }
+    stats[0] += t0;
+    stats[1] += t1;
+  }
 }
 
 __global__ void loss_values_kernel(const double* __restrict__ sums, const unsigned int* __restrict__ maxes, float entropy_coef,
@@ -595,8 +606,7 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
 }
 
 int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(batch < 65536 ? (batch + 255) / 256 : 256), dim3(256), 0, stream, advantage, stats,
-                     batch);
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, stream, advantage, stats, batch);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -46,12 +46,37 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 }
 
 // clip coefficient of torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g||_2 + 1e-6))
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int n, double* __restrict__ out) {
+// ONE workgroup, fixed summation order (eight independent 16-byte loads in flight per thread, thread-strided partial sums, wave butterflies,
+// the sixteen waves in order): the squared norm -- and with it the clip coefficient -- is bitwise reproducible (until round 3: fp64 atomics
+// of up to 1 024 wave sums, in whatever order they arrived).  sqnorm[0] += the sum (the caller passes a zeroed slot).
+__global__ __launch_bounds__(1024) void sqnorm_kernel(const float* __restrict__ g, int n, double* __restrict__ out) {
+  __shared__ double red[16];
   double s = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += (double)g[i] * g[i];
+  // views of the flat gradient start anywhere: up to three leading elements, then 16-byte pieces, then the tail
+  int head = (int)(((16 - (reinterpret_cast<size_t>(g) & 15)) & 15) >> 2);
+  head = head < n ? head : n;
+  const int n4 = (n - head) / 4;
+  const float4* g4 = reinterpret_cast<const float4*>(g + head);
+  if ((int)threadIdx.x < head) s += (double)g[threadIdx.x] * g[threadIdx.x];
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * 1024) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; v[u] = g4[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * 1024 < n4) s += ((double)v[u].x * v[u].x + (double)v[u].y * v[u].y) + ((double)v[u].z * v[u].z + (double)v[u].w * v[u].w);
+  }
+  for (int i = head + 4 * n4 + threadIdx.x; i < n; i += 1024) s += (double)g[i] * g[i];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += red[w];
+    out[0] += t;
+  }
 }
 __global__ void clip_coef_kernel(const double* __restrict__ sq, float max_norm, float* __restrict__ coef) {
   const float nrm = (float)sqrt(sq[0]);
@@ -394,8 +419,7 @@ int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
 
 // sqnorm: device fp64[1] zeroed by the caller; coef: device float[1]
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream) {
-  const int blocks = (n + 255) / 256 < 256 ? (n + 255) / 256 : 256;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, stream, grads, n, sqnorm);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(1), dim3(1024), 0, stream, grads, n, sqnorm);
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sqnorm, max_norm, coef);
   GRL_CHECK_LAUNCH();
   return 0;
