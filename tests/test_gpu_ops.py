@@ -348,3 +348,27 @@ def test_readout_head(n):
     ((mean * Rm.to(d)).sum() + (sigma * Rs.to(d)).sum() + (hidden * Rh.to(d)).sum()).backward()
     for name, a, b in zip(["dlat", "dWd", "dbd", "dWs", "dbs"], dl, ref_leaves):
         check(name, a.grad, b.grad, 2e-4)
+
+
+def test_fixed_order_sums_are_repeatable():
+    """grl_adv_stats and grl_clip_coef: one workgroup, fixed summation order -- the fp64 sums match an fp64 reference and two launches give the
+    same BITS, on views of any alignment and length (the flat gradient is clipped per network: views that start anywhere)."""
+    from geometry_rl_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(300000, generator=g).to(d)
+    for lo, n in ((0, 149000), (1, 7), (3, 150001), (2, 1), (5, 280013), (0, 4), (7, 4096)):
+        v = base[lo:lo + n]
+        outs = []
+        for _ in range(2):
+            sq = torch.zeros(1, device=d, dtype=torch.float64)
+            coef = torch.empty(1, device=d)
+            hip.call("grl_clip_coef", v, n, 0.5, sq, coef)
+            st = torch.zeros(2, device=d, dtype=torch.float64)
+            hip.call("grl_adv_stats", v.contiguous(), st, n)
+            outs.append((float(sq), float(coef), float(st[0]), float(st[1])))
+        assert outs[0] == outs[1], (lo, n, outs)
+        ref2 = float((v.double() ** 2).sum())
+        assert abs(outs[0][0] - ref2) <= 1e-13 * ref2 and abs(outs[0][3] - ref2) <= 1e-13 * ref2, (lo, n)
+        assert abs(outs[0][2] - float(v.double().sum())) <= 1e-10 * max(1.0, n ** 0.5), (lo, n)
+        assert abs(outs[0][1] - min(1.0, 0.5 / (ref2 ** 0.5 + 1e-6))) <= 1e-6
