@@ -36,7 +36,13 @@ FLOPS_PER_ROW = {
 # Algorithmic HBM bytes per row of the same kernels with fp32 latents (bf16 latents: half): the row gathers of the edge
 # kernels (x_src | x_src + dM; the per-node stores, 256 B / in-degree, are left out) and the row streams of the node kernels
 BYTES_PER_ROW = {"edge_conv_fwd_kernel": 256, "edge_bwd16_kernel": 512, "node_mlp_fwd_kernel": 768, "node_mlp_bwd16_kernel": 768}
-ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel",   # (entry names are normalised: _bf16 / _balanced suffixes dropped) "grl_node_mlp_fwd": "node_mlp_fwd_kernel",
+# the second roofline convention (a backward pass is priced at 2 x its forward, no credit for the chain / z recompute the
+# fused kernels execute): `frac_alg_3xfwd` beside `frac` (= executed FLOPs) in the line and per kernel; forward kernels: the same figure
+FLOPS_PER_ROW_3XFWD = {"edge_conv_fwd_kernel": _CHAIN + 2 * 64, "edge_bwd16_kernel": 2 * (_CHAIN + 2 * 64),
+                       "node_mlp_fwd_kernel": 4 * 64 * 256, "node_mlp_bwd16_kernel": 2 * (4 * 64 * 256)}
+# (entry names are normalised before the lookup: _bf16 / _balanced / _img suffixes dropped)
+ENTRY_TO_KERNEL = {"grl_edge_conv_fwd": "edge_conv_fwd_kernel",
+                   "grl_node_mlp_fwd": "node_mlp_fwd_kernel",
                    "grl_node_mlp_bwd": "node_mlp_bwd16_kernel"}
 PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md:42 (the path is specified and checked in f32)
 PEAK_BF16X3 = 2500.0 / 3.0     # TFLOP/s of f32-equivalent products when each is three dense bf16 MFMAs (guide: ~2.5 PF dense)
@@ -358,7 +364,7 @@ def main():
             entry = hip.kernel_time_summary()
             inner = hip.kernel_prof_summary()   # the kernels inside grl_edge_conv_bwd / grl_node_mlp_bwd, one by one
             hip.kernel_prof_enable(False)
-            entry = {k.replace("_bf16", "").replace("_balanced", ""): v for k, v in entry.items()}
+            entry = {k.replace("_bf16", "").replace("_balanced", "").replace("_img", ""): v for k, v in entry.items()}
             rec = {ENTRY_TO_KERNEL.get(k, k): v for k, v in entry.items() if k != "grl_edge_conv_bwd"}
             rec.update(inner)
             per_step.append(rec)
@@ -371,7 +377,7 @@ def main():
                    "edge_conv_bwd_w_kernel": "grl_edge_conv_bwd", "edge_bwd16_kernel": "grl_edge_conv_bwd",
                    "node_mlp_fwd_kernel": "grl_node_mlp_fwd",
                    "node_mlp_bwd16_kernel": "grl_node_mlp_bwd"}
-        rows_step = {k.replace("_bf16", "").replace("_balanced", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
+        rows_step = {k.replace("_bf16", "").replace("_balanced", "").replace("_img", ""): v for k, v in hip.KERNEL_ROWS.items()}   # rows handed to each entry point (last profiled step)
         pipe_peak = 2500.0 if cfg.precision == "bf16" else PEAK_BF16X3
         kernels = {}
         for k, fl in FLOPS_PER_ROW.items():
@@ -383,7 +389,12 @@ def main():
             gbs = BYTES_PER_ROW.get(k, 0) * (0.5 if cfg.precision == "bf16" else 1.0) * rows_step[rows_of[k]] / (ms_step * 1e-3) / 1e9
             kernels[k] = {"launches_per_step": launches, "avg_launch_ms": ms_step / launches, "ms_per_step": ms_step,
                           "rows_per_step": rows_step[rows_of[k]], "gflop_per_launch": flops_step / launches / 1e9, "achieved": ach,
-                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / pipe_peak, "alg_gbyte_per_s": gbs, "frac_of_hbm": gbs / 8000.0}
+                          "frac": ach / PEAK_F32_MFMA, "frac_of_bf16x3": ach / pipe_peak, "alg_gbyte_per_s": gbs, "frac_of_hbm": gbs / 8000.0,
+                          "frac_alg_3xfwd": ach / pipe_peak * FLOPS_PER_ROW_3XFWD.get(k, fl) / fl}
+        # every MFMA kernel the profiled step ran must have been priced (a mapping lost in the literal above dropped
+        # node_mlp_fwd_kernel silently out of `mfma_kernels` and out of the choice of the dominant kernel)
+        lost = [k for k in summ if k in ("grl_edge_conv_fwd", "grl_node_mlp_fwd", "grl_node_mlp_bwd", "grl_edge_conv_bwd")]
+        assert not lost and all(k in kernels for k in FLOPS_PER_ROW if k in summ), ("unpriced MFMA kernels", lost, sorted(summ))
         # The same MFMA launches as the TIMED region runs them -- replayed from the recorded hipGraph: the step is recorded once more with
         # wall-clock stamp kernels in front of and behind those launches (in-library, grl_prof_enable(2); ordinary kernel nodes, re-run by
         # every replay) and the stamps of 8 replays are read back.  Reported beside the HIP-event figures, which stay the line's `frac`.
@@ -467,7 +478,11 @@ def main():
             head = {"bound": "hbm", "kernel": name, "achieved": d["alg_gbyte_per_s"], "peak": 8000.0, "unit": "GB/s", "frac": d["frac_of_hbm"],
                     "mfma_frac_of_bf16_pipe": d["frac_of_bf16x3"]}
         else:
-            head = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": pipe_peak, "unit": "TFLOP/s", "frac": d["frac_of_bf16x3"]}
+            head = {"bound": "mfma", "kernel": name, "achieved": d["achieved"], "peak": pipe_peak, "unit": "TFLOP/s", "frac": d["frac_of_bf16x3"],
+                    "frac_alg_3xfwd": d["frac_alg_3xfwd"],
+                    "frac_note": "frac = EXECUTED algorithmic FLOPs (the fused backward's one chain recompute included: 52 992 per edge-row) / "
+                                 "launch time / peak; frac_alg_3xfwd = the same launch priced by SURVEY.md 8(d)'s rule (backward = 2 x forward = "
+                                 "36 608 per edge-row, no recompute credit)"}
         roof = {**head, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],

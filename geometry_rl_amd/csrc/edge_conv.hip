@@ -12,6 +12,7 @@
 // The next pass's indices / positions and this pass's x_src rows are requested before the MFMA chain starts, so the gather
 // latency hides behind it.
 #include "grl_common.h"
+#include "grl_wimg.h"
 #include <type_traits>
 #define GRL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 
@@ -22,8 +23,8 @@ constexpr int O = 16;            // orientations
 constexpr int TD = 2;            // destination nodes per wave tile (forward)
 constexpr int LDT = C + 4;       // padded row of an LDS activation tile
 constexpr int LDW = GRL_LD(64);  // 68   fp32 images (backward: column reads)
-constexpr int LDB = GRL_LDB(64); // 72   split-bf16 images (chain)
-constexpr int LDB1 = GRL_LDB(16);// 24
+constexpr int LDB = WI_LDB;      // 72   split-bf16 images (chain): ChainW, grl_wimg.h
+constexpr int LDB1 = WI_LDB1;    // 24
 
 struct EdgeParams {
   const st_t* x_src;     // [Ns,16,64] (storage type: grl_common.h)
@@ -45,6 +46,7 @@ struct EdgeParams {
   // tensor for the i-th edge of THEIR order (erow == nullptr: row i, i.e. the kernel walks the destination-sorted order itself).
   const int* erow = nullptr;
   int per_edge = 0;
+  const void* wimg = nullptr;   // optional pre-split ChainW image of this forward pass (grl_weight_images, kind WIMG_EDGE32)
 };
 
 // Polynomial features of (a, b) in the reference order (ponita.py:233-244):
@@ -64,15 +66,7 @@ GRL_DEVINL void poly_frags(float a, float b, int h, float4& f0, float4& f1) {
 
 // One pass of the chain for this lane's row.  Returns the kernel fragments K (8 float4); optionally keeps the
 // pre-activation derivatives for the backward pass.
-// Weight images of the chain in LDS: bf16 hi/lo rows (grl_common.h "split-bf16 MFMA path")
-struct ChainW {
-  unsigned short W1h[64 * LDB1], W1l[64 * LDB1];
-  unsigned short W2h[64 * LDB], W2l[64 * LDB];
-  unsigned short Wkh[64 * LDB], Wkl[64 * LDB];
-  float b1s[64];
-  float b2s[64];
-  float grid_s[64];
-};
+// Weight images of the chain in LDS: bf16 hi/lo rows (grl_common.h "split-bf16 MFMA path"): struct ChainW, grl_wimg.h
 
 // Split-bf16 fragments of the chain's activations (rows on the lanes): the B operands of the next layer and, in the backward,
 // the inputs of the register-level transposes for the row-reduction products.
@@ -241,6 +235,10 @@ struct BwdW {
 };
 
 GRL_DEVINL void load_chain_weights(ChainW& s, const EdgeParams& p) {
+  if (p.wimg) {   // built once per forward pass by grl_weight_images: a linear copy
+    copy_image<256>(&s, p.wimg, (int)sizeof(ChainW));
+    return;
+  }
   stage_split<64, 16, 14, 256>(s.W1h, s.W1l, p.W1, LDB1);
   stage_split<64, 64, 64, 256>(s.W2h, s.W2l, p.W2, LDB);
   stage_split<64, 64, 64, 256>(s.Wkh, s.Wkl, p.Wk, LDB);
@@ -305,6 +303,7 @@ GRL_DEVINL void meta_invariants(const EdgeParams& p, const float* grid_s, int o,
 #define GRL_FWD_WAVES 4
 #endif
 constexpr int FWD_WAVES = GRL_FWD_WAVES;
+static_assert(FWD_WAVES >= 4, "load_chain_weights copies a pre-split image with 256 threads");
 #ifndef GRL_FWD_SPLIT_TILES
 #define GRL_FWD_SPLIT_TILES 512   // at most this many destination tiles: one workgroup per tile (edge_conv_fwd_kernel<true>)
 #endif
@@ -754,6 +753,20 @@ __global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, c
 extern "C" {
 
 #if !GRL_PREC   // shape queries: shared by both precision builds of this file
+// launch shape of the forward for n_dst destination nodes (host-side partitioning, ops.build_edge_set): the image kind its kernel copies
+// (grl_weight_images: 1 = the one-workgroup-per-tile 32-row kernel of small launches, 0 = the 16-row kernel), the wave slots a balanced
+// partition has to cover (0: the launch ignores partitions) and the nodes per round-robin chunk
+int grl_edge_fwd_image_kind(int n_dst) { return (n_dst + TD - 1) / TD <= GRL_FWD_SPLIT_TILES ? 1 : 0; }
+int grl_edge_fwd_chunk_nodes(int n_dst);   // edge_conv16.hip
+int grl_edge_bwd_chunk_nodes(int n_src);
+int grl_edge_fwd_slots(int n_dst) {
+  if ((n_dst + TD - 1) / TD <= GRL_FWD_SPLIT_TILES) return 0;
+  const int npw = grl_edge_fwd_chunk_nodes(n_dst), chunks = (n_dst + npw - 1) / npw;
+  int blocks = (chunks + 3) / 4;
+  const int cap = grl_edge_fwd_chunk_nodes(-1);   // (-1: the grid cap, workgroups)
+  if (blocks > cap) blocks = cap;
+  return 4 * blocks;
+}
 int grl_edge_partial_size() { return EDGE_PARTIAL; }
 int grl_edge_bwd_blocks(int n_edges) {
   const int b = ((n_edges + 1) / 2 + 3) / 4;
@@ -770,7 +783,8 @@ int grl_edge_bwd_blocks(int n_edges);
 int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                  const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                                 const float* Wk, st_t* out, const st_t* dres, const int* split, int n_slots, hipStream_t stream);
+                                 const float* Wk, st_t* out, const st_t* dres, const int* split, int n_slots, const void* wimg,
+                                 hipStream_t stream);
 
 // fused 16-row backward (edge_conv16.hip edge_bwd16_kernel): d x_src and the weight gradients in one launch, one chain recompute
 #ifndef GRL_EDGE_BWD16
@@ -780,24 +794,29 @@ int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const 
                                      const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
                                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                                      const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, const int* split,
-                                     hipStream_t stream);
+                                     const void* wimg, hipStream_t stream);
 
 // grl_edge_conv_fwd_balanced: the same with split_d [n_slots + 1] (n_slots = a multiple of 4, at most 3072): node boundaries of an
 // in-edge-balanced partition of the destination-sorted CSR over the launch's wave slots; NULL = round-robin chunks.
+// wimg16 / wimg32: optional pre-split weight images of this forward pass (grl_weight_images kinds 0 / 1; the launch takes the one its
+// kernel needs -- grl_edge_fwd_image_kind(n_dst) -- and stages the weights itself when that one is NULL).
 int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
-                      const float* W2, const float* b2, const float* Wk, st_t* x1, const int* split_d, int n_slots, hipStream_t stream);
+                      const float* W2, const float* b2, const float* Wk, st_t* x1, const int* split_d, int n_slots, const void* wimg16,
+                      const void* wimg32, hipStream_t stream);
 int GRL_ENTRY(grl_edge_conv_fwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, st_t* x1, hipStream_t stream) {
   return GRL_ENTRY(grl_edge_conv_fwd_balanced)(x_src, pos_src, pos_dst, rowptr, e_src, e_dst, n_dst, grid, dim, W1, b1, W2, b2, Wk, x1, nullptr,
-                                               0, stream);
+                                               0, nullptr, nullptr, stream);
 }
 int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
-                      const float* W2, const float* b2, const float* Wk, st_t* x1, const int* split_d, int n_slots, hipStream_t stream) {
+                      const float* W2, const float* b2, const float* Wk, st_t* x1, const int* split_d, int n_slots, const void* wimg16,
+                      const void* wimg32, hipStream_t stream) {
   if (n_dst <= 0) return 0;
   EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
+  p.wimg = wimg32;
   const int n_tiles = (n_dst + TD - 1) / TD;
   const size_t smem = sizeof(ChainW), smem_split = smem + sizeof(float4) * FWD_WAVES * 8 * 64;
   GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_split));
@@ -821,7 +840,7 @@ int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_sr
   (void)smem;
   grl_prof_begin_replay("edge_conv_fwd_kernel", stream);
   const int rc16 = GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2,
-                                                b2, Wk, x1, nullptr, split_d, n_slots, stream);
+                                                b2, Wk, x1, nullptr, split_d, n_slots, wimg16, stream);
   grl_prof_end_replay(stream);
   return rc16;
 }
@@ -830,25 +849,28 @@ int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_sr
 // source-sorted (rowptr_s [n_src+1], src_s [E], dst_s [E]) for the d x_src kernel.  dx_src [n_src,16,64] is fully overwritten:
 // dx_src = (dres ? dres : 0) + sum over out-edges; dres [n_src,16,64] = gradient of another use of x_src (the residual branch), or NULL.
 // partial must hold grl_edge_bwd_blocks(n_edges) rows of grl_edge_partial_size() floats.
-// grl_edge_conv_bwd_balanced: the same with ``split_s`` [4 * grl_edge_bwd_blocks(n_edges) + 1] -- node boundaries of an edge-balanced
-// partition of the source-sorted CSR over the launch's wave slots (split_s[0] = 0, split_s[last] = n_src, non-decreasing); NULL = none.
+// grl_edge_conv_bwd_balanced: the same with ``split_s`` [n_slots_s + 1], n_slots_s = 4 * grl_edge_bwd_blocks(n_edges) -- node boundaries of
+// an edge-balanced partition of the source-sorted CSR over the launch's wave slots (split_s[0] = 0, split_s[last] = n_src, non-decreasing);
+// NULL = none; an array built for another slot count is IGNORED (round-robin chunks), never read past its end.
+// wimg16: optional Edge16Image of this step's weights (grl_weight_images kind 0); NULL = the kernel stages the five images itself.
 int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, const int* split_s,
-                      hipStream_t stream);
+                      int n_slots_s, const void* wimg16, hipStream_t stream);
 int GRL_ENTRY(grl_edge_conv_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, hipStream_t stream) {
   return GRL_ENTRY(grl_edge_conv_bwd_balanced)(x_src, pos_src, pos_dst, rowptr, e_src, e_dst, n_dst, n_edges, rowptr_s, src_s, dst_s, n_src,
-                                               grid, dim, W1, b1, W2, b2, Wk, dx1, dres, dx_src, partial, nullptr, stream);
+                                               grid, dim, W1, b1, W2, b2, Wk, dx1, dres, dx_src, partial, nullptr, 0, nullptr, stream);
 }
 int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s, int n_src,
                       const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                       const float* Wk, const st_t* dx1, const st_t* dres, st_t* dx_src, float* partial, const int* split_s,
-                      hipStream_t stream) {
+                      int n_slots_s, const void* wimg16, hipStream_t stream) {
+  if (split_s && n_slots_s != 4 * grl_edge_bwd_blocks(n_edges)) split_s = nullptr;   // built for another launch shape: not usable
   if (n_edges <= 0) {   // an empty edge set: d x_src is the residual branch alone, the weight gradients are zero (the caller sums
     if (n_src > 0) {    // grl_edge_bwd_blocks(n_edges) partial rows: they must hold zeros, not whatever the allocation held)
       if (dres) hipMemcpyAsync(dx_src, dres, sizeof(st_t) * (size_t)n_src * O * C, hipMemcpyDeviceToDevice, stream);
@@ -869,7 +891,7 @@ int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_sr
     grl_prof_begin("edge_conv_bwd_x_kernel", stream);
     if (GRL_EDGE16) {
       GRL_ENTRY(grl_edge16_launch)(1, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2,
-                                   Wk, dx_src, dres, nullptr, 0, stream);
+                                   Wk, dx_src, dres, nullptr, 0, nullptr, stream);
     } else {
       const int n_tiles_s = (n_src + TD - 1) / TD;
       int xblocks = (n_tiles_s + 3) / 4;
@@ -888,7 +910,7 @@ int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_sr
   (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;   // the destination-sorted view is the legacy weight kernel's
   grl_prof_begin("edge_bwd16_kernel", stream);
   const int rc = GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, grid, dim,
-                                                  W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, split_s, stream);
+                                                  W1, b1, W2, b2, Wk, dres, dx_src, partial, blocks, split_s, wimg16, stream);
   grl_prof_end(stream);
   return rc;
 }
@@ -913,7 +935,7 @@ int GRL_ENTRY(grl_edge_messages_fwd)(const st_t* x_src, const float* pos_src, co
   }
 #endif
   return GRL_ENTRY(grl_edge16_launch)(2, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, n_edges, 1, grid, dim, W1, b1,
-                                      W2, b2, Wk, msg, nullptr, nullptr, 0, stream);
+                                      W2, b2, Wk, msg, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
@@ -946,7 +968,7 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
     if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
     if (GRL_EDGE16)
       GRL_ENTRY(grl_edge16_launch)(1, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2, Wk,
-                                   dx_src, dres, nullptr, 0, stream);
+                                   dx_src, dres, nullptr, 0, nullptr, stream);
     else
       hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
     GRL_CHECK_LAUNCH();
@@ -957,7 +979,7 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
 #endif
   (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;
   return GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, grid, dim, W1, b1,
-                                          W2, b2, Wk, dres, dx_src, partial, blocks, nullptr, stream);
+                                          W2, b2, Wk, dres, dx_src, partial, blocks, nullptr, nullptr, stream);
 }
 
 #if defined(GRL_PHASE_PROF) && !GRL_PREC

@@ -21,6 +21,7 @@
 // in registers exactly as in the 32-row kernels.  Three waves per SIMD: every MFMA group is fenced (all fragment loads, then the
 // MFMAs, then a read of the accumulator: DESIGN.md finding 3).
 #include "grl_tile16.h"
+#include "grl_wimg.h"
 #include <cstdlib>
 
 namespace {
@@ -34,39 +35,7 @@ constexpr int C = 64, O = 16;
 #define GRL_E16_WGS 3                    // workgroups per CU the register budget is cut for (and the grid is capped at)
 #endif
 constexpr int E16_WAVES = GRL_E16_WAVES, E16_THREADS = 64 * E16_WAVES;
-#ifndef GRL_LD1
-#define GRL_LD1 40
-#endif
-constexpr int LD1 = GRL_LD1;  // bf16 elements per image row, layer 1 (K = 14 padded to one 32-deep step): 40 (80-B rows) is 2-way conflicted for
-                              // the ds_read_b128 lane groups, 48 (96-B rows) conflict-free (tools: the bank model of MI355X_MICROARCH.md)
-constexpr int LD2 = 64 + 16;  // layers 2 and 3: 160-B rows put the 16 lanes of every ds_read_b128 group on disjoint banks (72: 2-way)
-struct ChainW16 {
-  unsigned short W1h[64 * LD1], W1l[64 * LD1];
-  unsigned short W2h[64 * LD2], W2l[64 * LD2];
-  unsigned short Wkh[64 * LD2], Wkl[64 * LD2];
-  float b1s[64], b2s[64], grid_s[64];
-};
-
-// image[n][32 s + 8 g + j] = W[n][32 s + 16 (j >> 2) + 4 g + (j & 3)]   (zero beyond KSRC); one (n, s, g) item per thread and step:
-// two 16-byte global loads (when aligned), one 16-byte LDS store per image
-//   TRANS: the image of W^T (row n of the image = column n of W [64,64]): the backward chain's dg = dZ W products
-template <int KSRC, int KPAD, int NT, bool TRANS = false>
-GRL_DEVINL void stage16(unsigned short* hi, unsigned short* lo, const float* __restrict__ W, int ld) {
-  constexpr int ITEMS = 64 * (KPAD / 32) * 4;
-  for (int idx = threadIdx.x; idx < ITEMS; idx += NT) {
-    const int g = idx & 3, s = (idx >> 2) % (KPAD / 32), n = idx / (4 * (KPAD / 32));
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int f = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
-      v[j] = f < KSRC ? (TRANS ? W[f * 64 + n] : W[n * KSRC + f]) : 0.f;
-    }
-    bf16x8 h, l;
-    split_pair(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, l);
-    *reinterpret_cast<bf16x8*>(hi + n * ld + 32 * s + 8 * g) = h;
-    GRL_LO(*reinterpret_cast<bf16x8*>(lo + n * ld + 32 * s + 8 * g) = l;)
-  }
-}
+constexpr int LD1 = WI_LD1, LD2 = WI_LD2;   // image row lengths, ChainW16 / Edge16Image, stage16: grl_wimg.h (shared with the image producer)
 
 struct Edge16Params {
   const st_t* x_in;       // rows gathered per edge: x_src [Ns,16,64] (forward / messages) or dx1 [Nd or E,16,64] (d x_src kernel)
@@ -82,20 +51,21 @@ struct Edge16Params {
   int per_edge;           // 1: x_in rows are per edge (erow or the edge's own position)
   int npw;                // anchor nodes per wave chunk, 1..16 (host: as large as still leaves every wave slot several chunks)
   const int* split;       // optional [4 gridDim.x + 1] (forward only): wave slot s walks the anchor nodes split[s] .. split[s + 1]
+  const void* wimg;       // optional pre-split image (grl_weight_images: a ChainW16 for the forward kernels, an Edge16Image for the backward)
 };
 
 GRL_DEVINL void load_w16(ChainW16& s, const Edge16Params& p) {
 #ifdef GRL_KNOCK_STAGE   // timing knock-out: no weight staging (results are wrong)
   return;
 #endif
+  if (p.wimg) {   // the image of this forward pass (built once per step): a linear copy
+    copy_image<E16_THREADS>(&s, p.wimg, (int)sizeof(ChainW16));
+    return;
+  }
   stage16<14, 32, E16_THREADS>(s.W1h, s.W1l, p.W1, LD1);
   stage16<64, 64, E16_THREADS>(s.W2h, s.W2l, p.W2, LD2);
   stage16<64, 64, E16_THREADS>(s.Wkh, s.Wkl, p.Wk, LD2);
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
-    s.b1s[i] = p.b1[i];
-    s.b2s[i] = p.b2[i];
-    s.grid_s[i] = i < 48 ? p.grid[i] : 0.f;
-  }
+  stage_chain16_small<E16_THREADS>(s, p.b1, p.b2, p.grid);
 }
 
 // one fenced group: acc(16 features of n-tile nt x 16 rows) = init + sum over KS K-steps of W-tile . X, split-bf16
@@ -413,9 +383,7 @@ struct Stage16 {
   unsigned short Bh[STG], Bl[STG];   // B side: g2 / g1 / phi
 };
 struct Bwd16Smem {
-  ChainW16 w;
-  unsigned short WkTh[64 * LD2], WkTl[64 * LD2];
-  unsigned short W2Th[64 * LD2], W2Tl[64 * LD2];
+  Edge16Image img;   // chain images + the two transposes (grl_wimg.h)
   Stage16 st[4];
 };
 constexpr int BWD16_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;   // = EDGE_PARTIAL of edge_conv.hip
@@ -497,17 +465,19 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   Bwd16Smem& sm = *reinterpret_cast<Bwd16Smem*>(smem_raw);
   const Edge16Params& p = bp.e;
 #ifndef GRL_KNOCK_STAGE
-  stage16<14, 32, 256>(sm.w.W1h, sm.w.W1l, p.W1, LD1);
-  stage16<64, 64, 256>(sm.w.W2h, sm.w.W2l, p.W2, LD2);
-  stage16<64, 64, 256>(sm.w.Wkh, sm.w.Wkl, p.Wk, LD2);
-  stage16<64, 64, 256, true>(sm.WkTh, sm.WkTl, p.Wk, LD2);
-  stage16<64, 64, 256, true>(sm.W2Th, sm.W2Tl, p.W2, LD2);
-#endif
-  for (int i = threadIdx.x; i < 64; i += 256) {
-    sm.w.b1s[i] = p.b1[i];
-    sm.w.b2s[i] = p.b2[i];
-    sm.w.grid_s[i] = i < 48 ? p.grid[i] : 0.f;
+  if (p.wimg) {   // the five images of this step, built once by grl_weight_images: a linear copy (91 KB, 23 16-byte loads per thread)
+    copy_image<256>(&sm.img, p.wimg, (int)sizeof(Edge16Image));
+  } else {
+    stage16<14, 32, 256>(sm.img.w.W1h, sm.img.w.W1l, p.W1, LD1);
+    stage16<64, 64, 256>(sm.img.w.W2h, sm.img.w.W2l, p.W2, LD2);
+    stage16<64, 64, 256>(sm.img.w.Wkh, sm.img.w.Wkl, p.Wk, LD2);
+    stage16<64, 64, 256, true>(sm.img.WkTh, sm.img.WkTl, p.Wk, LD2);
+    stage16<64, 64, 256, true>(sm.img.W2Th, sm.img.W2Tl, p.W2, LD2);
+    stage_chain16_small<256>(sm.img.w, p.b1, p.b2, p.grid);
   }
+#else
+  stage_chain16_small<256>(sm.img.w, p.b1, p.b2, p.grid);
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   Stage16& st = sm.st[wave];
   for (int i = lane; i < STG / 2; i += 64) {
@@ -515,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
     reinterpret_cast<unsigned*>(st.Bh)[i] = 0u; reinterpret_cast<unsigned*>(st.Bl)[i] = 0u;
   }
   __syncthreads();
-  const ChainW16& w = sm.w;
+  const ChainW16& w = sm.img.w;
   const float gx = w.grid_s[3 * r], gy = w.grid_s[3 * r + 1], gz = w.grid_s[3 * r + 2];
   const bool g0 = g == 0, g1_ = g == 1, g2_ = g == 2;
 
@@ -673,8 +643,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         // MFMAs of group k + 1 and the epilogue (GELU / products) of group k -- loads a group ahead, matrix pipe beside the vector work.
         // The sixteen 64-deep groups, in order: W2 (4), Wk (4), Wk^T (4), W2^T (4).
 #define BAR() __builtin_amdgcn_sched_barrier(0)
-        auto wptr_h = [&](int i) { const unsigned short* m = i < 4 ? w.W2h : i < 8 ? w.Wkh : i < 12 ? sm.WkTh : sm.W2Th; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
-        auto wptr_l = [&](int i) { const unsigned short* m = i < 4 ? w.W2l : i < 8 ? w.Wkl : i < 12 ? sm.WkTl : sm.W2Tl; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
+        auto wptr_h = [&](int i) { const unsigned short* m = i < 4 ? w.W2h : i < 8 ? w.Wkh : i < 12 ? sm.img.WkTh : sm.img.W2Th; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
+        auto wptr_l = [&](int i) { const unsigned short* m = i < 4 ? w.W2l : i < 8 ? w.Wkl : i < 12 ? sm.img.WkTl : sm.img.W2Tl; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
         // a 64-deep layer: groups base .. base + 3 (wf[base & 1] already requested); epi(nt, c) consumes tile nt one region later
         auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
           f32x4v c[4];
@@ -858,21 +828,37 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 
 extern "C" {
 
+#if !GRL_PREC   // launch-shape queries (host-side partitioning): the constants live here, ops.build_edge_set asks instead of copying them
+static_assert(E16_WAVES == 4, "grl_edge_fwd_slots (edge_conv.hip) counts four wave slots per workgroup");
+int grl_edge_fwd_chunk_nodes(int n_dst) {   // nodes per round-robin chunk of the forward; n_dst < 0: the grid cap in workgroups
+  if (n_dst < 0) return 256 * GRL_E16_WGS;
+  const int npw = n_dst / (4 * 256 * E16_WAVES * GRL_E16_WGS);
+  return npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
+}
+int grl_edge_bwd_chunk_nodes(int n_src) {
+  const int npw = n_src / (4 * 1024);            // ~4 chunks per wave (256 CUs x 4 waves)
+  return npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
+}
+#else
+int grl_edge_fwd_chunk_nodes(int n_dst);
+int grl_edge_bwd_chunk_nodes(int n_src);
+#endif
+
 // Internal entry points used by edge_conv.hip's C-ABI functions when the 16-row kernels are selected (GRL_EDGE16).
 int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                  const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
-                                 const float* Wk, st_t* out, const st_t* dres, const int* split, int n_slots, hipStream_t stream) {
+                                 const float* Wk, st_t* out, const st_t* dres, const int* split, int n_slots, const void* wimg,
+                                 hipStream_t stream) {
   if (n_anchor <= 0) return 0;
   // chunks: at least ~4 per wave slot of the chip (256 CUs x 12 waves) while the graph allows it
-  int npw = n_anchor / (4 * 256 * E16_WAVES * GRL_E16_WGS);
-  npw = npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
+  int npw = grl_edge_fwd_chunk_nodes(n_anchor);
 #ifdef GRL_E16_TUNE
   static const int env_npw = getenv("GRL_E16_NPW") ? atoi(getenv("GRL_E16_NPW")) : 0;
   if (env_npw > 0) npw = env_npw;
 #endif
   Edge16Params p{x_in, pos_src, pos_dst, rowptr, e_src, e_dst, erow, grid, W1, b1, W2, b2, Wk, n_anchor, n_edges, dim, anchor_is_dst,
-                 per_edge, npw, (mode == 0 && split && n_slots >= E16_WAVES && n_slots % E16_WAVES == 0) ? split : nullptr};
+                 per_edge, npw, (mode == 0 && split && n_slots >= E16_WAVES && n_slots % E16_WAVES == 0) ? split : nullptr, wimg};
   const int n_chunks = (n_anchor + npw - 1) / npw;
   int blocks = p.split ? n_slots / E16_WAVES : (n_chunks + E16_WAVES - 1) / E16_WAVES;
   int cap = 256 * GRL_E16_WGS;
@@ -905,10 +891,10 @@ int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const 
                                      const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
                                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
                                      const float* Wk, const st_t* dres, st_t* dx_src, float* partial, int blocks, const int* split,
-                                     hipStream_t stream) {
-  int npw = n_src / (4 * 1024);            // ~4 chunks per wave (256 CUs x 4 waves)
-  npw = npw < 1 ? 1 : (npw > NPW_MAX ? NPW_MAX : npw);
-  Bwd16Params bp{{dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, erow, grid, W1, b1, W2, b2, Wk, n_src, n_edges, dim, 0, per_edge, npw},
+                                     const void* wimg, hipStream_t stream) {
+  const int npw = grl_edge_bwd_chunk_nodes(n_src);
+  Bwd16Params bp{{dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, erow, grid, W1, b1, W2, b2, Wk, n_src, n_edges, dim, 0, per_edge, npw,
+                  nullptr, wimg},
                  x_src, dres, dx_src, partial, split};
   // one wave per SIMD is a precondition of the unfenced MFMA groups of this kernel (DESIGN.md finding 3): more than half the LDS per
   // workgroup makes a second workgroup on the CU impossible, whatever the register allocation of a future compiler

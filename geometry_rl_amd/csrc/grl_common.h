@@ -12,6 +12,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- diagnostic switches that produce WRONG RESULTS (timing knock-outs: a part of a kernel removed to see what it costs) ------------
+// They compile only together with -DGRL_DIAG, and a GRL_DIAG object exports `grl_diag_build`: geometry_rl_amd/hip.py refuses to build
+// such flags into libgrl_hip.so and refuses to load a library that exports the symbol as the product library (tools/build_variants.sh
+// builds them under _variants/, bench.py loads those only with GRL_ALLOW_DIAG_LIB=1).  One mis-set flag can no longer ship a wrong kernel.
+#if defined(GRL_KNOCK_MFMA) || defined(GRL_KNOCK_STAGE) || defined(GRL_E16_NOLDS) || defined(GRL_E16_NOGELU) || defined(GRL_E16_NOGATHER) || \
+    defined(GRL_E16_LDSONLY) || defined(GRL_E16_NOMFMA) || defined(GRL_B16_NOROWMMA) || defined(GRL_B16_NOGELU) || defined(GRL_B16_NOGATHER) || \
+    defined(GRL_MLPB_NOMFMA) || defined(GRL_MLPB_NOGELU) || defined(GRL_MLPB_NOBARRIER) || defined(GRL_M16_KNOCK) || \
+    (defined(GRL_FENCED_2W) && !(GRL_FENCED_2W))   /* only a command-line definition is visible here */
+#ifndef GRL_DIAG
+#error "timing knock-out switches produce wrong results: they need -DGRL_DIAG (and can then not be linked into the product library)"
+#endif
+#endif
+#ifdef GRL_DIAG
+extern "C" __attribute__((weak, visibility("default"))) int grl_diag_build() { return 1; }
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GRL_DEVINL __device__ __forceinline__

@@ -8,6 +8,7 @@
 #define GRL_KNOCK_MFMA
 #endif
 #include "grl_common.h"
+#include "grl_wimg.h"
 #ifdef GRL_MLPB_NOBARRIER   // timing knock-out: the chunk loop of the fused backward without its barriers (results are wrong)
 #define MLPB_SYNC()
 #else
@@ -24,17 +25,9 @@ namespace {
 #endif
 constexpr int C = 64, O = 16, W = 256;
 constexpr float LN_EPS = 1e-5f;
-// split-bf16 weight images for the forward kernel (same bytes as the fp32 image)
-constexpr int LB3 = GRL_LDB(64);   // 72
-constexpr int LB4 = GRL_LDB(256);  // 264
-struct MlpSmemBf {
-  unsigned short W3h[W * LB3], W3l[W * LB3];
-  unsigned short W4h[C * LB4], W4l[C * LB4];
-  float b3s[W];
-  float b4s[C];
-  float gam[C];
-  float bet[C];
-};
+// split-bf16 weight images for the forward kernel: struct MlpSmemBf (grl_wimg.h, shared with the image producer)
+constexpr int LB3 = WI_LB3;   // 72
+constexpr int LB4 = WI_LB4;   // 264
 
 GRL_DEVINL float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
@@ -72,15 +65,19 @@ GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
 __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restrict__ x2, const st_t* __restrict__ x_dst,
                                                            const float* W3, const float* b3, const float* W4, const float* b4,
                                                            const float* gam, const float* bet, st_t* __restrict__ out,
-                                                           int n_rows, int accumulate) {
+                                                           int n_rows, int accumulate, const void* __restrict__ wimg) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   MlpSmemBf& s = *reinterpret_cast<MlpSmemBf*>(smem_raw);
+  if (wimg) {   // the whole struct, built once per forward pass by grl_weight_images (kind 2): a linear copy
+    copy_image<512>(&s, wimg, (int)sizeof(MlpSmemBf));
+  } else {
 #ifndef GRL_KNOCK_STAGE   // (timing knock-out: no weight staging; results are wrong)
-  stage_split<W, C, C, 512>(s.W3h, s.W3l, W3, LB3);
-  stage_split<C, W, W, 512>(s.W4h, s.W4l, W4, LB4);
+    stage_split<W, C, C, 512>(s.W3h, s.W3l, W3, LB3);
+    stage_split<C, W, W, 512>(s.W4h, s.W4l, W4, LB4);
 #endif
-  for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) { s.b4s[i] = b4[i]; s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
+    for (int i = threadIdx.x; i < W; i += blockDim.x) s.b3s[i] = b3[i];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) { s.b4s[i] = b4[i]; s.gam[i] = gam[i]; s.bet[i] = bet[i]; }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int n_tiles = (n_rows + 31) >> 5;
@@ -660,17 +657,22 @@ int grl_node_mlp_bwd_blocks(int n_rows) { return blocks_for(n_rows, 32, 256); }
 int grl_node_mlp_bwd_blocks(int n_rows);
 #endif
 
-// rows = n_nodes*16.  out = (accumulate ? out : 0) + x_dst + MLP(LN(x2))
-int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
-                     const float* gamma, const float* beta, st_t* out, int n_rows, int accumulate, hipStream_t stream) {
+// rows = n_nodes*16.  out = (accumulate ? out : 0) + x_dst + MLP(LN(x2)).  grl_node_mlp_fwd_img: the same with an optional pre-split
+// weight image of this forward pass (grl_weight_images kind 2; NULL = the kernel stages W3 / W4 itself)
+int GRL_ENTRY(grl_node_mlp_fwd_img)(const st_t* x2, const st_t* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, st_t* out, int n_rows, int accumulate, const void* wimg, hipStream_t stream) {
   if (n_rows <= 0) return 0;
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
   grl_prof_begin_replay("node_mlp_fwd_kernel", stream);
   hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
-                     W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate);
+                     W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate, wimg);
   grl_prof_end_replay(stream);
   GRL_CHECK_LAUNCH();
   return 0;
+}
+int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, st_t* out, int n_rows, int accumulate, hipStream_t stream) {
+  return GRL_ENTRY(grl_node_mlp_fwd_img)(x2, x_dst, W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate, nullptr, stream);
 }
 
 // partial [grl_node_mlp_bwd_blocks(n_rows) + 1][grl_node_mlp_partial_size()]: one gradient row per workgroup, and the LAST row is scratch
@@ -680,9 +682,16 @@ int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* 
 #endif
 int GRL_ENTRY(grl_node_mlp_bwd16_launch)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4,
                                          const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, int blocks,
-                                         hipStream_t stream);
+                                         const void* wimg, hipStream_t stream);
+int GRL_ENTRY(grl_node_mlp_bwd_img)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, const void* wimg, hipStream_t stream);
 int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, hipStream_t stream) {
+  return GRL_ENTRY(grl_node_mlp_bwd_img)(x2, dout, W3, b3, W4, b4, gamma, beta, dx2, partial, n_rows, nullptr, stream);
+}
+// the same with an optional pre-split fragment image of this step's weights (grl_weight_images kind 3; used by the 16-row kernel)
+int GRL_ENTRY(grl_node_mlp_bwd_img)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                     const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, const void* wimg, hipStream_t stream) {
   (void)b4;
   if (n_rows <= 0) {   // no rows: zero gradients (the caller sums grl_node_mlp_bwd_blocks(n_rows) = 1 partial row)
     hipMemsetAsync(partial, 0, sizeof(float) * MLP_PARTIAL, stream);
@@ -690,7 +699,7 @@ int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W
   }
   if (GRL_MLP_BWD16 && n_rows % 16 == 0) {
     grl_prof_begin_replay("node_mlp_bwd16_kernel", stream);
-    const int rc = GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), stream);
+    const int rc = GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), wimg, stream);
     grl_prof_end_replay(stream);
     return rc;
   }

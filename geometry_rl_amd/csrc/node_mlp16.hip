@@ -20,6 +20,7 @@
 //     double-buffered.
 // Partial slab per workgroup (unchanged): [dW3 256x64 | db3 256 | dW4 64x256 | db4 64 | dgamma 64 | dbeta 64].
 #include "grl_tile16.h"
+#include "grl_wimg.h"
 
 namespace {
 
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
                                                                  const float* __restrict__ W3, const float* __restrict__ b3,
                                                                  const float* __restrict__ W4, const float* __restrict__ gam,
                                                                  const float* __restrict__ bet, st_t* __restrict__ dx2,
-                                                                 float* __restrict__ partial, st_t* __restrict__ dump, int n_chunks) {
+                                                                 float* __restrict__ partial, st_t* __restrict__ dump, int n_chunks,
+                                                                 const Mlp16Image* __restrict__ wimg) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   Mlp16Smem& sm = *reinterpret_cast<Mlp16Smem*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -123,6 +125,24 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
     }
   }
 #else
+  if (wimg) {   // the fragments of this step's weights, pre-split once by grl_weight_images (kind 3): 48 coalesced 16-byte loads per lane
+                // instead of 16 vector + 128 strided dword loads and 48 splits
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      b3q[nt] = *reinterpret_cast<const float4*>(b3 + j0 + 16 * nt + 4 * g);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        w3f.h[nt][s] = __builtin_bit_cast(bf16x8, wimg->w3f[wave][nt][s][0][lane]);
+        w3t.h[nt][s] = __builtin_bit_cast(bf16x8, wimg->w3t[wave][nt][s][0][lane]);
+        sm.W4F[wave][nt][s][0][lane] = wimg->w4f[wave][nt][s][0][lane];
+#if !GRL_PREC
+        w3f.l[nt][s] = __builtin_bit_cast(bf16x8, wimg->w3f[wave][nt][s][1][lane]);
+        w3t.l[nt][s] = __builtin_bit_cast(bf16x8, wimg->w3t[wave][nt][s][1][lane]);
+        sm.W4F[wave][nt][s][1][lane] = wimg->w4f[wave][nt][s][1][lane];
+#endif
+      }
+    }
+  } else {
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     b3q[nt] = *reinterpret_cast<const float4*>(b3 + j0 + 16 * nt + 4 * g);
@@ -148,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
         split_pair(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), w3t.h[nt][s], w3t.l[nt][s]);
       }
     }
+  }
   }
 #endif
 #ifndef GRL_M16_PIN_STATIC
@@ -547,14 +568,14 @@ extern "C" {
 // n_nodes * 16), `blocks` workgroups are launched and each writes its partial row.
 int GRL_ENTRY(grl_node_mlp_bwd16_launch)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4,
                                          const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, int blocks,
-                                         hipStream_t stream) {
+                                         const void* wimg, hipStream_t stream) {
   if (n_rows % 16) return -3;
   static_assert(sizeof(Mlp16Smem) > 80 * 1024, "one workgroup per CU (one wave per SIMD) is a precondition of the unfenced MFMA groups");
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Mlp16Smem)));
   // partial holds blocks + 1 rows (ABI 201); the first 4 KB of the last one take the dump rows (garbage, shared by all workgroups)
   st_t* dump = reinterpret_cast<st_t*>(partial + (size_t)blocks * MLP_PARTIAL);
   hipLaunchKernelGGL(node_mlp_bwd16_kernel, dim3(blocks), dim3(256), sizeof(Mlp16Smem), stream, x2, dout, W3, b3, W4, gamma, beta, dx2,
-                     partial, dump, n_rows / 16);
+                     partial, dump, n_rows / 16, reinterpret_cast<const Mlp16Image*>(wimg));
   GRL_CHECK_LAUNCH();
   return 0;
 }

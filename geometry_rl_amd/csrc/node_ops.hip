@@ -26,15 +26,17 @@ struct FiberDfks { const float* p[4]; };
 // vector feature min(v, V-1) (clamped duplicates meet zero weights / are dropped), and the values are broadcast from that register with
 // v_readlane when they are used.  (Scalar loads of the same 32 values came out as seven s_waitcnt-separated groups per node: seven
 // serialised scalar-cache round trips per iteration.)  `scal` / `vec` stand in for each other when S / V is zero (any readable floats).
-struct LiftLane { const float* base; long long stride; int off; };
+struct LiftLane { const float* base; long long stride; int off; bool valid; };   // valid: the lane holds a real input (not a clamped duplicate)
 GRL_DEVINL LiftLane lift_lane(const float* scal, const float* vec, int S, int V) {
   const int i = threadIdx.x & 31;        // lanes 32..63 mirror 0..31
   LiftLane L;
   if (i < 8) {
     L.base = S > 0 ? scal : vec; L.stride = S > 0 ? S : 0; L.off = i < S ? i : (S > 0 ? S - 1 : 0);
+    L.valid = i < S;
   } else {
     const int v = (i - 8) / 3, d = (i - 8) - 3 * v;
     L.base = V > 0 ? vec : scal; L.stride = V > 0 ? 3 * V : 0; L.off = V > 0 ? 3 * (v < V ? v : V - 1) + d : 0;
+    L.valid = v < V;
   }
   return L;
 }
@@ -76,7 +78,11 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
     for (int m = 0; m < LIFT_CHUNK * 4 * 32 / 256; ++m) {
       const int idx = threadIdx.x + 256 * m, i = idx >> 7, w_ = (idx >> 5) & 3;
       const long long node = (long long)(4 * blockIdx.x + w_) + (long long)(it0 + i) * n_waves;
-      stage[idx] = lift_fetch(L, node < N ? (int)node : N - 1);   // (clamped, not skipped: a branch per load would serialise them)
+      // (clamped, not skipped: a branch per load would serialise them.)  Slots past S / V hold clamped duplicates -- with S == 0 or V == 0
+      // even node 0's value of the OTHER array: they are zeroed where the register goes to LDS (never right behind the load, finding 31b),
+      // so a non-finite input of one node cannot reach another node through NaN * 0
+      const float fetched = lift_fetch(L, node < N ? (int)node : N - 1);
+      stage[idx] = L.valid ? fetched : 0.f;
     }
     __syncthreads();
     for (int i = 0; i < LIFT_CHUNK; ++i) {
@@ -558,6 +564,7 @@ constexpr int RED_WAVES = 8;
 // memory latencies -- with 4 in flight the longest columns (2048 rows: gradients fed by two convolutions) took 64 round trips.
 constexpr int RED_DEPTH = 16;
 GRL_DEVINL float column_sum(const float* __restrict__ src /*column base*/, size_t ld, int n_rows, int wave) {
+  if (n_rows <= 0) return 0.f;   // (the clamped remainder loads below would index row -1)
   float a[RED_DEPTH];
 #pragma unroll
   for (int u = 0; u < RED_DEPTH; ++u) a[u] = 0.f;
@@ -577,7 +584,7 @@ GRL_DEVINL float column_sum(const float* __restrict__ src /*column base*/, size_
       v[u] = src[(size_t)(row < n_rows ? row : n_rows - 1) * ld];
     }
 #pragma unroll
-    for (int u = 0; u < RED_DEPTH; ++u) a[u] = fmaf(w + u * RED_WAVES < n_rows ? 1.f : 0.f, v[u], a[u]);
+    for (int u = 0; u < RED_DEPTH; ++u) a[u] += w + u * RED_WAVES < n_rows ? v[u] : 0.f;   // (a select, not a 0/1 factor: NaN * 0 = NaN)
   }
 #pragma unroll
   for (int st = RED_DEPTH / 2; st > 0; st >>= 1)
@@ -642,6 +649,7 @@ struct ReduceMulti {
 // columns per workgroup 16 CUs pulled the whole slab at ~95 GB/s each (tools/ubench/reduce_bench.py).
 GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_rows, int row0) {
   constexpr int STEP = 4 * RED_WAVES;
+  if (n_rows <= 0) return make_float4(0.f, 0.f, 0.f, 0.f);
   float4 a[RED_DEPTH];
 #pragma unroll
   for (int u = 0; u < RED_DEPTH; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -663,8 +671,8 @@ GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_ro
     }
 #pragma unroll
     for (int u = 0; u < RED_DEPTH; ++u) {
-      const float m = w + u * STEP < n_rows ? 1.f : 0.f;
-      a[u] = make_float4(fmaf(m, v[u].x, a[u].x), fmaf(m, v[u].y, a[u].y), fmaf(m, v[u].z, a[u].z), fmaf(m, v[u].w, a[u].w));
+      const bool m = w + u * STEP < n_rows;   // (selects, not 0/1 factors: a non-finite clamped row must not turn into NaN * 0)
+      a[u] = make_float4(a[u].x + (m ? v[u].x : 0.f), a[u].y + (m ? v[u].y : 0.f), a[u].z + (m ? v[u].z : 0.f), a[u].w + (m ? v[u].w : 0.f));
     }
   }
 #pragma unroll

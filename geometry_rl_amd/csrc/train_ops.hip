@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherJobs jobs, 
   const long long total = (long long)n_rows * wpr;
   const unsigned int* __restrict__ src = jobs.src[k];
   unsigned int* __restrict__ dst = jobs.dst[k];
-  if (total < (1ll << 31)) {   // the usual case: 32-bit index arithmetic, four independent (index, word) load pairs in flight per thread
+  // the usual case: 32-bit index arithmetic, four independent (index, word) load pairs in flight per thread.  `w0 + u * stride` and
+  // `w0 += 4 * stride` must not wrap: the fast path is taken only while total + 8 * stride stays below 2^31
+  if (total + 8ll * gridDim.x * blockDim.x < (1ll << 31)) {
     const int tot = (int)total, stride = gridDim.x * blockDim.x;
     for (int w0 = blockIdx.x * blockDim.x + threadIdx.x; w0 < tot; w0 += 4 * stride) {
       long long row[4];
@@ -389,7 +391,7 @@ extern "C" {
 
 // ABI version of this library: major * 10000 + minor * 100 + patch.  Bumped whenever a declared signature changes
 // (include/grl_hip.h GRL_HIP_VERSION must agree: geometry_rl_amd/hip.py checks it at load time).
-int grl_version(void) { return 202; }
+int grl_version(void) { return 203; }
 
 // step = 1-based Adam step count.  scale_dev: optional device scalar multiplied into the gradient (clip coefficient).
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,

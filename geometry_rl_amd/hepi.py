@@ -172,10 +172,23 @@ class HEPi(nn.Module):
                     need.update((s, d))
         return [t for t in graph.node_types if t in need]
 
-    def _conv(self, conv, x_src, x_dst, graph, et, grid3, fks, prev):
+    def _weight_images(self, graph: GraphBatch):
+        """Pre-split weight images of every convolution block this pass will run, from ONE launch (ops.weight_images): the MFMA kernels
+        copy them instead of re-splitting the weights in each of their workgroups' prologues; the backward pass reuses them."""
+        items = [(et, conv) for rnd in self.processor for et, conv in rnd.items() if et in graph.edges and not getattr(conv, "attention", False)]
+        b = self.basis_fn
+        imgs = ops.weight_images([(c.kernel.weight, graph.edges[et].n_dst,
+                                   (c.node_mlp[0].weight, c.node_mlp[0].bias, c.node_mlp[1].weight, c.node_mlp[1].bias, c.node_mlp[3].weight,
+                                    c.node_mlp[3].bias)) for et, c in items],
+                                 self.grid3, (b[1].weight, b[1].bias, b[3].weight, b[3].bias), self._prec,
+                                 with_backward=torch.is_grad_enabled())
+        return {id(c): im for (et, c), im in zip(items, imgs)}
+
+    def _conv(self, conv, x_src, x_dst, graph, et, grid3, fks, prev, wimgs=None):
         es = graph.edges[et]
         s, _, d = et
         b = self.basis_fn
+        wimg = wimgs.get(id(conv)) if wimgs else None
         # x feeds the convolution AND the residual of its own node block: the two gradients are summed inside the d x_src kernel
         res = {} if (x_src is x_dst and prev is None and torch.is_grad_enabled() and x_src.requires_grad) else None
         if getattr(conv, "attention", False):
@@ -186,12 +199,12 @@ class HEPi(nn.Module):
             x1 = ops.SoftmaxAggregate.apply(gate, msg, es, self._prec)
         else:
             x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
-                                    conv.kernel.weight, es, self.dim, res, self._prec)
+                                    conv.kernel.weight, es, self.dim, res, self._prec, wimg)
         fk = fks[id(conv)]
         x2 = ops.FiberConv.apply(x1, fk, conv.bias, self._prec)
         m = conv.node_mlp
         return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res,
-                                 self._prec), x1, fk
+                                 self._prec, wimg), x1, fk
 
     # ------------------------------------------------------------------ forward
     def latent_step(self, graph: GraphBatch, u_dict) -> torch.Tensor:
@@ -201,13 +214,14 @@ class HEPi(nn.Module):
         x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight, self._prec)
              for t in self._needed_types(graph)}
         fks = self._fiber_kernels(graph)
+        wimgs = self._weight_images(graph)
         for rnd in self.processor:
             outs = {}
             for et, conv in rnd.items():
                 if et not in graph.edges:  # empty edge set: skipped like hetero_fiber_conv.py:48-49
                     continue
                 s, _, d = et
-                outs[d], _, _ = self._conv(conv, x[s], x[d], graph, et, grid3, fks, outs.get(d))
+                outs[d], _, _ = self._conv(conv, x[s], x[d], graph, et, grid3, fks, outs.get(d), wimgs)
             x.update(outs)
         lat = x[graph.output_mask_key]
         return lat.float() if lat.dtype != torch.float32 else lat   # the read-out of the few actuator nodes runs in fp32

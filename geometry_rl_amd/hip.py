@@ -14,9 +14,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
-ABI_VERSION = 202   # include/grl_hip.h GRL_HIP_VERSION
+ABI_VERSION = 203   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "head_ops.hip", "critic_ops.hip",
-           "train_ops.hip"]
+           "train_ops.hip", "weight_images.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
 # per-source compiler flags.  edge_conv16.hip: its 512-register backward kernel keeps the chain's MFMA results in VGPRs (the default
@@ -31,31 +31,52 @@ FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-
               "node_mlp.hip": ["-fno-slp-vectorize", "-DGRL_GELU4_SCALAR=1"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp16.hip", ["-DGRL_PREC=1"], ".bf16"),
-            ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16")]
+            ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16"), ("weight_images.hip", ["-DGRL_PREC=1"], ".bf16")]
+
+
+BUILD_INFO = os.path.join(os.path.dirname(_HERE), "BUILD_INFO.json")
 
 
 def build(verbose: bool = True, force: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link libgrl_hip.so in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 and link libgrl_hip.so in-tree (hipcc cross-compiles without a GPU).  Writes BUILD_INFO.json at
+    the repository root: which objects this call recompiled ("prebuilt" = none: the library on disk was newer than every source)."""
+    import json
+    import time
+    all_flags = [f for fl in FILE_FLAGS.values() for f in fl] + [f for _, fl, _ in VARIANTS for f in fl]
+    if any(f.startswith("-DGRL_DIAG") for f in all_flags):
+        raise RuntimeError("GRL_DIAG (timing knock-outs: wrong results) must never be built into libgrl_hip.so -- use tools/build_variants.sh")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "grl_common.h"), os.path.join(CSRC, "grl_tile16.h"), os.path.abspath(__file__)]
+
+    def info(mode, rebuilt):
+        try:
+            with open(BUILD_INFO, "w") as f:
+                json.dump({"build_mode": mode, "objects_rebuilt": rebuilt, "objects_total": len(srcs) + len(VARIANTS), "library": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)),
+                           "library_bytes": os.path.getsize(LIB_PATH) if os.path.exists(LIB_PATH) else None, "abi_version": ABI_VERSION,
+                           "forced": bool(force), "time": time.strftime("%Y-%m-%dT%H:%M:%S")}, f, indent=1)
+        except OSError:
+            pass
+    headers = [os.path.join(CSRC, h) for h in ("grl_common.h", "grl_tile16.h", "grl_wimg.h")]
+    deps = srcs + headers + [os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        info("prebuilt (library newer than every source: nothing compiled)", [])
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    rebuilt = []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     jobs = [(s, [], "") for s in srcs] + [(os.path.join(CSRC, s), fl, sfx) for s, fl, sfx in VARIANTS]
     for s, flags, sfx in jobs:
         o = os.path.join(CSRC, "build", os.path.basename(s) + sfx + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d)
-                                                    for d in [s, os.path.join(CSRC, "grl_common.h"), os.path.join(CSRC, "grl_tile16.h"),
-                                                              os.path.abspath(__file__)]):
+                                                    for d in [s] + headers + [os.path.abspath(__file__)]):
             continue
         cmd = ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + FILE_FLAGS.get(os.path.basename(s), [])
                + flags + ["-c", s, "-o", o])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        rebuilt.append(os.path.basename(o))
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
@@ -64,6 +85,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    info("compiled from source" if len(rebuilt) == len(objs) else "incremental (objects newer than their sources were kept)", rebuilt)
     return LIB_PATH
 
 
@@ -78,6 +100,9 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'). "
                 "geometry_rl_amd has no CPU or PyTorch fallback path.")
         _lib = ctypes.CDLL(LIB_PATH)
+        if hasattr(_lib, "grl_diag_build") and not os.environ.get("GRL_ALLOW_DIAG_LIB"):
+            raise RuntimeError(f"{LIB_PATH} is a GRL_DIAG build (timing knock-outs: its results are wrong).  Diagnostic libraries are loaded "
+                               "only with GRL_ALLOW_DIAG_LIB=1 (tools/run_variants.sh); rebuild the product library with __graft_entry__.build()")
         _lib.grl_version.restype = ctypes.c_int
         if _lib.grl_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH} reports ABI version {_lib.grl_version()}, this package binds version {ABI_VERSION} "

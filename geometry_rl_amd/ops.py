@@ -34,9 +34,13 @@ class EdgeSet:
 
 
 def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
-    """edge_index [2,E] (row 0 = source, row 1 = destination) -> CSR by destination.  Runs once per cached topology."""
+    """edge_index [2,E] (row 0 = source, row 1 = destination) -> CSR by destination.  Runs once per cached topology, never under stream
+    capture: it synchronises with the host (sort keys, the balance check of the wave partitions)."""
     src, dst = edge_index[0].long(), edge_index[1].long()
     dev = edge_index.device
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("build_edge_set synchronises with the host: build the topology before the step is recorded "
+                           "(HyperData.check_topology / the first, eager step do)")
 
     def csr(anchor, other, n_anchor):
         order = torch.argsort(anchor * (int(other.max().item()) + 1 if other.numel() else 1) + other)
@@ -76,19 +80,19 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         return split.int().contiguous()
 
     split_s = split_d = None
-    if E > 0:
-        # backward (csrc/edge_conv16.hip grl_edge_bwd16_launch): 4 waves x grl_edge_bwd_blocks(E) workgroups, npw = n_src / 4096 in [1, 16]
-        # (one wave per SIMD: a wave that finishes early leaves its SIMD idle -- every per cent of imbalance is a per cent of the launch)
-        split_s = balanced_split(rp_s, n_src, 4 * hip.query("grl_edge_bwd_blocks", E), max(1, min(16, n_src // 4096)), 1.04)
-        # forward (grl_edge16_launch): npw = n_dst / 12288 in [1, 16], up to 768 workgroups of 4 waves; launches of <= 512 32-row tiles take
-        # the one-workgroup-per-tile forward instead (edge_conv.hip GRL_FWD_SPLIT_TILES) and ignore the partition
-        npw_d = max(1, min(16, n_dst // 12288))
-        blocks_d = min(768, ((n_dst + npw_d - 1) // npw_d + 3) // 4)
-        if (n_dst + 1) // 2 > 512 and blocks_d >= 1:
+    if E > 0 and dev.type == "cuda":   # (the launch shapes are the library's: asked for, not copied -- ADVICE r3; CPU tensors: no partitions)
+        # backward (csrc/edge_conv16.hip grl_edge_bwd16_launch): 4 waves x grl_edge_bwd_blocks(E) workgroups, chunks of
+        # grl_edge_bwd_chunk_nodes(n_src) nodes dealt round-robin (one wave per SIMD: a wave that finishes early leaves its SIMD idle --
+        # every per cent of imbalance is a per cent of the launch)
+        split_s = balanced_split(rp_s, n_src, 4 * hip.query("grl_edge_bwd_blocks", E), hip.query("grl_edge_bwd_chunk_nodes", n_src), 1.04)
+        # forward (grl_edge16_launch): grl_edge_fwd_slots(n_dst) wave slots (0: the launch takes the one-workgroup-per-tile kernel of small
+        # graphs, which ignores partitions), chunks of grl_edge_fwd_chunk_nodes(n_dst) nodes
+        slots_d = hip.query("grl_edge_fwd_slots", n_dst)
+        if slots_d > 0:
             # three waves share a SIMD here: the waves that are left when the others finish run faster, so a moderately uneven deal heals
             # itself (rigid HEPi, 17 % uneven: the partition costs 0.9 % of the step) -- only grossly uneven graphs are partitioned (the
             # merged EMPN graph: actuator nodes with 17 in-edges behind object nodes with 3: -2 %)
-            split_d = balanced_split(rp_d, n_dst, 4 * blocks_d, npw_d, 1.25)
+            split_d = balanced_split(rp_d, n_dst, slots_d, hip.query("grl_edge_fwd_chunk_nodes", n_dst), 1.25)
     return EdgeSet(n_src, n_dst, E, rp_d, src_d, dst_d, rp_s, src_s, dst_s, s2d, split_s, split_d)
 
 
@@ -182,6 +186,68 @@ def _emit_grads(partial: torch.Tensor, segments):
     return outs
 
 
+class WeightImages:
+    """Pre-split weight images of ONE convolution block for one forward pass (csrc/grl_wimg.h, grl_weight_images): device byte buffers
+    whose contents are the MFMA kernels' LDS structs.  ``e16``: edge chain for the 16-row kernels (forward prefix + the backward's
+    transposes), ``e32``: edge chain of the few-tile 32-row forward, ``mlp_f`` / ``mlp_b``: ConvNeXt block forward / backward.  Any
+    member may be None (the kernel then stages the weights itself).  Valid until the weights change (the optimizer step)."""
+    __slots__ = ("e16", "e32", "mlp_f", "mlp_b")
+
+    def __init__(self, e16=None, e32=None, mlp_f=None, mlp_b=None):
+        self.e16, self.e32, self.mlp_f, self.mlp_b = e16, e32, mlp_f, mlp_b
+
+
+WIMG_EDGE16, WIMG_EDGE32, WIMG_MLP_FWD, WIMG_MLP_BWD16 = 0, 1, 2, 3
+USE_WEIGHT_IMAGES = os.environ.get("GRL_WEIGHT_IMAGES", "1") != "0"   # A/B switch: 0 = every launch stages its weights itself (round 3)
+
+
+@torch.no_grad()
+def weight_images(blocks, grid3, basis, prec: str = "", with_backward: bool = True):
+    """One launch for all pre-split weight images of a forward pass.  ``blocks``: [(conv_kernel_weight [64,64], n_dst of the block's edge
+    convolution, (gamma, beta, W3, b3, W4, b4) of its ConvNeXt block)]; ``basis`` = (W1, b1, W2, b2) of the shared basis MLP.
+    -> [WeightImages] in the order of ``blocks`` (None entries when switched off)."""
+    import ctypes
+    if not USE_WEIGHT_IMAGES or not blocks:
+        return [None] * len(blocks)
+    dev = grid3.device
+    w1, b1, w2, b2 = [t.detach().contiguous() for t in basis]
+    size = {k: hip.query("grl_wimg_bytes", k) for k in range(4)}
+    jobs = []   # (kind, sources, block index, member)
+    for i, (wk, n_dst, mlp) in enumerate(blocks):
+        wk = wk.detach().contiguous()
+        edge_src = [w1, b1, w2, b2, wk, grid3]
+        fwd_kind = hip.query("grl_edge_fwd_image_kind", int(n_dst))
+        if with_backward or fwd_kind == WIMG_EDGE16:
+            jobs.append((WIMG_EDGE16, edge_src, i, "e16"))
+        if fwd_kind == WIMG_EDGE32:
+            jobs.append((WIMG_EDGE32, edge_src, i, "e32"))
+        gamma, beta, w3, b3, w4, b4 = [t.detach().contiguous() for t in mlp]
+        jobs.append((WIMG_MLP_FWD, [w3, b3, w4, b4, gamma, beta], i, "mlp_f"))
+        if with_backward and w3.data_ptr() % 16 == 0:
+            jobs.append((WIMG_MLP_BWD16, [w3, w4], i, "mlp_b"))
+    offs, total = [], 0
+    for kind, *_ in jobs:
+        offs.append(total)
+        total += (size[kind] + 255) & ~255
+    buf = torch.empty(total, device=dev, dtype=torch.uint8)
+    out = [WeightImages() for _ in blocks]
+    views = []
+    for (kind, srcs, i, member), o in zip(jobs, offs):
+        v = buf[o:o + size[kind]]
+        setattr(out[i], member, v)
+        views.append(v)
+    cap = hip.query("grl_wimg_max_jobs")
+    for j0 in range(0, len(jobs), cap):
+        part = jobs[j0:j0 + cap]
+        n = len(part)
+        ptrs = []
+        for kind, srcs, _, _ in part:
+            ptrs += [t.data_ptr() for t in srcs] + [0] * (6 - len(srcs))
+        hip.call("grl_weight_images" + prec, n, (ctypes.c_int * n)(*[p_[0] for p_ in part]), (ctypes.c_void_p * (6 * n))(*ptrs),
+                 (ctypes.c_void_p * n)(*[v.data_ptr() for v in views[j0:j0 + n]]))
+    return out
+
+
 class LiftEncode(torch.autograd.Function):
     """x[n,o,:] = [scalars | vectors . grid_o] W_enc^T   (reference hepi.py:136-143)."""
 
@@ -218,9 +284,11 @@ class EdgeConv(torch.autograd.Function):
     """x1[d] = sum_{e->d} Wk(basis_mlp(invariants_e)) * x_src[src(e)]   (reference hepi.py:145-157, conv.py:79-86,115-149)."""
 
     @staticmethod
-    def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int, residual=None, prec: str = ""):
+    def forward(ctx, x_src, pos_src, pos_dst, grid3, w1, b1, w2, b2, wk, edges: EdgeSet, dim: int, residual=None, prec: str = "",
+                wimg: Optional[WeightImages] = None):
         """``residual``: optional dict shared with the NodeMLP of the same layer when x_src is also that block's residual input:
-        NodeMLP.backward leaves d(out)/d(x_dst) there and this backward adds it inside the d x_src kernel (no separate add pass)."""
+        NodeMLP.backward leaves d(out)/d(x_dst) there and this backward adds it inside the d x_src kernel (no separate add pass).
+        ``wimg``: the block's pre-split weight images of this pass (``weight_images``), reused by the backward."""
         hip.check_f32(pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
         hip.check_latent(prec, x_src)
         global PRE_EDGE_HOOK
@@ -231,9 +299,10 @@ class EdgeConv(torch.autograd.Function):
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
         sd = edges.split_d if SPLIT_FORWARD else None
         hip.call("grl_edge_conv_fwd_balanced" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
-                 dim, *args, x1, sd, (sd.numel() - 1) if sd is not None else 0, rows=edges.n_edges * 16)
+                 dim, *args, x1, sd, (sd.numel() - 1) if sd is not None else 0, wimg.e16 if wimg else None, wimg.e32 if wimg else None,
+                 rows=edges.n_edges * 16)
         ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
-        ctx.edges, ctx.dim, ctx.residual, ctx.prec = edges, dim, residual, prec
+        ctx.edges, ctx.dim, ctx.residual, ctx.prec, ctx.wimg = edges, dim, residual, prec, wimg
         ctx.params = (w1, b1, w2, b2, wk)
         return x1
 
@@ -247,13 +316,14 @@ class EdgeConv(torch.autograd.Function):
         partial = torch.empty(blocks, psize, device=dev, dtype=torch.float32)
         dx_src = torch.empty_like(x_src)
         dres = ctx.residual.pop("dres", None) if ctx.residual is not None else None
+        ss = e.split_s if SPLIT_BACKWARD else None
         hip.call("grl_edge_conv_bwd_balanced" + ctx.prec, x_src, pos_src, pos_dst, e.rowptr_d, e.src_d, e.dst_d, e.n_dst, e.n_edges, e.rowptr_s,
                  e.src_s, e.dst_s, e.n_src, grid3, ctx.dim, w1, b1, w2, b2, wk, dx1.contiguous(), dres, dx_src, partial,
-                 e.split_s if SPLIT_BACKWARD else None, rows=e.n_edges * 16)
+                 ss, (ss.numel() - 1) if ss is not None else 0, ctx.wimg.e16 if ctx.wimg else None, rows=e.n_edges * 16)
         pw1, pb1, pw2, pb2, pwk = ctx.params
         dw1, db1, dw2, db2, dwk = _emit_grads(partial, [(0, 896, (64, 14), pw1), (896, 64, (64,), pb1), (960, 4096, (64, 64), pw2),
                                                          (5056, 64, (64,), pb2), (5120, 4096, (64, 64), pwk)])
-        return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None, None, None)
+        return (dx_src, None, None, None, dw1, db1, dw2, db2, dwk, None, None, None, None, None)
 
 
 class EdgeMessages(torch.autograd.Function):
@@ -399,15 +469,17 @@ class NodeMLP(torch.autograd.Function):
     """out = [prev +] x_dst + W4 GELU(W3 LN(x2) + b3) + b4   (reference conv.py:64-69,112; hetero_fiber_conv.py:63-64)."""
 
     @staticmethod
-    def forward(ctx, x2, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor], residual=None, prec: str = ""):
+    def forward(ctx, x2, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor], residual=None, prec: str = "",
+                wimg: Optional[WeightImages] = None):
         hip.check_f32(gamma, beta, w3, b3, w4, b4)
         hip.check_latent(prec, x2, x_dst, prev)
         ws = [a.contiguous() for a in (w3, b3, w4, b4, gamma, beta)]
         n_rows = x2.shape[0] * 16
         out = prev.clone() if prev is not None else torch.empty_like(x2)
-        hip.call("grl_node_mlp_fwd" + prec, x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0, rows=n_rows)
+        hip.call("grl_node_mlp_fwd_img" + prec, x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0, wimg.mlp_f if wimg else None,
+                 rows=n_rows)
         ctx.save_for_backward(x2, *ws)
-        ctx.has_prev, ctx.prec = prev is not None, prec
+        ctx.has_prev, ctx.prec, ctx.wimg = prev is not None, prec, wimg
         ctx.residual = residual
         ctx.params = (w3, b3, w4, b4, gamma, beta)
         return out
@@ -422,7 +494,8 @@ class NodeMLP(torch.autograd.Function):
         blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
         psize = hip.query("grl_node_mlp_partial_size")
         partial = torch.empty(blocks + 1, psize, device=dev, dtype=torch.float32)   # last row: scratch (shared W3 fragment image)
-        hip.call("grl_node_mlp_bwd" + ctx.prec, x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows, rows=n_rows)
+        hip.call("grl_node_mlp_bwd_img" + ctx.prec, x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows,
+                 ctx.wimg.mlp_b if ctx.wimg else None, rows=n_rows)
         partial = partial[:blocks]
         pw3, pb3, pw4, pb4, pg, pbt = ctx.params
         dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
@@ -432,7 +505,7 @@ class NodeMLP(torch.autograd.Function):
         if ctx.residual is not None:   # handed to the EdgeConv backward of the same layer (same tensor x feeds both)
             ctx.residual["dres"] = dout
             d_dst = None
-        return (dx2, d_dst, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None, None, None)
+        return (dx2, d_dst, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None, None, None, None)
 
 
 class Readout(torch.autograd.Function):

@@ -129,19 +129,28 @@ class PonitaGCN(nn.Module):
         self._merged_cache[id(graph.edges)] = (graph.edges, merged)
         return merged
 
-    def _layer_merged(self, layer, x, pos, es, grid3, fk, lo=0, collect=None):
+    def _weight_images(self, plan):
+        """Pre-split weight images of the interaction layers of this pass from ONE launch (ops.weight_images); ``plan`` = [(layer, edge set)]."""
+        b = self.ponita.basis_fn
+        imgs = ops.weight_images([(l.conv.kernel.weight, es.n_dst, (l.norm.weight, l.norm.bias, l.linear_1.weight, l.linear_1.bias,
+                                                                    l.linear_2.weight, l.linear_2.bias)) for l, es in plan],
+                                 self.grid3, (b[1].weight, b[1].bias, b[3].weight, b[3].bias), self._prec,
+                                 with_backward=torch.is_grad_enabled())
+        return {id(l): im for (l, _), im in zip(plan, imgs)}
+
+    def _layer_merged(self, layer, x, pos, es, grid3, fk, lo=0, collect=None, wimg=None):
         """One interaction layer on the homogeneous graph: x [N,16,64] -> [N_dst,16,64]; destinations = nodes lo .. (all, or the read-out tail)."""
         b = self.ponita.basis_fn
         x_dst, pos_dst = (x, pos) if lo == 0 else (x[lo:], pos[lo:])
         # x feeds the convolution AND the residual of its own node block: the two gradients are summed inside the fused edge backward
         res = {} if (lo == 0 and torch.is_grad_enabled() and x.requires_grad) else None
         x1 = ops.EdgeConv.apply(x, pos, pos_dst, grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias, layer.conv.kernel.weight, es,
-                                self.dim, res, self._prec)
+                                self.dim, res, self._prec, wimg)
         x2 = ops.FiberConv.apply(x1, fk, layer.conv.bias, self._prec)
         if collect is not None:
             collect.update(x1=x1, fk=fk)
         return ops.NodeMLP.apply(x2, x_dst, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
-                                 layer.linear_2.weight, layer.linear_2.bias, None, res, self._prec)
+                                 layer.linear_2.weight, layer.linear_2.bias, None, res, self._prec, wimg)
 
     def latent_step(self, graph: GraphBatch, u_dict):
         grid3 = self.grid3
@@ -149,11 +158,13 @@ class PonitaGCN(nn.Module):
         x = ops.LiftEncode.apply(graph.scalar_all, graph.vec_all, grid3, self.ponita.x_embedder.weight, self._prec)
         fks = self._fiber_kernels()
         layers = list(self.ponita.interaction_layers)
+        last = lambda i: i == len(layers) - 1 and self.prune_last_layer
+        wimgs = self._weight_images([(l, mg["es_last"] if last(i) else mg["es_all"]) for i, l in enumerate(layers)])
         for i, layer in enumerate(layers):
-            if i == len(layers) - 1 and self.prune_last_layer:
-                x = self._layer_merged(layer, x, graph.pos_all, mg["es_last"], grid3, fks[id(layer.conv)], lo=mg["lo"])
+            if last(i):
+                x = self._layer_merged(layer, x, graph.pos_all, mg["es_last"], grid3, fks[id(layer.conv)], lo=mg["lo"], wimg=wimgs[id(layer)])
             else:
-                x = self._layer_merged(layer, x, graph.pos_all, mg["es_all"], grid3, fks[id(layer.conv)])
+                x = self._layer_merged(layer, x, graph.pos_all, mg["es_all"], grid3, fks[id(layer.conv)], wimg=wimgs[id(layer)])
         lat = x if x.shape[0] == mg["n_ro"] else x[mg["lo"]:]
         return lat.float() if lat.dtype != torch.float32 else lat
 

@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 202
+#define GRL_HIP_VERSION 203
 int grl_version(void);
 
 /* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
@@ -47,11 +47,19 @@ int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
 /* (ABI 202) the same with split_d [n_slots + 1], n_slots a multiple of 4 (or NULL / 0): node boundaries of an in-edge-balanced partition of
- * the destination-sorted CSR over n_slots wave slots (n_slots / 4 workgroups are launched); see grl_edge_conv_bwd_balanced. */
+ * the destination-sorted CSR over n_slots wave slots (n_slots / 4 workgroups are launched); see grl_edge_conv_bwd_balanced.
+ * (ABI 203) wimg16 / wimg32: optional pre-split weight images of this forward pass (grl_weight_images kinds 0 / 1, below); the launch
+ * copies the one its kernel needs (grl_edge_fwd_image_kind(n_dst)) and stages W1 / W2 / Wk itself when that one is NULL.
+ * grl_edge_fwd_slots(n_dst): the wave slots split_d has to cover for this n_dst (0: the launch ignores partitions);
+ * grl_edge_fwd_chunk_nodes / grl_edge_bwd_chunk_nodes: destination / source nodes per round-robin chunk (what a partition replaces). */
 int grl_edge_conv_fwd_balanced(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                                const float* W2, const float* b2, const float* Wk, float* x1, const int* split_d, int n_slots,
-                               hipStream_t stream);
+                               const void* wimg16, const void* wimg32, hipStream_t stream);
+int grl_edge_fwd_image_kind(int n_dst);
+int grl_edge_fwd_slots(int n_dst);
+int grl_edge_fwd_chunk_nodes(int n_dst);
+int grl_edge_bwd_chunk_nodes(int n_src);
 int grl_edge_partial_size(void);
 int grl_edge_bwd_blocks(int n_edges);
 int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
@@ -62,12 +70,28 @@ int grl_edge_conv_bwd(const float* x_src, const float* pos_src, const float* pos
 /* (ABI 202) the same with split_s [4 * grl_edge_bwd_blocks(n_edges) + 1], or NULL: node boundaries of an edge-balanced partition of the
  * source-sorted CSR over the launch's wave slots (split_s[0] = 0, split_s[last] = n_src, non-decreasing; wave slot s walks the source
  * nodes split_s[s] .. split_s[s+1]).  The reference has no counterpart (PyG scatter kernels balance per element); results do not depend
- * on the partition beyond the summation order of the weight-gradient partial rows, and are reproducible for a given partition. */
+ * on the partition beyond the summation order of the weight-gradient partial rows, and are reproducible for a given partition.
+ * (ABI 203) n_slots_s = the length of split_s minus one: a partition built for another slot count is ignored (never read past its end);
+ * wimg16: optional Edge16Image of this step's weights (grl_weight_images kind 0), NULL = the kernel stages its five images itself. */
 int grl_edge_conv_bwd_balanced(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
                                int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
                                const float* b2, const float* Wk, const float* dx1, const float* dres, float* dx_src, float* partial,
-                               const int* split_s, hipStream_t stream);
+                               const int* split_s, int n_slots_s, const void* wimg16, hipStream_t stream);
+
+/* ---- pre-split weight images (ABI 203; no reference counterpart: the reference's GEMMs read fp32 weights) -------------------------------
+ * The MFMA kernels run their dense products as split-bf16 (three bf16 MFMAs per fp32 product) from LDS images of the weights.  Until
+ * round 3 every launch rebuilt those images in each workgroup's prologue (15-40 us per launch at any batch size); grl_weight_images
+ * builds them ONCE per forward pass, for all convolutions of the pass, in one launch -- the image bytes are the kernels' LDS structs, a
+ * kernel's prologue is a linear copy.  kinds: 0 = edge chain, 16-row kernels, forward prefix + the backward's transposes (W1 [64,14], b1,
+ * W2 [64,64], b2, Wk [64,64], grid [16,3]); 1 = edge chain of the few-tile 32-row forward (same six sources); 2 = ConvNeXt block forward
+ * (W3 [256,64], b3, W4 [64,256], b4, gamma, beta); 3 = ConvNeXt block backward, per-lane operand fragments (W3, W4).
+ * kinds [n] (HOST), srcs [n][6] (HOST array of device pointers, unused slots NULL), outs [n] (HOST array of device buffers of
+ * grl_wimg_bytes(kind) bytes, 16-byte aligned).  The images are valid until the weights change (the optimizer step). */
+int grl_wimg_bytes(int kind);
+int grl_wimg_max_jobs(void);
+int grl_weight_images(int n, const int* kinds, const float* const* srcs, void* const* outs, hipStream_t stream);
+int grl_weight_images_bf16(int n, const int* kinds, const float* const* srcs, void* const* outs, hipStream_t stream);
 
 /* ---- attention aggregation: FiberBundleConv(aggr="AttentionalAggregation"), ponita/conv.py:21-26,58-61,138-139;
  *      configs/algorithm/pyg_agent/model/hepi_attention.yaml; PyG 2.5.2 AttentionalAggregation / utils.softmax [upstream] ---------------
@@ -105,7 +129,7 @@ int grl_edge_conv_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const fl
 int grl_edge_conv_fwd_balanced_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                     const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                                     const float* W2, const float* b2, const float* Wk, grl_bf16* x1, const int* split_d, int n_slots,
-                                    hipStream_t stream);
+                                    const void* wimg16, const void* wimg32, hipStream_t stream);
 int grl_edge_conv_bwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                            const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
                            int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
@@ -115,7 +139,7 @@ int grl_edge_conv_bwd_balanced_bf16(const grl_bf16* x_src, const float* pos_src,
                                     const int* e_dst, int n_dst, int n_edges, const int* rowptr_s, const int* src_s, const int* dst_s,
                                     int n_src, const float* grid, int dim, const float* W1, const float* b1, const float* W2,
                                     const float* b2, const float* Wk, const grl_bf16* dx1, const grl_bf16* dres, grl_bf16* dx_src,
-                                    float* partial, const int* split_s, hipStream_t stream);
+                                    float* partial, const int* split_s, int n_slots_s, const void* wimg16, hipStream_t stream);
 int grl_edge_messages_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                const int* e_dst, int n_dst, int n_edges, const float* grid, int dim, const float* W1,
                                const float* b1, const float* W2, const float* b2, const float* Wk, grl_bf16* msg, hipStream_t stream);
@@ -135,6 +159,12 @@ int grl_node_mlp_fwd_bf16(const grl_bf16* x2, const grl_bf16* x_dst, const float
                           const float* gamma, const float* beta, grl_bf16* out, int n_rows, int accumulate, hipStream_t stream);
 int grl_node_mlp_bwd_bf16(const grl_bf16* x2, const grl_bf16* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                           const float* gamma, const float* beta, grl_bf16* dx2, float* partial, int n_rows, hipStream_t stream);
+int grl_node_mlp_fwd_img_bf16(const grl_bf16* x2, const grl_bf16* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                              const float* gamma, const float* beta, grl_bf16* out, int n_rows, int accumulate, const void* wimg,
+                              hipStream_t stream);
+int grl_node_mlp_bwd_img_bf16(const grl_bf16* x2, const grl_bf16* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                              const float* gamma, const float* beta, grl_bf16* dx2, float* partial, int n_rows, const void* wimg,
+                              hipStream_t stream);
 
 /* ---- fiber kernel basis (parameter-only, 256 rows): hepi.py:109-123,157 / ponita.py:246-268 + conv.py:62 ------------------------
  * Phi = GELU(W2 GELU(W1 poly + b1) + b2), fk_i = Phi Wf_i^T for n_conv <= 4 convolutions, one launch each way.
@@ -166,6 +196,13 @@ int grl_node_mlp_partial_size(void);
 int grl_node_mlp_bwd_blocks(int n_rows);
 int grl_node_mlp_bwd(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, hipStream_t stream);
+/* (ABI 203) the same with an optional pre-split weight image of this step (grl_weight_images kind 2 for the forward, kind 3 for the
+ * backward; NULL = the kernel stages / fragments the weights itself) */
+int grl_node_mlp_fwd_img(const float* x2, const float* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
+                         const float* gamma, const float* beta, float* out, int n_rows, int accumulate, const void* wimg, hipStream_t stream);
+int grl_node_mlp_bwd_img(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
+                         const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, const void* wimg,
+                         hipStream_t stream);
 
 /* ---- read-out + contextual std head: hepi.py:173-190 (ponita_gcn.py:129-146),
  *      algorithms/trust_region_projections/models/policy/gnn_gaussian_policy_diag.py:65-87 ------------------------------------

@@ -82,3 +82,22 @@ def test_synthetic_shapes_follow_reference_layout():
     assert c["position_vectors"].shape[1] == 1395 and c["velocity_vectors"].shape[1] == 687
     r = syn.make_rope_obs(3)
     assert r["position_vectors"].shape[1] == 486 and r["velocity_vectors"].shape[1] == 246
+
+
+def test_knockout_switches_need_grl_diag_and_the_product_library_is_not_a_diag_build(tmp_path):
+    """the timing knock-outs (wrong results) compile only with -DGRL_DIAG, a GRL_DIAG object exports
+    ``grl_diag_build``, and the product library neither exports it nor would be loaded if it did."""
+    import subprocess
+    from geometry_rl_amd import hip
+    src = tmp_path / "t.hip"
+    src.write_text('#include "grl_common.h"\n')
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I", hip.CSRC, str(src)]
+    for flag in ("-DGRL_E16_NOGELU", "-DGRL_KNOCK_MFMA", "-DGRL_B16_NOGATHER", "-DGRL_MLPB_NOBARRIER", "-DGRL_FENCED_2W=false"):
+        r = subprocess.run(base + [flag], capture_output=True, text=True)
+        assert r.returncode != 0 and "GRL_DIAG" in r.stderr, flag
+    assert subprocess.run(base + ["-DGRL_E16_NOGELU", "-DGRL_DIAG"], capture_output=True).returncode == 0
+    assert subprocess.run(base + ["-DGRL_FENCED_2W=true"], capture_output=True).returncode == 0
+    lib = ctypes.CDLL(hip.build(verbose=False))
+    assert not hasattr(lib, "grl_diag_build")
+    info = __import__("json").load(open(os.path.join(ROOT, "BUILD_INFO.json")))
+    assert info["abi_version"] == hip.ABI_VERSION and "build_mode" in info and isinstance(info["objects_rebuilt"], list)

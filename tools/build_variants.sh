@@ -2,6 +2,7 @@
 # Run HERE (hipcc cross-compiles): build one libgrl_hip variant per set of flags under _variants/ (git-ignored, shipped by gpurun);
 # `gpurun -- 'bash tools/run_variants.sh'` then times them on ONE box.   usage: bash tools/build_variants.sh name1 "-DA=0 -DB=1" name2 "..." ...
 # A flag written @file.hip:-flag applies to that source file only (e.g. "@edge_conv16.hip:-fno-slp-vectorize").
+# Timing knock-outs (-DGRL_E16_NOGELU, -DGRL_KNOCK_STAGE, ...: wrong results) compile only together with -DGRL_DIAG (csrc/grl_common.h).
 # The per-file flags of geometry_rl_amd/hip.py FILE_FLAGS are applied first (a variant's flags come later on the command line and win).
 set -e
 cd "$(dirname "$0")/.."

@@ -1,6 +1,7 @@
 #!/bin/bash
 # On the GPU box: bench every _variants/lib_*.so (alternating, two rounds) on this one box; prints steps/s and the five MFMA kernels' ms per step.
 cd $GRAFT_REPO_ROOT
+export GRL_ALLOW_DIAG_LIB=1   # knock-out variants are GRL_DIAG builds: geometry_rl_amd/hip.py loads them only with this set
 ARGS=${GRL_VARIANT_ARGS:---steps 30 --warmup 5 --pool 16 --no-parity-gate}
 for round in ${GRL_VARIANT_ROUNDS:-1 2}; do
   for lib in _variants/lib_*.so; do
