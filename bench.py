@@ -329,7 +329,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
-    upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else f" ({'one hipGraph' if world == 1 else 'hipGraph segments between the collectives'})")
+    n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
+    upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else
+                                 f" ({'one hipGraph' if n_graphs == 1 else str(n_graphs) + ' single-stream hipGraphs on two lanes' if world == 1 else 'hipGraph segments between the collectives'})")
 
     # ---- GAE + shifted critic pass over the whole 4096 x 128 rollout (once per 640 updates; outside the timed region)
     gae_ms = None

@@ -146,6 +146,19 @@ class PolicyUpdater:
         self._static = None
         self._program = None
         self._pending = []   # asynchronous collectives in flight
+        # Leaf gradients are WRITTEN by the one fold launch at the end of the backward pass (ops.flush_deferred_grads(overwrite=True)) instead
+        # of accumulated into a zeroed buffer: the per-step ``gflat.zero_()`` launch -- the first node of the recorded step, in front of the
+        # fork of the two lanes -- disappears.  Valid while every leaf gradient of the step comes through the fold queue: not with the stock
+        # torch transformer actor or the attention gate (torch's AccumulateGrad adds into .grad), nor with per-op folds on a third stream.
+        gnn = getattr(loss_module.actor_network, "gnn", None)
+        self._fold_overwrite = (os.environ.get("GRL_FOLD_OVERWRITE", "1") != "0" and not self.overlap_folds
+                                and not getattr(loss_module.actor_network, "post_fc", False)
+                                and not any(getattr(mod, "attention", False) for mod in (gnn.modules() if gnn is not None else [])))
+        # one rank: the critic folds and applies its own gradients on its lane (its own Adam launch over its slice of the flat buffer): the
+        # actor's lane neither carries them nor waits for the critic before its fold
+        self._critic_own_adam = os.environ.get("GRL_CRITIC_OWN_ADAM", "1") != "0"
+        # one rank: the step as a two-lane program of single-stream graphs (default) instead of ONE graph with a fork / join inside -- see _plan
+        self._lanes = os.environ.get("GRL_LANES", "1") != "0"
         if group is not None:
             self.sync_replicas()
 
@@ -208,8 +221,20 @@ class PolicyUpdater:
         if not m.critic_coef:
             raise NotImplementedError("PolicyUpdater expects the critic term (critic_coef > 0 in every TRPL config)")
 
+        ow = self._fold_overwrite
+
+        def adam(lo, hi, i_):   # one optimizer's step over its slice of the flat buffer (train.py:308-316)
+            coef = None
+            if self.clip:  # train.py:308-310
+                sq = st["zw"][23 + i_:24 + i_]
+                coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
+                hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
+            hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                     hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef, 1.0)
+
         def s0():  # critic features, first critic stage, advantage statistics
-            self.gflat.zero_()
+            if not ow:
+                self.gflat.zero_()
             b = dict(batch)
             if "var" not in b:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
@@ -219,8 +244,9 @@ class PolicyUpdater:
             with torch.no_grad():
                 vf.train(True)
                 _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
-                # one zeroed fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (12) | maxes (2 x u32) | clip (2)
-                zw = st["zw"] = torch.zeros(26, device=x.device, dtype=torch.float64)
+                # one fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (12) | maxes (2 x u32) | clip (2); every slot is
+                # WRITTEN by its producer (ABI 203): no zeroing launch
+                zw = st["zw"] = torch.empty(26, device=x.device, dtype=torch.float64)
                 st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
                 st["pipe"].fwd1()
                 st["adv"] = None
@@ -252,7 +278,7 @@ class PolicyUpdater:
             with torch.no_grad():
                 grads = st["pipe"].bwd1(leaves)
             assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
-            ops.flush_deferred_grads()
+            ops.flush_deferred_grads(overwrite=ow)
             ops.DEFERRED = None
 
         def s5():  # optimizers + reported values (train.py:308-316, trpl.py:280-321)
@@ -260,17 +286,16 @@ class PolicyUpdater:
                 if not st.pop("step_bumped", False):
                     self.step_dev.add_(1)
                 na, n = self.n_actor, self.flat.numel()
-                # the two optimizers of train.py:120-127 have identical hyper-parameters and schedules: without per-network gradient
-                # clipping their two Adam steps are ONE launch over the flat buffer (element-wise: the same numbers)
-                for i_, (lo, hi) in enumerate(((0, na), (na, n)) if self.clip else ((0, n),)):
-                    coef = None
-                    if self.clip:  # train.py:308-310
-                        sq = st["zw"][23 + i_:24 + i_]
-                        coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
-                        hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
-                    hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                             hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef,
-                             1.0)
+                if st.pop("critic_adam_done", False):
+                    adam(0, na, 0)   # the critic's optimizer has run on its own lane
+                else:
+                    # the two optimizers of train.py:120-127 have identical hyper-parameters and schedules: without per-network gradient
+                    # clipping their two Adam steps are ONE launch over the flat buffer (element-wise: the same numbers)
+                    for i_, (lo, hi) in enumerate(((0, na), (na, n)) if self.clip else ((0, n),)):
+                        adam(lo, hi, i_)
+                join = st.pop("join_side", None)
+                if join is not None:   # the critic's lane ends here (nothing of the actor's lane is queued behind this: no cost on its path)
+                    join()
                 a_loss, c_loss, mt = st.pop("lv", None) or loss_values(m, st["sums"], st["maxes"])
                 out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": c_loss, "loc": st["loc"], "sigma": st["sigma"],
                        "state_value": st["value"].unsqueeze(-1)}
@@ -281,7 +306,6 @@ class PolicyUpdater:
         #      a second stream beside the actor -- forward beside the actor forward, backward beside the actor backward -- and
         #      fills the SIMDs the big kernels leave idle at their heads and tails.  Recorded into the graph as a fork / join.
         def o_fwd():
-            self.gflat.zero_()
             b = dict(batch)
             if "var" not in b:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
@@ -289,8 +313,20 @@ class PolicyUpdater:
             st["obs"] = [b[k] for k in m.in_features]
             st["cobs"] = [b[k] for k in m.critic_in_features]
             cur, cs = torch.cuda.current_stream(), self._critic_stream()
+            if not ow:
+                self.gflat.zero_()
             cs.wait_stream(cur)
             with torch.cuda.stream(cs), torch.no_grad():
+                # inputs of the fused loss kernel and of Adam that depend on the minibatch alone come FIRST on this lane: the step's workspace
+                # (every slot written by its producer: no zeroing), the advantage statistics, the optimizer step count -- the critic's
+                # forward behind them is what the actor's first edge convolution may have to wait for
+                zw = st["zw"] = torch.empty(26, device=self.flat.device, dtype=torch.float64)
+                st["adv"] = None
+                if m.normalize_advantage and st["obs"][0].shape[0] > 1:
+                    st["adv"] = zw[8:10]
+                    adv_stats_local(m, b, st["adv"])
+                self.step_dev.add_(1)
+                st["step_bumped"] = True
                 vf.train(True)
                 _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
                 pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
@@ -299,12 +335,6 @@ class PolicyUpdater:
                 ev1.record(cs)
                 pipe.fwd2()
                 value = pipe.fwd3()
-                # (the step's zeroed workspace and the advantage statistics: inputs of the fused loss kernel only -- off the actor's lane)
-                zw = st["zw"] = torch.zeros(26, device=self.flat.device, dtype=torch.float64)
-                st["adv"] = None
-                if m.normalize_advantage and st["obs"][0].shape[0] > 1:
-                    st["adv"] = zw[8:10]
-                    adv_stats_local(m, b, st["adv"])
             ops.DEFERRED = []
             if self.overlap_folds:   # leaf-gradient folds beside the backward kernels, on a third stream (ops.FOLD_STREAM)
                 ops.FOLD_STREAM = self._fold_stream()
@@ -329,25 +359,32 @@ class PolicyUpdater:
                 fold, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],
                                                                 maxes=zw[22:23].view(torch.int32), defer_fold=True)
             cs.wait_stream(cur)   # fork: critic backward beside the actor backward
+            own = self._critic_own_adam and not self.overlap_folds
             with torch.cuda.stream(cs), torch.no_grad():
                 sums, maxes = fold()
                 st["lv"] = loss_values(m, sums, maxes)   # reported values only: beside the backward pass, not behind Adam
                 pipe.bwd3(dvalue)
                 pipe.bwd2()
                 grads = pipe.bwd1(leaves)
-                self.step_dev.add_(1)   # Adam's step counter: behind the critic's backward, long before the join -- not on the actor's lane
-                st["step_bumped"] = True
+                if own:   # the critic's gradients are complete: folded and applied HERE, on its lane (only its slabs are queued so far)
+                    na, n = self.n_actor, self.flat.numel()
+                    ops.flush_deferred_grads(overwrite=ow)
+                    adam(na, n, 1)
+                    st["critic_adam_done"] = True
             assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
             torch.autograd.backward([loc, sigma], [dloc, dsigma])
-            cur.wait_stream(cs)   # join: every partial slab is complete
-            ops.flush_deferred_grads()
+            if own:
+                st["join_side"] = lambda: cur.wait_stream(cs)   # joined behind the actor's Adam (s5): off the actor's path
+            else:
+                cur.wait_stream(cs)   # join: every partial slab is complete
+            ops.flush_deferred_grads(overwrite=ow)
             ops.DEFERRED = None
             ops.FOLD_STREAM = None
             st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes)
 
-        if world == 1 and self.overlap_critic:
+        if world == 1 and self.overlap_critic and not self._lanes:
             return [("run", o_fwd), ("run", s5)]
-        if world == 1:   # (overlap_critic switched off) one rank, one stream
+        if world == 1 and not self.overlap_critic:   # one rank, one stream
             return [("run", s0), ("run", s1), ("run", s2), ("run", s3), ("run", s4), ("run", s5)]
 
         # ---- several ranks: two lanes.  The critic with ALL FOUR of its reductions runs on a second stream ("s" items) beside the
@@ -356,14 +393,15 @@ class PolicyUpdater:
         #      referenced in ``st`` for the whole step, so neither allocator pool can hand their memory out while the other lane
         #      still uses it.
         def m_prep():
-            self.gflat.zero_()
+            if not ow:
+                self.gflat.zero_()
             b = dict(batch)
             if "var" not in b:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
             st["b"] = b
             st["obs"] = [b[k] for k in m.in_features]
             st["cobs"] = [b[k] for k in m.critic_in_features]
-            st["zw"] = torch.zeros(26, device=self.flat.device, dtype=torch.float64)
+            st["zw"] = torch.empty(26, device=self.flat.device, dtype=torch.float64)   # every slot is written by its producer
 
         def c_fwd1():
             with torch.no_grad():
@@ -385,10 +423,13 @@ class PolicyUpdater:
 
         def head():  # fused TRPL kernel
             loc, sigma = st["loc_g"], st["sigma_g"]
+            defer = world == 1   # one rank: the per-workgroup loss sums are folded later, on the critic's lane (reported values only)
             with torch.no_grad():
                 zw = st["zw"]
                 sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, st["value"], st["b"], st["adv"], sums=zw[10:22],
-                                                                maxes=zw[22:23].view(torch.int32))
+                                                                maxes=zw[22:23].view(torch.int32), defer_fold=defer)
+            if defer:
+                st["fold"], sums = sums, None
             st.update(loc=loc.detach(), sigma=sigma.detach(), sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma, dvalue=dvalue)
 
         def c_bwd3():
@@ -404,10 +445,41 @@ class PolicyUpdater:
             torch.autograd.backward([st.pop("loc_g"), st.pop("sigma_g")], [st["dloc"], st["dsigma"]])
 
         def fold():
-            ops.flush_deferred_grads()
+            ops.flush_deferred_grads(overwrite=ow)
             ops.DEFERRED = None
 
         S = "s"
+        if world == 1 and self.overlap_critic and self._lanes:
+            # One rank as a two-lane PROGRAM of single-stream graphs (the form the data-parallel step has anyway): this HIP runtime replays a
+            # captured graph with two branches through the host -- hipGraphLaunch returned after 2/3 of the DEVICE time of the step (0.26 /
+            # 0.48 / 2.1 ms at 32 / 512 / 4096 frames against 24 us for a one-stream graph of the same kernels; tools/ubench/graph_branches.py:
+            # two independent 20-kernel chains replay in 139 us, host-bound, one 40-kernel chain in 77) -- and every cross-branch edge costs a
+            # 6-11 us gap.  Lanes as separate graphs on two streams: four short host launches per step, cross-lane edges are stream waits.
+            def c_fwd():
+                with torch.no_grad():
+                    self.step_dev.add_(1)   # Adam's step count: on this lane, in front of the join that both optimizer launches follow
+                    st["step_bumped"] = True
+                c_fwd1()
+                s1()
+                c_fwd3()
+
+            def c_bwd():
+                with torch.no_grad():   # reported values only: folded and evaluated on the critic's lane
+                    sums, maxes = st.pop("fold")()
+                    st.update(sums=sums, maxes=maxes)
+                    st["lv"] = loss_values(m, sums, maxes)
+                c_bwd3()
+                s3()
+                c_bwd1()
+                if self._critic_own_adam:
+                    with torch.no_grad():
+                        na, n = self.n_actor, self.flat.numel()
+                        ops.flush_deferred_grads(overwrite=ow, only=lambda g: g.data_ptr() >= self.gflat.data_ptr() + 4 * na)
+                        adam(na, n, 1)
+                        st["critic_adam_done"] = True
+
+            return [("fork", None), ("run", m_prep), ("run", a_fwd), ("run", c_fwd, S), ("join", None),
+                    ("run", head), ("fork", None), ("run", c_bwd, S), ("run", a_bwd), ("run", fold), ("run", s5), ("join", None)]
         plan = [("run", m_prep), ("fork", None),
                 ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S), ("sum", lambda: st["adv"], S),
                 ("run", a_fwd),
@@ -430,7 +502,16 @@ class PolicyUpdater:
 
     def _critic_stream(self):
         if getattr(self, "_cstream", None) is None:
-            self._cstream = torch.cuda.Stream()
+            # the LOWEST priority the device offers: the critic's small launches take the compute units the actor's kernels leave (heads,
+            # tails, the latency-bound loss kernel) instead of displacing their workgroups (DESIGN.md finding 33)
+            prio = 0
+            if os.environ.get("GRL_CRITIC_PRIO", "1") != "0" and hasattr(torch.cuda.Stream, "priority_range"):
+                try:
+                    prio = max(torch.cuda.Stream.priority_range())
+                except Exception:
+                    prio = 0
+            self._cstream = torch.cuda.Stream(priority=prio)
+            self._cstream_priority = prio
         return self._cstream
 
     def _reduce(self, kind, t):

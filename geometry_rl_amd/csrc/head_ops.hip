@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void trpl_fold_kernel(const double* __restrict_
   }
 }
 
-// sum and sum of squares of the advantages (fp64) ADDED to stats[0..1] -- ONE workgroup, fixed summation order (thread-strided partial sums,
+// sum and sum of squares of the advantages (fp64) WRITTEN to stats[0..1] (round 4: the slots need not be zeroed) -- ONE workgroup, fixed summation order (thread-strided partial sums,
 // wave butterflies, the sixteen waves in order): bitwise reproducible.  (Until round 3 every wave of a multi-workgroup grid added its sums
 // with fp64 atomics: the order of 64 additions, hence the last bits of the normalised advantages, depended on the run.)
 __global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict__ adv, double* __restrict__ stats, int B) {
@@ -528,8 +528,8 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict
     double t0 = red[0][0], t1 = red[0][1];
 #pragma unroll
     for (int w = 1; w < 16; ++w) { t0 += red[w][0]; t1 += red[w][1]; }
-    stats[0] += t0;
-    stats[1] += t1;
+    stats[0] = t0;
+    stats[1] = t1;
   }
 }
 

@@ -642,12 +642,16 @@ struct ReduceMulti {
   int n_rows[RED_MULTI_MAX], ld[RED_MULTI_MAX], start[RED_MULTI_MAX];
   float* dst[RED_MULTI_MAX];                                           // destinations
   int len[RED_MULTI_MAX], first[RED_MULTI_MAX], count[RED_MULTI_MAX];
+  int blk0[RED_MULTI_MAX + 1];                                         // first workgroup of destination d (64 columns per workgroup): a flat grid
+  int n_dst;
+  int overwrite;                                                       // 1: dst = sum (destination not read) instead of dst += sum
   unsigned char vec[RED_MULTI_MAX];                                    // destination group eligible for the float4 path
 };
 // float4 variant: a wave covers 4 rows x 64 columns per load (16 lanes x float4 per row, lane >> 4 picks the row), so a
 // workgroup still owns only 64 columns -- tall thin slabs (1024-2048 rows x 4096 columns) need that many workgroups: with 256
 // columns per workgroup 16 CUs pulled the whole slab at ~95 GB/s each (tools/ubench/reduce_bench.py).
-GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_rows, int row0) {
+template <int RED_DEPTH>
+GRL_DEVINL float4 column_sum4_d(const float* __restrict__ src, size_t ld, int n_rows, int row0) {
   constexpr int STEP = 4 * RED_WAVES;
   if (n_rows <= 0) return make_float4(0.f, 0.f, 0.f, 0.f);
   float4 a[RED_DEPTH];
@@ -661,8 +665,9 @@ GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_ro
 #pragma unroll
     for (int u = 0; u < RED_DEPTH; ++u) a[u] = f4_add(a[u], v[u]);
   }
-  {  // remainder: all of its (< RED_DEPTH) loads in flight together -- rows past the end are loaded CLAMPED and dropped at the add: a guard
-     // around the load is a branch per load with a wait at each join (finding 31a), and the 257-row slabs of the MLP backward are all remainder
+  if (w < n_rows) {   // (one branch around the whole batch: slabs of exactly RED_DEPTH * STEP rows have no remainder)
+     // remainder: all of its (< RED_DEPTH) loads in flight together -- rows past the end are loaded CLAMPED and dropped at the add: a guard
+     // around each load is a branch per load with a wait at each join (finding 31a)
     float4 v[RED_DEPTH];
 #pragma unroll
     for (int u = 0; u < RED_DEPTH; ++u) {
@@ -681,16 +686,29 @@ GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_ro
     for (int u = 0; u < st; ++u) a[u] = f4_add(a[u], a[u + st]);
   return a[0];
 }
+// Loads in flight per lane sized to the slab (workgroup-uniform): the slabs of the 256-workgroup MFMA launches have exactly 256 rows = 8 loads
+// of 32 rows -- with the fixed depth of 16 half of every lane's loads were clamped duplicates of the last row (round 3: 87 MB of slabs
+// read as 174 MB of requests)
+GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_rows, int row0) {
+  constexpr int STEP = 4 * RED_WAVES;
+  if (n_rows <= 2 * STEP) return column_sum4_d<2>(src, ld, n_rows, row0);
+  if (n_rows <= 4 * STEP) return column_sum4_d<4>(src, ld, n_rows, row0);
+  if (n_rows <= 8 * STEP) return column_sum4_d<8>(src, ld, n_rows, row0);
+  return column_sum4_d<16>(src, ld, n_rows, row0);
+}
 GRL_DEVINL float4 f4_shfl_xor(float4 v, int m) {
   return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
 }
 __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(ReduceMulti m) {
   __shared__ float4 red[RED_WAVES][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int d = blockIdx.y;
-  if (blockIdx.x * 64 >= m.len[d]) return;
+  // flat grid: exactly one workgroup per 64 columns of every destination (round 3 launched max_len / 64 x n_dst workgroups, ~8 of 10 of
+  // which found themselves outside their destination and left at once -- ten thousand empty 512-thread workgroups per step)
+  int d = 0;
+  while (d + 1 < m.n_dst && (int)blockIdx.x >= m.blk0[d + 1]) ++d;
+  const int bx = (int)blockIdx.x - m.blk0[d];
   if (m.vec[d]) {   // every source slab and the destination 16-byte aligned, lengths multiples of 4
-    const int j = blockIdx.x * 64 + 4 * (lane & 15);
+    const int j = bx * 64 + 4 * (lane & 15);
     const bool active = j < m.len[d];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active)
@@ -705,18 +723,18 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(R
 #pragma unroll
       for (int g = 1; g < RED_WAVES; ++g) t = f4_add(t, red[g][lane]);
       float4* dp = reinterpret_cast<float4*>(m.dst[d] + j);
-      *dp = f4_add(*dp, t);
+      *dp = m.overwrite ? t : f4_add(*dp, t);
     }
     return;
   }
-  const int j = blockIdx.x * 64 + lane;
+  const int j = bx * 64 + lane;
   const bool active = j < m.len[d];
   float v = 0.f;
   if (active)
     for (int q = m.first[d]; q < m.first[d] + m.count[d]; ++q)
       v += column_sum(m.partial[q] + m.start[q] + j, (size_t)m.ld[q], m.n_rows[q], wave);
   __shared__ float reds[RED_WAVES][64];
-  fold_and_add(v, m.dst[d] + j, active, reds);
+  fold_and_add(v, m.dst[d] + j, active, reds, m.overwrite != 0);
 }
 
 int cap_blocks(long long work, int per_block, int cap) {
@@ -865,8 +883,16 @@ int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg,
 
 // n_seg <= 64 folds in one launch: dst[i][0..len[i]) += sum over n_rows[i] rows of partial[i][row*ld[i] + start[i] + j]
 // (all arrays are HOST arrays of length n_seg).  Segments with the same destination are summed by the same workgroup, in order.
+int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                                 const int* len, float* const* dst, int overwrite, hipStream_t stream);
 int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
                               const int* len, float* const* dst, hipStream_t stream) {
+  return grl_reduce_partials_multi_ow(n_seg, partial, n_rows, ld, start, len, dst, 0, stream);
+}
+// overwrite != 0: every destination is WRITTEN with the sum of its slabs (not accumulated into): the caller needs no zeroed gradient
+// buffer, provided every slab of a destination is in THIS call (they are summed by one workgroup in the order given)
+int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                                 const int* len, float* const* dst, int overwrite, hipStream_t stream) {
   if (n_seg <= 0) return 0;
   if (n_seg > RED_MULTI_MAX) return -2;
   ReduceMulti m{};
@@ -889,9 +915,14 @@ int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int*
     m.count[n_dst] = n_src - m.first[n_dst];
     m.vec[n_dst] = vec ? 1 : 0;
     if (len[i] > max_len) max_len = len[i];
+    m.blk0[n_dst + 1] = m.blk0[n_dst] + (len[i] + 63) / 64;
     ++n_dst;
   }
-  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((max_len + 63) / 64, n_dst), dim3(64 * RED_WAVES), 0, stream, m);
+  (void)max_len;
+  m.n_dst = n_dst;
+  m.overwrite = overwrite ? 1 : 0;
+  if (m.blk0[n_dst] <= 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(m.blk0[n_dst]), dim3(64 * RED_WAVES), 0, stream, m);
   GRL_CHECK_LAUNCH();
   return 0;
 }

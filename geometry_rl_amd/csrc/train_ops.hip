@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 // clip coefficient of torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g||_2 + 1e-6))
 // ONE workgroup, fixed summation order (eight independent 16-byte loads in flight per thread, thread-strided partial sums, wave butterflies,
 // the sixteen waves in order): the squared norm -- and with it the clip coefficient -- is bitwise reproducible (until round 3: fp64 atomics
-// of up to 1 024 wave sums, in whatever order they arrived).  sqnorm[0] += the sum (the caller passes a zeroed slot).
-__global__ __launch_bounds__(1024) void sqnorm_kernel(const float* __restrict__ g, int n, double* __restrict__ out) {
+// of up to 1 024 wave sums, in whatever order they arrived).  sqnorm[0] = the sum (written: round 4 -- the slot need not be zeroed), and the
+// coefficient comes out of the same launch (its own one-thread kernel was a launch on the step's tail in every clipped configuration).
+__global__ __launch_bounds__(1024) void sqnorm_kernel(const float* __restrict__ g, int n, double* __restrict__ out, float max_norm,
+                                                     float* __restrict__ coef) {
   __shared__ double red[16];
   double s = 0;
   // views of the flat gradient start anywhere: up to three leading elements, then 16-byte pieces, then the tail
@@ -75,12 +77,9 @@ __global__ __launch_bounds__(1024) void sqnorm_kernel(const float* __restrict__ 
     double t = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) t += red[w];
-    out[0] += t;
+    out[0] = t;
+    coef[0] = fminf(1.f, max_norm / ((float)sqrt(t) + 1e-6f));
   }
-}
-__global__ void clip_coef_kernel(const double* __restrict__ sq, float max_norm, float* __restrict__ coef) {
-  const float nrm = (float)sqrt(sq[0]);
-  coef[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
 }
 
 // One thread per environment, sequential over time (the recursion is inherently serial in t; N envs run in parallel).
@@ -419,10 +418,9 @@ int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
   return 0;
 }
 
-// sqnorm: device fp64[1] zeroed by the caller; coef: device float[1]
+// sqnorm: device fp64[1] (written: the squared norm), coef: device float[1]; one launch
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream) {
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(1), dim3(1024), 0, stream, grads, n, sqnorm);
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sqnorm, max_norm, coef);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(1), dim3(1024), 0, stream, grads, n, sqnorm, max_norm, coef);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -114,43 +114,64 @@ FOLD_STREAM = None
 _FOLD_KEEP = []   # partial slabs whose fold is in flight (kept alive until flush_deferred_grads joins the side stream)
 
 
-def _launch_folds(jobs):
+def _launch_folds(jobs, overwrite=False):
+    """One launch per <= 64 slabs; every slab of a destination goes into the SAME launch (the kernel sums a destination's slabs in one
+    workgroup, in the order given) -- with ``overwrite`` that is a requirement, not just the cheaper form."""
     import ctypes
-    for i in range(0, len(jobs), 64):
-        part = jobs[i:i + 64]
+    order, by_dst = [], {}
+    for j in jobs:                       # group by destination, first-appearance order (the summation order of a destination's slabs)
+        k = j[3].data_ptr()
+        if k not in by_dst:
+            by_dst[k] = []
+            order.append(k)
+        by_dst[k].append(j)
+    batches, cur = [], []
+    for k in order:
+        grp = by_dst[k]
+        if len(grp) > 64:
+            raise RuntimeError("more than 64 partial slabs feed one gradient")
+        if len(cur) + len(grp) > 64:
+            batches.append(cur)
+            cur = []
+        cur += grp
+    if cur:
+        batches.append(cur)
+    for part in batches:
         n = len(part)
-        hip.call("grl_reduce_partials_multi", n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part]),
+        hip.call("grl_reduce_partials_multi_ow", n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part]),
                  (ctypes.c_int * n)(*[j[0].shape[0] for j in part]), (ctypes.c_int * n)(*[j[0].shape[1] for j in part]),
                  (ctypes.c_int * n)(*[j[1] for j in part]), (ctypes.c_int * n)(*[j[2] for j in part]),
-                 (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]))
+                 (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]), 1 if overwrite else 0)
 
 
-def flush_deferred_grads():
-    import ctypes
+def flush_deferred_grads(overwrite=False, only=None):
+    """Fold every queued slab into its leaf gradient.  ``overwrite``: the gradients are WRITTEN (the caller keeps no zeroed buffer; every
+    leaf gradient of the pass must then come through this queue -- PolicyUpdater checks that).  ``only``: a predicate on the destination
+    tensor -- fold just those jobs now and leave the others queued (the critic's lane folds its own gradients)."""
     global DEFERRED
     jobs = DEFERRED or []
+    keep = []
+    if only is not None:
+        keep = [j for j in jobs if not only(j[3])]
+        jobs = [j for j in jobs if only(j[3])]
     if DEFERRED is not None:
-        DEFERRED = []
+        DEFERRED = keep
     if FOLD_STREAM is not None:
         if jobs:
             _launch_folds(jobs)
         torch.cuda.current_stream().wait_stream(FOLD_STREAM)   # join: every fold has landed in the flat gradient
         _FOLD_KEEP.clear()
         return
-    for i in range(0, len(jobs), 64):
-        part = jobs[i:i + 64]
-        n = len(part)
-        hip.call("grl_reduce_partials_multi", n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part]),
-                 (ctypes.c_int * n)(*[j[0].shape[0] for j in part]), (ctypes.c_int * n)(*[j[0].shape[1] for j in part]),
-                 (ctypes.c_int * n)(*[j[1] for j in part]), (ctypes.c_int * n)(*[j[2] for j in part]),
-                 (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]))
+    if jobs:
+        _launch_folds(jobs, overwrite)
 
 
 def _emit_grads(partial: torch.Tensor, segments):
     """Fold per-workgroup partial rows into gradients with ONE launch.  ``segments`` = [(start, length, shape, tensor)]:
     when ``tensor`` is a leaf whose ``.grad`` buffer already exists (PolicyUpdater keeps every parameter's grad as a view of
     one flat buffer) the sum is accumulated in place and ``None`` is handed to autograd (no AccumulateGrad add kernel);
-    otherwise a fresh gradient tensor is returned."""
+    otherwise a fresh gradient tensor is returned.  While a DEFERRED queue is installed the leaf segments are only queued (one launch
+    for all of them at the end of the backward pass) and the fresh ones are produced at once."""
     import ctypes
     dev = partial.device
     outs, dsts, starts, lens, fresh_flags = [], [], [], [], []
@@ -167,22 +188,24 @@ def _emit_grads(partial: torch.Tensor, segments):
             fresh_flags.append(1)
         starts.append(start)
         lens.append(length)
-    if DEFERRED is not None and not any(fresh_flags):
-        jobs = [(partial, st, ln, d) for st, ln, d in zip(starts, lens, dsts)]
-        if FOLD_STREAM is not None:   # fold now, on the side stream, behind the kernel that has just been queued on this stream
+    now = list(range(len(segments)))
+    if DEFERRED is not None:
+        jobs = [(partial, st, ln, d) for st, ln, d, f in zip(starts, lens, dsts, fresh_flags) if not f]
+        now = [i for i, f in enumerate(fresh_flags) if f]
+        if FOLD_STREAM is not None and jobs:   # fold now, on the side stream, behind the kernel that has just been queued on this stream
             FOLD_STREAM.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(FOLD_STREAM):
                 _launch_folds(jobs)
             _FOLD_KEEP.append(partial)
-            return outs
-        DEFERRED.extend(jobs)   # keeps `partial` alive until the flush
-        return outs
-    for i in range(0, len(segments), 8):
-        n = min(8, len(segments) - i)
-        mask = sum(f << k for k, f in enumerate(fresh_flags[i:i + n]))
+        else:
+            DEFERRED.extend(jobs)   # keeps `partial` alive until the flush
+    for i0 in range(0, len(now), 8):
+        idx = now[i0:i0 + 8]
+        n = len(idx)
+        mask = sum(fresh_flags[i] << k for k, i in enumerate(idx))
         hip.call("grl_reduce_partials_seg", partial, partial.shape[0], partial.shape[1], n,
-                 (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts[i:i + n]]), (ctypes.c_int * n)(*starts[i:i + n]),
-                 (ctypes.c_int * n)(*lens[i:i + n]), mask)
+                 (ctypes.c_void_p * n)(*[dsts[i].data_ptr() for i in idx]), (ctypes.c_int * n)(*[starts[i] for i in idx]),
+                 (ctypes.c_int * n)(*[lens[i] for i in idx]), mask)
     return outs
 
 

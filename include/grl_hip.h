@@ -224,6 +224,7 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  *               projection type: 0 KL | 1 Frobenius | 2 Wasserstein (commutative, precision-scaled)}
  * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
  *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
+/* stats fp64[2] = (sum, sum of squares) of the advantages, WRITTEN (ABI 203; <= 202 added to a zeroed slot): one workgroup, fixed order */
 int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream);
 /* (ABI 202) sums == NULL in grl_trpl_fwd_bwd: the per-workgroup slots are left unfolded and the caller runs grl_trpl_fold later, e.g. on a
  * side stream -- the sums / maxes are reported values (trpl.py:280-321), nothing on the gradient path reads them. */
@@ -296,12 +297,17 @@ int grl_reduce_partials_seg(const float* partial, int n_rows, int ld, int n_seg,
 /* n_seg <= 64 independent folds in ONE launch (all arrays HOST arrays of length n_seg): every leaf gradient of a backward pass */
 int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
                               const int* len, float* const* dst, hipStream_t stream);
+/* (ABI 203) overwrite != 0: every destination is WRITTEN with the sum of its slabs instead of accumulated into (no zeroed gradient buffer
+ * needed), provided all slabs of a destination are in this call; the launch is a flat grid of one workgroup per 64 columns */
+int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                                 const int* len, float* const* dst, int overwrite, hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
 /* the same update with the step count (int[1]) AND the learning rate (float[1]) in device memory: recordable into a hipGraph, and
  * a learning-rate schedule (anneal_lr, train.py:264-271; configs/algorithm/optim/default.yaml:5) reaches the replayed launch */
 int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, const float* lr_dev, float beta1,
                       float beta2, float eps, const int* step_dev, const float* scale_dev, float scale_host, hipStream_t stream);
+/* torch.nn.utils.clip_grad_norm_ (train.py:308-310): sqnorm fp64[1] = |g|^2 (WRITTEN since ABI 203), coef float[1] = min(1, max_norm / (|g| + 1e-6)); one launch */
 int grl_clip_coef(const float* grads, int n, float max_norm, double* sqnorm, float* coef, hipStream_t stream);
 int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned char* terminated, const float* values,
                  float* advantage, float* value_target, int n_env, int n_steps, float gamma, float lmbda, hipStream_t stream);

@@ -5,7 +5,7 @@ TAG=${1:-run}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/tl_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for mb in 32 512 4096; do
+for mb in ${GRL_TL_SIZES:-32 512 4096}; do
   rocprofv3 --kernel-trace --output-format csv -d $OUT/p$mb -o g$mb -- python3 $GRAFT_REPO_ROOT/bench.py --minibatch $mb --steps 20 --warmup 4 --pool 8 --no-cpu-baseline --no-roofline --no-parity-gate > /dev/null 2>&1
   f=$(find $OUT/p$mb -name "*kernel_trace.csv" | head -1)
   python3 $GRAFT_REPO_ROOT/tools/timeline.py $f > $OUT/timeline_$mb.txt 2>&1
