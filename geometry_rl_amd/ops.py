@@ -645,15 +645,21 @@ class DeepSetsPipeline:
 
 
 @torch.no_grad()
-def deepsets_values_groups(x: torch.Tensor, params, groups: int) -> torch.Tensor:
+def deepsets_values_groups(x: torch.Tensor, params, groups: int, group=None) -> torch.Tensor:
     """No-grad critic pass over ``groups`` independent batches in three launches: x [groups * B, n, d] (group-major) -> V [groups, B].
     Every group has its own whole-tensor LayerNorm statistics, exactly as if ``DeepSetsValue`` had been called once per group
     (gnn_vf_net.py:72-80 loops over the time steps of a [N, T, .] input); the per-group launch grid is the single-batch grid, so the
-    values are bitwise those of the loop.  ``params``: the 14 tensors in DeepSetsPipeline.PARAM_ORDER."""
+    values are bitwise those of the loop.  ``params``: the 14 tensors in DeepSetsPipeline.PARAM_ORDER.
+    ``group``: torch.distributed process group of a data-parallel run -- every rank holds B of the world * B samples of each group; the
+    [groups, slots] statistic arrays are summed over the ranks by ONE all-reduce per LayerNorm stage (two per call, whatever ``groups``)."""
     hip.check_f32(x, *params)
     GB, n, d = x.shape
     assert GB % groups == 0
     B, dev = GB // groups, x.device
+    world = 1
+    if group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
     P = [t.contiguous() for t in params]
     ns = 2 * hip.query("grl_deepsets_stat_slots")
     slots = torch.empty(2, groups, ns, device=dev, dtype=torch.float64)
@@ -663,8 +669,13 @@ def deepsets_values_groups(x: torch.Tensor, params, groups: int) -> torch.Tensor
     value = torch.empty(groups, B, device=dev, dtype=torch.float32)
     w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, wv, bv = P
     hip.call("grl_deepsets_fwd1_groups", x.contiguous(), w1, b1, h1, slots[0], B, n, d, groups)
-    hip.call("grl_deepsets_fwd2_groups", h1, slots[0], ctypes_double(float(B * n * 64)), g1, be1, w2, b2, w3, b3, z, u1, slots[1], B, n, groups)
-    hip.call("grl_deepsets_fwd3_groups", u1, slots[1], ctypes_double(float(B * 64)), g2, be2, w4, b4, wv, bv, value, B, groups)
+    if world > 1:
+        dist.all_reduce(slots[0], group=group)
+    hip.call("grl_deepsets_fwd2_groups", h1, slots[0], ctypes_double(float(B * world * n * 64)), g1, be1, w2, b2, w3, b3, z, u1, slots[1], B, n,
+             groups)
+    if world > 1:
+        dist.all_reduce(slots[1], group=group)
+    hip.call("grl_deepsets_fwd3_groups", u1, slots[1], ctypes_double(float(B * world * 64)), g2, be2, w4, b4, wv, bv, value, B, groups)
     return value
 
 

@@ -73,26 +73,17 @@ class RolloutDriver:
 
     # ---- train.py:134-140,249-251: critic over the T+1 frames of every environment, then the shifted GAE scan
     @torch.no_grad()
-    def compute_advantages(self, buf: RolloutBuffer, next_last: Dict[str, torch.Tensor], chunk: int = 16) -> None:
+    def compute_advantages(self, buf: RolloutBuffer, next_last: Dict[str, torch.Tensor]) -> None:
         """``next_last``: observation groups of the frame after the last one, [N, 1, width].  Writes ``state_value``,
         ``advantage`` and ``value_target`` [N, T, 1] into the buffer."""
         critic = self.updater.loss_module.critic_network
         N, T = buf.N, buf.T
         vals = torch.empty(N, T + 1, device=buf.data["reward"].device, dtype=torch.float32)
-        if getattr(critic._network1, "group", None) is None:
-            # all T frames of every environment as ONE time-batched critic call (policy.GNNVFNet._values_time_batched: the time steps are
-            # groups of one launch set, statistics per step), the frame after the last one as a second, one-step call
-            vals[:, :T] = critic(*[buf.data[k] for k in self.spec.in_features], train=False).reshape(N, T)
-            vals[:, T:] = critic(*[next_last[k] for k in self.spec.in_features], train=False).reshape(N, 1)
-        else:   # data parallel: the per-step statistics are all-reduced between the stages -- the looped form, time-chunked
-            for t0 in range(0, T + 1, chunk):
-                t1 = min(t0 + chunk, T + 1)
-                obs = []
-                for k in self.spec.in_features:
-                    x = buf.data[k]
-                    x = torch.cat([x, next_last[k]], dim=1) if t1 > T else x
-                    obs.append(x[:, t0:t1].contiguous())
-                vals[:, t0:t1] = critic(*obs, train=False).reshape(N, t1 - t0)
+        # all T frames of every environment as ONE time-batched critic call (policy.GNNVFNet._values_time_batched: the time steps are groups
+        # of one launch set, statistics per step; data parallel: the per-step statistics of a chunk travel in one all-reduce per LayerNorm
+        # stage -- two collectives per chunk, where the looped form issued two per time step), the frame after the last one as a second call
+        vals[:, :T] = critic(*[buf.data[k] for k in self.spec.in_features], train=False).reshape(N, T)
+        vals[:, T:] = critic(*[next_last[k] for k in self.spec.in_features], train=False).reshape(N, 1)
         adv, tgt = _agent.gae(buf.data["reward"].reshape(N, T), buf.data["done"].reshape(N, T), buf.data["terminated"].reshape(N, T),
                               vals, self.gamma, self.lmbda)
         buf.data["state_value"] = vals[:, :T].reshape(N, T, 1).contiguous()

@@ -190,3 +190,56 @@ def test_two_ranks_rccl():
             assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (r, k, losses[k], v)
         assert (flat - ref_flat).abs().max().item() <= 3e-5
     assert torch.equal(ret[0][1], ret[1][1]), "replicas diverged"
+
+
+# ---- the once-per-rollout critic pass under data parallelism: the time-batched launch set with ONE all-reduce per
+#      LayerNorm stage for all time steps of a chunk (gnn_vf_net.py:72-80: statistics per time step, here of the WHOLE sharded batch)
+def _critic_inputs(N, T):
+    from geometry_rl_amd import graph, synthetic as syn
+    spec = graph.rigid_spec()
+    frames = [syn.make_rigid_obs(N, seed=70 + t) for t in range(T)]
+    return spec, {k: torch.stack([f[k] for f in frames], dim=1) for k in spec.in_features}
+
+
+def _critic_worker(rank, world, port, N, T, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from geometry_rl_amd import agent
+    dev = torch.device("cuda:0")
+    spec, obs = _critic_inputs(N, T)
+    torch.manual_seed(0)
+    actor, critic, proj, loss = agent.build_agent(spec, agent.AgentConfig(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2),
+                                                  device=dev, group=dist.group.WORLD)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    shard = [obs[k][lo:hi].contiguous().to(dev) for k in spec.in_features]
+    calls = {"n": 0}
+    orig = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    dist.all_reduce = counting
+    with torch.no_grad():
+        v = critic(*shard, train=False)
+    dist.all_reduce = orig
+    ret[rank] = (v.reshape(hi - lo, T).cpu(), calls["n"])
+    dist.destroy_process_group()
+
+
+def test_time_batched_critic_pass_two_ranks_equals_one_rank():
+    from geometry_rl_amd import agent
+    N, T, world = 12, 9, 2
+    dev = torch.device("cuda:0")
+    spec, obs = _critic_inputs(N, T)
+    torch.manual_seed(0)
+    actor, critic, proj, loss = agent.build_agent(spec, agent.AgentConfig(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2), device=dev)
+    with torch.no_grad():
+        ref = critic(*[obs[k].to(dev) for k in spec.in_features], train=False).reshape(N, T).cpu()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_critic_worker, args=(world, _free_port(), N, T, ret), nprocs=world, join=True)
+    got = torch.cat([ret[r][0] for r in range(world)], dim=0)
+    err = (got - ref).abs().max().item()
+    print(f"time-batched critic, {world} ranks vs 1: max |dV| = {err:.3e} (|V| max {ref.abs().max().item():.3e}); all-reduces per rank: {ret[0][1]}")
+    assert err <= 1e-6 * max(1.0, ref.abs().max().item())
+    assert ret[0][1] == 2 and ret[1][1] == 2, "one collective per LayerNorm stage for ALL time steps of the chunk"
