@@ -334,11 +334,37 @@ def main():
         out = upd.step_from(buf, next(mb))
     barrier()
     dt = time.perf_counter() - t0
+    dp_info = None
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        own = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+        per_rank = [1e3 * float(x.item()) / args.steps for x in every]
+        t = own.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the first hardware run must describe itself: which backend carried the collectives, how many ranks it saw,
+        # every collective of the step by name with its payload and the time its lane was held by it (HIP events on the lane's stream around
+        # the call: waiting for the other ranks + transfer), how long the main lane stood at the two joins with the critic's lane, and the
+        # ranks' own step times (max / min) -- five extra steps with the log on, all ranks in lock-step, behind the timed region
+        n_log = 5
+        upd.collective_log = {}
+        for i in range(n_log):
+            upd.step_from(buf, next(mb))
+        coll = upd.collective_summary(n_log)
+        upd.collective_log = None
+        try:
+            lib_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            lib_version = None
+        dp_info = {"collective_backend": dist.get_backend(), "collective_library_version": lib_version, "ranks_seen": dist.get_world_size(),
+                   "per_rank_ms_per_step": per_rank, "rank_spread_max_over_min": max(per_rank) / max(min(per_rank), 1e-9),
+                   "collectives_per_step": sum(v["per_step"] for k, v in coll.items() if not k.startswith(("join", "wait"))),
+                   "collectives": coll,
+                   "main_lane_waits_ms": {k: v["mean_ms"] for k, v in coll.items() if k.startswith(("join", "wait"))},
+                   "note": "rank 0's lanes; mean / max over 5 logged steps behind the timed region; 'flat_gradient' is the one collective the "
+                           "main lane waits for, the critic's four LayerNorm-statistic reductions and the advantage statistics run on the side lane"}
     ms = 1e3 * dt / args.steps
     n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
     upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else
@@ -528,11 +554,13 @@ def main():
                        "parallelism": f"dp{world}"},
             "gae_ms_per_rollout_scan": gae_ms, "advantage_pass_ms": adv_ms, "advantage_pass_ms_cold": adv_ms_cold,
             "advantage_pass": f"critic over the {T_roll} + 1 frames of all {B} environments per GPU + shifted GAE, once per rollout (train.py:249-251); "
-                              "warm = second call; single GPU: the time steps are groups of one launch set (per-step LayerNorm statistics)",
+                              "warm = second call; the time steps are groups of one launch set (per-step LayerNorm statistics"
+                              + ("" if world == 1 else ", summed over the ranks by one all-reduce per LayerNorm stage and chunk") + ")",
             "minibatches": f"sampled without replacement from a device-resident {B} x {T_roll}-frame rollout per GPU (one frame per env), "
                            "gathered into the static inputs of the recorded step by one launch",
             "loss": {k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_critic", "kl")},
             "roofline": roof, "cpu_baseline": cpu, "parity_gate": gate, "determinism_selfcheck": det,
+            "data_parallel": dp_info,
         }
         if det is not None and not det["passed"]:   # a box (or a build) whose MFMA kernels are not reproducible reports no number
             line["invalid_value"], line["value"] = line["value"], None

@@ -480,18 +480,20 @@ class PolicyUpdater:
 
             return [("fork", None), ("run", m_prep), ("run", a_fwd), ("run", c_fwd, S), ("join", None),
                     ("run", head), ("fork", None), ("run", c_bwd, S), ("run", a_bwd), ("run", fold), ("run", s5), ("join", None)]
+        # (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
         plan = [("run", m_prep), ("fork", None),
-                ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S), ("sum", lambda: st["adv"], S),
+                ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"), ("sum", lambda: st["adv"], S, "advantage_stats"),
                 ("run", a_fwd),
-                ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S), ("run", c_fwd3, S),
-                ("join", None),
+                ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"), ("run", c_fwd3, S),
+                ("join", None, "m", "join_critic_forward"),
                 ("run", head), ("fork", None),
-                ("run", c_bwd3, S), ("sum", lambda: st["pipe"].bst2, S), ("run", s3, S), ("sum", lambda: st["pipe"].bst1, S),
+                ("run", c_bwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"), ("run", s3, S),
+                ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
                 ("run", c_bwd1, S),
-                ("sum_async", lambda: st["sums"]), ("max_async", lambda: st["maxes"]),   # loss terms: already scaled by 1/B_global
+                ("sum_async", lambda: st["sums"], "m", "loss_sums"), ("max_async", lambda: st["maxes"], "m", "loss_maxes"),   # loss terms: already scaled by 1/B_global
                 ("run", a_bwd),
-                ("join", None), ("wait", None),
-                ("run", fold), ("sum", lambda: self.gflat)]
+                ("join", None, "m", "join_critic_backward"), ("wait", None, "m", "wait_async_loss_terms"),
+                ("run", fold), ("sum", lambda: self.gflat, "m", "flat_gradient")]
         plan += [("run", s5)]
         return plan
 
@@ -514,20 +516,53 @@ class PolicyUpdater:
             self._cstream_priority = prio
         return self._cstream
 
-    def _reduce(self, kind, t):
+    # ``collective_log``: None, or {} to record -- per label a list of (start event, end event, payload bytes) on the lane's stream: how long
+    # the lane was held by each collective (wait for the other ranks + transfer).  Read with ``collective_summary()``.
+    collective_log = None
+
+    def _log_span(self, label, nbytes=0):
+        """Context manager: HIP events on the current stream around a collective / cross-lane wait when the log is on."""
+        import contextlib
+        if self.collective_log is None or label is None:
+            return contextlib.nullcontext()
+        upd = self
+
+        @contextlib.contextmanager
+        def span():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            yield
+            e1.record()
+            upd.collective_log.setdefault(label, []).append((e0, e1, nbytes))
+        return span()
+
+    def collective_summary(self, n_steps: int):
+        """{label: {per_step, mean_ms, max_ms, bytes}} from the recorded events (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for label, recs in (self.collective_log or {}).items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[label] = {"per_step": len(recs) / max(1, n_steps), "mean_ms": sum(ms) / len(ms), "max_ms": max(ms), "bytes": recs[0][2]}
+        return out
+
+    def _reduce(self, kind, t, label=None):
         import torch.distributed as dist
         if kind == "wait":
-            for w in self._pending:
-                w.wait()
+            with self._log_span(label):
+                for w in self._pending:
+                    w.wait()
             self._pending = []
             return
         if t is None:
             return
+        nbytes = t.numel() * t.element_size()
         if kind in ("sum_async", "max_async"):
             op = dist.ReduceOp.SUM if kind == "sum_async" else dist.ReduceOp.MAX
-            self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+            with self._log_span((label or kind) + " (issue only: asynchronous)", nbytes):
+                self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
             return
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=self.group)
+        with self._log_span(label or kind, nbytes):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=self.group)
 
     def _compile(self, batch):
         """Record the plan's segments into hipGraphs (adjacent segments without a reduction between them share one graph)."""
@@ -541,25 +576,26 @@ class PolicyUpdater:
         groups, cur, cur_lane = [], [], None
         for entry in plan:
             kind, item, lane = entry[0], entry[1], (entry[2] if len(entry) > 2 else "m")
+            label = entry[3] if len(entry) > 3 else None
             if kind == "run" and (not cur or lane == cur_lane):
                 cur.append(item)
                 cur_lane = lane
                 continue
             if cur:
-                groups.append(("run", cur, cur_lane))
+                groups.append(("run", cur, cur_lane, None))
                 cur, cur_lane = [], None
             if kind == "run":
                 cur, cur_lane = [item], lane
             else:
-                groups.append((kind, item, lane))
+                groups.append((kind, item, lane, label))
         if cur:
-            groups.append(("run", cur, cur_lane))
+            groups.append(("run", cur, cur_lane, None))
         program, pools = [], {}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        for kind, item, lane in groups:
+        for kind, item, lane, label in groups:
             if kind != "run":
-                program.append((kind, item, lane))
+                program.append((kind, item, lane, label))
                 continue
             g = torch.cuda.CUDAGraph()
             # one allocator pool per lane: graphs of different lanes are replayed concurrently and must not share scratch memory
@@ -568,7 +604,7 @@ class PolicyUpdater:
                 for fn in item:
                     fn()
             pools[lane] = g.pool()
-            program.append(("graph", g, lane))
+            program.append(("graph", g, lane, None))
         torch.cuda.current_stream().wait_stream(side)
         self._program = program
 
@@ -644,7 +680,7 @@ class PolicyUpdater:
         if not self.use_graph or B not in seen:     # the first step of a minibatch size always runs eagerly: it builds the
             seen.add(B)                             # cached topology of that size and the kernels' one-time attributes
             st = {}
-            self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m") for e in self._plan(batch, st)])
+            self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m", e[3] if len(e) > 3 else None) for e in self._plan(batch, st)])
             return st["out"]
         if self._program is not None and any(self._static[k].shape != batch[k].shape for k in self._static if k in batch):
             self.reset_graph()                      # another minibatch size: record again for it
@@ -673,25 +709,29 @@ class PolicyUpdater:
         caller's stream, lane "s" the critic stream; "fork": the side lane waits for the main lane, "join": the reverse."""
         main = torch.cuda.current_stream()
         side = None
-        for kind, item, lane in program:
+        for kind, item, lane, label in program:
             if kind in ("fork", "join"):
                 side = side or self._critic_stream()
-                (side if kind == "fork" else main).wait_stream(main if kind == "fork" else side)
+                if kind == "join":
+                    with self._log_span(label):   # how long the main lane stood waiting for the critic's lane
+                        main.wait_stream(side)
+                else:
+                    side.wait_stream(main)
                 continue
             if lane == "s":
                 side = side or self._critic_stream()
                 with torch.cuda.stream(side):
-                    self._do(kind, item)
+                    self._do(kind, item, label)
             else:
-                self._do(kind, item)
+                self._do(kind, item, label)
 
-    def _do(self, kind, item):
+    def _do(self, kind, item, label=None):
         if kind == "run":
             item()
         elif kind == "graph":
             item.replay()
         else:
-            self._reduce(kind, item() if item is not None else None)
+            self._reduce(kind, item() if item is not None else None, label)
 
 
 def gae(reward, done, terminated, values, gamma=0.99, lmbda=0.95):

@@ -35,6 +35,18 @@ def test_two_rank_bench_line():
     assert two["roofline"] is not None and two["roofline"]["frac"] > 0     # the profiling leg ran in lock-step on both ranks
     for k, v in two["loss"].items():
         assert v == v and abs(v) < 1e6, (k, v)
+    # the N > 1 line describes its collectives: backend, ranks, every collective by name with count / payload / time
+    dp = two["data_parallel"]
+    assert dp["collective_backend"] == "gloo" and dp["ranks_seen"] == 2 and len(dp["per_rank_ms_per_step"]) == 2
+    assert dp["rank_spread_max_over_min"] >= 1.0
+    names = set(dp["collectives"])
+    for want in ("critic_ln1_fwd_stats", "critic_ln2_fwd_stats", "critic_ln2_bwd_stats", "critic_ln1_bwd_stats", "advantage_stats",
+                 "flat_gradient", "join_critic_forward", "join_critic_backward"):
+        assert want in names, (want, names)
+        assert dp["collectives"][want]["per_step"] == 1.0 and dp["collectives"][want]["mean_ms"] >= 0.0
+    # 4 critic LayerNorm statistics + advantage statistics + loss sums + loss maxes (asynchronous) + the flat gradient
+    assert dp["collectives"]["flat_gradient"]["bytes"] > 500_000 and dp["collectives_per_step"] == 8.0, dp["collectives_per_step"]
+    assert two["advantage_pass_ms"] > 0 and "one all-reduce per LayerNorm stage" in two["advantage_pass"]
     one = _bench("--gpus", "1", "--minibatch", "512", "--steps", "20", "--warmup", "3", "--pool", "4", "--no-parity-gate", "--no-roofline")
     assert one["n_gpus"] == 1 and "hipGraph" in one["mode"] and one["mode"].startswith("graph")
     # Two 512-frame shards time-share ONE GPU here: every one of the step's 9 collectives is host-staged by gloo AND forces the GPU to
