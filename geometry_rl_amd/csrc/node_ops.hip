@@ -45,14 +45,15 @@ GRL_DEVINL float lift_fetch(const LiftLane& L, int n) { return L.base[(long long
 #define LIFT_V(val, v, d) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), 8 + 3 * (v) + (d)))
 
 constexpr int LIFT_CHUNK = 16;   // iterations per input refill (8 KB of LDS)
-__global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
-                                                              const float* __restrict__ grid, const float* __restrict__ Wenc,
-                                                              st_t* __restrict__ x, int N, int S, int V) {
-  __shared__ float stage[LIFT_CHUNK * 4 * 32];
+// (blk, n_blk): this workgroup's index among the workgroups that share the node set -- blockIdx.x / gridDim.x for the one-type launch, the
+// position inside the type's block range for the multi-type launch (lift_encode_fwd_multi_kernel)
+GRL_DEVINL void lift_encode_fwd_body(const float* __restrict__ scal, const float* __restrict__ vec, const float* __restrict__ grid,
+                                     const float* __restrict__ Wenc, st_t* __restrict__ x, int N, int S, int V, int blk, int n_blk,
+                                     float* stage /* [LIFT_CHUNK * 4 * 32] LDS */) {
   const int KF = S + V;
   const int lane = threadIdx.x & 63, c4 = lane & 15, o4 = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wave = 4 * blockIdx.x + wv, n_waves = gridDim.x * 4;
+  const int wave = 4 * blk + wv, n_waves = n_blk * 4;
   // wa[.][k]: weight of scalar feature k (0 for k >= S), wb[.][v]: of vector feature v (0 for v >= V) -- every slot takes the same
   // multiply-adds, no branch (a zero weight adds an exact zero for finite inputs; a non-finite input poisons its node either way)
   float wa[4][KF_MAX], wb[4][KF_MAX], g[4][3];
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
 #pragma unroll
     for (int m = 0; m < LIFT_CHUNK * 4 * 32 / 256; ++m) {
       const int idx = threadIdx.x + 256 * m, i = idx >> 7, w_ = (idx >> 5) & 3;
-      const long long node = (long long)(4 * blockIdx.x + w_) + (long long)(it0 + i) * n_waves;
+      const long long node = (long long)(4 * blk + w_) + (long long)(it0 + i) * n_waves;
       // (clamped, not skipped: a branch per load would serialise them.)  Slots past S / V hold clamped duplicates -- with S == 0 or V == 0
       // even node 0's value of the OTHER array: they are zeroed where the register goes to LDS (never right behind the load, finding 31b),
       // so a non-finite input of one node cannot reach another node through NaN * 0
@@ -114,18 +115,43 @@ __global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __res
   }
 }
 
+__global__ __launch_bounds__(256) void lift_encode_fwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
+                                                              const float* __restrict__ grid, const float* __restrict__ Wenc,
+                                                              st_t* __restrict__ x, int N, int S, int V) {
+  __shared__ float stage[LIFT_CHUNK * 4 * 32];
+  lift_encode_fwd_body(scal, vec, grid, Wenc, x, N, S, V, (int)blockIdx.x, (int)gridDim.x, stage);
+}
+// Every node type of a graph in ONE launch (round 4: the two lift launches of a HEPi pass -- object points, actuators -- were two ~11 us
+// links of the step's serial chain at small minibatches): the types share the encoder weights and the feature widths; a workgroup belongs
+// to the type whose block range holds it.  The backward likewise; its partial rows of all types stack into one slab (one fold, one dW).
+constexpr int LIFT_MAX_TYPES = 4;
+struct LiftMulti {
+  const float* scal[LIFT_MAX_TYPES];
+  const float* vec[LIFT_MAX_TYPES];
+  st_t* x[LIFT_MAX_TYPES];          // forward: outputs; backward: the incoming gradients (read only)
+  int N[LIFT_MAX_TYPES];
+  int blk0[LIFT_MAX_TYPES + 1];     // first workgroup of every type
+  int n_types;
+};
+__global__ __launch_bounds__(256) void lift_encode_fwd_multi_kernel(LiftMulti m, const float* __restrict__ grid, const float* __restrict__ Wenc,
+                                                                    int S, int V) {
+  __shared__ float stage[LIFT_CHUNK * 4 * 32];
+  int t = 0;
+  while (t + 1 < m.n_types && (int)blockIdx.x >= m.blk0[t + 1]) ++t;
+  lift_encode_fwd_body(m.scal[t], m.vec[t], grid, Wenc, m.x[t], m.N[t], S, V, (int)blockIdx.x - m.blk0[t], m.blk0[t + 1] - m.blk0[t], stage);
+}
+
 // dW[c,k] = sum_{n,o} dx[n,o,c] feat[n,o,k]; partial[block][64*KF].  With D0[n,c] = sum_o dx and Dd[n,c] = sum_o grid[o,d] dx:
 // dW[c,s] = sum_n scal[n,s] D0,  dW[c,S+v] = sum_n vec[n,v,:] . D[n,c,:]  -- 4 multiply-adds per dx element instead of S+V.
 // Same wave-per-node layout as the forward: a node's dx is four 1 KB loads (those of the next node are in flight while this one is
 // folded); a lane folds ITS four orientations into D and straight on into its own dW partial -- dW is linear in D, so the sum over
 // the four orientation groups of lanes waits until the end of the launch (two shuffles per accumulator, once).
-__global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
-                                                              const float* __restrict__ grid, const st_t* __restrict__ dx,
-                                                              float* __restrict__ partial, int N, int S, int V) {
-  __shared__ float red[4][C * KF_MAX];
+GRL_DEVINL void lift_encode_bwd_body(const float* __restrict__ scal, const float* __restrict__ vec, const float* __restrict__ grid,
+                                     const st_t* __restrict__ dx, float* __restrict__ partial_row, int N, int S, int V, int blk, int n_blk,
+                                     float (*red)[C * KF_MAX] /* [4][C * KF_MAX] LDS */) {
   const int KF = S + V;
   const int lane = threadIdx.x & 63, c4 = lane & 15, o4 = lane >> 4, wv = threadIdx.x >> 6;
-  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = gridDim.x * 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blk * 256 + threadIdx.x) >> 6)), n_waves = n_blk * 4;
   float g[4][3];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -187,8 +213,22 @@ __global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __res
   for (int i = threadIdx.x; i < C * KF; i += 256) {
     const int c = i / KF, k = i - c * KF;
     const int s_ = c * KF_MAX + k;
-    partial[(size_t)blockIdx.x * C * KF + i] = red[0][s_] + red[1][s_] + red[2][s_] + red[3][s_];
+    partial_row[i] = red[0][s_] + red[1][s_] + red[2][s_] + red[3][s_];
   }
+}
+__global__ __launch_bounds__(256) void lift_encode_bwd_kernel(const float* __restrict__ scal, const float* __restrict__ vec,
+                                                              const float* __restrict__ grid, const st_t* __restrict__ dx,
+                                                              float* __restrict__ partial, int N, int S, int V) {
+  __shared__ float red[4][C * KF_MAX];
+  lift_encode_bwd_body(scal, vec, grid, dx, partial + (size_t)blockIdx.x * C * (S + V), N, S, V, (int)blockIdx.x, (int)gridDim.x, red);
+}
+__global__ __launch_bounds__(256) void lift_encode_bwd_multi_kernel(LiftMulti m, const float* __restrict__ grid, float* __restrict__ partial,
+                                                                    int S, int V) {
+  __shared__ float red[4][C * KF_MAX];
+  int t = 0;
+  while (t + 1 < m.n_types && (int)blockIdx.x >= m.blk0[t + 1]) ++t;
+  lift_encode_bwd_body(m.scal[t], m.vec[t], grid, m.x[t], partial + (size_t)blockIdx.x * C * (S + V), m.N[t], S, V,
+                       (int)blockIdx.x - m.blk0[t], m.blk0[t + 1] - m.blk0[t], red);
 }
 
 // ------------------------------------------------------------------------------------------------ fiber conv
@@ -756,6 +796,12 @@ int grl_fiber_partial_size() { return FIBER_PARTIAL; }
 // 66 KB partial row that the fold has to read back
 int grl_fiber_bwd_blocks(int n_nodes) { const int b = cap_blocks(n_nodes, 4 * FB, 512); return b < 256 ? cap_blocks(n_nodes, FB, 256) : b; }
 int grl_lift_bwd_blocks(int n_nodes) { return lift_blocks(n_nodes); }
+int grl_lift_bwd_blocks_multi(int n_types, const int* n_nodes) {   // n_nodes: HOST array
+  int b = 0;
+  for (int t = 0; t < n_types; ++t)
+    if (n_nodes[t] > 0) b += lift_blocks(n_nodes[t]);
+  return b;
+}
 #else
 int grl_fiber_bwd_blocks(int n_nodes);
 int grl_lift_bwd_blocks(int n_nodes);
@@ -768,6 +814,43 @@ int GRL_ENTRY(grl_lift_encode_fwd)(const float* scal, const float* vec, const fl
   const int blocks = lift_blocks(n_nodes);
   hipLaunchKernelGGL(lift_encode_fwd_kernel, dim3(blocks), dim3(256), 0, stream, scal, vec, grid, Wenc, x, n_nodes, n_scal,
                      n_vec);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// n_types <= 4 node sets that share the encoder (hepi.py:136-143 lifts every node type with the one node_encoder) in ONE launch.
+// scal / vec / x: HOST arrays of n_types device pointers, n_nodes: HOST int array; types with n_nodes <= 0 are skipped.
+static int lift_multi_fill(LiftMulti& m, int n_types, const float* const* scal, const float* const* vec, st_t* const* x, const int* n_nodes) {
+  if (n_types < 1 || n_types > LIFT_MAX_TYPES) return -2;
+  m.n_types = 0;
+  m.blk0[0] = 0;
+  for (int t = 0; t < n_types; ++t) {
+    if (n_nodes[t] <= 0) continue;
+    const int k = m.n_types++;
+    m.scal[k] = scal[t]; m.vec[k] = vec[t]; m.x[k] = x[t]; m.N[k] = n_nodes[t];
+    m.blk0[k + 1] = m.blk0[k] + lift_blocks(n_nodes[t]);
+  }
+  return 0;
+}
+int GRL_ENTRY(grl_lift_encode_fwd_multi)(int n_types, const float* const* scal, const float* const* vec, const float* grid, const float* Wenc,
+                                         st_t* const* x, const int* n_nodes, int n_scal, int n_vec, hipStream_t stream) {
+  if (n_scal + n_vec > KF_MAX) return -2;
+  LiftMulti m{};
+  if (const int rc = lift_multi_fill(m, n_types, scal, vec, x, n_nodes)) return rc;
+  if (m.n_types == 0) return 0;
+  hipLaunchKernelGGL(lift_encode_fwd_multi_kernel, dim3(m.blk0[m.n_types]), dim3(256), 0, stream, m, grid, Wenc, n_scal, n_vec);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+// partial: [grl_lift_bwd_blocks_multi(n_types, n_nodes)][64 * (n_scal + n_vec)] -- the types' rows stacked (sum ALL rows: one dW);
+// dx: HOST array of n_types device pointers (a type without a gradient: n_nodes[t] = 0)
+int GRL_ENTRY(grl_lift_encode_bwd_multi)(int n_types, const float* const* scal, const float* const* vec, const float* grid,
+                                         const st_t* const* dx, float* partial, const int* n_nodes, int n_scal, int n_vec, hipStream_t stream) {
+  if (n_scal + n_vec > KF_MAX) return -2;
+  LiftMulti m{};
+  if (const int rc = lift_multi_fill(m, n_types, scal, vec, const_cast<st_t* const*>(dx), n_nodes)) return rc;
+  if (m.n_types == 0) return 0;
+  hipLaunchKernelGGL(lift_encode_bwd_multi_kernel, dim3(m.blk0[m.n_types]), dim3(256), 0, stream, m, grid, partial, n_scal, n_vec);
   GRL_CHECK_LAUNCH();
   return 0;
 }

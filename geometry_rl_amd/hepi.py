@@ -211,8 +211,12 @@ class HEPi(nn.Module):
         """hepi.py:125-173: lift/encode, message-passing rounds; returns the actuator latents [B*G, 16, 64]."""
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
-        x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight, self._prec)
-             for t in self._needed_types(graph)}
+        types = self._needed_types(graph)
+        if 1 < len(types) <= 4:   # every node type in ONE lift launch (each way)
+            xs = ops.LiftEncodeMulti.apply(grid3, self.node_encoder.weight, self._prec, *[a for t in types for a in (scalar_dict[t], vector_dict[t])])
+            x = dict(zip(types, xs))
+        else:
+            x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight, self._prec) for t in types}
         fks = self._fiber_kernels(graph)
         wimgs = self._weight_images(graph)
         for rnd in self.processor:

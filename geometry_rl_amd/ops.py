@@ -299,6 +299,53 @@ class LiftEncode(torch.autograd.Function):
         return None, None, None, dw, None
 
 
+class LiftEncodeMulti(torch.autograd.Function):
+    """LiftEncode for every node type of a graph in ONE launch each way (the types share the encoder and the feature widths, reference
+    hepi.py:136-143): apply(grid3, w_enc, prec, scal_0, vec_0, scal_1, vec_1, ...) -> (x_0, x_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, grid3, w_enc, prec, *sv):
+        import ctypes
+        scal, vec = list(sv[0::2]), list(sv[1::2])
+        hip.check_f32(grid3, w_enc, *scal, *vec)
+        T = len(scal)
+        s, v = scal[0].shape[1], vec[0].shape[1]
+        if any(a.shape[1] != s or b.shape[1] != v for a, b in zip(scal, vec)):
+            raise ValueError("LiftEncodeMulti: the node types must share the feature widths")
+        dev = grid3.device
+        xs = [torch.empty(a.shape[0], 16, 64, device=dev, dtype=hip.storage_dtype(prec)) for a in scal]
+        ns = [int(a.shape[0]) for a in scal]
+        hip.call("grl_lift_encode_fwd_multi" + prec, T, (ctypes.c_void_p * T)(*[a.data_ptr() for a in scal]),
+                 (ctypes.c_void_p * T)(*[b.data_ptr() for b in vec]), grid3, w_enc.contiguous(),
+                 (ctypes.c_void_p * T)(*[x.data_ptr() for x in xs]), (ctypes.c_int * T)(*ns), s, v)
+        ctx.save_for_backward(grid3, *scal, *vec)
+        ctx.kf, ctx.w_enc, ctx.prec, ctx.T, ctx.sv = s + v, w_enc, prec, T, (s, v)
+        ctx.set_materialize_grads(False)   # a type whose latent never reaches the loss has no gradient: skipped, not zero-filled
+        return tuple(xs)
+
+    @staticmethod
+    def backward(ctx, *dxs):
+        import ctypes
+        grid3, *rest = ctx.saved_tensors
+        T = ctx.T
+        scal, vec = rest[:T], rest[T:]
+        s, v = ctx.sv
+        dxs = [d.contiguous() if d is not None else None for d in dxs]
+        for d in dxs:
+            if d is not None:
+                hip.check_latent(ctx.prec, d)
+        ns = (ctypes.c_int * T)(*[int(a.shape[0]) if d is not None else 0 for a, d in zip(scal, dxs)])
+        blocks = hip.query("grl_lift_bwd_blocks_multi", T, ns)
+        if blocks == 0:
+            return (None,) * (3 + 2 * T)
+        partial = torch.empty(blocks, 64 * ctx.kf, device=grid3.device, dtype=torch.float32)
+        hip.call("grl_lift_encode_bwd_multi" + ctx.prec, T, (ctypes.c_void_p * T)(*[a.data_ptr() for a in scal]),
+                 (ctypes.c_void_p * T)(*[b.data_ptr() for b in vec]), grid3,
+                 (ctypes.c_void_p * T)(*[(d.data_ptr() if d is not None else 0) for d in dxs]), partial, ns, s, v)
+        (dw,) = _emit_grads(partial, [(0, 64 * ctx.kf, (64, ctx.kf), ctx.w_enc)])
+        return (None, dw, None) + (None,) * (2 * T)
+
+
 # One-shot hook(n_source_nodes) run in front of the NEXT edge convolution's launch (PolicyUpdater: join the critic's forward there -- see agent.py).
 PRE_EDGE_HOOK = None
 
@@ -549,6 +596,7 @@ class Readout(torch.autograd.Function):
         ctx.save_for_backward(lat, grid3, wd_, bd_, ws_, bs_)
         ctx.cfg = (float(shift), od, ov)
         ctx.params = (wd, bd, ws, bs)
+        ctx.set_materialize_grads(False)   # ``hidden`` is rarely used: no zero tensor (a fill launch on the step's chain) for its gradient
         return mean, sigma, hidden
 
     @staticmethod

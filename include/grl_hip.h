@@ -31,6 +31,14 @@ int grl_lift_encode_fwd(const float* scal, const float* vec, const float* grid, 
 int grl_lift_bwd_blocks(int n_nodes);
 int grl_lift_encode_bwd(const float* scal, const float* vec, const float* grid, const float* dx, float* partial, int n_nodes,
                         int n_scal, int n_vec, hipStream_t stream);
+/* (ABI 203) every node type of a graph in ONE launch (the types share the encoder and the feature widths: hepi.py:136-143):
+ * scal / vec / x (dx): HOST arrays of n_types <= 4 device pointers, n_nodes: HOST int array (<= 0: the type is skipped);
+ * backward: partial [grl_lift_bwd_blocks_multi(n_types, n_nodes)][64 * (n_scal + n_vec)], the types' rows stacked -- sum all rows */
+int grl_lift_encode_fwd_multi(int n_types, const float* const* scal, const float* const* vec, const float* grid, const float* Wenc,
+                              float* const* x, const int* n_nodes, int n_scal, int n_vec, hipStream_t stream);
+int grl_lift_bwd_blocks_multi(int n_types, const int* n_nodes);
+int grl_lift_encode_bwd_multi(int n_types, const float* const* scal, const float* const* vec, const float* grid, const float* const* dx,
+                              float* partial, const int* n_nodes, int n_scal, int n_vec, hipStream_t stream);
 
 /* ---- fused edge pipeline: hepi.py:76-82,109-123,145-157 (invariants, PolynomialFeatures, basis MLP),
  *      ponita/conv.py:79-86,115-149 (kernel Linear, message, torch_scatter sum)  ==  ponita/ponita.py:153,161,327-345 ------
@@ -123,6 +131,10 @@ int grl_lift_encode_fwd_bf16(const float* scal, const float* vec, const float* g
                              int n_scal, int n_vec, hipStream_t stream);
 int grl_lift_encode_bwd_bf16(const float* scal, const float* vec, const float* grid, const grl_bf16* dx, float* partial, int n_nodes,
                              int n_scal, int n_vec, hipStream_t stream);
+int grl_lift_encode_fwd_multi_bf16(int n_types, const float* const* scal, const float* const* vec, const float* grid, const float* Wenc,
+                                   grl_bf16* const* x, const int* n_nodes, int n_scal, int n_vec, hipStream_t stream);
+int grl_lift_encode_bwd_multi_bf16(int n_types, const float* const* scal, const float* const* vec, const float* grid,
+                                   const grl_bf16* const* dx, float* partial, const int* n_nodes, int n_scal, int n_vec, hipStream_t stream);
 int grl_edge_conv_fwd_bf16(const grl_bf16* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                            const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                            const float* W2, const float* b2, const float* Wk, grl_bf16* x1, hipStream_t stream);
