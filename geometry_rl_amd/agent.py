@@ -133,6 +133,7 @@ class PolicyUpdater:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)  # optimizer step, device side (graph replays)
+        self.step_dev_c = torch.zeros(1, device=dev, dtype=torch.int32)  # the same count kept by the critic's lane (one rank, two lanes)
         # learning rate, device side: the recorded Adam launches read it, so an annealed rate (train.py:264-271 writes
         # ``group["lr"] = lr * alpha`` before every iteration; configs/algorithm/optim/default.yaml:5) takes effect under replay
         self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
@@ -209,7 +210,7 @@ class PolicyUpdater:
     # ---- the plan: [("run", fn) | ("sum", tensor getter) | ("max", tensor getter)] --------------------------------------
     def _plan(self, batch: Dict[str, torch.Tensor], st: dict):
         from . import ops
-        from .trpl import adv_stats_local, loss_values, trpl_launch
+        from .trpl import adv_stats_local, loss_values, report_values, trpl_launch, value_loss
         m = self.loss_module
         world = m.world_size
         actor = m.actor_network
@@ -223,14 +224,15 @@ class PolicyUpdater:
 
         ow = self._fold_overwrite
 
-        def adam(lo, hi, i_):   # one optimizer's step over its slice of the flat buffer (train.py:308-316)
+        def adam(lo, hi, i_, step_dev=None):   # one optimizer's step over its slice of the flat buffer (train.py:308-316)
             coef = None
             if self.clip:  # train.py:308-310
                 sq = st["zw"][23 + i_:24 + i_]
                 coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
                 hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
             hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                     hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, coef, 1.0)
+                     hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                     step_dev if step_dev is not None else self.step_dev, coef, 1.0)
 
         def s0():  # critic features, first critic stage, advantage statistics
             if not ow:
@@ -450,36 +452,67 @@ class PolicyUpdater:
 
         S = "s"
         if world == 1 and self.overlap_critic and self._lanes:
-            # One rank as a two-lane PROGRAM of single-stream graphs (the form the data-parallel step has anyway): this HIP runtime replays a
-            # captured graph with two branches through the host -- hipGraphLaunch returned after 2/3 of the DEVICE time of the step (0.26 /
-            # 0.48 / 2.1 ms at 32 / 512 / 4096 frames against 24 us for a one-stream graph of the same kernels; tools/ubench/graph_branches.py:
-            # two independent 20-kernel chains replay in 139 us, host-bound, one 40-kernel chain in 77) -- and every cross-branch edge costs a
-            # 6-11 us gap.  Lanes as separate graphs on two streams: four short host launches per step, cross-lane edges are stream waits.
-            def c_fwd():
+            # One rank as a two-lane PROGRAM of single-stream graphs: this HIP runtime replays a captured graph with two branches through
+            # the host -- hipGraphLaunch returned after 2/3 of the DEVICE time of the step (0.26 / 0.48 / 2.1 ms at 32 / 512 / 4096 frames
+            # against 24 us for a one-stream graph of the same kernels; tools/ubench/graph_branches.py: two independent 20-kernel chains
+            # replay in 139 us, host-bound, one 40-kernel chain in 77) -- and every cross-branch edge costs a 6-11 us gap.  A graph boundary
+            # on a lane costs ~15 us as well (the next graph's launch), so each lane is ONE graph and the lanes never meet inside a step:
+            #   actor's lane : features, lift, convolutions, read-out, fused loss kernel (actor terms only; the batch's advantage statistics
+            #                  are summed inside it), backward, fold, Adam over the actor's slice, fold + evaluation of the reported values;
+            #   critic's lane: features, the three forward stages, its OWN loss (clipped value loss: elementwise in the frame), the three
+            #                  backward stages, fold, Adam over the critic's slice.
+            # Actor and critic share no parameter and no intermediate (train.py:279-316 runs two backward passes and two optimizers); the
+            # lanes are forked at the step's start and joined at its end.
+            def main_all():
+                m_prep()
                 with torch.no_grad():
-                    self.step_dev.add_(1)   # Adam's step count: on this lane, in front of the join that both optimizer launches follow
+                    self.step_dev.add_(1)
                     st["step_bumped"] = True
-                c_fwd1()
-                s1()
-                c_fwd3()
+                a_fwd()
+                loc, sigma = st["loc_g"], st["sigma_g"]
+                with torch.no_grad():
+                    zw = st["zw"]
+                    fold_, maxes, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], None, sums=zw[10:22],
+                                                                maxes=zw[22:23].view(torch.int32), defer_fold=True,
+                                                                adv_local=bool(m.normalize_advantage and loc.shape[0] > 1))
+                st.update(loc=loc.detach(), sigma=sigma.detach(), dloc=dloc, dsigma=dsigma)
+                a_bwd()
+                fold()
+                with torch.no_grad():
+                    adam(0, self.n_actor, 0)
+                    a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
+                    st.update(sums=fold_.sums, maxes=fold_.maxes, lv_main=(a_loss, mt))
 
-            def c_bwd():
-                with torch.no_grad():   # reported values only: folded and evaluated on the critic's lane
-                    sums, maxes = st.pop("fold")()
-                    st.update(sums=sums, maxes=maxes)
-                    st["lv"] = loss_values(m, sums, maxes)
-                c_bwd3()
-                s3()
-                c_bwd1()
-                if self._critic_own_adam:
-                    with torch.no_grad():
-                        na, n = self.n_actor, self.flat.numel()
-                        ops.flush_deferred_grads(overwrite=ow, only=lambda g: g.data_ptr() >= self.gflat.data_ptr() + 4 * na)
-                        adam(na, n, 1)
-                        st["critic_adam_done"] = True
+            def critic_all():
+                ops.DEFERRED = []
+                with torch.no_grad():
+                    self.step_dev_c.add_(1)
+                    vf.train(True)
+                    _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
+                    pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
+                    pipe.fwd1()
+                    pipe.fwd2()
+                    value = st["value"] = pipe.fwd3()
+                    dvalue, c_loss, _ = value_loss(m, value, st["b"])
+                    pipe.bwd3(dvalue)
+                    pipe.bwd2()
+                    grads = pipe.bwd1(leaves)
+                    assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
+                    ops.flush_deferred_grads(overwrite=ow)
+                    ops.DEFERRED = None
+                    adam(self.n_actor, self.flat.numel(), 1, self.step_dev_c)
+                    st["c_loss"] = c_loss
 
-            return [("fork", None), ("run", m_prep), ("run", a_fwd), ("run", c_fwd, S), ("join", None),
-                    ("run", head), ("fork", None), ("run", c_bwd, S), ("run", a_bwd), ("run", fold), ("run", s5), ("join", None)]
+            def finish():
+                a_loss, mt = st.pop("lv_main")
+                mt = dict(mt)
+                out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": st.pop("c_loss"), "loc": st["loc"], "sigma": st["sigma"],
+                       "state_value": st["value"].unsqueeze(-1)}
+                out.update(mt)
+                st["out"] = out
+
+            # (finish only builds the dict of output views: it records nothing; kept as a "run" so that eager steps execute it too)
+            return [("fork", None), ("run", main_all), ("run", critic_all, S), ("join", None), ("run_host", finish)]
         # (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
         plan = [("run", m_prep), ("fork", None),
                 ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"), ("sum", lambda: st["adv"], S, "advantage_stats"),
@@ -586,6 +619,8 @@ class PolicyUpdater:
                 cur, cur_lane = [], None
             if kind == "run":
                 cur, cur_lane = [item], lane
+            elif kind == "run_host":   # host-only bookkeeping (output dict of views): once, when the step is recorded
+                groups.append(("run_host_once", item, lane, label))
             else:
                 groups.append((kind, item, lane, label))
         if cur:
@@ -594,6 +629,9 @@ class PolicyUpdater:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         for kind, item, lane, label in groups:
+            if kind == "run_host_once":
+                item()
+                continue
             if kind != "run":
                 program.append((kind, item, lane, label))
                 continue
@@ -726,7 +764,7 @@ class PolicyUpdater:
                 self._do(kind, item, label)
 
     def _do(self, kind, item, label=None):
-        if kind == "run":
+        if kind in ("run", "run_host"):
             item()
         elif kind == "graph":
             item.replay()

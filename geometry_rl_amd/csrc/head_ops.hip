@@ -200,6 +200,7 @@ constexpr int TRPL_SLOT = 14;   // per-workgroup record: the 12 sums + the 2 max
 struct TrplCfg {
   double mean_bound, cov_bound, tr_coeff, ent_coef, critic_coef, clip_value, inv_batch, adv_count;
   int A;
+  int adv_local;   // 1: the advantage statistics are those of THIS launch's batch, summed inside the kernel (one rank: no statistics launch)
 };
 
 GRL_DEVINL double kl_of_eta(double eta, const double* t, const double* o, int A) {
@@ -231,6 +232,25 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
   double acc[11];
   for (int i = 0; i < 11; ++i) acc[i] = 0.0;
   float mmax = 0.f, cmax = 0.f;
+  // One rank: every workgroup sums the batch's advantages itself (trpl.py:248-252, 286-289) -- B floats, thread-strided partial sums, wave
+  // butterflies, the two waves in order: the SAME order in every workgroup and every run (bitwise reproducible), and one launch plus one
+  // cross-lane dependency fewer on the step's chain than the separate statistics kernel (which the data-parallel step keeps: its sums
+  // are all-reduced).
+  __shared__ double adv_sh[2][2];
+  double adv_sum0 = 0.0, adv_sum1 = 0.0;
+  if (cfg.adv_local) {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      const double a_ = advantage[i];
+      adv_sum0 += a_;
+      adv_sum1 += a_ * a_;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { adv_sum0 += __shfl_xor(adv_sum0, off, 64); adv_sum1 += __shfl_xor(adv_sum1, off, 64); }
+    if ((threadIdx.x & 63) == 0) { adv_sh[threadIdx.x >> 6][0] = adv_sum0; adv_sh[threadIdx.x >> 6][1] = adv_sum1; }
+    __syncthreads();
+    adv_sum0 = adv_sh[0][0] + adv_sh[1][0];
+    adv_sum1 = adv_sh[0][1] + adv_sh[1][1];
+  }
   if (b < B) {
     double mu[AMAX], S[AMAX], mo[AMAX], So[AMAX], t[AMAX], o[AMAX], a[AMAX];
     _Pragma("unroll") for (int i = 0; i < A; ++i) {
@@ -332,9 +352,10 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     const double ratio = exp(lw);
     // advantage normalisation (trpl.py:286-289): batch mean / unbiased std (clamped at 1e-6) from the device-side sums
     double adv = (double)advantage[b];
-    if (adv_stats && cfg.adv_count > 1.0) {
-      const double am = adv_stats[0] / cfg.adv_count;
-      double var = (adv_stats[1] - cfg.adv_count * am * am) / (cfg.adv_count - 1.0);
+    if ((adv_stats || cfg.adv_local) && cfg.adv_count > 1.0) {
+      const double s0_ = cfg.adv_local ? adv_sum0 : adv_stats[0], s1_ = cfg.adv_local ? adv_sum1 : adv_stats[1];
+      const double am = s0_ / cfg.adv_count;
+      double var = (s1_ - cfg.adv_count * am * am) / (cfg.adv_count - 1.0);
       double sd = var > 0.0 ? sqrt(var) : 0.0;
       if (sd < 1e-6) sd = 1e-6;
       adv = (adv - am) / sd;
@@ -533,6 +554,44 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict
   }
 }
 
+// ---- the critic's share of the loss on the critic's lane (one rank): clipped value loss (trpl.py:213-228, objectives/utils.py:5-28, l2) and
+//      its gradient d loss_critic / d V -- elementwise in the frame, so it needs nothing from the fused actor kernel: the critic's forward,
+//      loss, backward, fold and optimizer step form ONE chain that never meets the actor's.  ONE workgroup, fixed summation order.
+//      out2: [0] = sum over the frames of critic_coef * loss (fp64), [1] = that sum / n_global (the reported loss_critic, as a double)
+__global__ __launch_bounds__(1024) void value_loss_kernel(const float* __restrict__ value, const float* __restrict__ old_value,
+                                                         const float* __restrict__ value_target, double clip_value, double critic_coef,
+                                                         double inv_batch, float* __restrict__ dvalue, double* __restrict__ out2,
+                                                         float* __restrict__ mean_out, int B) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    const double V = value[b], Vo = old_value[b], R = value_target[b];
+    const double l1 = (V - R) * (V - R);
+    double l = l1, g = 2.0 * (V - R);
+    if (clip_value > 0.0) {
+      const double dlt = V - Vo;
+      const bool inside = dlt >= -clip_value && dlt <= clip_value;
+      const double Vc = Vo + fmin(fmax(dlt, -clip_value), clip_value);
+      const double l2 = (Vc - R) * (Vc - R);
+      if (l2 > l1) { l = l2; g = inside ? 2.0 * (Vc - R) : 0.0; }
+    }
+    s += l * critic_coef;
+    dvalue[b] = (float)(g * critic_coef * inv_batch);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += red[w];
+    out2[0] = t;
+    out2[1] = t * inv_batch;
+    if (mean_out) mean_out[0] = (float)(t * inv_batch);
+  }
+}
+
 __global__ void loss_values_kernel(const double* __restrict__ sums, const unsigned int* __restrict__ maxes, float entropy_coef,
                                    float* __restrict__ out) {
   const double n = sums[10];
@@ -553,6 +612,46 @@ __global__ void loss_values_kernel(const double* __restrict__ sums, const unsign
   out[11] = (float)(sums[9] / n);
   out[12] = actor - (tr + ent);
   out[13] = mc + cc;   // "constraint": the projection's own measure (= kl for the KL projection)
+}
+
+// slots -> sums / maxes (trpl_fold_kernel) AND the reported values (loss_values_kernel) in ONE launch: the actor's lane ends with it
+__global__ __launch_bounds__(64) void trpl_report_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
+                                                        unsigned int* __restrict__ maxes, float entropy_coef, float* __restrict__ out) {
+  __shared__ double sh[12];
+  __shared__ unsigned int shm[2];
+  const int i = threadIdx.x;
+  if (i < 12) {
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
+    sums[i] = s;
+    sh[i] = s;
+  } else if (i < 14) {
+    double m = 0.0;
+    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
+    maxes[i - 12] = __float_as_uint((float)m);
+    shm[i - 12] = __float_as_uint((float)m);
+  }
+  __syncthreads();
+  if (i == 0) {
+    const double n = sh[10];
+    const float tr = (float)(sh[1] / n), ent = -entropy_coef * (float)(sh[2] / n);
+    const float actor = (float)((sh[0] + sh[1] - (double)entropy_coef * sh[2]) / n);
+    out[0] = actor;
+    out[1] = (float)(sh[3] / n);
+    out[2] = tr;
+    out[3] = ent;
+    out[4] = (float)(sh[4] * sh[4] / sh[5] / n);
+    const float mc = (float)(sh[6] / n), cc = (float)(sh[7] / n);
+    out[5] = (float)(sh[11] / n);
+    out[6] = mc;
+    out[7] = __uint_as_float(shm[0]);
+    out[8] = cc;
+    out[9] = __uint_as_float(shm[1]);
+    out[10] = (float)(sh[8] / n);
+    out[11] = (float)(sh[9] / n);
+    out[12] = actor - (tr + ent);
+    out[13] = mc + cc;
+  }
 }
 
 // ---- collector-side action sampling: torch.distributions.MultivariateNormal(loc, covariance_matrix = diag(sigma^2)).rsample()
@@ -611,11 +710,23 @@ int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t 
   return 0;
 }
 
-// cfg9 (HOST pointer): 9 doubles {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
-// 1/B_global, B_global, projection type (0 KL, 1 Frobenius, 2 Wasserstein)}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
+// cfg9 (HOST pointer): TEN doubles since ABI 203 {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
+// 1/B_global, B_global, projection type (0 KL, 1 Frobenius, 2 Wasserstein), adv_local (1: the advantage statistics are summed inside the
+// kernel from this launch's batch -- adv_stats is then ignored; 0: adv_stats as below)}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
 // grl_adv_stats, all-reduced when data parallel) or NULL for no normalisation.  sums: fp64[12], maxes: u32[2], zeroed by the caller.  value/old_value/value_target/dvalue may be
 // NULL together (actor-only call); proj_mean/proj_var may be NULL.
 int grl_trpl_slot_doubles(int batch) { return TRPL_SLOT * ((batch + 127) / 128 < 1 ? 1 : (batch + 127) / 128); }
+
+// value / old_value / value_target [batch], dvalue [batch], out2 fp64[2] (sum, sum / n_global), mean_out float[1] or NULL (the mean again, as
+// the float the loss dict reports): see value_loss_kernel
+int grl_value_loss(const float* value, const float* old_value, const float* value_target, double clip_value, double critic_coef,
+                   double inv_batch, float* dvalue, double* out2, float* mean_out, int batch, hipStream_t stream) {
+  if (batch < 1 || !value || !old_value || !value_target || !dvalue || !out2) return -2;
+  hipLaunchKernelGGL(value_loss_kernel, dim3(1), dim3(1024), 0, stream, value, old_value, value_target, clip_value, critic_coef, inv_batch,
+                     dvalue, out2, mean_out, batch);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
 
 static int trpl_launch(const double* cfg9, int action_dim, const float* mean, const float* sigma, const float* action,
                        const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
@@ -623,7 +734,7 @@ static int trpl_launch(const double* cfg9, int action_dim, const float* mean, co
                        float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
                        unsigned int* maxes, double* slots, const float* tgt_mean, const float* tgt_S, int batch, hipStream_t stream) {
   if (action_dim > AMAX || action_dim < 1 || batch < 1 || !slots) return -2;
-  TrplCfg c{cfg9[0], cfg9[1], cfg9[2], cfg9[3], cfg9[4], cfg9[5], cfg9[6], cfg9[7], action_dim};
+  TrplCfg c{cfg9[0], cfg9[1], cfg9[2], cfg9[3], cfg9[4], cfg9[5], cfg9[6], cfg9[7], action_dim, (int)cfg9[9]};
   const int proj = (int)cfg9[8];
   if (proj < 0 || proj > 2) return -3;
 #define GRL_TRPL_LAUNCH(AT, PJ)                                                                                               \
@@ -679,6 +790,14 @@ int grl_trpl_target_terms(const double* cfg9, int action_dim, const float* mean,
   // action := target mean, old distribution := target (finite arithmetic in the skipped projection), advantage := 0
   return trpl_launch(cfg9, action_dim, mean, sigma, tgt_mean, tgt_mean, tgt_S, zeros_b, zeros_b, nullptr, nullptr, nullptr, dmean,
                      dsigma, nullptr, nullptr, nullptr, nullptr, sums, maxes, slots, tgt_mean, tgt_S, batch, stream);
+}
+
+// grl_trpl_fold + grl_trpl_loss_values in one launch (one rank: nothing to all-reduce in between)
+int grl_trpl_report(const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
+  if (!slots || !sums || !maxes || !out14 || batch < 1) return -2;
+  hipLaunchKernelGGL(trpl_report_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes, entropy_coef, out14);
+  GRL_CHECK_LAUNCH();
+  return 0;
 }
 
 // Reported values from the (globally reduced) sums / maxes of the fused kernel (trpl.py:280-321), one tiny launch instead of a

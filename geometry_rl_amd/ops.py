@@ -776,7 +776,7 @@ TRPL_SUM_KEYS = ("loss_objective", "loss_trust_region", "entropy_dist", "loss_cr
 
 def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value,
                  global_batch: int, adv_stats: Optional[torch.Tensor], want_projection: bool = False, sums=None, maxes=None,
-                 proj_type: int = 0, defer_fold: bool = False):
+                 proj_type: int = 0, defer_fold: bool = False, adv_local: bool = False):
     """Launches the fused TRPL kernel (proj_type 0 KL | 1 Frobenius | 2 Wasserstein).  Returns (sums fp64[12], maxes u32[2], dloc,
     dsigma, dvalue, proj_mean, proj_var).  ``defer_fold``: the per-workgroup slots are not folded into ``sums`` / ``maxes`` by this call;
     the returned ``sums`` is then a callable that does it (on whatever stream is current when it is called) and returns (sums, maxes)."""
@@ -784,8 +784,9 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
     hip.check_f32(loc, sigma)
     B, A = loc.shape
     dev = loc.device
-    cfg = (ctypes.c_double * 9)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
-                                clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch), float(proj_type))
+    cfg = (ctypes.c_double * 10)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef,
+                                 clip_value if clip_value else 0.0, 1.0 / global_batch, float(global_batch), float(proj_type),
+                                 1.0 if adv_local else 0.0)   # adv_local: the batch's advantage statistics are summed inside the kernel
     if sums is None:   # otherwise: views of the caller's per-step workspace (written in full by the launch)
         sums = torch.empty(12, device=dev, dtype=torch.float64)
         maxes = torch.empty(2, device=dev, dtype=torch.int32)
@@ -805,6 +806,7 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
         def fold(sums=sums, maxes=maxes, slots=slots):
             hip.call("grl_trpl_fold", slots, B, sums, maxes)
             return sums, maxes
+        fold.slots, fold.batch, fold.sums, fold.maxes = slots, B, sums, maxes   # (for a caller that folds and reports in one launch)
         return fold, maxes, dloc, dsigma, dvalue, pm, pv
     return sums, maxes, dloc, dsigma, dvalue, pm, pv
 
@@ -817,8 +819,8 @@ def trpl_target_terms(loc, sigma, tgt_mean, tgt_S, *, mean_bound, cov_bound, tru
     hip.check_f32(loc, sigma, tgt_mean, tgt_S)
     B, A = loc.shape
     dev = loc.device
-    cfg = (ctypes.c_double * 9)(mean_bound, cov_bound, trust_region_coeff, 0.0, 0.0, 0.0, 1.0 / global_batch, float(global_batch),
-                                float(proj_type))
+    cfg = (ctypes.c_double * 10)(mean_bound, cov_bound, trust_region_coeff, 0.0, 0.0, 0.0, 1.0 / global_batch, float(global_batch),
+                                 float(proj_type), 0.0)
     sums = torch.empty(12, device=dev, dtype=torch.float64)
     maxes = torch.empty(2, device=dev, dtype=torch.int32)
     slots = torch.empty(hip.query("grl_trpl_slot_doubles", B), device=dev, dtype=torch.float64)

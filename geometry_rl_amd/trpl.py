@@ -168,9 +168,11 @@ def adv_stats_local(m, batch, out):
     hip.call("grl_adv_stats", adv, out, adv.numel())
 
 
-def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None, defer_fold=False):
+def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None, defer_fold=False, adv_local=False):
     """One launch of the fused kernel on detached inputs: rank-local (sums, maxes) and the gradients of the (1/B_global-scaled)
-    losses with respect to loc, sigma and value.  ``defer_fold``: see ops.trpl_fwd_bwd (``sums`` comes back as the folding callable)."""
+    losses with respect to loc, sigma and value.  ``defer_fold``: see ops.trpl_fwd_bwd (``sums`` comes back as the folding callable).
+    ``adv_local`` (one rank): the advantage statistics are summed inside the kernel; ``value=None``: actor-only (the critic's share of
+    the loss comes from ``value_loss`` on the critic's lane)."""
     p = m.projection
     B = loc.shape[0]
     sums, maxes, dloc, dsigma, dvalue, _, _ = ops.trpl_fwd_bwd(
@@ -178,8 +180,35 @@ def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None, d
         cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
         entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, critic_coef=m.critic_coef,
         clip_value=float(m.clip_value) if m.clip_value is not None else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats,
-        sums=sums, maxes=maxes, proj_type=getattr(p, "proj_code", 0), defer_fold=defer_fold)
+        sums=sums, maxes=maxes, proj_type=getattr(p, "proj_code", 0), defer_fold=defer_fold, adv_local=adv_local)
     return sums, maxes, dloc, dsigma, dvalue
+
+
+def value_loss(m, value, batch):
+    """The critic's share of the loss on its own (clipped l2 value loss, trpl.py:213-228): -> (dvalue [B], loss_critic float32 0-d, sums
+    fp64[2] = summed loss and its mean over the global batch).  One launch; one rank (nothing is all-reduced)."""
+    import ctypes
+    B = value.shape[0]
+    dev = value.device
+    dvalue = torch.empty(B, device=dev, dtype=torch.float32)
+    out2 = torch.empty(2, device=dev, dtype=torch.float64)
+    mean = torch.empty(1, device=dev, dtype=torch.float32)
+    hip.call("grl_value_loss", value.reshape(B).contiguous(), batch["state_value"].reshape(B).contiguous(),
+             batch["value_target"].reshape(B).contiguous(), ctypes.c_double(float(m.clip_value) if m.clip_value is not None else 0.0),
+             ctypes.c_double(float(m.critic_coef)), ctypes.c_double(1.0 / (B * m.world_size)), dvalue, out2, mean, B)
+    return dvalue, mean[0], out2
+
+
+def report_values(m, slots, B, sums, maxes):
+    """Fold of the fused kernel's per-workgroup slots and the reported values in ONE launch (one rank): -> (actor loss, critic loss,
+    metrics dict) like ``loss_values``."""
+    ent_coef = m.entropy_coef if m.entropy_bonus else 0.0
+    o = torch.empty(14, device=sums.device, dtype=torch.float32)
+    hip.call("grl_trpl_report", slots, B, sums, maxes, float(ent_coef), o)
+    metrics = {"loss_trust_region": o[2], "loss_entropy": o[3], "ESS": o[4], "kl": o[5], "constraint": o[13], "mean_constraint": o[6],
+               "mean_constraint_max": o[7], "cov_constraint": o[8], "cov_constraint_max": o[9], "entropy": o[10],
+               "entropy_diff": o[11], "loss_objective_value": o[12]}
+    return o[0], o[1], metrics
 
 
 def loss_values(m, sums, maxes):

@@ -232,10 +232,18 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  *      projections/kl_projection_layer.py:15-111 (+ ITPAL BatchedDiagCovOnlyProjection), utils/projection_utils.py:34-67,
  *      objectives/utils.py:5-28 ---------------------------------------------------------------------------------------------
  *      projections/frob_projection_layer.py:9-88, projections/w2_projection_layer.py:14-76 (diagonal policy, closed forms)
- * cfg9 (HOST): {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value, 1/B_global, B_global,
- *               projection type: 0 KL | 1 Frobenius | 2 Wasserstein (commutative, precision-scaled)}
+ * cfg9 (HOST, TEN doubles since ABI 203): {mean_bound, cov_bound, trust_region_coeff, entropy_coef, critic_coef, clip_value, 1/B_global, B_global,
+ *               projection type: 0 KL | 1 Frobenius | 2 Wasserstein (commutative, precision-scaled),
+ *               adv_local: 1 = the advantage statistics are summed inside the kernel from this launch's batch (one rank), 0 = adv_stats}
  * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
  *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
+/* (ABI 203) the critic's share of the loss on its own: clipped l2 value loss (trpl.py:213-228, objectives/utils.py:5-28) and d loss / d V per
+ * frame (already scaled by critic_coef / B_global) -- elementwise, so the critic's lane needs nothing from the fused actor kernel (which is
+ * then called with value = NULL).  out2 fp64[2] = {sum over the frames of critic_coef * loss, that sum * inv_batch}; one workgroup */
+int grl_value_loss(const float* value, const float* old_value, const float* value_target, double clip_value, double critic_coef,
+                   double inv_batch, float* dvalue, double* out2, float* mean_out /* float[1] or NULL */, int batch, hipStream_t stream);
+/* (ABI 203) grl_trpl_fold + grl_trpl_loss_values in one launch (one rank: nothing is all-reduced in between) */
+int grl_trpl_report(const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 /* stats fp64[2] = (sum, sum of squares) of the advantages, WRITTEN (ABI 203; <= 202 added to a zeroed slot): one workgroup, fixed order */
 int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t stream);
 /* (ABI 202) sums == NULL in grl_trpl_fwd_bwd: the per-workgroup slots are left unfolded and the caller runs grl_trpl_fold later, e.g. on a
