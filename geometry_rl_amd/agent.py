@@ -210,7 +210,7 @@ class PolicyUpdater:
     # ---- the plan: [("run", fn) | ("sum", tensor getter) | ("max", tensor getter)] --------------------------------------
     def _plan(self, batch: Dict[str, torch.Tensor], st: dict):
         from . import ops
-        from .trpl import adv_stats_local, loss_values, report_values, trpl_launch, value_loss
+        from .trpl import adv_stats_local, loss_values, report_dict, report_values, trpl_launch, value_loss
         m = self.loss_module
         world = m.world_size
         actor = m.actor_network
@@ -463,12 +463,19 @@ class PolicyUpdater:
             #                  backward stages, fold, Adam over the critic's slice.
             # Actor and critic share no parameter and no intermediate (train.py:279-316 runs two backward passes and two optimizers); the
             # lanes are forked at the step's start and joined at its end.
+            # (clipping needs the finished gradient norm first; gradients that reach .grad through torch's AccumulateGrad -- attention gate,
+            # stock transformer: exactly the cases without overwrite mode -- are not in the fold queue, so their parameters would be skipped)
+            fuse_tail = os.environ.get("GRL_FUSED_TAIL", "1") != "0" and not self.clip and ow
+            adam_args = lambda lo, hi, cnt: dict(grads=self.gflat[lo:hi], params=self.flat[lo:hi], exp_avg=self.exp_avg[lo:hi],
+                                                 exp_avg_sq=self.exp_avg_sq[lo:hi], lr_dev=self.lr_dev, betas=self.betas, eps=self.eps,
+                                                 step_dev=cnt)
+
             def main_all():
                 m_prep()
-                with torch.no_grad():
-                    self.step_dev.add_(1)
-                    st["step_bumped"] = True
+                st["step_bumped"] = True
+                actor.hyper_data.bump_next = self.step_dev   # the step count rides on the lane's first launch (grl_build_features_bump)
                 a_fwd()
+                assert actor.hyper_data.bump_next is None, "the actor's feature launch did not take the step count"
                 loc, sigma = st["loc_g"], st["sigma_g"]
                 with torch.no_grad():
                     zw = st["zw"]
@@ -477,18 +484,28 @@ class PolicyUpdater:
                                                                 adv_local=bool(m.normalize_advantage and loc.shape[0] > 1))
                 st.update(loc=loc.detach(), sigma=sigma.detach(), dloc=dloc, dsigma=dsigma)
                 a_bwd()
-                fold()
                 with torch.no_grad():
-                    adam(0, self.n_actor, 0)
-                    a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
+                    done = False
+                    if fuse_tail:   # fold + Adam + reported values: ONE launch at the lane's end (ops.fold_adam_report)
+                        o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
+                        ent = m.entropy_coef if m.entropy_bonus else 0.0
+                        done = ops.fold_adam_report(ow, adam_args(0, self.n_actor, self.step_dev),
+                                                    dict(slots=fold_.slots, batch=fold_.batch, sums=fold_.sums, maxes=fold_.maxes,
+                                                         ent_coef=ent, out14=o14))
+                        if done:
+                            ops.DEFERRED = None
+                            a_loss, mt = report_dict(o14)
+                    if not done:
+                        fold()
+                        adam(0, self.n_actor, 0)
+                        a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
                     st.update(sums=fold_.sums, maxes=fold_.maxes, lv_main=(a_loss, mt))
 
             def critic_all():
                 ops.DEFERRED = []
                 with torch.no_grad():
-                    self.step_dev_c.add_(1)
                     vf.train(True)
-                    _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
+                    _, x = vf.hyper_data.build_data(*st["cobs"], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
                     pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                     pipe.fwd1()
                     pipe.fwd2()
@@ -498,9 +515,10 @@ class PolicyUpdater:
                     pipe.bwd2()
                     grads = pipe.bwd1(leaves)
                     assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
-                    ops.flush_deferred_grads(overwrite=ow)
+                    if not (fuse_tail and ops.fold_adam_report(ow, adam_args(self.n_actor, self.flat.numel(), self.step_dev_c))):
+                        ops.flush_deferred_grads(overwrite=ow)
+                        adam(self.n_actor, self.flat.numel(), 1, self.step_dev_c)
                     ops.DEFERRED = None
-                    adam(self.n_actor, self.flat.numel(), 1, self.step_dev_c)
                     st["c_loss"] = c_loss
 
             def finish():
@@ -742,10 +760,34 @@ class PolicyUpdater:
         self._execute(self._program)
         return self._st["out"]
 
+    def _actor_stream(self):
+        """One rank, two lanes: the actor's lane runs on a stream of its own with the HIGHEST priority the device offers (the critic's lane
+        keeps the default): when both lanes have workgroups to place, the actor's go first, and the critic's small launches take what the
+        actor's kernels leave -- their heads and tails, the latency-bound loss kernel -- instead of sitting on compute units the first edge
+        convolution then finds occupied (DESIGN.md finding 33: 319 -> 382 us for that launch at 4096 frames with both lanes at one priority)."""
+        if getattr(self, "_astream", None) is None:
+            prio = 0
+            # MEASURED round 4 (tools/prio_ab.sh, one box) and left OFF: 32 / 512 frames 0.370 -> 0.409 / 0.705 -> 0.736 ms per step, 4096
+            # frames 3.195 -> 3.196, cloth 5.42 -> 5.48, EMPN 4.80 -> 4.91: the two extra stream hand-overs per step (caller -> own stream
+            # -> caller) cost more than the priority buys -- the critic's resident workgroups are not evicted by it
+            if os.environ.get("GRL_ACTOR_PRIO", "0") != "0" and hasattr(torch.cuda.Stream, "priority_range"):
+                try:
+                    prio = min(torch.cuda.Stream.priority_range())
+                except Exception:
+                    prio = 0
+            self._astream = torch.cuda.Stream(priority=prio) if prio != 0 else False
+            self._astream_priority = prio
+        return self._astream or None
+
     def _execute(self, program):
         """Run a program: ("run" closure | "graph" replay | collective | "fork" | "join" | "wait", item, lane).  Lane "m" is the
-        caller's stream, lane "s" the critic stream; "fork": the side lane waits for the main lane, "join": the reverse."""
-        main = torch.cuda.current_stream()
+        caller's stream (one rank with two lanes: a high-priority stream of the updater's, joined back into the caller's at the end), lane
+        "s" the critic stream; "fork": the side lane waits for the main lane, "join": the reverse."""
+        caller = torch.cuda.current_stream()
+        own = self._actor_stream() if (self._lanes and self.group is None and self.overlap_critic) else None
+        main = own or caller
+        if own is not None:
+            own.wait_stream(caller)
         side = None
         for kind, item, lane, label in program:
             if kind in ("fork", "join"):
@@ -760,8 +802,13 @@ class PolicyUpdater:
                 side = side or self._critic_stream()
                 with torch.cuda.stream(side):
                     self._do(kind, item, label)
+            elif own is not None:
+                with torch.cuda.stream(own):
+                    self._do(kind, item, label)
             else:
                 self._do(kind, item, label)
+        if own is not None:
+            caller.wait_stream(own)
 
     def _do(self, kind, item, label=None):
         if kind in ("run", "run_host"):

@@ -7,6 +7,7 @@
 //   projections/kl_projection_layer.py:15-111, utils/projection_utils.py:34-67, objectives/utils.py:5-28; ITPAL's diagonal
 //   covariance projection restated from its KKT system): one thread per frame, fp64 inside.
 #include "grl_common.h"
+#include "grl_report.h"
 
 namespace {
 
@@ -196,7 +197,6 @@ constexpr int AMAX = 12;
 //                     6 mean_constraint 7 cov_constraint 8 entropy(p) 9 entropy_diff 10 count 11 kl(p || proj_p)
 // (6, 7: the projection's own trust-region measure of (p, proj_p); equal to the KL parts for the KL projection)
 // maxes layout (fp32 bits, values >= 0): 0 mean_constraint_max 1 cov_constraint_max
-constexpr int TRPL_SLOT = 14;   // per-workgroup record: the 12 sums + the 2 maxes
 struct TrplCfg {
   double mean_bound, cov_bound, tr_coeff, ent_coef, critic_coef, clip_value, inv_batch, adv_count;
   int A;
@@ -614,44 +614,12 @@ __global__ void loss_values_kernel(const double* __restrict__ sums, const unsign
   out[13] = mc + cc;   // "constraint": the projection's own measure (= kl for the KL projection)
 }
 
-// slots -> sums / maxes (trpl_fold_kernel) AND the reported values (loss_values_kernel) in ONE launch: the actor's lane ends with it
+// slots -> sums / maxes (trpl_fold_kernel) AND the reported values (loss_values_kernel) in ONE launch (body: grl_report.h)
 __global__ __launch_bounds__(64) void trpl_report_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
                                                         unsigned int* __restrict__ maxes, float entropy_coef, float* __restrict__ out) {
   __shared__ double sh[12];
   __shared__ unsigned int shm[2];
-  const int i = threadIdx.x;
-  if (i < 12) {
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
-    sums[i] = s;
-    sh[i] = s;
-  } else if (i < 14) {
-    double m = 0.0;
-    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
-    maxes[i - 12] = __float_as_uint((float)m);
-    shm[i - 12] = __float_as_uint((float)m);
-  }
-  __syncthreads();
-  if (i == 0) {
-    const double n = sh[10];
-    const float tr = (float)(sh[1] / n), ent = -entropy_coef * (float)(sh[2] / n);
-    const float actor = (float)((sh[0] + sh[1] - (double)entropy_coef * sh[2]) / n);
-    out[0] = actor;
-    out[1] = (float)(sh[3] / n);
-    out[2] = tr;
-    out[3] = ent;
-    out[4] = (float)(sh[4] * sh[4] / sh[5] / n);
-    const float mc = (float)(sh[6] / n), cc = (float)(sh[7] / n);
-    out[5] = (float)(sh[11] / n);
-    out[6] = mc;
-    out[7] = __uint_as_float(shm[0]);
-    out[8] = cc;
-    out[9] = __uint_as_float(shm[1]);
-    out[10] = (float)(sh[8] / n);
-    out[11] = (float)(sh[9] / n);
-    out[12] = actor - (tr + ent);
-    out[13] = mc + cc;
-  }
+  trpl_report_body(slots, n_blocks, sums, maxes, entropy_coef, out, sh, shm);
 }
 
 // ---- collector-side action sampling: torch.distributions.MultivariateNormal(loc, covariance_matrix = diag(sigma^2)).rsample()

@@ -4,6 +4,7 @@
 //   slab reduction of per-workgroup weight-gradient partials
 // All are streaming kernels: one coalesced pass over [N,16,64] fp32 node tensors, weights held in registers / LDS.
 #include "grl_common.h"
+#include "grl_report.h"
 
 namespace {
 
@@ -687,6 +688,37 @@ struct ReduceMulti {
   int overwrite;                                                       // 1: dst = sum (destination not read) instead of dst += sum
   unsigned char vec[RED_MULTI_MAX];                                    // destination group eligible for the float4 path
 };
+// The step's tail in ONE launch (one rank, no gradient clipping): while a workgroup still holds the freshly summed gradient entries it
+// applies Adam to the parameters they belong to (the optimizer launch and its read of the gradient disappear; the gradient is stored as
+// well: .grad stays inspectable), and one EXTRA workgroup folds the fused loss kernel's slots, evaluates the reported values and advances
+// the optimizer's step count for the next step -- three more launches of the lane's tail gone (fold + Adam + report + count were
+// 32 + 6 + 6 + 6 us at 512 frames).  Arithmetic of the update: adam_dev_kernel's (train_ops.hip), bit for bit.
+struct FoldTail {
+  long long d_param, d_m, d_v;     // element offsets from a gradient entry to its parameter / first moment / second moment
+  const float* lr_dev;
+  const int* step_dev;             // the count of the step in progress (advanced earlier on the lane: grl_build_features_bump)
+  float b1, b2, eps;
+  int adam;                        // 1: apply the update
+  // report workgroup (blockIdx.x == number of fold workgroups)
+  int report;
+  const double* slots;
+  int n_slot_blocks;
+  double* sums;
+  unsigned int* maxes;
+  float ent_coef;
+  float* out14;
+};
+GRL_DEVINL void adam_apply(float g, float* __restrict__ gp, const FoldTail& t, float lr, float bc1, float bc2_sqrt) {
+  float* p = gp + t.d_param;
+  float* m = gp + t.d_m;
+  float* v = gp + t.d_v;
+  const float mi = t.b1 * *m + (1.f - t.b1) * g;
+  const float vi = t.b2 * *v + (1.f - t.b2) * g * g;
+  *m = mi;
+  *v = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + t.eps;
+  *p -= (lr / bc1) * (mi / denom);
+}
 // float4 variant: a wave covers 4 rows x 64 columns per load (16 lanes x float4 per row, lane >> 4 picks the row), so a
 // workgroup still owns only 64 columns -- tall thin slabs (1024-2048 rows x 4096 columns) need that many workgroups: with 256
 // columns per workgroup 16 CUs pulled the whole slab at ~95 GB/s each (tools/ubench/reduce_bench.py).
@@ -739,9 +771,25 @@ GRL_DEVINL float4 column_sum4(const float* __restrict__ src, size_t ld, int n_ro
 GRL_DEVINL float4 f4_shfl_xor(float4 v, int m) {
   return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
 }
-__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(ReduceMulti m) {
+template <bool TAIL>
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(ReduceMulti m, FoldTail tail) {
   __shared__ float4 red[RED_WAVES][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float lr = 0.f, bc1 = 1.f, bc2_sqrt = 1.f;
+  if (TAIL) {
+    if (tail.report && (int)blockIdx.x == m.blk0[m.n_dst]) {   // the extra workgroup: reported values (its first 64 threads)
+      __shared__ double sh[12];
+      __shared__ unsigned int shm[2];
+      trpl_report_body(tail.slots, tail.n_slot_blocks, tail.sums, tail.maxes, tail.ent_coef, tail.out14, sh, shm);
+      return;
+    }
+    if (tail.adam) {
+      const float t_ = (float)tail.step_dev[0];
+      lr = tail.lr_dev[0];
+      bc1 = 1.f - powf(tail.b1, t_);
+      bc2_sqrt = sqrtf(1.f - powf(tail.b2, t_));
+    }
+  }
   // flat grid: exactly one workgroup per 64 columns of every destination (round 3 launched max_len / 64 x n_dst workgroups, ~8 of 10 of
   // which found themselves outside their destination and left at once -- ten thousand empty 512-thread workgroups per step)
   int d = 0;
@@ -763,7 +811,13 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(R
 #pragma unroll
       for (int g = 1; g < RED_WAVES; ++g) t = f4_add(t, red[g][lane]);
       float4* dp = reinterpret_cast<float4*>(m.dst[d] + j);
-      *dp = m.overwrite ? t : f4_add(*dp, t);
+      const float4 gq = m.overwrite ? t : f4_add(*dp, t);
+      *dp = gq;
+      if (TAIL && tail.adam) {
+        float* gp = m.dst[d] + j;
+        adam_apply(gq.x, gp, tail, lr, bc1, bc2_sqrt); adam_apply(gq.y, gp + 1, tail, lr, bc1, bc2_sqrt);
+        adam_apply(gq.z, gp + 2, tail, lr, bc1, bc2_sqrt); adam_apply(gq.w, gp + 3, tail, lr, bc1, bc2_sqrt);
+      }
     }
     return;
   }
@@ -775,6 +829,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(R
       v += column_sum(m.partial[q] + m.start[q] + j, (size_t)m.ld[q], m.n_rows[q], wave);
   __shared__ float reds[RED_WAVES][64];
   fold_and_add(v, m.dst[d] + j, active, reds, m.overwrite != 0);
+  if (TAIL && tail.adam && wave == 0 && active) adam_apply(m.dst[d][j], m.dst[d] + j, tail, lr, bc1, bc2_sqrt);   // (this thread wrote the entry)
 }
 
 int cap_blocks(long long work, int per_block, int cap) {
@@ -974,11 +1029,50 @@ int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int*
 }
 // overwrite != 0: every destination is WRITTEN with the sum of its slabs (not accumulated into): the caller needs no zeroed gradient
 // buffer, provided every slab of a destination is in THIS call (they are summed by one workgroup in the order given)
+static int fold_fill(ReduceMulti& m, int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                     const int* len, float* const* dst, int overwrite);
 int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
                                  const int* len, float* const* dst, int overwrite, hipStream_t stream) {
   if (n_seg <= 0) return 0;
-  if (n_seg > RED_MULTI_MAX) return -2;
   ReduceMulti m{};
+  if (const int rc = fold_fill(m, n_seg, partial, n_rows, ld, start, len, dst, overwrite)) return rc;
+  if (m.blk0[m.n_dst] <= 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel<false>, dim3(m.blk0[m.n_dst]), dim3(64 * RED_WAVES), 0, stream, m, FoldTail{});
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+// The step's tail in one launch (one rank): the fold above, PLUS (adam != 0) the Adam update of every parameter entry whose gradient this
+// launch produces -- grads / params / exp_avg / exp_avg_sq are parallel flat buffers (every dst lies inside grads; entries no slab feeds
+// keep their zero gradient: Adam would not move them either), lr_dev float[1], step_dev int[1] = the count of THIS step --
+// PLUS (slots != NULL) one extra workgroup doing grl_trpl_report's work.  Gradient clipping needs the finished norm first: not here.
+int grl_fold_adam_report(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                         float* const* dst, int overwrite, int adam, const float* grads, float* params, float* exp_avg, float* exp_avg_sq,
+                         const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev, const double* slots, int batch,
+                         double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
+  ReduceMulti m{};
+  if (n_seg > 0)
+    if (const int rc = fold_fill(m, n_seg, partial, n_rows, ld, start, len, dst, overwrite)) return rc;
+  FoldTail t{};
+  if (adam) {
+    if (!grads || !params || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev) return -2;
+    t.adam = 1;
+    t.d_param = params - grads; t.d_m = exp_avg - grads; t.d_v = exp_avg_sq - grads;
+    t.lr_dev = lr_dev; t.step_dev = step_dev; t.b1 = beta1; t.b2 = beta2; t.eps = eps;
+  }
+  if (slots) {
+    if (!sums || !maxes || !out14 || batch < 1) return -2;
+    t.report = 1;
+    t.slots = slots; t.n_slot_blocks = (batch + 127) / 128; t.sums = sums; t.maxes = maxes; t.ent_coef = entropy_coef; t.out14 = out14;
+  }
+  const int blocks = m.blk0[m.n_dst] + (t.report ? 1 : 0);
+  if (blocks <= 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel<true>, dim3(blocks), dim3(64 * RED_WAVES), 0, stream, m, t);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+static int fold_fill(ReduceMulti& m, int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
+                     const int* len, float* const* dst, int overwrite) {
+  if (n_seg > RED_MULTI_MAX) return -2;
   int n_dst = 0, n_src = 0, max_len = 0;
   bool used[RED_MULTI_MAX] = {false};
   for (int i = 0; i < n_seg; ++i) {
@@ -1004,9 +1098,6 @@ int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const i
   (void)max_len;
   m.n_dst = n_dst;
   m.overwrite = overwrite ? 1 : 0;
-  if (m.blk0[n_dst] <= 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(m.blk0[n_dst]), dim3(64 * RED_WAVES), 0, stream, m);
-  GRL_CHECK_LAUNCH();
   return 0;
 }
 #endif   // !GRL_PREC

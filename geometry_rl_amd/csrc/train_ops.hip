@@ -184,7 +184,10 @@ struct FeatDesc {
 };
 constexpr int FEAT_MAX = 24;
 struct FeatDescs { FeatDesc d[FEAT_MAX]; };
-__global__ __launch_bounds__(256) void build_features_kernel(FeatDescs all) {
+__global__ __launch_bounds__(256) void build_features_kernel(FeatDescs all, int* __restrict__ bump) {
+  // (optional) the optimizer's step count rides on this launch -- the first of a lane's recorded step: one thread advances it, every
+  // later kernel of the lane (Adam) reads the new value; a separate one-element launch was ~6 us of every step's chain
+  if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) bump[0] += 1;
   const FeatDesc& f = all.d[blockIdx.y];
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < f.n_nodes; n += gridDim.x * blockDim.x) {
     const long long flat = f.gather ? f.gather[n] : (long long)n;
@@ -438,7 +441,10 @@ int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned 
 // descs: HOST array of n_desc <= 24 records of 18 8-byte words each:
 //   [out, a, b, gather (pointers; 0 = absent), out_row_stride, out_col, rows_per_sample, row_off, n_nodes, n_per,
 //    a_stride, a_off, a_bcast, b_stride, b_off, b_bcast, onehot_col, n_types]
-int grl_build_features(const long long* descs, int n_desc, hipStream_t stream) {
+int grl_build_features_bump(const long long* descs, int n_desc, int* bump, hipStream_t stream);
+int grl_build_features(const long long* descs, int n_desc, hipStream_t stream) { return grl_build_features_bump(descs, n_desc, nullptr, stream); }
+// the same; bump (device int[1] or NULL) is advanced by one by this launch
+int grl_build_features_bump(const long long* descs, int n_desc, int* bump, hipStream_t stream) {
   if (n_desc <= 0) return 0;
   if (n_desc > FEAT_MAX) return -2;
   FeatDescs all{};
@@ -458,7 +464,7 @@ int grl_build_features(const long long* descs, int n_desc, hipStream_t stream) {
     if (f.n_nodes > max_nodes) max_nodes = f.n_nodes;
   }
   const int bx = (max_nodes + 255) / 256 < 256 ? (max_nodes + 255) / 256 : 256;
-  hipLaunchKernelGGL(build_features_kernel, dim3(bx, n_desc), dim3(256), 0, stream, all);
+  hipLaunchKernelGGL(build_features_kernel, dim3(bx, n_desc), dim3(256), 0, stream, all, bump);
   GRL_CHECK_LAUNCH();
   return 0;
 }

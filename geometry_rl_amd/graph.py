@@ -150,6 +150,7 @@ class HyperData:
         else:
             self.node_type_list = list(spec.node_types)
         self._cache = {}
+        self.bump_next = None   # one-shot: a device int32[1] the NEXT build_data's feature launch advances by one (PolicyUpdater: step count)
         self.check_topology_always = bool(int(os.environ.get("GRL_CHECK_TOPOLOGY", "0")))
 
     # ---- cached topology: invariant and guards
@@ -390,7 +391,11 @@ class HyperData:
                               n_types]
                 row_off += n_t
             n_desc = len(words) // 18
-            hip.call("grl_build_features", (ctypes.c_longlong * len(words))(*words), n_desc)
+            # kw["bump"]: optional device int32[1] advanced by this launch (PolicyUpdater: the optimizer's step count of the recorded step)
+            bump = kw.get("bump")
+            if bump is None and self.bump_next is not None:
+                bump, self.bump_next = self.bump_next, None
+            hip.call("grl_build_features_bump", (ctypes.c_longlong * len(words))(*words), n_desc, bump)
             self._keepalive = obs  # the launch reads these buffers asynchronously
             graph = GraphBatch(B, list(self.node_type_list), {t: (topo["n_main"] if t == main else B * topo["n_per"][t])
                                                               for t in self.node_type_list}, graph_pos,

@@ -144,6 +144,39 @@ def _launch_folds(jobs, overwrite=False):
                  (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]), 1 if overwrite else 0)
 
 
+def fold_adam_report(overwrite, adam=None, report=None):
+    """The queued folds, the Adam update of the parameters they feed and the reported loss values in ONE launch
+    (grl_fold_adam_report).  ``adam``: dict(grads, params, exp_avg, exp_avg_sq, lr_dev, betas, eps, step_dev) or None; ``report``:
+    dict(slots, batch, sums, maxes, ent_coef, out14) or None.  Returns False (nothing launched, queue untouched) when the queue does not fit
+    one launch -- the caller then takes the separate launches."""
+    import ctypes
+    global DEFERRED
+    jobs = DEFERRED or []
+    if len(jobs) > 64 or FOLD_STREAM is not None:
+        return False
+    by_dst = {}
+    for j in jobs:
+        by_dst.setdefault(j[3].data_ptr(), []).append(j)
+    part = [j for grp in by_dst.values() for j in grp]
+    n = len(part)
+    a, r = adam or {}, report or {}
+    if adam is not None:   # every destination must lie inside the flat gradient buffer the optimizer state is parallel to
+        lo, hi = a["grads"].data_ptr(), a["grads"].data_ptr() + 4 * a["grads"].numel()
+        if any(not (lo <= j[3].data_ptr() and j[3].data_ptr() + 4 * j[2] <= hi) for j in part):
+            return False
+    hip.call("grl_fold_adam_report", n, (ctypes.c_void_p * max(n, 1))(*[j[0].data_ptr() for j in part]),
+             (ctypes.c_int * max(n, 1))(*[j[0].shape[0] for j in part]), (ctypes.c_int * max(n, 1))(*[j[0].shape[1] for j in part]),
+             (ctypes.c_int * max(n, 1))(*[j[1] for j in part]), (ctypes.c_int * max(n, 1))(*[j[2] for j in part]),
+             (ctypes.c_void_p * max(n, 1))(*[j[3].data_ptr() for j in part]), 1 if overwrite else 0, 1 if adam is not None else 0,
+             a.get("grads"), a.get("params"), a.get("exp_avg"), a.get("exp_avg_sq"), a.get("lr_dev"),
+             float(a["betas"][0]) if adam else 0.0, float(a["betas"][1]) if adam else 0.0, float(a["eps"]) if adam else 0.0,
+             a.get("step_dev"), r.get("slots"), int(r.get("batch", 0)), r.get("sums"), r.get("maxes"), float(r.get("ent_coef", 0.0)),
+             r.get("out14"))
+    if DEFERRED is not None:
+        DEFERRED = []
+    return True
+
+
 def flush_deferred_grads(overwrite=False, only=None):
     """Fold every queued slab into its leaf gradient.  ``overwrite``: the gradients are WRITTEN (the caller keeps no zeroed buffer; every
     leaf gradient of the pass must then come through this queue -- PolicyUpdater checks that).  ``only``: a predicate on the destination

@@ -199,6 +199,13 @@ def value_loss(m, value, batch):
     return dvalue, mean[0], out2
 
 
+def report_dict(o):
+    """The 14-float output of grl_trpl_report / grl_fold_adam_report as (actor loss, metrics dict of views)."""
+    return o[0], {"loss_trust_region": o[2], "loss_entropy": o[3], "ESS": o[4], "kl": o[5], "constraint": o[13], "mean_constraint": o[6],
+                  "mean_constraint_max": o[7], "cov_constraint": o[8], "cov_constraint_max": o[9], "entropy": o[10],
+                  "entropy_diff": o[11], "loss_objective_value": o[12]}
+
+
 def report_values(m, slots, B, sums, maxes):
     """Fold of the fused kernel's per-workgroup slots and the reported values in ONE launch (one rank): -> (actor loss, critic loss,
     metrics dict) like ``loss_values``."""

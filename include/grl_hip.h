@@ -321,6 +321,14 @@ int grl_reduce_partials_multi(int n_seg, const float* const* partial, const int*
  * needed), provided all slabs of a destination are in this call; the launch is a flat grid of one workgroup per 64 columns */
 int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start,
                                  const int* len, float* const* dst, int overwrite, hipStream_t stream);
+/* (ABI 203) the step's tail in ONE launch (one rank, no gradient clipping; train.py:308-316): the fold above, plus -- adam != 0 -- the Adam
+ * update (grl_adam_step_dev's arithmetic, bit for bit) of every parameter entry whose gradient this launch produces (grads / params /
+ * exp_avg / exp_avg_sq: parallel flat buffers, every dst inside grads; the gradient is stored too), plus -- slots != NULL -- one extra
+ * workgroup that does grl_trpl_report's work.  step_dev: the count of THIS step (advanced earlier, e.g. by grl_build_features_bump). */
+int grl_fold_adam_report(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                         float* const* dst, int overwrite, int adam, const float* grads, float* params, float* exp_avg, float* exp_avg_sq,
+                         const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev, const double* slots, int batch,
+                         double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                   float eps, int step, const float* scale_dev, float scale_host, hipStream_t stream);
 /* the same update with the step count (int[1]) AND the learning rate (float[1]) in device memory: recordable into a hipGraph, and
@@ -336,6 +344,8 @@ int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned 
  * records of 18 8-byte words: [out, a, b, gather (device pointers, 0 = absent), out_row_stride, out_col, rows_per_sample,
  * row_off, n_nodes, n_per, a_stride, a_off, a_bcast, b_stride, b_off, b_bcast, onehot_col, n_types] */
 int grl_build_features(const long long* descs, int n_desc, hipStream_t stream);
+/* (ABI 203) the same; bump (device int[1] or NULL) is advanced by one by the launch: the optimizer's step count of a recorded step */
+int grl_build_features_bump(const long long* descs, int n_desc, int* bump, hipStream_t stream);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */
 int grl_copy_many(void* const* dst, const void* const* src, const long long* bytes, int n, hipStream_t stream);
 /* minibatch assembly from a device-resident rollout (train.py:120,128,258-261): dst[k][i,:] = src[k][idx[i],:] for k < n <= 24
