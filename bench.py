@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the recorded hipGraph(s)")
+    ap.add_argument("--dp-plan", action="store_true", help="one GPU, but the DATA-PARALLEL program of the step: a one-rank RCCL process group, "
+                    "every collective issued, graph segments between them -- what a shard's step costs before any inter-GPU latency")
     args = ap.parse_args()
 
     # ---- `python bench.py --gpus N` outside a launcher: start the N ranks ourselves.  Nothing above has touched the GPU (no HIP call,
@@ -263,6 +265,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = dist.group.WORLD
+    elif args.dp_plan:
+        import socket
+        import torch.distributed as dist
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), GRL_FORCE_DP_PLAN="1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         group = dist.group.WORLD
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -335,7 +345,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dp_info = None
-    if world > 1:
+    if world > 1 or args.dp_plan:
         import torch.distributed as dist
         own = torch.tensor([dt], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(own) for _ in range(world)]
@@ -368,7 +378,7 @@ def main():
     ms = 1e3 * dt / args.steps
     n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
     upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else
-                                 f" ({'one hipGraph' if n_graphs == 1 else str(n_graphs) + ' single-stream hipGraphs on two lanes' if world == 1 else 'hipGraph segments between the collectives'})")
+                                 f" ({'one hipGraph' if n_graphs == 1 else str(n_graphs) + ' single-stream hipGraphs on two lanes' if (world == 1 and not args.dp_plan) else str(n_graphs) + ' hipGraph segments between the collectives'})")
 
     # ---- GAE + shifted critic pass over the whole 4096 x 128 rollout (once per 640 updates; outside the timed region)
     gae_ms = None
@@ -551,7 +561,7 @@ def main():
             "mode": upd.mode_timed, "host_cores": os.cpu_count(),
             "config": {"workload": f"{cfg_name}, 4096 synthetic envs x 128 steps, minibatch {args.minibatch} frames "
                                    f"({B} per GPU), 640 updates per rollout", "global_minibatch": args.minibatch,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}" + (" (data-parallel program on a one-rank RCCL group: --dp-plan)" if args.dp_plan else "")},
             "gae_ms_per_rollout_scan": gae_ms, "advantage_pass_ms": adv_ms, "advantage_pass_ms_cold": adv_ms_cold,
             "advantage_pass": f"critic over the {T_roll} + 1 frames of all {B} environments per GPU + shifted GAE, once per rollout (train.py:249-251); "
                               "warm = second call; the time steps are groups of one launch set (per-step LayerNorm statistics"
@@ -571,7 +581,7 @@ def main():
             print(json.dumps(line))
             raise SystemExit("parity gate failed: " + json.dumps(gate))
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.dp_plan:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -160,6 +160,14 @@ class PolicyUpdater:
         self._critic_own_adam = os.environ.get("GRL_CRITIC_OWN_ADAM", "1") != "0"
         # one rank: the step as a two-lane program of single-stream graphs (default) instead of ONE graph with a fork / join inside -- see _plan
         self._lanes = os.environ.get("GRL_LANES", "1") != "0"
+        # the critic's lane reduces on a communicator of its own (see _plan): created collectively, here, in construction order
+        self.group_c = None
+        if group is not None and os.environ.get("GRL_DP_JOINED", "0") == "0":
+            import torch.distributed as dist
+            try:
+                self.group_c = dist.new_group(ranks=dist.get_process_group_ranks(group))
+            except Exception:
+                self.group_c = None
         if group is not None:
             self.sync_replicas()
 
@@ -213,6 +221,9 @@ class PolicyUpdater:
         from .trpl import adv_stats_local, loss_values, report_dict, report_values, trpl_launch, value_loss
         m = self.loss_module
         world = m.world_size
+        # GRL_FORCE_DP_PLAN=1 with a process group of ONE rank: the data-parallel program (lanes with joins, graph segments between the
+        # collectives, every all-reduce issued) on one GPU -- what a shard's step costs before any inter-GPU latency (bench.py --dp-plan)
+        one_rank = world == 1 and not (self.group is not None and os.environ.get("GRL_FORCE_DP_PLAN", "0") != "0")
         actor = m.actor_network
         vf = m.critic_network._network1
         ia, ib = vf.gnn.mlp_inner, vf.gnn.mlp_outer
@@ -384,9 +395,9 @@ class PolicyUpdater:
             ops.FOLD_STREAM = None
             st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes)
 
-        if world == 1 and self.overlap_critic and not self._lanes:
+        if one_rank and self.overlap_critic and not self._lanes:
             return [("run", o_fwd), ("run", s5)]
-        if world == 1 and not self.overlap_critic:   # one rank, one stream
+        if one_rank and not self.overlap_critic:   # one rank, one stream
             return [("run", s0), ("run", s1), ("run", s2), ("run", s3), ("run", s4), ("run", s5)]
 
         # ---- several ranks: two lanes.  The critic with ALL FOUR of its reductions runs on a second stream ("s" items) beside the
@@ -425,7 +436,7 @@ class PolicyUpdater:
 
         def head():  # fused TRPL kernel
             loc, sigma = st["loc_g"], st["sigma_g"]
-            defer = world == 1   # one rank: the per-workgroup loss sums are folded later, on the critic's lane (reported values only)
+            defer = False
             with torch.no_grad():
                 zw = st["zw"]
                 sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, st["value"], st["b"], st["adv"], sums=zw[10:22],
@@ -451,7 +462,7 @@ class PolicyUpdater:
             ops.DEFERRED = None
 
         S = "s"
-        if world == 1 and self.overlap_critic and self._lanes:
+        if one_rank and self.overlap_critic and self._lanes:
             # One rank as a two-lane PROGRAM of single-stream graphs: this HIP runtime replays a captured graph with two branches through
             # the host -- hipGraphLaunch returned after 2/3 of the DEVICE time of the step (0.26 / 0.48 / 2.1 ms at 32 / 512 / 4096 frames
             # against 24 us for a one-stream graph of the same kernels; tools/ubench/graph_branches.py: two independent 20-kernel chains
@@ -531,7 +542,101 @@ class PolicyUpdater:
 
             # (finish only builds the dict of output views: it records nothing; kept as a "run" so that eager steps execute it too)
             return [("fork", None), ("run", main_all), ("run", critic_all, S), ("join", None), ("run_host", finish)]
-        # (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
+        # ---- several ranks, round 4: the lanes do not meet inside a step here either.  The critic's lane carries ALL of the critic -- its four
+        #      LayerNorm-statistic reductions, its own loss (value_loss: elementwise in the frame), the all-reduce of ITS slice of the flat
+        #      gradient and its optimizer step -- on a communicator of its own (collectives of one communicator execute in issue order on
+        #      one internal stream: a critic reduction that waits for a critic kernel would hold back the actor's gradient all-reduce
+        #      issued behind it).  The actor's lane: statistics of the advantages (all-reduced: 16 bytes) | forward, fused loss kernel
+        #      (actor terms), backward, fold | all-reduce of the actor's slice | Adam, reported values: THREE graphs and two collectives on
+        #      its path (round 3: five graphs, two joins with the critic's lane, one collective).
+        #      (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
+        if os.environ.get("GRL_DP_JOINED", "0") == "0":
+            na, n_all = self.n_actor, self.flat.numel()
+
+            def p_stats():
+                m_prep()
+                st["adv"] = None
+                if m.normalize_advantage and st["obs"][0].shape[0] * world > 1:
+                    with torch.no_grad():
+                        st["adv"] = st["zw"][8:10]
+                        adv_stats_local(m, st["b"], st["adv"])
+
+            def p_main():
+                st["step_bumped"] = True
+                actor.hyper_data.bump_next = self.step_dev
+                a_fwd()
+                assert actor.hyper_data.bump_next is None
+                loc, sigma = st["loc_g"], st["sigma_g"]
+                with torch.no_grad():
+                    zw = st["zw"]
+                    sums, maxes, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], st["adv"], sums=zw[10:22],
+                                                               maxes=zw[22:23].view(torch.int32))
+                st.update(loc=loc.detach(), sigma=sigma.detach(), sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma)
+                a_bwd()
+                fold()
+
+            def p_tail():
+                with torch.no_grad():
+                    adam(0, na, 0)
+
+            def p_report():   # behind the wait for the (asynchronously reduced) loss sums
+                with torch.no_grad():
+                    st["lv_main"] = loss_values(m, st["sums"], st["maxes"])
+
+            def q_fwd1():
+                with torch.no_grad():
+                    vf.train(True)
+                    _, x = vf.hyper_data.build_data(*st["cobs"], train=True, bump=self.step_dev_c)
+                    st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
+                    st["pipe"].fwd1()
+
+            def q_fwd3():
+                with torch.no_grad():
+                    st["value"] = st["pipe"].fwd3()
+                    dvalue, _mean, out2 = value_loss(m, st["value"], st["b"])
+                    st["vl"] = out2
+                    st["pipe"].bwd3(dvalue)
+
+            def q_bwd1():
+                keep = ops.DEFERRED
+                ops.DEFERRED = []          # the critic's slabs are folded here, on its lane, into its slice of the flat gradient
+                with torch.no_grad():
+                    grads = st["pipe"].bwd1(leaves)
+                    ops.flush_deferred_grads(overwrite=ow)
+                ops.DEFERRED = keep
+                assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
+
+            def q_tail():
+                with torch.no_grad():
+                    adam(na, n_all, 1, self.step_dev_c)
+                    st["c_loss"] = st["vl"][1].float()   # (the all-reduced sum of the ranks' shares, already divided by B_global)
+
+            def finish_dp():
+                a_loss, _c, mt = st.pop("lv_main")
+                mt = dict(mt)
+                out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": st.pop("c_loss"), "loc": st["loc"], "sigma": st["sigma"],
+                       "state_value": st["value"].unsqueeze(-1)}
+                out.update(mt)
+                st["out"] = out
+
+            # (host order = enqueue order: the critic's segments are interleaved so that its lane is fed early; each lane's own order is what
+            #  the device sees.  p_stats comes first: it also prepares the step's inputs for both lanes.)
+            return [("fork", None),
+                    ("run", p_stats), ("sum", lambda: st["adv"], "m", "advantage_stats"),
+                    ("run", q_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"),
+                    ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"),
+                    ("run", p_main),
+                    ("sum", lambda: self.gflat[:na], "m", "flat_gradient_actor"),
+                    ("sum_async", lambda: st["sums"], "m", "loss_sums"), ("max_async", lambda: st["maxes"], "m", "loss_maxes"),
+                    ("run", q_fwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"),
+                    ("run", s3, S), ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
+                    ("run", p_tail), ("wait", None, "m", "wait_async_loss_terms"), ("run", p_report),
+                    ("run", q_bwd1, S), ("sum", lambda: self.gflat[na:], S, "flat_gradient_critic"), ("sum", lambda: st["vl"], S, "loss_critic_sum"),
+                    ("run", q_tail, S),
+                    ("join", None, "m", "join_critic_lane"), ("run_host", finish_dp)]
+
+        # ---- the joined form of rounds 2-3 (GRL_DP_JOINED=1): the critic's lane is forked after the input preparation and after the
+        #      fused loss kernel and joined in front of both
         plan = [("run", m_prep), ("fork", None),
                 ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"), ("sum", lambda: st["adv"], S, "advantage_stats"),
                 ("run", a_fwd),
@@ -596,8 +701,9 @@ class PolicyUpdater:
             out[label] = {"per_step": len(recs) / max(1, n_steps), "mean_ms": sum(ms) / len(ms), "max_ms": max(ms), "bytes": recs[0][2]}
         return out
 
-    def _reduce(self, kind, t, label=None):
+    def _reduce(self, kind, t, label=None, lane="m"):
         import torch.distributed as dist
+        group = self.group_c if (lane == "s" and self.group_c is not None) else self.group
         if kind == "wait":
             with self._log_span(label):
                 for w in self._pending:
@@ -610,10 +716,10 @@ class PolicyUpdater:
         if kind in ("sum_async", "max_async"):
             op = dist.ReduceOp.SUM if kind == "sum_async" else dist.ReduceOp.MAX
             with self._log_span((label or kind) + " (issue only: asynchronous)", nbytes):
-                self._pending.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+                self._pending.append(dist.all_reduce(t, op=op, group=group, async_op=True))
             return
         with self._log_span(label or kind, nbytes):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=group)
 
     def _compile(self, batch):
         """Record the plan's segments into hipGraphs (adjacent segments without a reduction between them share one graph)."""
@@ -784,7 +890,7 @@ class PolicyUpdater:
         caller's stream (one rank with two lanes: a high-priority stream of the updater's, joined back into the caller's at the end), lane
         "s" the critic stream; "fork": the side lane waits for the main lane, "join": the reverse."""
         caller = torch.cuda.current_stream()
-        own = self._actor_stream() if (self._lanes and self.group is None and self.overlap_critic) else None
+        own = self._actor_stream() if (self._lanes and self.group is None and self.overlap_critic) else None   # (off by default)
         main = own or caller
         if own is not None:
             own.wait_stream(caller)
@@ -801,7 +907,7 @@ class PolicyUpdater:
             if lane == "s":
                 side = side or self._critic_stream()
                 with torch.cuda.stream(side):
-                    self._do(kind, item, label)
+                    self._do(kind, item, label, lane)
             elif own is not None:
                 with torch.cuda.stream(own):
                     self._do(kind, item, label)
@@ -810,13 +916,13 @@ class PolicyUpdater:
         if own is not None:
             caller.wait_stream(own)
 
-    def _do(self, kind, item, label=None):
+    def _do(self, kind, item, label=None, lane="m"):
         if kind in ("run", "run_host"):
             item()
         elif kind == "graph":
             item.replay()
         else:
-            self._reduce(kind, item() if item is not None else None, label)
+            self._reduce(kind, item() if item is not None else None, label, lane)
 
 
 def gae(reward, done, terminated, values, gamma=0.99, lmbda=0.95):
