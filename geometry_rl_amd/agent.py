@@ -547,8 +547,9 @@ class PolicyUpdater:
         #      gradient and its optimizer step -- on a communicator of its own (collectives of one communicator execute in issue order on
         #      one internal stream: a critic reduction that waits for a critic kernel would hold back the actor's gradient all-reduce
         #      issued behind it).  The actor's lane: statistics of the advantages (all-reduced: 16 bytes) | forward, fused loss kernel
-        #      (actor terms), backward, fold | all-reduce of the actor's slice | Adam, reported values: THREE graphs and two collectives on
-        #      its path (round 3: five graphs, two joins with the critic's lane, one collective).
+        #      (actor terms), backward, fold | all-reduce of the actor's slice, all-gather of the ranks' loss records (one collective
+        #      for sums and maxes) | Adam, reported values: THREE graphs and three collectives on its path (round 3: five graphs, two
+        #      joins with the critic's lane, one synchronous + two asynchronous collectives and a wait).
         #      (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
         if os.environ.get("GRL_DP_JOINED", "0") == "0":
             na, n_all = self.n_actor, self.flat.numel()
@@ -569,19 +570,24 @@ class PolicyUpdater:
                 loc, sigma = st["loc_g"], st["sigma_g"]
                 with torch.no_grad():
                     zw = st["zw"]
-                    sums, maxes, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], st["adv"], sums=zw[10:22],
-                                                               maxes=zw[22:23].view(torch.int32))
-                st.update(loc=loc.detach(), sigma=sigma.detach(), sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma)
+                    fold_, maxes, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], st["adv"], sums=zw[10:22],
+                                                                maxes=zw[22:23].view(torch.int32), defer_fold=True)
+                    # this rank's loss sums / maxes as ONE record; the ranks' records are all-gathered (one collective, not a SUM and a MAX)
+                    st["rec"] = torch.empty(14, device=self.flat.device, dtype=torch.float64)
+                    st["recs"] = torch.empty(world, 14, device=self.flat.device, dtype=torch.float64)
+                    hip.call("grl_trpl_fold_record", fold_.slots, fold_.batch, st["rec"])
+                st.update(loc=loc.detach(), sigma=sigma.detach(), sums=fold_.sums, maxes=fold_.maxes, dloc=dloc, dsigma=dsigma)
                 a_bwd()
                 fold()
 
-            def p_tail():
+            def p_tail():   # behind the two collectives of the lane: Adam on the reduced gradient, reported values of the gathered records
                 with torch.no_grad():
                     adam(0, na, 0)
-
-            def p_report():   # behind the wait for the (asynchronously reduced) loss sums
-                with torch.no_grad():
-                    st["lv_main"] = loss_values(m, st["sums"], st["maxes"])
+                    ent = m.entropy_coef if m.entropy_bonus else 0.0
+                    o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
+                    hip.call("grl_trpl_report_records", st["recs"], world, st["sums"], st["maxes"], float(ent), o14)
+                    a_loss, mt = report_dict(o14)
+                    st["lv_main"] = (a_loss, None, mt)
 
             def q_fwd1():
                 with torch.no_grad():
@@ -627,10 +633,10 @@ class PolicyUpdater:
                     ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"),
                     ("run", p_main),
                     ("sum", lambda: self.gflat[:na], "m", "flat_gradient_actor"),
-                    ("sum_async", lambda: st["sums"], "m", "loss_sums"), ("max_async", lambda: st["maxes"], "m", "loss_maxes"),
+                    ("gather", lambda: (st["recs"], st["rec"]), "m", "loss_records"),
                     ("run", q_fwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"),
                     ("run", s3, S), ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
-                    ("run", p_tail), ("wait", None, "m", "wait_async_loss_terms"), ("run", p_report),
+                    ("run", p_tail),
                     ("run", q_bwd1, S), ("sum", lambda: self.gflat[na:], S, "flat_gradient_critic"), ("sum", lambda: st["vl"], S, "loss_critic_sum"),
                     ("run", q_tail, S),
                     ("join", None, "m", "join_critic_lane"), ("run_host", finish_dp)]
@@ -711,6 +717,14 @@ class PolicyUpdater:
             self._pending = []
             return
         if t is None:
+            return
+        if kind == "gather":   # t = (out [world, n], in [n])
+            out_t, in_t = t
+            with self._log_span(label or kind, in_t.numel() * in_t.element_size()):
+                if dist.get_backend(group) == "nccl":
+                    dist.all_gather_into_tensor(out_t, in_t, group=group)
+                else:   # (gloo: the list form; rows of out_t are contiguous views)
+                    dist.all_gather(list(out_t.unbind(0)), in_t, group=group)
             return
         nbytes = t.numel() * t.element_size()
         if kind in ("sum_async", "max_async"):
@@ -819,9 +833,13 @@ class PolicyUpdater:
         """Data parallel: the first training forward of a fresh actor re-initialises the conv kernels from rank-local data
         (conv.py:104-105).  Let it happen once, on every rank, BEFORE the first update, then adopt rank 0's result -- otherwise each
         replica would rescale its own weights (views of ``flat``) and the replicas would diverge for good."""
+        # (the latch FIRST: ``hasattr(gnn, "calibrated")`` evaluates the property, which reads the per-conv flags from the device -- until
+        #  round 4 every data-parallel step paid a device synchronisation here and the host never ran ahead of the device)
+        if self.group is None or getattr(self, "_calib_synced", False):
+            return None
         actor = self.loss_module.actor_network
         gnn = getattr(actor, "gnn", None)
-        if self.group is None or gnn is None or not hasattr(gnn, "calibrated") or getattr(self, "_calib_synced", False):
+        if gnn is None or not hasattr(gnn, "calibrated"):
             return None
         self._calib_synced = True
         return not gnn.calibrated   # True: this rank's actor still has to calibrate -> the caller syncs afterwards

@@ -760,6 +760,35 @@ int grl_trpl_target_terms(const double* cfg9, int action_dim, const float* mean,
                      dsigma, nullptr, nullptr, nullptr, nullptr, sums, maxes, slots, tgt_mean, tgt_S, batch, stream);
 }
 
+// Data parallel: a rank's slots -> ONE 14-double record (12 sums, 2 maxes as doubles); the ranks' records are all-gathered (one
+// collective for sums and maxes, where an all-reduce needs two: SUM and MAX) and grl_trpl_report_records sums / maximises over them and
+// evaluates the reported values -- the same code as over the workgroups' slots of one rank.
+__global__ __launch_bounds__(64) void trpl_fold_record_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ rec) {
+  const int i = threadIdx.x;
+  if (i < 12) {
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
+    rec[i] = s;
+  } else if (i < 14) {
+    double m = 0.0;
+    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
+    rec[i] = m;
+  }
+}
+int grl_trpl_fold_record(const double* slots, int batch, double* rec14, hipStream_t stream) {
+  if (!slots || !rec14 || batch < 1) return -2;
+  hipLaunchKernelGGL(trpl_fold_record_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, rec14);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+int grl_trpl_report_records(const double* records, int n_records, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
+                            hipStream_t stream) {
+  if (!records || !sums || !maxes || !out14 || n_records < 1) return -2;
+  hipLaunchKernelGGL(trpl_report_kernel, dim3(1), dim3(64), 0, stream, records, n_records, sums, maxes, entropy_coef, out14);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
 // grl_trpl_fold + grl_trpl_loss_values in one launch (one rank: nothing to all-reduce in between)
 int grl_trpl_report(const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
   if (!slots || !sums || !maxes || !out14 || batch < 1) return -2;

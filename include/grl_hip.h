@@ -242,6 +242,11 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  * then called with value = NULL).  out2 fp64[2] = {sum over the frames of critic_coef * loss, that sum * inv_batch}; one workgroup */
 int grl_value_loss(const float* value, const float* old_value, const float* value_target, double clip_value, double critic_coef,
                    double inv_batch, float* dvalue, double* out2, float* mean_out /* float[1] or NULL */, int batch, hipStream_t stream);
+/* (ABI 203) data parallel: a rank's slots -> ONE record of 14 doubles (12 sums, 2 maxes); all-gather the records (one collective instead of
+ * a SUM and a MAX all-reduce), then grl_trpl_report_records(records [n][14]) sums / maximises over the ranks and evaluates the values */
+int grl_trpl_fold_record(const double* slots, int batch, double* rec14, hipStream_t stream);
+int grl_trpl_report_records(const double* records, int n_records, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
+                            hipStream_t stream);
 /* (ABI 203) grl_trpl_fold + grl_trpl_loss_values in one launch (one rank: nothing is all-reduced in between) */
 int grl_trpl_report(const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 /* stats fp64[2] = (sum, sum of squares) of the advantages, WRITTEN (ABI 203; <= 202 added to a zeroed slot): one workgroup, fixed order */

@@ -41,12 +41,12 @@ def test_two_rank_bench_line():
     assert dp["rank_spread_max_over_min"] >= 1.0
     names = set(dp["collectives"])
     for want in ("critic_ln1_fwd_stats", "critic_ln2_fwd_stats", "critic_ln2_bwd_stats", "critic_ln1_bwd_stats", "advantage_stats",
-                 "flat_gradient_actor", "flat_gradient_critic", "loss_critic_sum", "join_critic_lane"):
+                 "flat_gradient_actor", "flat_gradient_critic", "loss_critic_sum", "loss_records", "join_critic_lane"):
         assert want in names, (want, names)
         assert dp["collectives"][want]["per_step"] == 1.0 and dp["collectives"][want]["mean_ms"] >= 0.0
-    # actor's lane: advantage statistics, loss sums + maxes (asynchronous), its slice of the flat gradient; critic's lane (own communicator):
-    # 4 LayerNorm statistics, its slice of the gradient, its loss sum
-    assert dp["collectives"]["flat_gradient_actor"]["bytes"] > 500_000 and dp["collectives_per_step"] == 10.0, dp["collectives_per_step"]
+    # actor's lane: advantage statistics, its slice of the flat gradient, the all-gather of the loss records; critic's lane (own
+    # communicator): 4 LayerNorm statistics, its slice of the gradient, its loss sum
+    assert dp["collectives"]["flat_gradient_actor"]["bytes"] > 500_000 and dp["collectives_per_step"] == 9.0, dp["collectives_per_step"]
     assert two["advantage_pass_ms"] > 0 and "one all-reduce per LayerNorm stage" in two["advantage_pass"]
     one = _bench("--gpus", "1", "--minibatch", "512", "--steps", "20", "--warmup", "3", "--pool", "4", "--no-parity-gate", "--no-roofline")
     assert one["n_gpus"] == 1 and "hipGraph" in one["mode"] and one["mode"].startswith("graph")

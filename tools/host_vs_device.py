@@ -10,15 +10,24 @@ from geometry_rl_amd import agent, synthetic as syn
 from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
 
 dev = torch.device("cuda:0")
+group = None
+if "--dp" in sys.argv:   # the data-parallel program on a one-rank RCCL group (GRL_FORCE_DP_PLAN)
+    import socket, torch.distributed as dist
+    sys.argv.remove("--dp")
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), GRL_FORCE_DP_PLAN="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    group = dist.group.WORLD
 for mb in [int(a) for a in sys.argv[1:]] or [32, 512, 4096]:
     spec, cfg, make_obs, _ = B.workload("rigid_hepi")
     torch.manual_seed(0)
-    actor, critic, proj, loss = agent.build_agent(spec, cfg, device=dev)
+    actor, critic, proj, loss = agent.build_agent(spec, cfg, device=dev, group=group)
     A = spec.num_actuators * cfg.output_dim_vec * 3
     pool = []
     for i in range(8):
         b = dict(make_obs(mb, 100 + i, 0)); b.update(syn.make_ppo_fields(mb, A, seed=i)); pool.append({k: v.to(dev) for k, v in b.items()})
-    upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True, group=group)
     data = {k: torch.stack([f[k] for f in pool], dim=1) for k in pool[0]}
     buf = RolloutBuffer(data)
     drv = RolloutDriver(upd, spec, ppo_epochs=5, seed=0)
@@ -33,6 +42,9 @@ for mb in [int(a) for a in sys.argv[1:]] or [32, 512, 4096]:
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
+    if group is not None:
+        print(f"minibatch {mb:5d} (data-parallel program, one-rank RCCL group): step {1e3 * t_all / n:.3f} ms wall, {1e3 * t_host / n:.3f} ms host enqueue")
+        continue
     # the graph replay alone (no gather, no Python bookkeeping of step_from)
     g = [p[1] for p in upd._program if p[0] == "graph"]
     torch.cuda.synchronize()
