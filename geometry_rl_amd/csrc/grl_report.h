@@ -4,25 +4,51 @@
 #pragma once
 #include "grl_common.h"
 
-constexpr int TRPL_SLOT = 14;   // per-workgroup record of trpl_kernel: the 12 sums + the 2 maxes
+constexpr int TRPL_SLOT = 14;   // per-workgroup record of the fused loss kernel: the 12 sums + the 2 maxes
+constexpr int TRPL_FPB = 16;    // frames per workgroup of that kernel (trpl_lanes_kernel, head_ops.hip)
+inline int trpl_blocks(int batch) { return (batch + TRPL_FPB - 1) / TRPL_FPB; }
 
-// the first 64 threads of the workgroup take part (i = threadIdx.x < 64); sh / shm: LDS scratch [12] / [2]; the caller's __syncthreads
-// must be reachable by every thread of the workgroup, so the barrier sits in the caller-visible part below
-GRL_DEVINL void trpl_report_body(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums, unsigned int* __restrict__ maxes,
-                                 float entropy_coef, float* __restrict__ out, double* sh, unsigned int* shm) {
-  const int i = threadIdx.x;
-  if (i < 12) {
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
-    sums[i] = s;
-    sh[i] = s;
-  } else if (i < 14) {
-    double m = 0.0;
-    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
-    maxes[i - 12] = __float_as_uint((float)m);
-    shm[i - 12] = __float_as_uint((float)m);
+// Column sums (12) and maxes (2) of the slot records [n_blocks][14] by a whole workgroup: thread (part p = tid / 16, column c = tid % 16)
+// adds the records p, p + NP, ... (four independent running sums: the loads of a 256-record fold -- 4096 frames -- were one dependent
+// ~0.4 us round trip each when a single thread walked a column: +92 us on the step's tail), the NP partial results are combined in part
+// order.  A fixed order: bitwise reproducible.  Result in sh[0..13] (sums 0..11, maxes 12..13 as doubles), valid after the closing barrier.
+template <int NT>
+GRL_DEVINL void trpl_fold_columns(const double* __restrict__ slots, int n_blocks, double* sh /* [14] */, double* part /* [NT / 16][16] */) {
+  constexpr int NP = NT / 16;
+  const int c = threadIdx.x & 15, p = threadIdx.x >> 4;
+  if (c < TRPL_SLOT && (int)threadIdx.x < NT) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = p;
+    if (c < 12) {
+      for (; b + 3 * NP < n_blocks; b += 4 * NP) {
+        a0 += slots[(size_t)b * TRPL_SLOT + c]; a1 += slots[(size_t)(b + NP) * TRPL_SLOT + c];
+        a2 += slots[(size_t)(b + 2 * NP) * TRPL_SLOT + c]; a3 += slots[(size_t)(b + 3 * NP) * TRPL_SLOT + c];
+      }
+      for (; b < n_blocks; b += NP) a0 += slots[(size_t)b * TRPL_SLOT + c];
+      part[p * 16 + c] = (a0 + a1) + (a2 + a3);
+    } else {
+      for (; b < n_blocks; b += NP) a0 = fmax(a0, slots[(size_t)b * TRPL_SLOT + c]);
+      part[p * 16 + c] = a0;
+    }
   }
   __syncthreads();
+  if ((int)threadIdx.x < TRPL_SLOT) {
+    double r = part[threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < NP; ++q) r = threadIdx.x < 12 ? r + part[q * 16 + threadIdx.x] : fmax(r, part[q * 16 + threadIdx.x]);
+    sh[threadIdx.x] = r;
+  }
+  __syncthreads();
+}
+
+// fold + reported values; NT threads of the workgroup take part (all of the workgroup's threads must call: barriers inside)
+template <int NT>
+GRL_DEVINL void trpl_report_body(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums, unsigned int* __restrict__ maxes,
+                                 float entropy_coef, float* __restrict__ out, double* sh /* [14] */, double* part /* [NT / 16][16] */) {
+  trpl_fold_columns<NT>(slots, n_blocks, sh, part);
+  const int i = threadIdx.x;
+  if (i < 12) sums[i] = sh[i];
+  else if (i < 14) maxes[i - 12] = __float_as_uint((float)sh[i]);
   if (i == 0) {
     const double n = sh[10];
     const float tr = (float)(sh[1] / n), ent = -entropy_coef * (float)(sh[2] / n);
@@ -35,9 +61,9 @@ GRL_DEVINL void trpl_report_body(const double* __restrict__ slots, int n_blocks,
     const float mc = (float)(sh[6] / n), cc = (float)(sh[7] / n);
     out[5] = (float)(sh[11] / n);
     out[6] = mc;
-    out[7] = __uint_as_float(shm[0]);
+    out[7] = (float)sh[12];
     out[8] = cc;
-    out[9] = __uint_as_float(shm[1]);
+    out[9] = (float)sh[13];
     out[10] = (float)(sh[8] / n);
     out[11] = (float)(sh[9] / n);
     out[12] = actor - (tr + ent);

@@ -192,7 +192,6 @@ __global__ __launch_bounds__(64 * RO_WAVES) void readout_bwd_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------------ TRPL
-constexpr int AMAX = 12;
 // sums layout (fp64): 0 loss_objective 1 loss_trust_region 2 entropy(dist) 3 loss_critic 4 sum exp(lw) 5 sum exp(2 lw)
 //                     6 mean_constraint 7 cov_constraint 8 entropy(p) 9 entropy_diff 10 count 11 kl(p || proj_p)
 // (6, 7: the projection's own trust-region measure of (p, proj_p); equal to the KL parts for the KL projection)
@@ -203,19 +202,57 @@ struct TrplCfg {
   int adv_local;   // 1: the advantage statistics are those of THIS launch's batch, summed inside the kernel (one rank: no statistics launch)
 };
 
-GRL_DEVINL double kl_of_eta(double eta, const double* t, const double* o, int A) {
-  double kl = 0.0;
-  _Pragma("unroll") for (int i = 0; i < A; ++i) {
-    const double v = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]);
-    kl += v / o[i] - 1.0 - log(v) + log(o[i]);
-  }
-  return 0.5 * kl;
-}
-
+// ------------------------------------------------------------------------------------------------ TRPL, lane-parallel form (round 4)
 // PROJ: 0 = KL (kl_projection_layer.py + ITPAL), 1 = Frobenius (frob_projection_layer.py:10-88), 2 = Wasserstein, commutative,
-//       precision-scaled (w2_projection_layer.py:15-76, projection_utils.py:107-149); diagonal policy throughout
-template <int AT, int PROJ>
-__global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __restrict__ mean, const float* __restrict__ sigma,
+//       precision-scaled (w2_projection_layer.py:15-76, projection_utils.py:107-149); diagonal policy throughout.
+// Covariance projection (KL): eta >= 0 with KL_cov(eta) = cov_bound.  With rho_i = v_i/o_i = (eta+1)/(eta+c_i), c_i = o_i/t_i:
+//   KL = 1/2 sum(rho_i - 1 - log rho_i),  dKL/deta = -1/2 sum (1-c_i)^2 / ((eta+1)(eta+c_i)^2) < 0, KL convex in eta: Newton from eta = 0
+//   approaches the root monotonically from the left (never overshoots).  Phase 1 runs the iteration in fp32 (hardware log2 / reciprocal)
+//   until the step is below 1e-5 of eta; phase 2 polishes in fp64: ONE Newton step from either side of the root lands left of it (the
+//   tangent lies below the curve), from there the iteration is monotone and stops at double precision.
+// External target (boundary methods get_trust_region_loss / compute_metrics, base_projection_layer.py:292-384): tgt_mean != NULL skips the
+//   projection; (tgt_mean, tgt_S) stands for the DETACHED proj_p / q and only the regression term's direct gradient is produced.
+// Rounds 1-3 ran ONE FRAME PER THREAD (per-dimension arrays in registers, instances unrolled per action width): ~8 000 fp64 instructions
+// issued per wave whatever the batch -- 31 us on the step's chain at every size (its wave count, not its arithmetic, shrinks with the
+// batch; DESIGN.md finding 9).  Here a frame's A action dimensions sit on L = 4 / 8 / 16 adjacent
+// lanes (A <= 4 / 8 / 16); every per-dimension array of the form above is a scalar, every sum over the dimensions a butterfly over the L
+// lanes (xor 1, 2, .. : each level adds the same pair on both sides, so all L lanes end with the bitwise-identical sum and every
+// per-frame decision -- bound active, Newton exit -- is uniform across the group).  16 frames per workgroup: slots record
+// b = frame / 16.  Same mathematics, line by line (kl_of_eta(0) is written with one log: v / o - 1 - log v + log o = rho - 1 - log rho
+// for rho = v / o; sum log pS is taken once for the log-probability, the entropy and the KL); sums over the dimensions are tree sums
+// instead of left-to-right ones: the last bits of the fp64 intermediates move, nothing at the fp32 outputs' resolution.
+// sums over the L lanes of a frame on the DPP network (no LDS round trips: ~40 of them sit on the kernel's dependent chain): quad_perm
+// xor 1, xor 2, then row_half_mirror (lane j <-> 7 - j: the other quad of the 8) and row_mirror (j <-> 15 - j: the other half of the 16);
+// both sides of every exchange add the same two numbers, so all L lanes hold the bitwise-identical sum
+template <int CTRL>
+GRL_DEVINL float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+GRL_DEVINL double dpp_d(double v) {
+  const long long u = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+template <int L>
+GRL_DEVINL double gsum(double x) {
+  x += dpp_d<0xB1>(x);
+  x += dpp_d<0x4E>(x);
+  if (L >= 8) x += dpp_d<0x141>(x);
+  if (L >= 16) x += dpp_d<0x140>(x);
+  return x;
+}
+template <int L>
+GRL_DEVINL float gsumf(float x) {
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  if (L >= 8) x += dpp_f<0x141>(x);
+  if (L >= 16) x += dpp_f<0x140>(x);
+  return x;
+}
+template <int L, int PROJ>
+__global__ __launch_bounds__(TRPL_FPB * L) void trpl_lanes_kernel(TrplCfg cfg, const float* __restrict__ mean, const float* __restrict__ sigma,
                                                   const float* __restrict__ action, const float* __restrict__ old_mean,
                                                   const float* __restrict__ old_var, const float* __restrict__ old_logp,
                                                   const float* __restrict__ advantage, const float* __restrict__ value,
@@ -224,23 +261,22 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
                                                   float* __restrict__ proj_mean_out, float* __restrict__ proj_var_out,
                                                   const double* __restrict__ adv_stats, double* __restrict__ slots,
                                                   const float* __restrict__ tgt_mean, const float* __restrict__ tgt_S, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  // external target (boundary methods get_trust_region_loss / compute_metrics, base_projection_layer.py:292-384): the projection is
-  // skipped, (tgt_mean, tgt_S) stands for the DETACHED proj_p / q and only the regression term's direct gradient is produced
+  constexpr int NT = TRPL_FPB * L, NW = (NT + 63) / 64;
+  const int A = cfg.A;
+  const int frame = blockIdx.x * TRPL_FPB + (int)(threadIdx.x / L), i = threadIdx.x & (L - 1);
+  const bool fr = frame < B, act = fr && i < A;
+  const int b = fr ? frame : B - 1, ii = i < A ? i : A - 1;   // clamped: the padding lanes compute duplicates that every sum masks out
   const bool ext = tgt_mean != nullptr;
-  const int A = AT > 0 ? AT : cfg.A;   // compile-time action width: the per-dimension loops unroll, arrays stay in registers
-  double acc[11];
-  for (int i = 0; i < 11; ++i) acc[i] = 0.0;
-  float mmax = 0.f, cmax = 0.f;
-  // One rank: every workgroup sums the batch's advantages itself (trpl.py:248-252, 286-289) -- B floats, thread-strided partial sums, wave
-  // butterflies, the two waves in order: the SAME order in every workgroup and every run (bitwise reproducible), and one launch plus one
-  // cross-lane dependency fewer on the step's chain than the separate statistics kernel (which the data-parallel step keeps: its sums
-  // are all-reduced).
-  __shared__ double adv_sh[2][2];
+#define M(x) (act ? (x) : 0.0)
+  // One rank: every workgroup sums the batch's advantages itself (trpl.py:248-252, 286-289) -- B floats, thread-strided partial sums,
+  // wave butterflies, the waves in order: the SAME order in every workgroup and every run (bitwise reproducible), and one launch plus
+  // one cross-lane dependency fewer on the step's chain than the separate statistics kernel (which the data-parallel step keeps: its
+  // sums are all-reduced).
+  __shared__ double adv_sh[NW][2];
   double adv_sum0 = 0.0, adv_sum1 = 0.0;
   if (cfg.adv_local) {
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-      const double a_ = advantage[i];
+    for (int k = threadIdx.x; k < B; k += NT) {
+      const double a_ = advantage[k];
       adv_sum0 += a_;
       adv_sum1 += a_ * a_;
     }
@@ -248,255 +284,196 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
     for (int off = 32; off > 0; off >>= 1) { adv_sum0 += __shfl_xor(adv_sum0, off, 64); adv_sum1 += __shfl_xor(adv_sum1, off, 64); }
     if ((threadIdx.x & 63) == 0) { adv_sh[threadIdx.x >> 6][0] = adv_sum0; adv_sh[threadIdx.x >> 6][1] = adv_sum1; }
     __syncthreads();
-    adv_sum0 = adv_sh[0][0] + adv_sh[1][0];
-    adv_sum1 = adv_sh[0][1] + adv_sh[1][1];
+    adv_sum0 = adv_sh[0][0];
+    adv_sum1 = adv_sh[0][1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { adv_sum0 += adv_sh[w][0]; adv_sum1 += adv_sh[w][1]; }
   }
-  if (b < B) {
-    double mu[AMAX], S[AMAX], mo[AMAX], So[AMAX], t[AMAX], o[AMAX], a[AMAX];
-    _Pragma("unroll") for (int i = 0; i < A; ++i) {
-      mu[i] = mean[(size_t)b * A + i];
-      const double sg = sigma[(size_t)b * A + i];
-      S[i] = sg * sg;                      // policy covariance diagonal == "std" seen by the projection (trpl.py:241)
-      mo[i] = old_mean[(size_t)b * A + i];
-      So[i] = old_var[(size_t)b * A + i];
-      a[i] = action[(size_t)b * A + i];
-      t[i] = S[i] * S[i];                  // kl_projection_layer.py:60-63: covariance(std) = std**2
-      o[i] = So[i] * So[i];
-    }
-    // ---- mean projection (base_projection_layer.py:71-100)
-    double mp = 0.0;
-    _Pragma("unroll") for (int i = 0; i < A; ++i) { const double d = (mu[i] - mo[i]) / So[i]; mp += d * d; }
-    if (PROJ == 0) mp *= 0.5;   // KL: 1/2 maha (projection_utils.py:34-67); Frobenius / W2: maha (mean_distance, :9-31)
-    const bool m_act = mp > cfg.mean_bound;
-    double omega = 0.0, D = 1.0, pm[AMAX];
-    if (m_act) { omega = sqrt(mp / cfg.mean_bound) - 1.0; D = 1.0 + omega + 1e-16; }
-    _Pragma("unroll") for (int i = 0; i < A; ++i) pm[i] = m_act ? (mu[i] + omega * mo[i]) / D : mu[i];
-    // ---- covariance projection: eta >= 0 with KL_cov(eta) = cov_bound.  With rho_i = v_i/o_i = (eta+1)/(eta+c_i), c_i = o_i/t_i:
-    //      KL = 1/2 sum(rho_i - 1 - log rho_i),  dKL/deta = -1/2 sum (1-c_i)^2 / ((eta+1)(eta+c_i)^2) < 0, KL convex in eta:
-    //      Newton from eta = 0 approaches the root monotonically from the left (never overshoots).
-    double eta = 0.0;
-    bool c_act;
-    double v[AMAX], pS[AMAX];
-    if (PROJ == 0) {
-      c_act = kl_of_eta(0.0, t, o, A) > cfg.cov_bound;
-      if (c_act) {
-        double cr[AMAX];
-        _Pragma("unroll") for (int i = 0; i < A; ++i) cr[i] = o[i] / t[i];
-        // Phase 1, fp32 (hardware log2 / reciprocal): the same Newton iteration, cheap, until the step is below 1e-5 of eta.
-        {
-          float crf[AMAX], e32 = 0.f;
-          _Pragma("unroll") for (int i = 0; i < A; ++i) crf[i] = (float)cr[i];
-          const float bound = (float)cfg.cov_bound;
-          for (int it = 0; it < 60; ++it) {
-            float f = 0.f, df = 0.f;
-            const float r1 = __builtin_amdgcn_rcpf(e32 + 1.f);
-            _Pragma("unroll") for (int i = 0; i < A; ++i) {
-              const float rden = __builtin_amdgcn_rcpf(e32 + crf[i]), rho = (e32 + 1.f) * rden, om = 1.f - crf[i];
-              f += rho - 1.f - 0.69314718056f * __builtin_amdgcn_logf(rho);
-              df += om * om * r1 * rden * rden;
-            }
-            f = 0.5f * f - bound;
-            df *= 0.5f;
-            if (!(f > 0.f) || !(df > 0.f)) break;
-            const float step = f / df;
-            e32 += step;
-            if (!(step > 1e-5f * e32)) break;
-          }
-          if (e32 == e32 && e32 >= 0.f && e32 < 3.0e38f) eta = (double)e32;   // otherwise phase 2 starts from 0 as before
+  const size_t k = (size_t)b * A + ii;
+  const double mu = mean[k], sg = sigma[k], mo = old_mean[k], So = old_var[k], ac = action[k];
+  const double S = sg * sg;                  // policy covariance diagonal == "std" seen by the projection (trpl.py:241)
+  const double t = S * S, o = So * So;       // kl_projection_layer.py:60-63: covariance(std) = std**2
+  // ---- mean projection (base_projection_layer.py:71-100)
+  double mp;
+  { const double d = (mu - mo) / So; mp = gsum<L>(M(d * d)); }
+  if (PROJ == 0) mp *= 0.5;
+  const bool m_act = mp > cfg.mean_bound;
+  double omega = 0.0, D = 1.0;
+  if (m_act) { omega = sqrt(mp / cfg.mean_bound) - 1.0; D = 1.0 + omega + 1e-16; }
+  double pm = m_act ? (mu + omega * mo) / D : mu;
+  // ---- covariance projection (derivation: the header above)
+  double eta = 0.0, v, pS;
+  bool c_act;
+  if (PROJ == 0) {
+    const double rho0 = t / o;
+    c_act = 0.5 * gsum<L>(M(rho0 - 1.0 - log(rho0))) > cfg.cov_bound;
+    if (c_act) {
+      const double cr = o / t;
+      {   // phase 1, fp32 (hardware log2 / reciprocal)
+        const float crf = (float)cr, bound = (float)cfg.cov_bound, om = 1.f - crf;
+        float e32 = 0.f;
+        for (int it = 0; it < 60; ++it) {
+          const float r1 = __builtin_amdgcn_rcpf(e32 + 1.f);
+          const float rden = __builtin_amdgcn_rcpf(e32 + crf), rho = (e32 + 1.f) * rden;
+          float f = gsumf<L>(act ? rho - 1.f - 0.69314718056f * __builtin_amdgcn_logf(rho) : 0.f);
+          float df = gsumf<L>(act ? om * om * r1 * rden * rden : 0.f);
+          f = 0.5f * f - bound;
+          df *= 0.5f;
+          if (!(f > 0.f) || !(df > 0.f)) break;
+          const float step = f / df;
+          e32 += step;
+          if (!(step > 1e-5f * e32)) break;
         }
-        // Phase 2, fp64 polish.  KL is convex and decreasing in eta, so ONE Newton step from either side of the root lands left
-        // of it (the tangent lies below the curve); from there the iteration is monotone as before and stops at double precision.
-        for (int it = 0; it < 100; ++it) {
-          double f = 0.0, df = 0.0;
-          _Pragma("unroll") for (int i = 0; i < A; ++i) {
-            const double den = eta + cr[i], rho = (eta + 1.0) / den, om = 1.0 - cr[i];
-            f += rho - 1.0 - log(rho);
-            df += om * om / ((eta + 1.0) * den * den);
-          }
-          f = 0.5 * f - cfg.cov_bound;
-          df *= 0.5;
-          if (df <= 0.0 || (it > 0 && f <= 0.0)) break;
-          const double step = f / df;
-          eta = fmax(eta + step, 0.0);
-          if (fabs(step) <= 1e-15 * eta) break;
-        }
+        if (e32 == e32 && e32 >= 0.f && e32 < 3.0e38f) eta = (double)e32;
       }
-      _Pragma("unroll") for (int i = 0; i < A; ++i) { v[i] = (eta + 1.0) / (eta / o[i] + 1.0 / t[i]); pS[i] = sqrt(v[i]); }
-    } else {
-      // closed forms: eta = sqrt(part / bound) - 1 where the bound is violated
-      double part = 0.0;
-      _Pragma("unroll") for (int i = 0; i < A; ++i) {
-        const double d = PROJ == 1 ? o[i] - t[i] : 1.0 - S[i] / So[i];   // |S_o^2 - S^2|_F^2  |  tr(I + S_o^-1 S^2 S_o^-1 - 2 S_o^-1 S)
-        part += d * d;
-      }
-      c_act = part > cfg.cov_bound;
-      if (c_act) eta = fabs(sqrt(part / cfg.cov_bound) - 1.0);
-      const double den = 1.0 + eta + 1e-16;
-      _Pragma("unroll") for (int i = 0; i < A; ++i) {
-        if (PROJ == 1) { v[i] = c_act ? (t[i] + eta * o[i]) / den : t[i]; pS[i] = c_act ? sqrt(v[i]) : S[i]; }   // chol of the mixed covariance
-        else { pS[i] = c_act ? (S[i] + eta * So[i]) / den : S[i]; v[i] = pS[i] * pS[i]; }
+      const double om = 1.0 - cr;
+      for (int it = 0; it < 100; ++it) {   // phase 2, fp64 polish
+        const double den = eta + cr, rho = (eta + 1.0) / den;
+        double f = gsum<L>(M(rho - 1.0 - log(rho)));
+        double df = gsum<L>(M(om * om / ((eta + 1.0) * den * den)));
+        f = 0.5 * f - cfg.cov_bound;
+        df *= 0.5;
+        if (df <= 0.0 || (it > 0 && f <= 0.0)) break;
+        const double step = f / df;
+        eta = fmax(eta + step, 0.0);
+        if (fabs(step) <= 1e-15 * eta) break;
       }
     }
-    if (ext) {
-      _Pragma("unroll") for (int i = 0; i < A; ++i) {
-        pm[i] = tgt_mean[(size_t)b * A + i];
-        pS[i] = tgt_S[(size_t)b * A + i];
-        v[i] = pS[i] * pS[i];
-      }
-    }
-    // ---- log-prob under the projected distribution (covariance = pS), importance weight, objective
-    const double LOG2PI = 1.8378770664093454836;
-    double q = 0.0, sl = 0.0;
-    _Pragma("unroll") for (int i = 0; i < A; ++i) { const double d = a[i] - pm[i]; q += d * d / pS[i]; sl += log(pS[i]); }
-    const double lw = -0.5 * (q + A * LOG2PI + sl) - (double)old_logp[b];
-    const double ratio = exp(lw);
-    // advantage normalisation (trpl.py:286-289): batch mean / unbiased std (clamped at 1e-6) from the device-side sums
-    double adv = (double)advantage[b];
-    if ((adv_stats || cfg.adv_local) && cfg.adv_count > 1.0) {
-      const double s0_ = cfg.adv_local ? adv_sum0 : adv_stats[0], s1_ = cfg.adv_local ? adv_sum1 : adv_stats[1];
-      const double am = s0_ / cfg.adv_count;
-      double var = (s1_ - cfg.adv_count * am * am) / (cfg.adv_count - 1.0);
-      double sd = var > 0.0 ? sqrt(var) : 0.0;
-      if (sd < 1e-6) sd = 1e-6;
-      adv = (adv - am) / sd;
-    }
-    acc[0] = -ratio * adv;
-    acc[4] = ratio;
-    acc[5] = ratio * ratio;
-    const double ent = 0.5 * (A * (1.0 + LOG2PI) + sl);
-    acc[2] = ent;
-    // ---- trust-region regression loss and metrics.  KL of (p, proj_p) is always reported; the constraint metrics are the
-    //      projection's own measure of (p, proj_p) (base_projection_layer.py:332-384), the loss is base.py:292-327 with that
-    //      measure (KL, W2: proj_p detached) or frob_projection_layer.py:73-88 (maha by the live S + squared distance, NOT detached)
-    double mk = 0.0, ck = 0.0, ldS = 0.0, ldP = 0.0, cd = 0.0, mS = 0.0, sq = 0.0;
-    _Pragma("unroll") for (int i = 0; i < A; ++i) {
-      const double d = (mu[i] - pm[i]) / pS[i];
-      mk += d * d;
-      const double rr = S[i] / pS[i];
-      ck += rr * rr;
-      ldS += log(S[i]);
-      ldP += log(pS[i]);
-      if (PROJ == 1) {
-        const double f = pS[i] * pS[i] - S[i] * S[i], dm = (mu[i] - pm[i]) / S[i], ds = S[i] - pS[i];
-        cd += f * f; mS += dm * dm; sq += ds * ds;
-      }
-      if (PROJ == 2) cd += (1.0 - rr) * (1.0 - rr);
-    }
-    const double md = mk;            // maha(mean, proj_mean, proj_S)
-    mk *= 0.5;
-    ck = 0.5 * (ck - A + 2.0 * ldP - 2.0 * ldS);
-    acc[10] = mk + ck;
-    if (PROJ == 0) { acc[1] = (mk + ck) * cfg.tr_coeff; acc[6] = mk; acc[7] = ck; }
-    if (PROJ == 1) { acc[1] = (mS + sq) * cfg.tr_coeff; acc[6] = md; acc[7] = cd; }
-    if (PROJ == 2) { acc[1] = (md + cd) * cfg.tr_coeff; acc[6] = md; acc[7] = cd; }
-    const double c_ent = 0.5 * A * 2.8378770664093454836;  // 0.5 k log(2 pi e)
-    acc[8] = c_ent + ldS;                                   // policy.entropy(p) with S as "std"
-    acc[9] = (c_ent + ldP) - (c_ent + ldS);
-    mmax = (float)acc[6];
-    cmax = (float)fmax(acc[7], 0.0);
-    // ---- gradients of actor_loss = objective + entropy bonus + trust region  (all already scaled by 1/B)
-    const double w_obj = -ratio * adv * cfg.inv_batch;
-    double g_pm[AMAX], g_pS[AMAX];
-    _Pragma("unroll") for (int i = 0; i < A; ++i) {
-      const double d = a[i] - pm[i];
-      g_pm[i] = w_obj * d / pS[i];
-      g_pS[i] = w_obj * 0.5 * (d * d / (pS[i] * pS[i]) - 1.0 / pS[i]) - cfg.ent_coef * cfg.inv_batch * 0.5 / pS[i];
-    }
-    const double ctr = cfg.tr_coeff * cfg.inv_batch;
-    if (ext) {   // detached target: nothing flows through the projection
-      _Pragma("unroll") for (int i = 0; i < A; ++i) { g_pm[i] = 0.0; g_pS[i] = 0.0; }
-    } else if (PROJ == 1) {   // the Frobenius regression loss also reaches the parameters THROUGH the projection
-      _Pragma("unroll") for (int i = 0; i < A; ++i) {
-        g_pm[i] -= ctr * 2.0 * (mu[i] - pm[i]) / (S[i] * S[i]);
-        g_pS[i] -= ctr * 2.0 * (S[i] - pS[i]);
-      }
-    }
-    double gmu[AMAX], gS[AMAX];
-    if (m_act && !ext) {
-      double dot = 0.0;
-      _Pragma("unroll") for (int i = 0; i < A; ++i) dot += g_pm[i] * (mo[i] - pm[i]) / D;
-      const double k = dot / (2.0 * (omega + 1.0) * cfg.mean_bound) * (PROJ == 0 ? 1.0 : 2.0);   // d(mean part)/d maha = 1/2 | 1
-      _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i] / D + k * (mu[i] - mo[i]) / (So[i] * So[i]);
-    } else {
-      _Pragma("unroll") for (int i = 0; i < A; ++i) gmu[i] = g_pm[i];
-    }
-    if (ext) {
-      _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = 0.0;
-    } else if (PROJ == 0) {
-      double gv[AMAX];
-      _Pragma("unroll") for (int i = 0; i < A; ++i) gv[i] = g_pS[i] / (2.0 * pS[i]);
-      if (c_act) {
-        double dvt[AMAX], dve[AMAX], gk[AMAX], denom = 0.0, num = 0.0;
-        _Pragma("unroll") for (int i = 0; i < A; ++i) {
-          dvt[i] = v[i] * v[i] / (t[i] * t[i] * (eta + 1.0));
-          dve[i] = -v[i] * v[i] * (1.0 / o[i] - 1.0 / t[i]) / ((eta + 1.0) * (eta + 1.0));
-          gk[i] = 0.5 * (1.0 / o[i] - 1.0 / v[i]);
-          denom += gk[i] * dve[i];
-          num += gv[i] * dve[i];
-        }
-        _Pragma("unroll") for (int i = 0; i < A; ++i) {
-          const double gt = gv[i] * dvt[i] - num * gk[i] * dvt[i] / denom;
-          gS[i] = gt * 2.0 * S[i];
-        }
-      } else {
-        _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = gv[i] * 2.0 * S[i];
-      }
-    } else if (c_act) {
-      // proj = (x + eta y) / (1 + eta) with eta = sqrt(part / bound) - 1: d proj_i / d S_j = delta_ij x'_j / den + (y_i - proj_i) / den * d eta / d S_j
-      const double den = 1.0 + eta + 1e-16, deta = 1.0 / (2.0 * (eta + 1.0) * cfg.cov_bound);
-      double st_ = 0.0;
-      _Pragma("unroll") for (int i = 0; i < A; ++i)
-        st_ += PROJ == 1 ? g_pS[i] / (2.0 * pS[i]) * (o[i] - v[i]) / den : g_pS[i] * (So[i] - pS[i]) / den;
-      _Pragma("unroll") for (int i = 0; i < A; ++i) {
-        if (PROJ == 1) gS[i] = g_pS[i] / (2.0 * pS[i]) * 2.0 * S[i] / den + st_ * deta * (-4.0 * (o[i] - t[i]) * S[i]);
-        else gS[i] = g_pS[i] / den + st_ * deta * (-2.0 * (1.0 - S[i] / So[i]) / So[i]);
-      }
-    } else {
-      _Pragma("unroll") for (int i = 0; i < A; ++i) gS[i] = g_pS[i];
-    }
-    _Pragma("unroll") for (int i = 0; i < A; ++i) {
-      if (PROJ == 0) {
-        gmu[i] += ctr * (mu[i] - pm[i]) / (pS[i] * pS[i]);
-        gS[i] += ctr * (S[i] / (pS[i] * pS[i]) - 1.0 / S[i]);
-      } else if (PROJ == 1) {
-        const double dm = mu[i] - pm[i];
-        gmu[i] += ctr * 2.0 * dm / (S[i] * S[i]);
-        gS[i] += ctr * (-2.0 * dm * dm / (S[i] * S[i] * S[i]) + 2.0 * (S[i] - pS[i]));
-      } else {
-        gmu[i] += ctr * 2.0 * (mu[i] - pm[i]) / (pS[i] * pS[i]);
-        gS[i] += ctr * (-2.0 * (1.0 - S[i] / pS[i]) / pS[i]);
-      }
-      dmean[(size_t)b * A + i] = (float)gmu[i];
-      dsigma[(size_t)b * A + i] = (float)(gS[i] * 2.0 * (double)sigma[(size_t)b * A + i]);
-      if (proj_mean_out) { proj_mean_out[(size_t)b * A + i] = (float)pm[i]; proj_var_out[(size_t)b * A + i] = (float)pS[i]; }
-    }
-    // ---- clipped value loss (trpl.py:213-228, objectives/utils.py:5-28), l2
-    if (value) {
-      const double V = value[b], Vo = old_value[b], R = value_target[b];
-      const double l1 = (V - R) * (V - R);
-      double l = l1, g = 2.0 * (V - R);
-      if (cfg.clip_value > 0.0) {
-        const double dlt = V - Vo;
-        const bool inside = dlt >= -cfg.clip_value && dlt <= cfg.clip_value;
-        const double Vc = Vo + fmin(fmax(dlt, -cfg.clip_value), cfg.clip_value);
-        const double l2 = (Vc - R) * (Vc - R);
-        if (l2 > l1) { l = l2; g = inside ? 2.0 * (Vc - R) : 0.0; }
-      }
-      acc[3] = l * cfg.critic_coef;
-      dvalue[b] = (float)(g * cfg.critic_coef * cfg.inv_batch);
-    }
+    v = (eta + 1.0) / (eta / o + 1.0 / t);
+    pS = sqrt(v);
+  } else {
+    const double d = PROJ == 1 ? o - t : 1.0 - S / So;
+    const double part = gsum<L>(M(d * d));
+    c_act = part > cfg.cov_bound;
+    if (c_act) eta = fabs(sqrt(part / cfg.cov_bound) - 1.0);
+    const double den = 1.0 + eta + 1e-16;
+    if (PROJ == 1) { v = c_act ? (t + eta * o) / den : t; pS = c_act ? sqrt(v) : S; }
+    else { pS = c_act ? (S + eta * So) / den : S; v = pS * pS; }
   }
-  // block reduction (2 waves) -> this workgroup's own slot (plain stores; trpl_fold_kernel adds the slots up in a fixed order:
-  // no atomics, the reported values are bitwise reproducible)
-  __shared__ double red[2][11];
-  __shared__ float redm[2][2];
+  if (ext) {
+    pm = tgt_mean[k];
+    pS = tgt_S[k];
+    v = pS * pS;
+  }
+  // ---- log-prob under the projected distribution, importance weight, objective
+  const double LOG2PI = 1.8378770664093454836;
+  const double da = ac - pm;
+  const double q = gsum<L>(M(da * da / pS)), sl = gsum<L>(M(log(pS)));
+  const double lw = -0.5 * (q + A * LOG2PI + sl) - (double)old_logp[b];
+  const double ratio = exp(lw);
+  double adv = (double)advantage[b];
+  if ((adv_stats || cfg.adv_local) && cfg.adv_count > 1.0) {
+    const double s0_ = cfg.adv_local ? adv_sum0 : adv_stats[0], s1_ = cfg.adv_local ? adv_sum1 : adv_stats[1];
+    const double am = s0_ / cfg.adv_count;
+    double var = (s1_ - cfg.adv_count * am * am) / (cfg.adv_count - 1.0);
+    double sd = var > 0.0 ? sqrt(var) : 0.0;
+    if (sd < 1e-6) sd = 1e-6;
+    adv = (adv - am) / sd;
+  }
+  double acc[11];
+  for (int j = 0; j < 11; ++j) acc[j] = 0.0;
+  acc[0] = -ratio * adv;
+  acc[4] = ratio;
+  acc[5] = ratio * ratio;
+  acc[2] = 0.5 * (A * (1.0 + LOG2PI) + sl);
+  // ---- trust-region regression loss and metrics
+  const double dmk = (mu - pm) / pS, rr = S / pS;
+  double mk = gsum<L>(M(dmk * dmk)), ck = gsum<L>(M(rr * rr));
+  const double ldS = gsum<L>(M(log(S))), ldP = sl;
+  double cd = 0.0, mS = 0.0, sq = 0.0;
+  if (PROJ == 1) {
+    const double f = pS * pS - S * S, dm = (mu - pm) / S, ds = S - pS;
+    cd = gsum<L>(M(f * f)); mS = gsum<L>(M(dm * dm)); sq = gsum<L>(M(ds * ds));
+  }
+  if (PROJ == 2) cd = gsum<L>(M((1.0 - rr) * (1.0 - rr)));
+  const double md = mk;
+  mk *= 0.5;
+  ck = 0.5 * (ck - A + 2.0 * ldP - 2.0 * ldS);
+  acc[10] = mk + ck;
+  if (PROJ == 0) { acc[1] = (mk + ck) * cfg.tr_coeff; acc[6] = mk; acc[7] = ck; }
+  if (PROJ == 1) { acc[1] = (mS + sq) * cfg.tr_coeff; acc[6] = md; acc[7] = cd; }
+  if (PROJ == 2) { acc[1] = (md + cd) * cfg.tr_coeff; acc[6] = md; acc[7] = cd; }
+  const double c_ent = 0.5 * A * 2.8378770664093454836;
+  acc[8] = c_ent + ldS;
+  acc[9] = (c_ent + ldP) - (c_ent + ldS);
+  float mmax = (float)acc[6], cmax = (float)fmax(acc[7], 0.0);
+  // ---- gradients of actor_loss = objective + entropy bonus + trust region  (all already scaled by 1/B)
+  const double w_obj = -ratio * adv * cfg.inv_batch;
+  double g_pm = w_obj * da / pS;
+  double g_pS = w_obj * 0.5 * (da * da / (pS * pS) - 1.0 / pS) - cfg.ent_coef * cfg.inv_batch * 0.5 / pS;
+  const double ctr = cfg.tr_coeff * cfg.inv_batch;
+  if (ext) { g_pm = 0.0; g_pS = 0.0; }
+  else if (PROJ == 1) {
+    g_pm -= ctr * 2.0 * (mu - pm) / (S * S);
+    g_pS -= ctr * 2.0 * (S - pS);
+  }
+  double gmu, gS;
+  if (m_act && !ext) {
+    const double dot = gsum<L>(M(g_pm * (mo - pm) / D));
+    const double kk = dot / (2.0 * (omega + 1.0) * cfg.mean_bound) * (PROJ == 0 ? 1.0 : 2.0);
+    gmu = g_pm / D + kk * (mu - mo) / (So * So);
+  } else gmu = g_pm;
+  if (ext) gS = 0.0;
+  else if (PROJ == 0) {
+    const double gv = g_pS / (2.0 * pS);
+    if (c_act) {
+      const double dvt = v * v / (t * t * (eta + 1.0));
+      const double dve = -v * v * (1.0 / o - 1.0 / t) / ((eta + 1.0) * (eta + 1.0));
+      const double gk = 0.5 * (1.0 / o - 1.0 / v);
+      const double denom = gsum<L>(M(gk * dve)), num = gsum<L>(M(gv * dve));
+      gS = (gv * dvt - num * gk * dvt / denom) * 2.0 * S;
+    } else gS = gv * 2.0 * S;
+  } else if (c_act) {
+    const double den = 1.0 + eta + 1e-16, deta = 1.0 / (2.0 * (eta + 1.0) * cfg.cov_bound);
+    const double st_ = gsum<L>(M(PROJ == 1 ? g_pS / (2.0 * pS) * (o - v) / den : g_pS * (So - pS) / den));
+    if (PROJ == 1) gS = g_pS / (2.0 * pS) * 2.0 * S / den + st_ * deta * (-4.0 * (o - t) * S);
+    else gS = g_pS / den + st_ * deta * (-2.0 * (1.0 - S / So) / So);
+  } else gS = g_pS;
+  if (PROJ == 0) {
+    gmu += ctr * (mu - pm) / (pS * pS);
+    gS += ctr * (S / (pS * pS) - 1.0 / S);
+  } else if (PROJ == 1) {
+    const double dm = mu - pm;
+    gmu += ctr * 2.0 * dm / (S * S);
+    gS += ctr * (-2.0 * dm * dm / (S * S * S) + 2.0 * (S - pS));
+  } else {
+    gmu += ctr * 2.0 * (mu - pm) / (pS * pS);
+    gS += ctr * (-2.0 * (1.0 - S / pS) / pS);
+  }
+  if (act) {
+    dmean[k] = (float)gmu;
+    dsigma[k] = (float)(gS * 2.0 * sg);
+    if (proj_mean_out) { proj_mean_out[k] = (float)pm; proj_var_out[k] = (float)pS; }
+  }
+  // ---- clipped value loss (trpl.py:213-228, objectives/utils.py:5-28), l2: once per frame
+  if (value) {
+    const double V = value[b], Vo = old_value[b], R = value_target[b];
+    const double l1 = (V - R) * (V - R);
+    double l = l1, g = 2.0 * (V - R);
+    if (cfg.clip_value > 0.0) {
+      const double dlt = V - Vo;
+      const bool inside = dlt >= -cfg.clip_value && dlt <= cfg.clip_value;
+      const double Vc = Vo + fmin(fmax(dlt, -cfg.clip_value), cfg.clip_value);
+      const double l2 = (Vc - R) * (Vc - R);
+      if (l2 > l1) { l = l2; g = inside ? 2.0 * (Vc - R) : 0.0; }
+    }
+    acc[3] = l * cfg.critic_coef;
+    if (fr && i == 0) dvalue[b] = (float)(g * cfg.critic_coef * cfg.inv_batch);
+  }
+#undef M
+  // workgroup reduction over its frames: lane 0 of every frame's group contributes; fixed order (wave butterflies, the waves in order)
+  const bool lead = fr && i == 0;
+  __shared__ double red[NW][11];
+  __shared__ float redm[NW][2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i = 0; i < 11; ++i) {
-    double x = acc[i];
+  for (int j = 0; j < 11; ++j) {
+    double x = lead ? acc[j] : 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    if (lane == 0) red[wv][i] = x;
+    if (lane == 0) red[wv][j] = x;
   }
+  mmax = lead ? mmax : 0.f;
+  cmax = lead ? cmax : 0.f;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     mmax = fmaxf(mmax, __shfl_xor(mmax, off, 64));
@@ -505,29 +482,33 @@ __global__ __launch_bounds__(128) void trpl_kernel(TrplCfg cfg, const float* __r
   if (lane == 0) { redm[wv][0] = mmax; redm[wv][1] = cmax; }
   __syncthreads();
   double* slot = slots + (size_t)blockIdx.x * TRPL_SLOT;
-  if (threadIdx.x < 10) slot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];
-  if (threadIdx.x == 13) slot[11] = red[0][10] + red[1][10];
-  if (threadIdx.x == 10) {
-    const int n_here = min(B - (int)(blockIdx.x * blockDim.x), (int)blockDim.x);
+  if (threadIdx.x < 11) {
+    double x = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) x += red[w][threadIdx.x];
+    slot[threadIdx.x < 10 ? threadIdx.x : 11] = x;
+  }
+  if (threadIdx.x == 11) {
+    const int n_here = min(B - (int)(blockIdx.x * TRPL_FPB), TRPL_FPB);
     slot[10] = (double)(n_here > 0 ? n_here : 0);
   }
-  if (threadIdx.x == 11) slot[12] = (double)fmaxf(redm[0][0], redm[1][0]);
-  if (threadIdx.x == 12) slot[13] = (double)fmaxf(redm[0][1], redm[1][1]);
+  if (threadIdx.x == 12 || threadIdx.x == 13) {
+    float x = redm[0][threadIdx.x - 12];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) x = fmaxf(x, redm[w][threadIdx.x - 12]);
+    slot[threadIdx.x] = (double)x;
+  }
 }
 
-// slots [n_blocks][14] -> sums[12] (written, not accumulated) and maxes[2] (float bits), block order fixed
-__global__ __launch_bounds__(64) void trpl_fold_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
-                                                      unsigned int* __restrict__ maxes) {
+// slots [n_blocks][14] -> sums[12] (written, not accumulated) and maxes[2] (float bits); fixed order (grl_report.h trpl_fold_columns)
+constexpr int FOLD_NT = 256;
+__global__ __launch_bounds__(FOLD_NT) void trpl_fold_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
+                                                           unsigned int* __restrict__ maxes) {
+  __shared__ double sh[16], part[FOLD_NT];
+  trpl_fold_columns<FOLD_NT>(slots, n_blocks, sh, part);
   const int i = threadIdx.x;
-  if (i < 12) {
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
-    sums[i] = s;
-  } else if (i < 14) {
-    double m = 0.0;
-    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
-    maxes[i - 12] = __float_as_uint((float)m);
-  }
+  if (i < 12) sums[i] = sh[i];
+  else if (i < 14) maxes[i - 12] = __float_as_uint((float)sh[i]);
 }
 
 // sum and sum of squares of the advantages (fp64) WRITTEN to stats[0..1] (round 4: the slots need not be zeroed) -- ONE workgroup, fixed summation order (thread-strided partial sums,
@@ -615,11 +596,10 @@ __global__ void loss_values_kernel(const double* __restrict__ sums, const unsign
 }
 
 // slots -> sums / maxes (trpl_fold_kernel) AND the reported values (loss_values_kernel) in ONE launch (body: grl_report.h)
-__global__ __launch_bounds__(64) void trpl_report_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
-                                                        unsigned int* __restrict__ maxes, float entropy_coef, float* __restrict__ out) {
-  __shared__ double sh[12];
-  __shared__ unsigned int shm[2];
-  trpl_report_body(slots, n_blocks, sums, maxes, entropy_coef, out, sh, shm);
+__global__ __launch_bounds__(FOLD_NT) void trpl_report_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
+                                                             unsigned int* __restrict__ maxes, float entropy_coef, float* __restrict__ out) {
+  __shared__ double sh[16], part[FOLD_NT];
+  trpl_report_body<FOLD_NT>(slots, n_blocks, sums, maxes, entropy_coef, out, sh, part);
 }
 
 // ---- collector-side action sampling: torch.distributions.MultivariateNormal(loc, covariance_matrix = diag(sigma^2)).rsample()
@@ -683,7 +663,7 @@ int grl_adv_stats(const float* advantage, double* stats, int batch, hipStream_t 
 // kernel from this launch's batch -- adv_stats is then ignored; 0: adv_stats as below)}.  adv_stats: device fp64[2] = (sum, sum of squares) of the GLOBAL batch's advantages (from
 // grl_adv_stats, all-reduced when data parallel) or NULL for no normalisation.  sums: fp64[12], maxes: u32[2], zeroed by the caller.  value/old_value/value_target/dvalue may be
 // NULL together (actor-only call); proj_mean/proj_var may be NULL.
-int grl_trpl_slot_doubles(int batch) { return TRPL_SLOT * ((batch + 127) / 128 < 1 ? 1 : (batch + 127) / 128); }
+int grl_trpl_slot_doubles(int batch) { return TRPL_SLOT * (trpl_blocks(batch) < 1 ? 1 : trpl_blocks(batch)); }
 
 // value / old_value / value_target [batch], dvalue [batch], out2 fp64[2] (sum, sum / n_global), mean_out float[1] or NULL (the mean again, as
 // the float the loss dict reports): see value_loss_kernel
@@ -701,30 +681,28 @@ static int trpl_launch(const double* cfg9, int action_dim, const float* mean, co
                        const float* value, const float* old_value, const float* value_target, float* dmean, float* dsigma,
                        float* dvalue, float* proj_mean, float* proj_var, const double* adv_stats, double* sums,
                        unsigned int* maxes, double* slots, const float* tgt_mean, const float* tgt_S, int batch, hipStream_t stream) {
-  if (action_dim > AMAX || action_dim < 1 || batch < 1 || !slots) return -2;
+  if (action_dim > 16 || action_dim < 1 || batch < 1 || !slots) return -2;
   TrplCfg c{cfg9[0], cfg9[1], cfg9[2], cfg9[3], cfg9[4], cfg9[5], cfg9[6], cfg9[7], action_dim, (int)cfg9[9]};
   const int proj = (int)cfg9[8];
   if (proj < 0 || proj > 2) return -3;
-#define GRL_TRPL_LAUNCH(AT, PJ)                                                                                               \
-  hipLaunchKernelGGL((trpl_kernel<AT, PJ>), dim3((batch + 127) / 128), dim3(128), 0, stream, c, mean, sigma, action, old_mean,  \
-                     old_var, old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var,   \
+#define GRL_TRPL_LAUNCH(LL, PJ)                                                                                                       \
+  hipLaunchKernelGGL((trpl_lanes_kernel<LL, PJ>), dim3(trpl_blocks(batch)), dim3(TRPL_FPB * LL), 0, stream, c, mean, sigma, action,     \
+                     old_mean, old_var, old_logp, advantage, value, old_value, value_target, dmean, dsigma, dvalue, proj_mean, proj_var, \
                      adv_stats, slots, tgt_mean, tgt_S, batch)
-  if (proj == 0) {
-    switch (action_dim) {   // the action widths of the reference tasks (G * n_vec * 3) get unrolled instances
-      case 3: GRL_TRPL_LAUNCH(3, 0); break;
-      case 6: GRL_TRPL_LAUNCH(6, 0); break;
-      case 12: GRL_TRPL_LAUNCH(12, 0); break;
-      default: GRL_TRPL_LAUNCH(0, 0); break;
-    }
-  } else if (proj == 1) {
-    if (action_dim == 6) GRL_TRPL_LAUNCH(6, 1); else GRL_TRPL_LAUNCH(0, 1);
-  } else {
-    if (action_dim == 6) GRL_TRPL_LAUNCH(6, 2); else GRL_TRPL_LAUNCH(0, 2);
-  }
+#define GRL_TRPL_WIDTH(PJ)                                        \
+  do {                                                            \
+    if (action_dim <= 4) GRL_TRPL_LAUNCH(4, PJ);                  \
+    else if (action_dim <= 8) GRL_TRPL_LAUNCH(8, PJ);             \
+    else GRL_TRPL_LAUNCH(16, PJ);                                 \
+  } while (0)
+  if (proj == 0) GRL_TRPL_WIDTH(0);
+  else if (proj == 1) GRL_TRPL_WIDTH(1);
+  else GRL_TRPL_WIDTH(2);
+#undef GRL_TRPL_WIDTH
 #undef GRL_TRPL_LAUNCH
   GRL_CHECK_LAUNCH();
   if (sums) {   // sums == NULL: the caller folds the slots later (grl_trpl_fold, on a stream of its choice: the sums are reported values only)
-    hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes);
+    hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(FOLD_NT), 0, stream, slots, trpl_blocks(batch), sums, maxes);
     GRL_CHECK_LAUNCH();
   }
   return 0;
@@ -732,7 +710,7 @@ static int trpl_launch(const double* cfg9, int action_dim, const float* mean, co
 
 int grl_trpl_fold(const double* slots, int batch, double* sums, unsigned int* maxes, hipStream_t stream) {
   if (!slots || !sums || !maxes || batch < 1) return -2;
-  hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes);
+  hipLaunchKernelGGL(trpl_fold_kernel, dim3(1), dim3(FOLD_NT), 0, stream, slots, trpl_blocks(batch), sums, maxes);
   GRL_CHECK_LAUNCH();
   return 0;
 }
@@ -763,28 +741,21 @@ int grl_trpl_target_terms(const double* cfg9, int action_dim, const float* mean,
 // Data parallel: a rank's slots -> ONE 14-double record (12 sums, 2 maxes as doubles); the ranks' records are all-gathered (one
 // collective for sums and maxes, where an all-reduce needs two: SUM and MAX) and grl_trpl_report_records sums / maximises over them and
 // evaluates the reported values -- the same code as over the workgroups' slots of one rank.
-__global__ __launch_bounds__(64) void trpl_fold_record_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ rec) {
-  const int i = threadIdx.x;
-  if (i < 12) {
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += slots[(size_t)b * TRPL_SLOT + i];
-    rec[i] = s;
-  } else if (i < 14) {
-    double m = 0.0;
-    for (int b = 0; b < n_blocks; ++b) m = fmax(m, slots[(size_t)b * TRPL_SLOT + i]);
-    rec[i] = m;
-  }
+__global__ __launch_bounds__(FOLD_NT) void trpl_fold_record_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ rec) {
+  __shared__ double sh[16], part[FOLD_NT];
+  trpl_fold_columns<FOLD_NT>(slots, n_blocks, sh, part);
+  if (threadIdx.x < TRPL_SLOT) rec[threadIdx.x] = sh[threadIdx.x];
 }
 int grl_trpl_fold_record(const double* slots, int batch, double* rec14, hipStream_t stream) {
   if (!slots || !rec14 || batch < 1) return -2;
-  hipLaunchKernelGGL(trpl_fold_record_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, rec14);
+  hipLaunchKernelGGL(trpl_fold_record_kernel, dim3(1), dim3(FOLD_NT), 0, stream, slots, trpl_blocks(batch), rec14);
   GRL_CHECK_LAUNCH();
   return 0;
 }
 int grl_trpl_report_records(const double* records, int n_records, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
                             hipStream_t stream) {
   if (!records || !sums || !maxes || !out14 || n_records < 1) return -2;
-  hipLaunchKernelGGL(trpl_report_kernel, dim3(1), dim3(64), 0, stream, records, n_records, sums, maxes, entropy_coef, out14);
+  hipLaunchKernelGGL(trpl_report_kernel, dim3(1), dim3(FOLD_NT), 0, stream, records, n_records, sums, maxes, entropy_coef, out14);
   GRL_CHECK_LAUNCH();
   return 0;
 }
@@ -792,7 +763,7 @@ int grl_trpl_report_records(const double* records, int n_records, double* sums, 
 // grl_trpl_fold + grl_trpl_loss_values in one launch (one rank: nothing to all-reduce in between)
 int grl_trpl_report(const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
   if (!slots || !sums || !maxes || !out14 || batch < 1) return -2;
-  hipLaunchKernelGGL(trpl_report_kernel, dim3(1), dim3(64), 0, stream, slots, (batch + 127) / 128, sums, maxes, entropy_coef, out14);
+  hipLaunchKernelGGL(trpl_report_kernel, dim3(1), dim3(FOLD_NT), 0, stream, slots, trpl_blocks(batch), sums, maxes, entropy_coef, out14);
   GRL_CHECK_LAUNCH();
   return 0;
 }

@@ -778,9 +778,8 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(R
   float lr = 0.f, bc1 = 1.f, bc2_sqrt = 1.f;
   if (TAIL) {
     if (tail.report && (int)blockIdx.x == m.blk0[m.n_dst]) {   // the extra workgroup: reported values (its first 64 threads)
-      __shared__ double sh[12];
-      __shared__ unsigned int shm[2];
-      trpl_report_body(tail.slots, tail.n_slot_blocks, tail.sums, tail.maxes, tail.ent_coef, tail.out14, sh, shm);
+      __shared__ double sh[16], part[64 * RED_WAVES];
+      trpl_report_body<64 * RED_WAVES>(tail.slots, tail.n_slot_blocks, tail.sums, tail.maxes, tail.ent_coef, tail.out14, sh, part);
       return;
     }
     if (tail.adam) {
@@ -1062,7 +1061,7 @@ int grl_fold_adam_report(int n_seg, const float* const* partial, const int* n_ro
   if (slots) {
     if (!sums || !maxes || !out14 || batch < 1) return -2;
     t.report = 1;
-    t.slots = slots; t.n_slot_blocks = (batch + 127) / 128; t.sums = sums; t.maxes = maxes; t.ent_coef = entropy_coef; t.out14 = out14;
+    t.slots = slots; t.n_slot_blocks = trpl_blocks(batch); t.sums = sums; t.maxes = maxes; t.ent_coef = entropy_coef; t.out14 = out14;
   }
   const int blocks = m.blk0[m.n_dst] + (t.report ? 1 : 0);
   if (blocks <= 0) return 0;
