@@ -405,6 +405,13 @@ def main():
         n_prof = 6
         per_step = []
         upd.use_graph = False   # per-kernel HIP events need the launches themselves, not a graph replay (same kernels, same stream)
+        # ... and ONE lane: with the critic's lane beside them (as in the timed region) the events of an MFMA launch also time whatever critic
+        # kernels happen to share the device with it -- eagerly issued, those land somewhere else than in the replayed step, and the
+        # figure moved 0.229-0.249 from box to box.  The roofline fraction is the kernel's own: the profiled steps run the one-stream plan
+        # (the same kernels in the same order; `replayed_launches` below are the launches of the timed program, lanes and all).
+        lanes_one_rank = world == 1 and not args.dp_plan
+        if lanes_one_rank:
+            upd.overlap_critic = False
         for i in range(n_prof):
             hip.KERNEL_TIMES = {}
             hip.KERNEL_ROWS.clear()
@@ -418,6 +425,8 @@ def main():
             rec.update(inner)
             per_step.append(rec)
         hip.KERNEL_TIMES = None
+        if lanes_one_rank:
+            upd.overlap_critic = True
         per_step = per_step[1:]
         n_prof = len(per_step)
         med = lambda xs: sorted(xs)[len(xs) // 2]
@@ -535,9 +544,10 @@ def main():
         roof = {**head, "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_src, "avg_launch_ms": d["avg_launch_ms"],
                 "launches_per_step": d["launches_per_step"], "gflop_per_launch": d["gflop_per_launch"],
-                "avg_launch_note": "HIP events on the launch stream around the eagerly issued launches of the profiled steps behind the timed region; "
-                                   "the replayed (hipGraph) launches of the timed region run a few % faster (`replayed_launches`; rocprofv3 "
-                                   "--kernel-trace of this command, profiles/), so achieved / frac are on the conservative side",
+                "avg_launch_note": "HIP events on the launch stream around the eagerly issued launches of the profiled steps behind the timed region, "
+                                   "run on ONE stream (no critic kernels beside the timed launch: the kernel's own duration); `replayed_launches` = "
+                                   "the same launches inside the replayed two-lane step (wall-clock stamp kernels in the graph); rocprofv3 "
+                                   "--kernel-trace of this command (profiles/) averages over both kinds",
                 "peak_note": "peak = the pipe the kernel runs on: every f32 product is three dense bf16 MFMAs (split-bf16, f32 "
                              f"accumulate), 2500 / 3 = {PEAK_BF16X3:.0f} TFLOP/s of f32-equivalent products (MI355X_MICROARCH.md: ~2.5 PF "
                              "dense bf16); achieved = algorithmic f32 FLOP per launch / HIP-event launch time",
