@@ -324,6 +324,7 @@ def main():
     def sampler():   # sampling without replacement, reshuffled every epoch
         while True:
             idx = drv.epoch_indices(B, T_roll, dev)
+            drv.publish_advantage_stats(buf, list(idx))   # N > 1: the epoch's advantage statistics by ONE all-reduce (rollout.py)
             for j in range(T_roll):
                 yield idx[j]
     mb = sampler()
@@ -373,8 +374,10 @@ def main():
                    "collectives_per_step": sum(v["per_step"] for k, v in coll.items() if not k.startswith(("join", "wait"))),
                    "collectives": coll,
                    "main_lane_waits_ms": {k: v["mean_ms"] for k, v in coll.items() if k.startswith(("join", "wait"))},
-                   "note": "rank 0's lanes; mean / max over 5 logged steps behind the timed region; 'flat_gradient' is the one collective the "
-                           "main lane waits for, the critic's four LayerNorm-statistic reductions and the advantage statistics run on the side lane"}
+                   "note": "rank 0's lanes; mean / max over 5 logged steps behind the timed region; the actor's lane waits for "
+                           "'flat_gradient_actor' and 'loss_records', the critic's lane (own communicator) for its four LayerNorm-statistic "
+                           "reductions, its gradient slice and its loss sum; the advantage statistics of all minibatches of an epoch are "
+                           "reduced once per epoch ('advantage_stats_epoch', outside the update)"}
     ms = 1e3 * dt / args.steps
     n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
     upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else

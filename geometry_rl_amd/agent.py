@@ -405,9 +405,9 @@ class PolicyUpdater:
         #      backward.  The main lane waits for ONE collective per step: the gradient all-reduce.  Tensors that cross lanes stay
         #      referenced in ``st`` for the whole step, so neither allocator pool can hand their memory out while the other lane
         #      still uses it.
-        def m_prep():
+        def m_prep(zero=None):
             if not ow:
-                self.gflat.zero_()
+                (self.gflat if zero is None else zero).zero_()
             b = dict(batch)
             if "var" not in b:
                 b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
@@ -553,16 +553,24 @@ class PolicyUpdater:
         #      (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
         if os.environ.get("GRL_DP_JOINED", "0") == "0":
             na, n_all = self.n_actor, self.flat.numel()
+            # ``adv_stats`` in the batch ([B, 2] fp64, every row = the GLOBAL (sum, sum of squares) of this minibatch's advantages:
+            # rollout.RolloutDriver.publish_advantage_stats, one all-reduce per EPOCH): the statistics kernel, its all-reduce and the graph
+            # boundary behind it leave the actor's lane -- two graphs and two collectives on its path.
+            published = m.normalize_advantage and "adv_stats" in batch
 
-            def p_stats():
-                m_prep()
+            def p_stats():   # (each lane zeroes its own slice of the flat gradient when the folds accumulate)
+                m_prep(self.gflat[:na])
                 st["adv"] = None
-                if m.normalize_advantage and st["obs"][0].shape[0] * world > 1:
+                if published:
+                    st["adv"] = batch["adv_stats"][0]
+                elif m.normalize_advantage and st["obs"][0].shape[0] * world > 1:
                     with torch.no_grad():
                         st["adv"] = st["zw"][8:10]
                         adv_stats_local(m, st["b"], st["adv"])
 
             def p_main():
+                if published:
+                    p_stats()
                 st["step_bumped"] = True
                 actor.hyper_data.bump_next = self.step_dev
                 a_fwd()
@@ -591,15 +599,17 @@ class PolicyUpdater:
 
             def q_fwd1():
                 with torch.no_grad():
+                    if not ow:
+                        self.gflat[na:].zero_()
                     vf.train(True)
-                    _, x = vf.hyper_data.build_data(*st["cobs"], train=True, bump=self.step_dev_c)
+                    _, x = vf.hyper_data.build_data(*[batch[k] for k in m.critic_in_features], train=True, bump=self.step_dev_c)
                     st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
                     st["pipe"].fwd1()
 
             def q_fwd3():
                 with torch.no_grad():
                     st["value"] = st["pipe"].fwd3()
-                    dvalue, _mean, out2 = value_loss(m, st["value"], st["b"])
+                    dvalue, _mean, out2 = value_loss(m, st["value"], batch)
                     st["vl"] = out2
                     st["pipe"].bwd3(dvalue)
 
@@ -627,8 +637,8 @@ class PolicyUpdater:
 
             # (host order = enqueue order: the critic's segments are interleaved so that its lane is fed early; each lane's own order is what
             #  the device sees.  p_stats comes first: it also prepares the step's inputs for both lanes.)
-            return [("fork", None),
-                    ("run", p_stats), ("sum", lambda: st["adv"], "m", "advantage_stats"),
+            head_ = [] if published else [("run", p_stats), ("sum", lambda: st["adv"], "m", "advantage_stats")]
+            return [("fork", None), *head_,
                     ("run", q_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"),
                     ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"),
                     ("run", p_main),
@@ -811,6 +821,8 @@ class PolicyUpdater:
         import ctypes
         keys = list(dict.fromkeys(list(self.loss_module.in_features) + list(self.loss_module.critic_in_features))) + ["action", "loc", "var" if "var" in buf.data else "covariance_matrix",
                                                      "sample_log_prob", "state_value", "advantage", "value_target"]
+        if "adv_stats" in buf.data and self.group is not None:   # the epoch's published advantage statistics (rollout.RolloutDriver)
+            keys.append("adv_stats")
         if not self.use_graph or self._program is None or int(idx.numel()) != self._static[keys[0]].shape[0]:
             return self.step(buf.rows(idx, keys))
         jobs = []

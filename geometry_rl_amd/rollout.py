@@ -114,10 +114,30 @@ class RolloutDriver:
         idx = self.epoch_indices(N, T, device)                    # [T, N]
         return [idx[j:j + k].reshape(-1) for j in range(0, T - k + 1, k)]   # k columns, column after column
 
+    def publish_advantage_stats(self, buf: RolloutBuffer, idxs) -> None:
+        """Data parallel: the batch normalisation of the advantages (trpl.py:248-252) needs the (sum, sum of squares) over ALL ranks'
+        shares of a minibatch.  The minibatches of an epoch are known when it starts, so their statistics are reduced by ONE all-reduce
+        per epoch ([n_minibatches, 2] fp64) instead of one per update, and written next to the advantages as a per-frame column
+        ``adv_stats`` (every frame carries its minibatch's global sums): the update's row gather brings them along and the fused loss
+        kernel reads row 0 -- no statistics kernel, no collective and no graph boundary for them inside the update
+        (``PolicyUpdater._plan``).  Rebuilt at every epoch (the sampler reshuffles)."""
+        upd = self.updater
+        if upd.group is None or not upd.loss_module.normalize_advantage:
+            return
+        idx = torch.stack([i.reshape(-1) for i in idxs])                           # [n_mb, frames per rank]
+        a = buf.flat("advantage").reshape(-1).double()[idx]
+        s = torch.stack([a.sum(1), (a * a).sum(1)], dim=1).contiguous()
+        upd._reduce("sum", s, "advantage_stats_epoch")
+        if "adv_stats" not in buf.data:
+            buf.data["adv_stats"] = torch.zeros(buf.N, buf.T, 2, device=s.device, dtype=torch.float64)
+        buf.flat("adv_stats")[idx.reshape(-1)] = s.repeat_interleave(idx.shape[1], dim=0)
+
     def minibatches(self, buf: RolloutBuffer) -> Iterator[torch.Tensor]:
         dev = next(iter(buf.data.values())).device
         for _ in range(self.ppo_epochs):
-            for idx in self.epoch_minibatches(buf.N, buf.T, dev):
+            idxs = self.epoch_minibatches(buf.N, buf.T, dev)
+            self.publish_advantage_stats(buf, idxs)
+            for idx in idxs:
                 yield idx
 
     def run(self, buf: RolloutBuffer, next_last: Optional[Dict[str, torch.Tensor]] = None):

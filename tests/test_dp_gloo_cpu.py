@@ -85,3 +85,45 @@ def test_sharded_minibatch_reproduces_full_batch_gradient():
     assert len(ret) == world
     for r, w in ret.items():
         assert w < 1e-9, (r, w)
+
+
+def _stats_worker(rank, world, port, ret):
+    """rollout.RolloutDriver.publish_advantage_stats: one all-reduce per EPOCH gives every frame the global (sum, sum of squares) of
+    the advantages of the minibatch it belongs to (minibatch j of the job = the ranks' minibatches j together)."""
+    from types import SimpleNamespace
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
+    N, T = 3, 4
+    g = torch.Generator().manual_seed(10 + rank)
+    buf = RolloutBuffer({"advantage": torch.randn(N, T, 1, generator=g)})
+    calls = []
+
+    def reduce_(kind, t, label=None, lane="m"):
+        calls.append(label)
+        dist.all_reduce(t)
+    upd = SimpleNamespace(group=dist.group.WORLD, loss_module=SimpleNamespace(normalize_advantage=True), _reduce=reduce_)
+    drv = RolloutDriver(updater=upd, spec=None, seed=5 + rank)    # every rank shuffles its own environments
+    ok = True
+    for epoch in range(2):
+        idxs = drv.epoch_minibatches(N, T, torch.device("cpu"))
+        drv.publish_advantage_stats(buf, idxs)
+        for idx in idxs:
+            mine = buf.flat("advantage").reshape(-1).double()[idx]
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            a = torch.cat(both)
+            want = torch.stack([a.sum(), (a * a).sum()])
+            got = buf.flat("adv_stats")[idx]
+            ok = ok and got.dtype == torch.float64 and torch.allclose(got, want.expand_as(got), rtol=1e-13, atol=1e-13)
+    ret[rank] = (ok, calls)
+    dist.destroy_process_group()
+
+
+def test_epoch_advantage_statistics_two_ranks():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_stats_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, calls = ret[r]
+        assert ok and calls == ["advantage_stats_epoch"] * 2, (ok, calls)   # ONE collective per epoch

@@ -32,7 +32,7 @@ def _setup(B, group):
     return spec, cfg, actor, critic, loss, {k: v.to(dev) for k, v in batch.items()}
 
 
-def _worker(rank, world, port, B, ret, use_graph=False, n_steps=1):
+def _worker(rank, world, port, B, ret, use_graph=False, n_steps=1, published=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from geometry_rl_amd import agent
@@ -41,9 +41,15 @@ def _worker(rank, world, port, B, ret, use_graph=False, n_steps=1):
         actor.forward_diag(*[batch[k] for k in spec.in_features], train=True)
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = {k: v[lo:hi].contiguous() for k, v in batch.items()}
+    if published:   # the minibatch's GLOBAL advantage sums as a per-frame column (rollout.RolloutDriver.publish_advantage_stats)
+        a = batch["advantage"].reshape(-1).double()
+        shard["adv_stats"] = torch.stack([a.sum(), (a * a).sum()]).expand(hi - lo, 2).contiguous()
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, group=dist.group.WORLD, use_graph=use_graph)
-    for _ in range(n_steps):
+    for i in range(n_steps):
+        if i == n_steps - 1:
+            upd.collective_log = {}
         out = upd.step(shard)
+    ret[f"collectives{rank}"] = sorted(upd.collective_summary(1))
     ret[rank] = ({k: float(out[k].detach()) for k in ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic", "kl",
                                                      "mean_constraint_max", "ESS")}, upd.flat.detach().cpu())
     dist.destroy_process_group()
@@ -63,7 +69,7 @@ def test_two_ranks_match_single_rank():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
-    assert len(ret) == world
+    assert all(r in ret for r in range(world))
     for r in range(world):
         losses, flat = ret[r]
         for k, v in ref_losses.items():
@@ -104,12 +110,29 @@ def test_two_ranks_with_graph_segments_match_single_rank(n_steps):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
-    assert len(ret) == world
+    assert all(r in ret for r in range(world))
     for r in range(world):
         losses, flat = ret[r]
         for k, v in ref_losses.items():
             assert abs(losses[k] - v) <= (1e-5 if n_steps == 2 else 1e-4) * max(1.0, abs(v)), (r, k, losses[k], v)
         assert (flat - ref_flat).abs().max().item() <= (4e-6 if n_steps == 2 else 3e-5)
+
+
+def test_two_ranks_with_published_advantage_statistics():
+    """The epoch-level advantage statistics (one all-reduce per epoch, carried as a per-frame column): the update has no
+    ``advantage_stats`` collective any more and still equals the single-rank update of the whole minibatch."""
+    B, world, n_steps = 16, 2, 3
+    ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps, True), nprocs=world, join=True)
+    for r in range(world):
+        losses, flat = ret[r]
+        names = ret[f"collectives{r}"]
+        assert "advantage_stats" not in names and "flat_gradient_actor" in names and "loss_records" in names, names
+        for k, v in ref_losses.items():
+            assert abs(losses[k] - v) <= 2e-5 * max(1.0, abs(v)), (r, k, losses[k], v)
+        assert (flat - ref_flat).abs().max().item() <= 8e-6
 
 
 def _worker_natural(rank, world, port, B, ret, backend="gloo", anneal=False):
