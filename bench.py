@@ -374,8 +374,8 @@ def main():
                    "collectives_per_step": sum(v["per_step"] for k, v in coll.items() if not k.startswith(("join", "wait"))),
                    "collectives": coll,
                    "main_lane_waits_ms": {k: v["mean_ms"] for k, v in coll.items() if k.startswith(("join", "wait"))},
-                   "note": "rank 0's lanes; mean / max over 5 logged steps behind the timed region; the actor's lane waits for "
-                           "'flat_gradient_actor' and 'loss_records', the critic's lane (own communicator) for its four LayerNorm-statistic "
+                   "note": "rank 0's lanes; mean / max over 5 logged steps behind the timed region; the actor's lane waits for ONE collective, "
+                           "'flat_gradient_actor+loss_records' (the ranks' loss records ride in front of the gradient slice), the critic's lane (own communicator) for its four LayerNorm-statistic "
                            "reductions, its gradient slice and its loss sum; the advantage statistics of all minibatches of an epoch are "
                            "reduced once per epoch ('advantage_stats_epoch', outside the update)"}
     ms = 1e3 * dt / args.steps

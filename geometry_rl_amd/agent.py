@@ -121,7 +121,16 @@ class PolicyUpdater:
         n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.gflat = torch.zeros(n, device=dev, dtype=torch.float32)
+        # the flat gradient, with room IN FRONT of it for the ranks' loss records ([world][14] (hi, lo) float pairs, grl_trpl_fold_record_pairs):
+        # data parallel, ``gbuf[:rec + n_actor]`` is ONE all-reduce -- the records ride on the actor's gradient slice
+        if group is not None:
+            import torch.distributed as dist
+            self.rank, n_ranks = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, n_ranks = 0, 1
+        self._rec = 28 * n_ranks
+        self.gbuf = torch.zeros(self._rec + n, device=dev, dtype=torch.float32)
+        self.gflat = self.gbuf[self._rec:]
         off = 0
         for p in self.params:
             k = p.numel()
@@ -580,10 +589,9 @@ class PolicyUpdater:
                     zw = st["zw"]
                     fold_, maxes, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], st["adv"], sums=zw[10:22],
                                                                 maxes=zw[22:23].view(torch.int32), defer_fold=True)
-                    # this rank's loss sums / maxes as ONE record; the ranks' records are all-gathered (one collective, not a SUM and a MAX)
-                    st["rec"] = torch.empty(14, device=self.flat.device, dtype=torch.float64)
-                    st["recs"] = torch.empty(world, 14, device=self.flat.device, dtype=torch.float64)
-                    hip.call("grl_trpl_fold_record", fold_.slots, fold_.batch, st["rec"])
+                    # this rank's loss sums / maxes as ONE record of float pairs in front of the flat gradient (own row, zeros in the
+                    # others): the SUM all-reduce of the actor's slice delivers every rank's record -- no collective of their own
+                    hip.call("grl_trpl_fold_record_pairs", fold_.slots, fold_.batch, self.rank, world, self.gbuf[:self._rec])
                 st.update(loc=loc.detach(), sigma=sigma.detach(), sums=fold_.sums, maxes=fold_.maxes, dloc=dloc, dsigma=dsigma)
                 a_bwd()
                 fold()
@@ -593,7 +601,7 @@ class PolicyUpdater:
                     adam(0, na, 0)
                     ent = m.entropy_coef if m.entropy_bonus else 0.0
                     o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
-                    hip.call("grl_trpl_report_records", st["recs"], world, st["sums"], st["maxes"], float(ent), o14)
+                    hip.call("grl_trpl_report_record_pairs", self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
                     a_loss, mt = report_dict(o14)
                     st["lv_main"] = (a_loss, None, mt)
 
@@ -642,8 +650,7 @@ class PolicyUpdater:
                     ("run", q_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"),
                     ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"),
                     ("run", p_main),
-                    ("sum", lambda: self.gflat[:na], "m", "flat_gradient_actor"),
-                    ("gather", lambda: (st["recs"], st["rec"]), "m", "loss_records"),
+                    ("sum", lambda: self.gbuf[:self._rec + na], "m", "flat_gradient_actor+loss_records"),
                     ("run", q_fwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"),
                     ("run", s3, S), ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
                     ("run", p_tail),

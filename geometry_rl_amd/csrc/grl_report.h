@@ -12,8 +12,22 @@ inline int trpl_blocks(int batch) { return (batch + TRPL_FPB - 1) / TRPL_FPB; }
 // adds the records p, p + NP, ... (four independent running sums: the loads of a 256-record fold -- 4096 frames -- were one dependent
 // ~0.4 us round trip each when a single thread walked a column: +92 us on the step's tail), the NP partial results are combined in part
 // order.  A fixed order: bitwise reproducible.  Result in sh[0..13] (sums 0..11, maxes 12..13 as doubles), valid after the closing barrier.
-template <int NT>
-GRL_DEVINL void trpl_fold_columns(const double* __restrict__ slots, int n_blocks, double* sh /* [14] */, double* part /* [NT / 16][16] */) {
+// PAIRS: a record value is stored as two floats (hi, lo) with hi + lo = the double to ~2^-48 -- the form that survives a float SUM
+// all-reduce of a buffer in which every rank fills its own row and zeroes the others (x + 0 is exact): the ranks' loss records then
+// travel with the flat gradient in ONE collective (PolicyUpdater._plan).  Same 8 bytes per value as a double.
+template <bool PAIRS>
+GRL_DEVINL double trpl_slot_value(const double* __restrict__ slots, size_t i) {
+  if constexpr (PAIRS) {
+    const float2 v = reinterpret_cast<const float2*>(slots)[i];
+    return (double)v.x + (double)v.y;
+  } else {
+    return slots[i];
+  }
+}
+
+template <int NT, bool PAIRS = false>
+GRL_DEVINL void trpl_fold_columns(const double* __restrict__ slots_, int n_blocks, double* sh /* [14] */, double* part /* [NT / 16][16] */) {
+  struct { const double* p; GRL_DEVINL double operator[](size_t i) const { return trpl_slot_value<PAIRS>(p, i); } } slots{slots_};
   constexpr int NP = NT / 16;
   const int c = threadIdx.x & 15, p = threadIdx.x >> 4;
   if (c < TRPL_SLOT && (int)threadIdx.x < NT) {
@@ -42,10 +56,10 @@ GRL_DEVINL void trpl_fold_columns(const double* __restrict__ slots, int n_blocks
 }
 
 // fold + reported values; NT threads of the workgroup take part (all of the workgroup's threads must call: barriers inside)
-template <int NT>
+template <int NT, bool PAIRS = false>
 GRL_DEVINL void trpl_report_body(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums, unsigned int* __restrict__ maxes,
                                  float entropy_coef, float* __restrict__ out, double* sh /* [14] */, double* part /* [NT / 16][16] */) {
-  trpl_fold_columns<NT>(slots, n_blocks, sh, part);
+  trpl_fold_columns<NT, PAIRS>(slots, n_blocks, sh, part);
   const int i = threadIdx.x;
   if (i < 12) sums[i] = sh[i];
   else if (i < 14) maxes[i - 12] = __float_as_uint((float)sh[i]);

@@ -746,6 +746,41 @@ __global__ __launch_bounds__(FOLD_NT) void trpl_fold_record_kernel(const double*
   trpl_fold_columns<FOLD_NT>(slots, n_blocks, sh, part);
   if (threadIdx.x < TRPL_SLOT) rec[threadIdx.x] = sh[threadIdx.x];
 }
+// The same as (hi, lo) float pairs into a [world][14] region that travels with the flat gradient: this rank's row, zeros in the others
+__global__ __launch_bounds__(FOLD_NT) void trpl_fold_record_pairs_kernel(const double* __restrict__ slots, int n_blocks, float2* __restrict__ region,
+                                                                        int rank, int world) {
+  __shared__ double sh[16], part[FOLD_NT];
+  trpl_fold_columns<FOLD_NT>(slots, n_blocks, sh, part);
+  for (int i = threadIdx.x; i < world * TRPL_SLOT; i += FOLD_NT) {
+    float2 v = make_float2(0.f, 0.f);
+    if (i / TRPL_SLOT == rank) {
+      const double x = sh[i % TRPL_SLOT];
+      v.x = (float)x;
+      v.y = (v.x - v.x == 0.f) ? (float)(x - (double)v.x) : 0.f;   // (inf / nan stay what they are)
+    }
+    region[i] = v;
+  }
+}
+__global__ __launch_bounds__(FOLD_NT) void trpl_report_pairs_kernel(const double* __restrict__ records, int n_records, double* __restrict__ sums,
+                                                                   unsigned int* __restrict__ maxes, float entropy_coef, float* __restrict__ out) {
+  __shared__ double sh[16], part[FOLD_NT];
+  trpl_report_body<FOLD_NT, true>(records, n_records, sums, maxes, entropy_coef, out, sh, part);
+}
+int grl_trpl_fold_record_pairs(const double* slots, int batch, int rank, int world, float* region, hipStream_t stream) {
+  if (!slots || !region || batch < 1 || world < 1 || rank < 0 || rank >= world) return -2;
+  hipLaunchKernelGGL(trpl_fold_record_pairs_kernel, dim3(1), dim3(FOLD_NT), 0, stream, slots, trpl_blocks(batch),
+                     reinterpret_cast<float2*>(region), rank, world);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+int grl_trpl_report_record_pairs(const float* region, int n_records, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
+                                 hipStream_t stream) {
+  if (!region || !sums || !maxes || !out14 || n_records < 1) return -2;
+  hipLaunchKernelGGL(trpl_report_pairs_kernel, dim3(1), dim3(FOLD_NT), 0, stream, reinterpret_cast<const double*>(region), n_records, sums,
+                     maxes, entropy_coef, out14);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
 int grl_trpl_fold_record(const double* slots, int batch, double* rec14, hipStream_t stream) {
   if (!slots || !rec14 || batch < 1) return -2;
   hipLaunchKernelGGL(trpl_fold_record_kernel, dim3(1), dim3(FOLD_NT), 0, stream, slots, trpl_blocks(batch), rec14);

@@ -247,6 +247,12 @@ int grl_value_loss(const float* value, const float* old_value, const float* valu
 int grl_trpl_fold_record(const double* slots, int batch, double* rec14, hipStream_t stream);
 int grl_trpl_report_records(const double* records, int n_records, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
                             hipStream_t stream);
+/* (ABI 203) the records as (hi, lo) float pairs inside a float buffer that is SUM-all-reduced -- the flat gradient's collective carries them:
+ * region float[world][14][2]; a rank writes its own row and zeroes the others (x + 0 is exact in any summation order), so the reduced
+ * region holds every rank's record; hi + lo restores the double to ~2^-48.  8-byte aligned. */
+int grl_trpl_fold_record_pairs(const double* slots, int batch, int rank, int world, float* region, hipStream_t stream);
+int grl_trpl_report_record_pairs(const float* region, int n_records, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
+                                 hipStream_t stream);
 /* (ABI 203) grl_trpl_fold + grl_trpl_loss_values in one launch (one rank: nothing is all-reduced in between) */
 int grl_trpl_report(const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 /* stats fp64[2] = (sum, sum of squares) of the advantages, WRITTEN (ABI 203; <= 202 added to a zeroed slot): one workgroup, fixed order */

@@ -129,7 +129,7 @@ def test_two_ranks_with_published_advantage_statistics():
     for r in range(world):
         losses, flat = ret[r]
         names = ret[f"collectives{r}"]
-        assert "advantage_stats" not in names and "flat_gradient_actor" in names and "loss_records" in names, names
+        assert "advantage_stats" not in names and "flat_gradient_actor+loss_records" in names and "loss_records" not in names, names
         for k, v in ref_losses.items():
             assert abs(losses[k] - v) <= 2e-5 * max(1.0, abs(v)), (r, k, losses[k], v)
         assert (flat - ref_flat).abs().max().item() <= 8e-6
@@ -266,3 +266,39 @@ def test_time_batched_critic_pass_two_ranks_equals_one_rank():
     print(f"time-batched critic, {world} ranks vs 1: max |dV| = {err:.3e} (|V| max {ref.abs().max().item():.3e}); all-reduces per rank: {ret[0][1]}")
     assert err <= 1e-6 * max(1.0, ref.abs().max().item())
     assert ret[0][1] == 2 and ret[1][1] == 2, "one collective per LayerNorm stage for ALL time steps of the chunk"
+
+
+def test_loss_records_ride_on_a_float_sum():
+    """grl_trpl_fold_record_pairs / grl_trpl_report_record_pairs: a rank's record as (hi, lo) float pairs in its own row of a
+    [world][14] region, zeros elsewhere -- the float SUM of the ranks' regions (what the gradient's all-reduce does to it) holds every
+    record to ~2^-48, and the values reported from it equal the ones from the all-gathered fp64 records."""
+    from geometry_rl_amd import hip
+    dev = torch.device("cuda:0")
+    world, batch = 3, 100
+    nb = (batch + 15) // 16
+    g = torch.Generator().manual_seed(0)
+    regions, recs = [], []
+    for r in range(world):
+        slots = (torch.randn(nb, 14, generator=g, dtype=torch.float64) * 10 ** torch.randint(-3, 4, (nb, 14), generator=g).double()).abs()
+        slots[:, 10] = 16.0                              # (column 10 counts the frames)
+        slots = slots.to(dev).contiguous()
+        rec = torch.empty(14, device=dev, dtype=torch.float64)
+        hip.call("grl_trpl_fold_record", slots, batch, rec)
+        region = torch.full((world * 28,), 7.0, device=dev, dtype=torch.float32)   # stale content must be overwritten
+        hip.call("grl_trpl_fold_record_pairs", slots, batch, r, world, region)
+        pairs = region.view(world, 14, 2).double()
+        assert torch.equal(pairs[torch.arange(world) != r], torch.zeros(world - 1, 14, 2, device=dev, dtype=torch.float64))
+        back = pairs[r, :, 0] + pairs[r, :, 1]
+        assert ((back - rec).abs() <= 2.0 ** -46 * rec.abs()).all(), (back, rec)
+        regions.append(region)
+        recs.append(rec)
+    summed = regions[2] + (regions[0] + regions[1])      # any order: adding zeros is exact
+    assert torch.equal(summed, regions[0] + regions[1] + regions[2])
+    out_a, out_b = torch.empty(14, device=dev), torch.empty(14, device=dev)
+    sums_a, sums_b = torch.empty(12, device=dev, dtype=torch.float64), torch.empty(12, device=dev, dtype=torch.float64)
+    mx_a, mx_b = torch.empty(2, device=dev, dtype=torch.int32), torch.empty(2, device=dev, dtype=torch.int32)
+    hip.call("grl_trpl_report_records", torch.stack(recs).contiguous(), world, sums_a, mx_a, 0.01, out_a)
+    hip.call("grl_trpl_report_record_pairs", summed, world, sums_b, mx_b, 0.01, out_b)
+    assert torch.equal(mx_a, mx_b)
+    assert ((sums_a - sums_b).abs() <= 1e-12 * sums_a.abs()).all()
+    assert torch.allclose(out_a, out_b, rtol=1e-6, atol=0)
