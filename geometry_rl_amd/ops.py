@@ -844,6 +844,47 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
     return sums, maxes, dloc, dsigma, dvalue, pm, pv
 
 
+def head_fused(lat, grid3, wd, bd, ws, bs, shift: float, min_std: float, od: int, ov: int, batch, *, mean_bound, cov_bound,
+               trust_region_coeff, entropy_coef, global_batch: int, adv_stats: Optional[torch.Tensor], sums, maxes, proj_type: int = 0,
+               adv_local: bool = False):
+    """Read-out forward + fused loss kernel (actor terms) + read-out backward in ONE launch (grl_head_fused): the three launches
+    ``Readout.forward`` -> ``trpl_fwd_bwd`` -> ``Readout.backward`` sat on the step's chain with ~10 us of latency each.  ``lat``
+    [B * G, 16, 64] (detached), parameters of the decoder / std head as the leaves that own ``.grad``: their partial rows go through
+    ``_emit_grads`` (queued while a DEFERRED list is installed).  Returns (fold, loc [B, A], sigma [B, A], dlat): ``fold`` as
+    ``trpl_fwd_bwd(defer_fold=True)`` returns it."""
+    import ctypes
+    hip.check_f32(lat, grid3, wd, bd, ws, bs)
+    n = lat.shape[0]
+    B = batch["action"].shape[0]
+    G = n // B
+    A = G * 3 * ov
+    dev = lat.device
+    cfg = (ctypes.c_double * 10)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, 0.0, 0.0, 1.0 / global_batch, float(global_batch),
+                                 float(proj_type), 1.0 if adv_local else 0.0)
+    loc = torch.empty(B, A, device=dev, dtype=torch.float32)
+    sigma = torch.empty(B, A, device=dev, dtype=torch.float32)
+    dlat = torch.empty_like(lat)
+    rows, psize = hip.query("grl_head_fused_rows", B), hip.query("grl_readout_partial_size")
+    partial = torch.empty(rows, psize, device=dev, dtype=torch.float32)
+    slots = torch.empty(hip.query("grl_trpl_slot_doubles", B), device=dev, dtype=torch.float64)
+    f = lambda t: t.reshape(B, -1).contiguous() if t.dim() > 1 else t.contiguous()
+    hip.call("grl_head_fused", cfg, A, lat.contiguous(), grid3, wd.contiguous(), bd.contiguous(), ws.contiguous(), bs.contiguous(),
+             ctypes.c_float(float(shift)), ctypes.c_float(float(min_std)), n, od, ov, G, f(batch["action"]), f(batch["loc"]), f(batch["var"]),
+             batch["sample_log_prob"].reshape(B).contiguous(), batch["advantage"].reshape(B).contiguous(), adv_stats, loc, sigma, dlat,
+             partial, slots, B)
+    J, aper = od + ov, 3 * ov
+    outs = _emit_grads(partial, [(0, J * 64, (J, 64), wd), (256, J, (J,), bd), (260, aper * 64, (aper, 64), ws), (260 + 384, aper, (aper,), bs)])
+    for t, g in zip((wd, bd, ws, bs), outs):   # (leaves without a .grad view: eager callers outside PolicyUpdater)
+        if g is not None:
+            t.grad = g if t.grad is None else t.grad + g
+
+    def fold(sums=sums, maxes=maxes, slots=slots):
+        hip.call("grl_trpl_fold", slots, B, sums, maxes)
+        return sums, maxes
+    fold.slots, fold.batch, fold.sums, fold.maxes = slots, B, sums, maxes
+    return fold, loc, sigma, dlat
+
+
 def trpl_target_terms(loc, sigma, tgt_mean, tgt_S, *, mean_bound, cov_bound, trust_region_coeff, global_batch: int, proj_type: int = 0):
     """Trust-region measure of (p, detached target) with its gradient -- the fused kernel with the projection skipped
     (grl_trpl_target_terms).  ``sigma`` = sqrt of the policy's covariance diagonal, ``tgt_S`` = the target's covariance diagonal.

@@ -237,6 +237,18 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  *               adv_local: 1 = the advantage statistics are summed inside the kernel from this launch's batch (one rank), 0 = adv_stats}
  * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
  *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
+/* (ABI 203) read-out forward (hepi.py:173-190, gnn_gaussian_policy_diag.py:65-87) + fused loss kernel (actor terms) + read-out backward in ONE
+ * launch: lat [n_nodes,16,64], n_nodes = batch * nodes_per_frame (node n = frame * nodes_per_frame + g), action_dim = nodes_per_frame * 3 ov <= 16.
+ * Writes mean [n_nodes,ov,3] (= loc [batch, action_dim]), sigma [n_nodes,3 ov], dlat [n_nodes,16,64], partial [grl_head_fused_rows(batch)]
+ * [grl_readout_partial_size()] (one row per 16 frames, layout of grl_readout_bwd) and slots (grl_trpl_slot_doubles(batch) doubles).  cfg9 /
+ * adv_stats as grl_trpl_fwd_bwd; no value terms (grl_value_loss), no external hidden gradient.  Same arithmetic per node / frame as the
+ * three launches it replaces. */
+int grl_head_fused_rows(int batch);
+int grl_head_fused(const double* cfg9, int action_dim, const float* lat, const float* grid, const float* Wd, const float* bd,
+                   const float* Ws, const float* bs, float shift, float min_std, int n_nodes, int od, int ov, int nodes_per_frame,
+                   const float* action, const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
+                   const double* adv_stats, float* mean_out, float* sigma_out, float* dlat, float* partial, double* slots, int batch,
+                   hipStream_t stream);
 /* (ABI 203) the critic's share of the loss on its own: clipped l2 value loss (trpl.py:213-228, objectives/utils.py:5-28) and d loss / d V per
  * frame (already scaled by critic_coef / B_global) -- elementwise, so the critic's lane needs nothing from the fused actor kernel (which is
  * then called with value = NULL).  out2 fp64[2] = {sum over the frames of critic_coef * loss, that sum * inv_batch}; one workgroup */
