@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
 ABI_VERSION = 203   # include/grl_hip.h GRL_HIP_VERSION
-SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "head_ops.hip", "critic_ops.hip",
-           "train_ops.hip", "weight_images.hip"]
+SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "node_mlp16w8.hip", "head_ops.hip",
+           "critic_ops.hip", "train_ops.hip", "weight_images.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
 # per-source compiler flags.  edge_conv16.hip: its 512-register backward kernel keeps the chain's MFMA results in VGPRs (the default
@@ -31,6 +31,7 @@ FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-
               "node_mlp.hip": ["-fno-slp-vectorize", "-DGRL_GELU4_SCALAR=1"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp16.hip", ["-DGRL_PREC=1"], ".bf16"),
+            ("node_mlp16w8.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16"), ("weight_images.hip", ["-DGRL_PREC=1"], ".bf16")]
 
 
