@@ -849,6 +849,8 @@ class PolicyUpdater:
             keys.append("adv_stats")
         if not self.use_graph or self._program is None or int(idx.numel()) != self._static[keys[0]].shape[0]:
             return self.step(buf.rows(idx, keys))
+        if any(k not in self._static for k in keys):   # (recorded without a key that is gathered now, e.g. adv_stats: re-record)
+            return self.step(buf.rows(idx, keys))
         jobs = []
         for k in keys:
             dst, src = self._static[k], buf.flat(k)
@@ -898,9 +900,10 @@ class PolicyUpdater:
             st = {}
             self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m", e[3] if len(e) > 3 else None) for e in self._plan(batch, st)])
             return st["out"]
-        if self._program is not None and any(self._static[k].shape != batch[k].shape for k in self._static if k in batch):
-            self.reset_graph()                      # another minibatch size: record again for it
-            self._eager_sizes.add(B)
+        if self._program is not None and (any(self._static[k].shape != batch[k].shape for k in self._static if k in batch)
+                                          or ("adv_stats" in batch) != ("adv_stats" in self._static)):
+            self.reset_graph()                      # another minibatch size (or the published advantage statistics appeared /
+            self._eager_sizes.add(B)                # disappeared: a different data-parallel plan): record again for it
         if self._program is None:
             try:
                 self._compile(batch)
