@@ -63,10 +63,21 @@ GRL_DEVINL void stage_put(unsigned short* ih, unsigned short* il, const bf16x8 (
 // a read-write "a" operand (updated in place, never copied), while the files that use it are compiled with
 // -mllvm -amdgpu-mfma-vgpr-form so that the chain's builtin MFMAs keep their results in ordinary VGPRs, where the activation reads them
 // (with the default selection a 512-register kernel puts EVERY MFMA result into AGPRs: 450 v_accvgpr moves per pass, a third of the
-// vector issue slots).  asm is opaque to the hazard recognizer: s_nop 1 covers an operand the compiler may have just copied with a
-// VALU move; the operands themselves come from LDS (counted loads: the compiler waits for them).
+// vector issue slots).  asm is opaque to the hazard recognizer; the operands come from LDS (counted loads: the compiler waits for them).
+// Round 4: the "s_nop 1" that used to stand in front of every asm MFMA is gone (30 instructions of the edge backward's 1 366 per pass, 24 of
+// the node-MLP backward's 828 per chunk: a lone wave pays ~5 cycles for each).  What it covered -- an operand register written by a VALU
+// instruction less than two wait states before the MFMA reads it (the compiler inserts those wait states for builtin MFMAs; asm is opaque
+// to its hazard recognizer) -- is now CHECKED on the generated ISA at build time instead: tools/isa_acc_lint.py (tests/test_isa_lint.py)
+// fails on any vector write to a source register of an asm MFMA inside that window.  -DGRL_MFMA_ASM_NOP=1 restores the nop.
+#ifndef GRL_MFMA_ASM_NOP
+#define GRL_MFMA_ASM_NOP 0
+#endif
 GRL_DEVINL void mfma32_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
+#if GRL_MFMA_ASM_NOP
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
 }
 // Before the accumulators are read with vector instructions at the end of a launch the last asm MFMA must have drained (an MFMA result
 // needs 18 wait states before a VALU read, invisible to the compiler for asm MFMAs).  Every tile is re-defined by an (empty, volatile) asm statement behind the drain, so no v_accvgpr_read of a tile can be scheduled above it (with a bare memory clobber the compiler hoisted reads

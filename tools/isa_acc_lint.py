@@ -6,7 +6,9 @@ tile behind the drain before the first read.  This lint compiles the files to as
 
   * a v_accvgpr_read / v_accvgpr_mov of a register inside a pinned tile appears within WINDOW instructions AFTER an asm MFMA that writes
     that tile (an in-flight tile read by compiler-generated code), or
-  * a kernel that contains asm MFMAs has no drain statement behind the last one.
+  * a kernel that contains asm MFMAs has no drain statement behind the last one, or
+  * (round 4) a vector instruction writes a SOURCE register of an asm MFMA less than two wait states before it (the asm statements no
+    longer carry their own s_nop: 2-3 % of the two backward kernels' instructions).
 (Compiler-generated v_accvgpr moves of pinned tiles far behind the last MFMA -- e.g. behind a loop's closing barrier -- are harmless and
 are not flagged; what the drain guarantees is that nothing can be scheduled INTO the window, whatever a future compiler does.)
 
@@ -91,6 +93,26 @@ def lint_kernel(name, lines):
                 break
             if not aj and any(tile_of(r) == tile for r in acc_regs(tj)):
                 findings.append(f"{name}: '{tj}' {j - i} instructions after asm '{t[:60]}'")
+    # (3) a source register of an asm MFMA written by a vector instruction less than two wait states before it (the compiler's hazard
+    #     recognizer does this for builtin MFMAs -- VALU write -> MFMA SrcA / SrcB read needs 2 wait states on gfx950 -- but not for asm)
+    def vregs(tok):
+        regs = []
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+            regs += list(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else [int(m.group(3))]
+        return regs
+    for i, t in asm_mfma:
+        ops_ = t.split(None, 1)[1].split(",")
+        srcs = set(vregs(ops_[1]) + vregs(ops_[2])) if len(ops_) >= 3 else set()
+        ws, j = 0, i - 1
+        while j >= 0 and ws < 2:
+            tj = insts[j][0]
+            mnop = re.match(r"s_nop\s+(\d+)", tj)
+            if tj.startswith("v_") and not tj.startswith("v_mfma") and not tj.startswith("v_cmp"):
+                dst = tj.split(None, 1)[1].split(",")[0] if " " in tj else ""
+                if srcs & set(vregs(dst)):
+                    findings.append(f"{name}: '{tj}' writes a source of asm '{t[:70]}' {ws} wait states before it")
+            ws += int(mnop.group(1)) + 1 if mnop else 1
+            j -= 1
     # (2) the drain
     last = asm_mfma[-1][0]
     drain = next((j for j in range(last, len(insts)) if insts[j][0].startswith("s_nop 15") and insts[j][1]), None)
