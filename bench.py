@@ -270,7 +270,7 @@ def main():
         import socket
         import torch.distributed as dist
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), GRL_FORCE_DP_PLAN="1")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         group = dist.group.WORLD
@@ -296,7 +296,7 @@ def main():
     # the natural order: the updater is built first; the data-dependent calibration (conv.py:104-105) happens inside its first step,
     # from statistics summed over the ranks (every replica computes the factors of the whole minibatch)
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group,
-                              use_graph=not args.no_graph)
+                              use_graph=not args.no_graph, force_dp_plan=args.dp_plan)
     if world > 1:
         import torch.distributed as dist
         assert dist.get_world_size() == world

@@ -94,22 +94,16 @@ class PolicyUpdater:
     eps=1e-5) steps (train.py:279-316).  Parameters of both networks live in ONE flat fp32 buffer (gradients likewise), so a
     data-parallel run needs a single RCCL all-reduce of the gradient per step and Adam is a single kernel per optimizer.
 
-    The step is laid out as an explicit plan (``_plan``) of device-only segments, each free of host synchronisation, so with
+    The step is laid out as an explicit program (``_plan``) of device-only segments, each free of host synchronisation, so with
     ``use_graph=True`` they are recorded once into hipGraphs (torch.cuda.CUDAGraph) and replayed -- the ~3 ms of per-step launch
-    overhead disappears, which is what strong scaling over 8 GPUs needs (512 frames per GPU are < 1 ms of device time).
-      * one rank: a single graph; the critic's small kernels run on a second stream beside the actor's (fork / join inside the graph);
-      * several ranks: a two-lane program (``_execute``): the main lane carries the actor, the TRPL kernel, the gradient folding and
-        Adam, the side lane the critic together with its four statistic all-reduces; segments are separate graphs and the
-        collectives stay ordinary eager torch.distributed calls between the replays.  The main lane waits for one collective per
-        step, the all-reduce of the flat gradient."""
+    overhead disappears, which is what strong scaling over 8 GPUs needs (512 frames per GPU are < 1 ms of device time).  One program per
+    case (``_plan_one_stream`` / ``_plan_lanes`` / ``_plan_dp``): see the comment above ``_plan``."""
 
     def __init__(self, loss_module: TRPLLoss, lr=3e-4, eps=1e-5, betas=(0.9, 0.999), clip_grad_norm=False, max_grad_norm=1.0,
-                 group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False):
+                 group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False, force_dp_plan=False):
         self.loss_module, self.group = loss_module, group
-        self.overlap_critic = overlap_critic and os.environ.get("GRL_OVERLAP_CRITIC", "1") != "0"   # one rank only: critic kernels on a second stream beside the actor's
-        self.overlap_folds = overlap_critic and os.environ.get("GRL_OVERLAP_FOLDS", "0") != "0"   # the leaf-gradient folds on a third
-        # stream, one launch per backward op (ops.FOLD_STREAM).  Measured round 3 and left OFF: 0.858 vs 0.783 ms per 512-frame step, 3.42 vs
-        # 3.38 ms at 4096 frames -- ten small launches with cross-stream edges in the graph cost more than the one 45 us launch they replace
+        self.overlap_critic = overlap_critic   # one rank: False = everything on the caller's stream (_plan_one_stream)
+        self.force_dp_plan = force_dp_plan     # a process group of ONE rank runs the data-parallel program (bench.py --dp-plan)
         self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
         self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
         self._hyper = dict(eps=eps, betas=tuple(betas), clip=clip_grad_norm, max_norm=max_grad_norm)
@@ -142,7 +136,7 @@ class PolicyUpdater:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)  # optimizer step, device side (graph replays)
-        self.step_dev_c = torch.zeros(1, device=dev, dtype=torch.int32)  # the same count kept by the critic's lane (one rank, two lanes)
+        self.step_dev_c = torch.zeros(1, device=dev, dtype=torch.int32)  # the same count kept by the critic's lane
         # learning rate, device side: the recorded Adam launches read it, so an annealed rate (train.py:264-271 writes
         # ``group["lr"] = lr * alpha`` before every iteration; configs/algorithm/optim/default.yaml:5) takes effect under replay
         self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
@@ -155,28 +149,26 @@ class PolicyUpdater:
             self.use_graph, self.mode = False, "eager (stock-torch transformer actor: not recorded)"
         self._static = None
         self._program = None
-        self._pending = []   # asynchronous collectives in flight
         # Leaf gradients are WRITTEN by the one fold launch at the end of the backward pass (ops.flush_deferred_grads(overwrite=True)) instead
-        # of accumulated into a zeroed buffer: the per-step ``gflat.zero_()`` launch -- the first node of the recorded step, in front of the
-        # fork of the two lanes -- disappears.  Valid while every leaf gradient of the step comes through the fold queue: not with the stock
-        # torch transformer actor or the attention gate (torch's AccumulateGrad adds into .grad), nor with per-op folds on a third stream.
+        # of accumulated into a zeroed buffer: no per-step zeroing launch.  Valid while EVERY leaf gradient of the step comes through the
+        # fold queue: not with the stock torch transformer actor or the attention gate (torch's AccumulateGrad adds into .grad) -- and
+        # checked on the first eager step of every updater (``_check_overwrite_coverage``).
         gnn = getattr(loss_module.actor_network, "gnn", None)
-        self._fold_overwrite = (os.environ.get("GRL_FOLD_OVERWRITE", "1") != "0" and not self.overlap_folds
-                                and not getattr(loss_module.actor_network, "post_fc", False)
+        self._fold_overwrite = (not getattr(loss_module.actor_network, "post_fc", False)
                                 and not any(getattr(mod, "attention", False) for mod in (gnn.modules() if gnn is not None else [])))
-        # one rank: the critic folds and applies its own gradients on its lane (its own Adam launch over its slice of the flat buffer): the
-        # actor's lane neither carries them nor waits for the critic before its fold
-        self._critic_own_adam = os.environ.get("GRL_CRITIC_OWN_ADAM", "1") != "0"
-        # one rank: the step as a two-lane program of single-stream graphs (default) instead of ONE graph with a fork / join inside -- see _plan
-        self._lanes = os.environ.get("GRL_LANES", "1") != "0"
-        # the critic's lane reduces on a communicator of its own (see _plan): created collectively, here, in construction order
+        self._overwrite_checked = not self._fold_overwrite
+        # the critic's lane reduces on a communicator of its own (_plan_dp).  dist.new_group is collective over the WHOLE default group
+        # and must be entered by every rank in the same order: ``group`` therefore has to span WORLD (asserted), and a failure propagates
+        # -- ranks that disagree on which communicator carries the critic's collectives would deadlock in the first step.
+        # GRL_DP_ONE_COMM=1 (the documented fallback, README "switches"): both lanes on ``group``.
         self.group_c = None
-        if group is not None and os.environ.get("GRL_DP_JOINED", "0") == "0":
+        if group is not None and os.environ.get("GRL_DP_ONE_COMM", "0") == "0":
             import torch.distributed as dist
-            try:
-                self.group_c = dist.new_group(ranks=dist.get_process_group_ranks(group))
-            except Exception:
-                self.group_c = None
+            ranks = dist.get_process_group_ranks(group)
+            if len(ranks) != dist.get_world_size():
+                raise ValueError("PolicyUpdater(group=...) must span the default process group (dist.new_group for the critic's lane is "
+                                 "collective over WORLD); set GRL_DP_ONE_COMM=1 to run both lanes on a sub-group's own communicator")
+            self.group_c = dist.new_group(ranks=ranks)
         if group is not None:
             self.sync_replicas()
 
@@ -224,63 +216,108 @@ class PolicyUpdater:
                 f.fill_(bool(v))
         actor._calib_checked = False   # re-inspect the latches on the next training forward
 
-    # ---- the plan: [("run", fn) | ("sum", tensor getter) | ("max", tensor getter)] --------------------------------------
+    # ---- the step's programs.  A program is a list of ("run", fn [, lane]) | ("sum", tensor getter, lane, label) | ("fork" | "join", None
+    #      [, lane, label]) | ("run_host", fn) entries; "run" entries between two collectives of a lane are recorded into ONE hipGraph.
+    #      There is exactly one program per case:
+    #        _plan_one_stream  one rank, everything on the caller's stream (overlap_critic=False: the per-kernel timing leg of bench.py, and
+    #                          the form every other program must agree with);
+    #        _plan_lanes       one rank (default): two lanes that never meet inside a step, ONE single-stream hipGraph each;
+    #        _plan_dp          several ranks (or force_dp_plan): the same two lanes with the collectives between their graph segments.
     def _plan(self, batch: Dict[str, torch.Tensor], st: dict):
-        from . import ops
-        from .trpl import adv_stats_local, head_launch, loss_values, report_dict, report_values, trpl_launch, value_loss
         m = self.loss_module
-        world = m.world_size
-        # GRL_FORCE_DP_PLAN=1 with a process group of ONE rank: the data-parallel program (lanes with joins, graph segments between the
-        # collectives, every all-reduce issued) on one GPU -- what a shard's step costs before any inter-GPU latency (bench.py --dp-plan)
-        one_rank = world == 1 and not (self.group is not None and os.environ.get("GRL_FORCE_DP_PLAN", "0") != "0")
-        actor = m.actor_network
-        vf = m.critic_network._network1
-        ia, ib = vf.gnn.mlp_inner, vf.gnn.mlp_outer
-        leaves = (ia.lins[0].weight, ia.lins[0].bias, ia.norms[0].weight, ia.norms[0].bias, ia.lins[1].weight, ia.lins[1].bias,
-                  ib.lins[0].weight, ib.lins[0].bias, ib.norms[0].weight, ib.norms[0].bias, ib.lins[1].weight, ib.lins[1].bias,
-                  vf.final.weight, vf.final.bias)
         if not m.critic_coef:
             raise NotImplementedError("PolicyUpdater expects the critic term (critic_coef > 0 in every TRPL config)")
+        one_rank = m.world_size == 1 and not (self.group is not None and self.force_dp_plan)
+        if one_rank and not self.overlap_critic:
+            return self._plan_one_stream(batch, st)
+        if one_rank:
+            return self._plan_lanes(batch, st)
+        return self._plan_dp(batch, st)
 
+    def _critic_leaves(self):
+        vf = self.loss_module.critic_network._network1
+        ia, ib = vf.gnn.mlp_inner, vf.gnn.mlp_outer
+        return (ia.lins[0].weight, ia.lins[0].bias, ia.norms[0].weight, ia.norms[0].bias, ia.lins[1].weight, ia.lins[1].bias,
+                ib.lins[0].weight, ib.lins[0].bias, ib.norms[0].weight, ib.norms[0].bias, ib.lins[1].weight, ib.lins[1].bias,
+                vf.final.weight, vf.final.bias)
+
+    def _adam(self, st, lo, hi, i_, step_dev=None):
+        """One optimizer's step over its slice [lo, hi) of the flat buffer (train.py:308-316); i_: 0 actor, 1 critic (clip workspace slot)."""
+        coef = None
+        if self.clip:  # train.py:308-310
+            sq = st["zw"][23 + i_:24 + i_]
+            coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
+            hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
+        hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                 hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                 step_dev if step_dev is not None else self.step_dev, coef, 1.0)
+
+    def _prep(self, batch, st, zero=None):
+        """Inputs of a step: the batch with its variance diagonal, the two networks' observation lists, the fp64 workspace
+        ((8 unused) | advantage sums (2) | loss sums (12) | maxes (2 x u32) | clip (2); every slot is WRITTEN by its producer).  ``zero``:
+        the slice of the flat gradient THIS lane owns -- zeroed here when the folds accumulate (no overwrite mode)."""
+        m = self.loss_module
+        if not self._fold_overwrite and zero is not None:
+            zero.zero_()
+        b = dict(batch)
+        if "var" not in b:
+            b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
+        st["b"] = b
+        st["obs"] = [b[k] for k in m.in_features]
+        st["cobs"] = [b[k] for k in m.critic_in_features]
+        st["zw"] = torch.empty(26, device=self.flat.device, dtype=torch.float64)
+
+    def _actor_head(self, st, adv, adv_local):
+        """Actor forward + fused loss kernel (actor terms only) + actor backward; -> the loss kernel's fold handle."""
+        from .trpl import trpl_launch
+        m, actor = self.loss_module, self.loss_module.actor_network
+        zw = st["zw"]
+        sums, maxes = zw[10:22], zw[22:23].view(torch.int32)
+        ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch at the lane's end
+        loc, sigma = actor.forward_diag(*st["obs"], train=True)
+        with torch.no_grad():
+            fold_, _mx, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], adv, sums=sums, maxes=maxes, defer_fold=True,
+                                                      adv_local=adv_local)
+        st.update(loc=loc.detach(), sigma=sigma.detach())
+        torch.autograd.backward([loc, sigma], [dloc, dsigma])
+        return fold_
+
+    @staticmethod
+    def _finish(st):
+        """Host only: the output dict of views (recorded once, valid for every replay)."""
+        a_loss, mt = st.pop("lv_main")
+        mt = dict(mt)
+        out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": st.pop("c_loss"), "loc": st["loc"], "sigma": st["sigma"],
+               "state_value": st["value"].unsqueeze(-1)}
+        out.update(mt)
+        st["out"] = out
+
+    def _plan_one_stream(self, batch, st):
+        """One rank, one stream: critic forward, actor forward, the fused loss kernel WITH the value terms, both backward passes, one fold,
+        the optimizer step(s), reported values -- six closures on the caller's stream (one hipGraph when recorded)."""
+        from .trpl import adv_stats_local, loss_values, trpl_launch
+        m = self.loss_module
+        actor, vf = m.actor_network, m.critic_network._network1
+        leaves = self._critic_leaves()
         ow = self._fold_overwrite
 
-        def adam(lo, hi, i_, step_dev=None):   # one optimizer's step over its slice of the flat buffer (train.py:308-316)
-            coef = None
-            if self.clip:  # train.py:308-310
-                sq = st["zw"][23 + i_:24 + i_]
-                coef = torch.empty(1, device=self.flat.device, dtype=torch.float32)
-                hip.call("grl_clip_coef", self.gflat[lo:hi], hi - lo, float(self.max_norm), sq, coef)
-            hip.call("grl_adam_step_dev", self.flat[lo:hi], self.gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                     hi - lo, self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                     step_dev if step_dev is not None else self.step_dev, coef, 1.0)
-
         def s0():  # critic features, first critic stage, advantage statistics
-            if not ow:
-                self.gflat.zero_()
-            b = dict(batch)
-            if "var" not in b:
-                b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
-            st["b"] = b
-            st["obs"] = [b[k] for k in m.in_features]
-            st["cobs"] = [b[k] for k in m.critic_in_features]
+            self._prep(batch, st, zero=self.gflat)
             with torch.no_grad():
                 vf.train(True)
                 _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
-                # one fp64 workspace per step: (8 unused) | advantage sums (2) | loss sums (12) | maxes (2 x u32) | clip (2); every slot is
-                # WRITTEN by its producer (ABI 203): no zeroing launch
-                zw = st["zw"] = torch.empty(26, device=x.device, dtype=torch.float64)
-                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
+                st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                 st["pipe"].fwd1()
                 st["adv"] = None
-                if m.normalize_advantage and x.shape[0] * world > 1:
-                    st["adv"] = zw[8:10]
-                    adv_stats_local(m, b, st["adv"])
+                if m.normalize_advantage and x.shape[0] > 1:
+                    st["adv"] = st["zw"][8:10]
+                    adv_stats_local(m, st["b"], st["adv"])
 
         def s1():
             st["pipe"].fwd2()
 
         def s2():  # value head, actor forward, fused TRPL kernel, actor backward, last critic stage backward
-            ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch in s4
+            ops.DEFERRED = []
             pipe = st["pipe"]
             value = pipe.fwd3()
             loc, sigma = actor.forward_diag(*st["obs"], train=True)
@@ -305,405 +342,203 @@ class PolicyUpdater:
 
         def s5():  # optimizers + reported values (train.py:308-316, trpl.py:280-321)
             with torch.no_grad():
-                if not st.pop("step_bumped", False):
-                    self.step_dev.add_(1)
-                na, n = self.n_actor, self.flat.numel()
-                if st.pop("critic_adam_done", False):
-                    adam(0, na, 0)   # the critic's optimizer has run on its own lane
-                else:
-                    # the two optimizers of train.py:120-127 have identical hyper-parameters and schedules: without per-network gradient
-                    # clipping their two Adam steps are ONE launch over the flat buffer (element-wise: the same numbers)
-                    for i_, (lo, hi) in enumerate(((0, na), (na, n)) if self.clip else ((0, n),)):
-                        adam(lo, hi, i_)
-                join = st.pop("join_side", None)
-                if join is not None:   # the critic's lane ends here (nothing of the actor's lane is queued behind this: no cost on its path)
-                    join()
-                a_loss, c_loss, mt = st.pop("lv", None) or loss_values(m, st["sums"], st["maxes"])
-                out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": c_loss, "loc": st["loc"], "sigma": st["sigma"],
-                       "state_value": st["value"].unsqueeze(-1)}
-                out.update(mt)
-                st["out"] = out
-
-        # ---- one rank: no reduction separates the critic stages, so the whole critic (small, latency-bound launches) runs on
-        #      a second stream beside the actor -- forward beside the actor forward, backward beside the actor backward -- and
-        #      fills the SIMDs the big kernels leave idle at their heads and tails.  Recorded into the graph as a fork / join.
-        def o_fwd():
-            b = dict(batch)
-            if "var" not in b:
-                b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
-            st["b"] = b
-            st["obs"] = [b[k] for k in m.in_features]
-            st["cobs"] = [b[k] for k in m.critic_in_features]
-            cur, cs = torch.cuda.current_stream(), self._critic_stream()
-            if not ow:
-                self.gflat.zero_()
-            cs.wait_stream(cur)
-            with torch.cuda.stream(cs), torch.no_grad():
-                # inputs of the fused loss kernel and of Adam that depend on the minibatch alone come FIRST on this lane: the step's workspace
-                # (every slot written by its producer: no zeroing), the advantage statistics, the optimizer step count -- the critic's
-                # forward behind them is what the actor's first edge convolution may have to wait for
-                zw = st["zw"] = torch.empty(26, device=self.flat.device, dtype=torch.float64)
-                st["adv"] = None
-                if m.normalize_advantage and st["obs"][0].shape[0] > 1:
-                    st["adv"] = zw[8:10]
-                    adv_stats_local(m, b, st["adv"])
                 self.step_dev.add_(1)
-                st["step_bumped"] = True
+                na, n = self.n_actor, self.flat.numel()
+                # the two optimizers of train.py:120-127 have identical hyper-parameters and schedules: without per-network gradient
+                # clipping their two Adam steps are ONE launch over the flat buffer (element-wise: the same numbers)
+                for i_, (lo, hi) in enumerate(((0, na), (na, n)) if self.clip else ((0, n),)):
+                    self._adam(st, lo, hi, i_)
+                a_loss, c_loss, mt = loss_values(m, st["sums"], st["maxes"])
+                st["lv_main"], st["c_loss"] = (a_loss, mt), c_loss
+
+        return [("run", s0), ("run", s1), ("run", s2), ("run", s3), ("run", s4), ("run", s5), ("run_host", lambda: self._finish(st))]
+
+    def _tail_args(self, lo, hi, cnt):
+        return dict(grads=self.gflat[lo:hi], params=self.flat[lo:hi], exp_avg=self.exp_avg[lo:hi], exp_avg_sq=self.exp_avg_sq[lo:hi],
+                    lr_dev=self.lr_dev, betas=self.betas, eps=self.eps, step_dev=cnt)
+
+    def _plan_lanes(self, batch, st):
+        """One rank as a two-lane PROGRAM of single-stream graphs.  This HIP runtime replays a captured graph with two branches through
+        the host (hipGraphLaunch returned after 2/3 of the DEVICE time of a forked step; tools/ubench/graph_branches.py) and every
+        cross-branch edge costs a 6-11 us gap; a graph boundary on a lane costs ~15 us as well.  So each lane is ONE graph and the lanes
+        never meet inside a step (DESIGN.md findings 37, 38):
+          actor's lane : features, lift, convolutions, read-out, fused loss kernel (actor terms only; the batch's advantage statistics are
+                         summed inside it), backward, then ONE tail launch: fold + Adam over the actor's slice + reported values;
+          critic's lane: features, the three forward stages, its OWN loss (clipped value loss: elementwise in the frame), the three
+                         backward stages, tail: fold + Adam over the critic's slice.
+        Actor and critic share no parameter and no intermediate (train.py:279-316 runs two backward passes and two optimizers); the lanes
+        are forked at the step's start and joined at its end.  Each lane zeroes ITS OWN slice of the flat gradient when the folds
+        accumulate (attention gate: torch's AccumulateGrad adds into .grad)."""
+        from .trpl import report_dict, report_values, value_loss
+        m = self.loss_module
+        actor, vf = m.actor_network, m.critic_network._network1
+        leaves = self._critic_leaves()
+        ow = self._fold_overwrite
+        na, n_all = self.n_actor, self.flat.numel()
+        # the one-launch tail needs every leaf gradient of the lane in the fold queue (overwrite mode) and no clipping (which needs the
+        # finished gradient norm before Adam)
+        fuse_tail = not self.clip and ow
+
+        def main_all():
+            self._prep(batch, st, zero=self.gflat[:na])
+            actor.hyper_data.bump_next = self.step_dev   # the step count rides on the lane's first launch (grl_build_features_bump)
+            fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
+            assert actor.hyper_data.bump_next is None, "the actor's feature launch did not take the step count"
+            with torch.no_grad():
+                done = False
+                if fuse_tail:   # fold + Adam + reported values: ONE launch at the lane's end (ops.fold_adam_report)
+                    o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
+                    ent = m.entropy_coef if m.entropy_bonus else 0.0
+                    done = ops.fold_adam_report(ow, self._tail_args(0, na, self.step_dev),
+                                                dict(slots=fold_.slots, batch=fold_.batch, sums=fold_.sums, maxes=fold_.maxes,
+                                                     ent_coef=ent, out14=o14))
+                    if done:
+                        a_loss, mt = report_dict(o14)
+                if not done:
+                    ops.flush_deferred_grads(overwrite=ow)
+                    self._adam(st, 0, na, 0)
+                    a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
+                ops.DEFERRED = None
+                st.update(sums=fold_.sums, maxes=fold_.maxes, lv_main=(a_loss, mt))
+
+        def critic_all():
+            ops.DEFERRED = []
+            with torch.no_grad():
+                if not ow:
+                    self.gflat[na:].zero_()   # on THIS lane, in front of its folds (ADVICE r4: never from the actor's lane)
                 vf.train(True)
-                _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
+                _, x = vf.hyper_data.build_data(*st["cobs"], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
                 pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                 pipe.fwd1()
-                ev1 = torch.cuda.Event()
-                ev1.record(cs)
                 pipe.fwd2()
-                value = pipe.fwd3()
-            ops.DEFERRED = []
-            if self.overlap_folds:   # leaf-gradient folds beside the backward kernels, on a third stream (ops.FOLD_STREAM)
-                ops.FOLD_STREAM = self._fold_stream()
-                ops.FOLD_STREAM.wait_stream(cur)   # behind the zeroing of the flat gradient
-            # The MFMA kernels size their grids to fill every CU exactly (all LDS, all VGPRs): a critic workgroup still resident when
-            # one of them starts displaces one of ITS workgroups, which then runs as a second round behind the others -- the first edge
-            # convolution of the EMPN step took 751 instead of 566 us that way (profiles/r03_stream_kernels_ab.txt).  So when the critic's forward
-            # is short enough to hide behind the actor's prologue (gather, features, lift: streaming kernels that share CUs gracefully)
-            # the first edge convolution waits for it; a long critic forward (cloth: 239 rows per frame, 0.7 ms) keeps running beside
-            # the actor instead -- waiting would cost more than the displacement.
-            mode = os.environ.get("GRL_CRITIC_JOIN", "auto")
-            rows = int(x.shape[0]) * (int(x.shape[1]) if x.dim() == 3 else 1)
-            if mode != "0":
-                ops.PRE_EDGE_HOOK = lambda n_nodes: (cur.wait_stream(cs) if (mode == "1" or (mode == "auto" and rows <= 4 * n_nodes)) else
-                                                     cur.wait_event(ev1) if mode in ("fwd1", "auto") else None)
-            try:
-                loc, sigma = actor.forward_diag(*st["obs"], train=True)
-            finally:
-                ops.PRE_EDGE_HOOK = None   # (one-shot; never left behind for another caller's edge convolution)
-            cur.wait_stream(cs)   # join: the fused loss kernel needs the values
-            with torch.no_grad():   # (the fold of the per-workgroup loss sums is deferred: reported values only, off the actor's lane)
-                fold, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, value, b, st["adv"], sums=zw[10:22],
-                                                                maxes=zw[22:23].view(torch.int32), defer_fold=True)
-            cs.wait_stream(cur)   # fork: critic backward beside the actor backward
-            own = self._critic_own_adam and not self.overlap_folds
-            with torch.cuda.stream(cs), torch.no_grad():
-                sums, maxes = fold()
-                st["lv"] = loss_values(m, sums, maxes)   # reported values only: beside the backward pass, not behind Adam
+                value = st["value"] = pipe.fwd3()
+                dvalue, c_loss, _ = value_loss(m, value, st["b"])
                 pipe.bwd3(dvalue)
                 pipe.bwd2()
                 grads = pipe.bwd1(leaves)
-                if own:   # the critic's gradients are complete: folded and applied HERE, on its lane (only its slabs are queued so far)
-                    na, n = self.n_actor, self.flat.numel()
+                assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
+                if not (fuse_tail and ops.fold_adam_report(ow, self._tail_args(na, n_all, self.step_dev_c))):
                     ops.flush_deferred_grads(overwrite=ow)
-                    adam(na, n, 1)
-                    st["critic_adam_done"] = True
-            assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
-            torch.autograd.backward([loc, sigma], [dloc, dsigma])
-            if own:
-                st["join_side"] = lambda: cur.wait_stream(cs)   # joined behind the actor's Adam (s5): off the actor's path
-            else:
-                cur.wait_stream(cs)   # join: every partial slab is complete
-            ops.flush_deferred_grads(overwrite=ow)
-            ops.DEFERRED = None
-            ops.FOLD_STREAM = None
-            st.update(loc=loc.detach(), sigma=sigma.detach(), value=value, sums=sums, maxes=maxes)
+                    self._adam(st, na, n_all, 1, self.step_dev_c)
+                ops.DEFERRED = None
+                st["c_loss"] = c_loss
 
-        if one_rank and self.overlap_critic and not self._lanes:
-            return [("run", o_fwd), ("run", s5)]
-        if one_rank and not self.overlap_critic:   # one rank, one stream
-            return [("run", s0), ("run", s1), ("run", s2), ("run", s3), ("run", s4), ("run", s5)]
+        return [("fork", None), ("run", main_all), ("run", critic_all, "s"), ("join", None), ("run_host", lambda: self._finish(st))]
 
-        # ---- several ranks: two lanes.  The critic with ALL FOUR of its reductions runs on a second stream ("s" items) beside the
-        #      actor forward / backward; the loss sums / maxes (reported values only) are reduced asynchronously behind the actor
-        #      backward.  The main lane waits for ONE collective per step: the gradient all-reduce.  Tensors that cross lanes stay
-        #      referenced in ``st`` for the whole step, so neither allocator pool can hand their memory out while the other lane
-        #      still uses it.
-        def m_prep(zero=None):
-            if not ow:
-                (self.gflat if zero is None else zero).zero_()
-            b = dict(batch)
-            if "var" not in b:
-                b["var"] = b["covariance_matrix"].diagonal(dim1=-2, dim2=-1).contiguous()
-            st["b"] = b
-            st["obs"] = [b[k] for k in m.in_features]
-            st["cobs"] = [b[k] for k in m.critic_in_features]
-            st["zw"] = torch.empty(26, device=self.flat.device, dtype=torch.float64)   # every slot is written by its producer
+    def _plan_dp(self, batch, st):
+        """Several ranks: the same two lanes, graph segments between the collectives (which stay eager torch.distributed calls).
+          actor's lane : [features ... forward, fused loss kernel (actor terms), backward, fold, this rank's loss record] -> ONE all-reduce:
+                         the ACTOR's slice of the flat gradient with the ranks' loss records riding in front of it -> [Adam, reported values];
+                         the advantage statistics come from the rollout driver (one all-reduce per EPOCH, ``adv_stats`` column) or, for a
+                         bare ``step(batch)``, from one more graph + collective at the head of the lane;
+          critic's lane: its four LayerNorm-statistic reductions, its own loss, the all-reduce of ITS slice and of its loss sum, its Adam --
+                         on a communicator of its own (``group_c``; collectives of one communicator execute in issue order on one internal
+                         stream: a critic reduction waiting for a critic kernel must not hold back the actor's gradient all-reduce issued
+                         behind it).  GRL_DP_ONE_COMM=1: both lanes on ``group`` (the documented fallback; same results).
+        Every rank enqueues the SAME sequence of collectives per communicator, in the order of this list (host order = enqueue order);
+        tests/test_dp_program_order.py checks that property of the program itself."""
+        from .trpl import adv_stats_local, report_dict, value_loss
+        m = self.loss_module
+        world = m.world_size
+        actor, vf = m.actor_network, m.critic_network._network1
+        leaves = self._critic_leaves()
+        ow = self._fold_overwrite
+        na, n_all = self.n_actor, self.flat.numel()
+        S = "s"
+        # ``adv_stats`` in the batch ([B, 2] fp64, every row = the GLOBAL (sum, sum of squares) of this minibatch's advantages:
+        # rollout.RolloutDriver.publish_advantage_stats): the statistics kernel, its all-reduce and the graph boundary behind it leave
+        # the actor's lane -- two graphs and one collective on its path.
+        published = m.normalize_advantage and "adv_stats" in batch
 
-        def c_fwd1():
-            with torch.no_grad():
-                vf.train(True)
-                _, x = vf.hyper_data.build_data(*st["cobs"], train=True)
-                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
-                st["pipe"].fwd1()
-                st["adv"] = None
-                if m.normalize_advantage and x.shape[0] * world > 1:
+        def p_stats():
+            self._prep(batch, st, zero=self.gflat[:na])
+            st["adv"] = None
+            if published:
+                st["adv"] = batch["adv_stats"][0]
+            elif m.normalize_advantage and st["obs"][0].shape[0] * world > 1:
+                with torch.no_grad():
                     st["adv"] = st["zw"][8:10]
                     adv_stats_local(m, st["b"], st["adv"])
 
-        def c_fwd3():
-            st["value"] = st["pipe"].fwd3()
-
-        def a_fwd():
-            ops.DEFERRED = []   # leaf-gradient folds of both backward passes are queued and executed by one launch in ``fold``
-            st["loc_g"], st["sigma_g"] = actor.forward_diag(*st["obs"], train=True)
-
-        def head():  # fused TRPL kernel
-            loc, sigma = st["loc_g"], st["sigma_g"]
-            defer = False
+        def p_main():
+            if published:
+                p_stats()
+            actor.hyper_data.bump_next = self.step_dev
+            fold_ = self._actor_head(st, st["adv"], False)
+            assert actor.hyper_data.bump_next is None
             with torch.no_grad():
-                zw = st["zw"]
-                sums, maxes, dloc, dsigma, dvalue = trpl_launch(m, loc, sigma, st["value"], st["b"], st["adv"], sums=zw[10:22],
-                                                                maxes=zw[22:23].view(torch.int32), defer_fold=defer)
-            if defer:
-                st["fold"], sums = sums, None
-            st.update(loc=loc.detach(), sigma=sigma.detach(), sums=sums, maxes=maxes, dloc=dloc, dsigma=dsigma, dvalue=dvalue)
-
-        def c_bwd3():
-            with torch.no_grad():
-                st["pipe"].bwd3(st["dvalue"])
-
-        def c_bwd1():
-            with torch.no_grad():
-                grads = st["pipe"].bwd1(leaves)
-            assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
-
-        def a_bwd():
-            torch.autograd.backward([st.pop("loc_g"), st.pop("sigma_g")], [st["dloc"], st["dsigma"]])
-
-        # read-out forward, loss kernel and read-out backward as ONE launch (trpl.head_launch, GRL_FUSED_HEAD=1).  Built as VERDICT r3 item 1c
-        # asked, measured, and left OFF: 0.3533 -> 0.3577 / 0.7218 -> 0.7278 / 3.3634 -> 3.3624 ms per step at 32 / 512 / 4096 frames on one
-        # box -- the three launches' 8 + 12 + 12 us are dependent latency that a workgroup pays between its barriers just the same; what
-        # the fusion saves (two ~2 us launch gaps) the 16-wave fold of the decoder's gradient sums spends (tests/test_gpu_fused_head.py
-        # keeps both paths equal).
-        fused_head = (os.environ.get("GRL_FUSED_HEAD", "0") != "0" and not getattr(actor, "post_fc", False)
-                      and hasattr(actor, "latent_diag") and hasattr(getattr(actor, "gnn", None), "decoder"))
-
-        def a_head(adv, adv_local):
-            """forward + loss (actor terms) + backward of the actor; -> the loss kernel's fold handle"""
-            zw = st["zw"]
-            sums, maxes = zw[10:22], zw[22:23].view(torch.int32)
-            B_ = st["obs"][0].shape[0]
-            if fused_head and st["b"]["action"].reshape(B_, -1).shape[1] <= 16:   # (the loss kernel's widest instance: 16 lanes per frame)
-                ops.DEFERRED = []
-                lat = actor.latent_diag(*st["obs"], train=True)
-                with torch.no_grad():
-                    fold_, loc, sigma, dlat = head_launch(m, actor, lat, st["b"], adv, sums, maxes, adv_local=adv_local)
-                st.update(loc=loc, sigma=sigma)
-                torch.autograd.backward([lat], [dlat])
-                return fold_
-            a_fwd()
-            loc, sigma = st["loc_g"], st["sigma_g"]
-            with torch.no_grad():
-                fold_, _mx, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], adv, sums=sums, maxes=maxes, defer_fold=True,
-                                                          adv_local=adv_local)
-            st.update(loc=loc.detach(), sigma=sigma.detach(), dloc=dloc, dsigma=dsigma)
-            a_bwd()
-            return fold_
-
-        def fold():
+                # this rank's loss sums / maxes as ONE record of float pairs in front of the flat gradient (own row, zeros in the
+                # others): the SUM all-reduce of the actor's slice delivers every rank's record -- no collective of their own
+                hip.call("grl_trpl_fold_record_pairs", fold_.slots, fold_.batch, self.rank, world, self.gbuf[:self._rec])
+            st.update(sums=fold_.sums, maxes=fold_.maxes)
             ops.flush_deferred_grads(overwrite=ow)
             ops.DEFERRED = None
 
-        S = "s"
-        if one_rank and self.overlap_critic and self._lanes:
-            # One rank as a two-lane PROGRAM of single-stream graphs: this HIP runtime replays a captured graph with two branches through
-            # the host -- hipGraphLaunch returned after 2/3 of the DEVICE time of the step (0.26 / 0.48 / 2.1 ms at 32 / 512 / 4096 frames
-            # against 24 us for a one-stream graph of the same kernels; tools/ubench/graph_branches.py: two independent 20-kernel chains
-            # replay in 139 us, host-bound, one 40-kernel chain in 77) -- and every cross-branch edge costs a 6-11 us gap.  A graph boundary
-            # on a lane costs ~15 us as well (the next graph's launch), so each lane is ONE graph and the lanes never meet inside a step:
-            #   actor's lane : features, lift, convolutions, read-out, fused loss kernel (actor terms only; the batch's advantage statistics
-            #                  are summed inside it), backward, fold, Adam over the actor's slice, fold + evaluation of the reported values;
-            #   critic's lane: features, the three forward stages, its OWN loss (clipped value loss: elementwise in the frame), the three
-            #                  backward stages, fold, Adam over the critic's slice.
-            # Actor and critic share no parameter and no intermediate (train.py:279-316 runs two backward passes and two optimizers); the
-            # lanes are forked at the step's start and joined at its end.
-            # (clipping needs the finished gradient norm first; gradients that reach .grad through torch's AccumulateGrad -- attention gate,
-            # stock transformer: exactly the cases without overwrite mode -- are not in the fold queue, so their parameters would be skipped)
-            fuse_tail = os.environ.get("GRL_FUSED_TAIL", "1") != "0" and not self.clip and ow
-            adam_args = lambda lo, hi, cnt: dict(grads=self.gflat[lo:hi], params=self.flat[lo:hi], exp_avg=self.exp_avg[lo:hi],
-                                                 exp_avg_sq=self.exp_avg_sq[lo:hi], lr_dev=self.lr_dev, betas=self.betas, eps=self.eps,
-                                                 step_dev=cnt)
+        def p_tail():   # behind the lane's collective: Adam on the reduced gradient, reported values of the delivered records
+            with torch.no_grad():
+                self._adam(st, 0, na, 0)
+                ent = m.entropy_coef if m.entropy_bonus else 0.0
+                o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
+                hip.call("grl_trpl_report_record_pairs", self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
+                st["lv_main"] = report_dict(o14)
 
-            def main_all():
-                m_prep()
-                st["step_bumped"] = True
-                actor.hyper_data.bump_next = self.step_dev   # the step count rides on the lane's first launch (grl_build_features_bump)
-                fold_ = a_head(None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
-                assert actor.hyper_data.bump_next is None, "the actor's feature launch did not take the step count"
-                with torch.no_grad():
-                    done = False
-                    if fuse_tail:   # fold + Adam + reported values: ONE launch at the lane's end (ops.fold_adam_report)
-                        o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
-                        ent = m.entropy_coef if m.entropy_bonus else 0.0
-                        done = ops.fold_adam_report(ow, adam_args(0, self.n_actor, self.step_dev),
-                                                    dict(slots=fold_.slots, batch=fold_.batch, sums=fold_.sums, maxes=fold_.maxes,
-                                                         ent_coef=ent, out14=o14))
-                        if done:
-                            ops.DEFERRED = None
-                            a_loss, mt = report_dict(o14)
-                    if not done:
-                        fold()
-                        adam(0, self.n_actor, 0)
-                        a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
-                    st.update(sums=fold_.sums, maxes=fold_.maxes, lv_main=(a_loss, mt))
+        def q_fwd1():
+            with torch.no_grad():
+                if not ow:
+                    self.gflat[na:].zero_()
+                vf.train(True)
+                _, x = vf.hyper_data.build_data(*[batch[k] for k in m.critic_in_features], train=True, bump=self.step_dev_c)
+                st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
+                st["pipe"].fwd1()
 
-            def critic_all():
-                ops.DEFERRED = []
-                with torch.no_grad():
-                    vf.train(True)
-                    _, x = vf.hyper_data.build_data(*st["cobs"], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
-                    pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
-                    pipe.fwd1()
-                    pipe.fwd2()
-                    value = st["value"] = pipe.fwd3()
-                    dvalue, c_loss, _ = value_loss(m, value, st["b"])
-                    pipe.bwd3(dvalue)
-                    pipe.bwd2()
-                    grads = pipe.bwd1(leaves)
-                    assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
-                    if not (fuse_tail and ops.fold_adam_report(ow, adam_args(self.n_actor, self.flat.numel(), self.step_dev_c))):
-                        ops.flush_deferred_grads(overwrite=ow)
-                        adam(self.n_actor, self.flat.numel(), 1, self.step_dev_c)
-                    ops.DEFERRED = None
-                    st["c_loss"] = c_loss
+        def q_fwd2():
+            st["pipe"].fwd2()
 
-            def finish():
-                a_loss, mt = st.pop("lv_main")
-                mt = dict(mt)
-                out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": st.pop("c_loss"), "loc": st["loc"], "sigma": st["sigma"],
-                       "state_value": st["value"].unsqueeze(-1)}
-                out.update(mt)
-                st["out"] = out
+        def q_fwd3():
+            with torch.no_grad():
+                st["value"] = st["pipe"].fwd3()
+                dvalue, _mean, out2 = value_loss(m, st["value"], batch)
+                st["vl"] = out2
+                st["pipe"].bwd3(dvalue)
 
-            # (finish only builds the dict of output views: it records nothing; kept as a "run" so that eager steps execute it too)
-            return [("fork", None), ("run", main_all), ("run", critic_all, S), ("join", None), ("run_host", finish)]
-        # ---- several ranks, round 4: the lanes do not meet inside a step here either.  The critic's lane carries ALL of the critic -- its four
-        #      LayerNorm-statistic reductions, its own loss (value_loss: elementwise in the frame), the all-reduce of ITS slice of the flat
-        #      gradient and its optimizer step -- on a communicator of its own (collectives of one communicator execute in issue order on
-        #      one internal stream: a critic reduction that waits for a critic kernel would hold back the actor's gradient all-reduce
-        #      issued behind it).  The actor's lane: statistics of the advantages (all-reduced: 16 bytes) | forward, fused loss kernel
-        #      (actor terms), backward, fold | all-reduce of the actor's slice, all-gather of the ranks' loss records (one collective
-        #      for sums and maxes) | Adam, reported values: THREE graphs and three collectives on its path (round 3: five graphs, two
-        #      joins with the critic's lane, one synchronous + two asynchronous collectives and a wait).
-        #      (collectives carry a label as fourth entry: PolicyUpdater.collective_log / bench.py's N > 1 line report them by name)
-        if os.environ.get("GRL_DP_JOINED", "0") == "0":
-            na, n_all = self.n_actor, self.flat.numel()
-            # ``adv_stats`` in the batch ([B, 2] fp64, every row = the GLOBAL (sum, sum of squares) of this minibatch's advantages:
-            # rollout.RolloutDriver.publish_advantage_stats, one all-reduce per EPOCH): the statistics kernel, its all-reduce and the graph
-            # boundary behind it leave the actor's lane -- two graphs and two collectives on its path.
-            published = m.normalize_advantage and "adv_stats" in batch
+        def q_bwd2():
+            st["pipe"].bwd2()
 
-            def p_stats():   # (each lane zeroes its own slice of the flat gradient when the folds accumulate)
-                m_prep(self.gflat[:na])
-                st["adv"] = None
-                if published:
-                    st["adv"] = batch["adv_stats"][0]
-                elif m.normalize_advantage and st["obs"][0].shape[0] * world > 1:
-                    with torch.no_grad():
-                        st["adv"] = st["zw"][8:10]
-                        adv_stats_local(m, st["b"], st["adv"])
+        def q_bwd1():
+            keep = ops.DEFERRED
+            ops.DEFERRED = []          # the critic's slabs are folded here, on its lane, into its slice of the flat gradient
+            with torch.no_grad():
+                grads = st["pipe"].bwd1(leaves)
+                ops.flush_deferred_grads(overwrite=ow)
+            ops.DEFERRED = keep
+            assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
 
-            def p_main():
-                if published:
-                    p_stats()
-                st["step_bumped"] = True
-                actor.hyper_data.bump_next = self.step_dev
-                fold_ = a_head(st["adv"], False)
-                assert actor.hyper_data.bump_next is None
-                with torch.no_grad():
-                    # this rank's loss sums / maxes as ONE record of float pairs in front of the flat gradient (own row, zeros in the
-                    # others): the SUM all-reduce of the actor's slice delivers every rank's record -- no collective of their own
-                    hip.call("grl_trpl_fold_record_pairs", fold_.slots, fold_.batch, self.rank, world, self.gbuf[:self._rec])
-                st.update(sums=fold_.sums, maxes=fold_.maxes)
-                fold()
+        def q_tail():
+            with torch.no_grad():
+                self._adam(st, na, n_all, 1, self.step_dev_c)
+                st["c_loss"] = st["vl"][1].float()   # (the all-reduced sum of the ranks' shares, already divided by B_global)
 
-            def p_tail():   # behind the two collectives of the lane: Adam on the reduced gradient, reported values of the gathered records
-                with torch.no_grad():
-                    adam(0, na, 0)
-                    ent = m.entropy_coef if m.entropy_bonus else 0.0
-                    o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
-                    hip.call("grl_trpl_report_record_pairs", self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
-                    a_loss, mt = report_dict(o14)
-                    st["lv_main"] = (a_loss, None, mt)
-
-            def q_fwd1():
-                with torch.no_grad():
-                    if not ow:
-                        self.gflat[na:].zero_()
-                    vf.train(True)
-                    _, x = vf.hyper_data.build_data(*[batch[k] for k in m.critic_in_features], train=True, bump=self.step_dev_c)
-                    st["pipe"] = ops.DeepSetsPipeline(x, leaves, world)
-                    st["pipe"].fwd1()
-
-            def q_fwd3():
-                with torch.no_grad():
-                    st["value"] = st["pipe"].fwd3()
-                    dvalue, _mean, out2 = value_loss(m, st["value"], batch)
-                    st["vl"] = out2
-                    st["pipe"].bwd3(dvalue)
-
-            def q_bwd1():
-                keep = ops.DEFERRED
-                ops.DEFERRED = []          # the critic's slabs are folded here, on its lane, into its slice of the flat gradient
-                with torch.no_grad():
-                    grads = st["pipe"].bwd1(leaves)
-                    ops.flush_deferred_grads(overwrite=ow)
-                ops.DEFERRED = keep
-                assert all(g is None for g in grads), "critic parameters must own .grad views of the flat buffer"
-
-            def q_tail():
-                with torch.no_grad():
-                    adam(na, n_all, 1, self.step_dev_c)
-                    st["c_loss"] = st["vl"][1].float()   # (the all-reduced sum of the ranks' shares, already divided by B_global)
-
-            def finish_dp():
-                a_loss, _c, mt = st.pop("lv_main")
-                mt = dict(mt)
-                out = {"loss_objective": mt.pop("loss_objective_value"), "loss_critic": st.pop("c_loss"), "loc": st["loc"], "sigma": st["sigma"],
-                       "state_value": st["value"].unsqueeze(-1)}
-                out.update(mt)
-                st["out"] = out
-
-            # (host order = enqueue order: the critic's segments are interleaved so that its lane is fed early; each lane's own order is what
-            #  the device sees.  p_stats comes first: it also prepares the step's inputs for both lanes.)
-            head_ = [] if published else [("run", p_stats), ("sum", lambda: st["adv"], "m", "advantage_stats")]
-            return [("fork", None), *head_,
-                    ("run", q_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"),
-                    ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"),
-                    ("run", p_main),
-                    ("sum", lambda: self.gbuf[:self._rec + na], "m", "flat_gradient_actor+loss_records"),
-                    ("run", q_fwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"),
-                    ("run", s3, S), ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
-                    ("run", p_tail),
-                    ("run", q_bwd1, S), ("sum", lambda: self.gflat[na:], S, "flat_gradient_critic"), ("sum", lambda: st["vl"], S, "loss_critic_sum"),
-                    ("run", q_tail, S),
-                    ("join", None, "m", "join_critic_lane"), ("run_host", finish_dp)]
-
-        # ---- the joined form of rounds 2-3 (GRL_DP_JOINED=1): the critic's lane is forked after the input preparation and after the
-        #      fused loss kernel and joined in front of both
-        plan = [("run", m_prep), ("fork", None),
-                ("run", c_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"), ("sum", lambda: st["adv"], S, "advantage_stats"),
-                ("run", a_fwd),
-                ("run", s1, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"), ("run", c_fwd3, S),
-                ("join", None, "m", "join_critic_forward"),
-                ("run", head), ("fork", None),
-                ("run", c_bwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"), ("run", s3, S),
-                ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
-                ("run", c_bwd1, S),
-                ("sum_async", lambda: st["sums"], "m", "loss_sums"), ("max_async", lambda: st["maxes"], "m", "loss_maxes"),   # loss terms: already scaled by 1/B_global
-                ("run", a_bwd),
-                ("join", None, "m", "join_critic_backward"), ("wait", None, "m", "wait_async_loss_terms"),
-                ("run", fold), ("sum", lambda: self.gflat, "m", "flat_gradient")]
-        plan += [("run", s5)]
-        return plan
-
-    def _fold_stream(self):
-        if getattr(self, "_fstream", None) is None:
-            self._fstream = torch.cuda.Stream()
-        return self._fstream
+        # (host order = enqueue order: the critic's segments are interleaved so that its lane is fed early; each lane's own order is what
+        #  the device sees.  p_stats comes first when present: it also prepares the step's inputs for both lanes.)
+        head_ = [] if published else [("run", p_stats), ("sum", lambda: st["adv"], "m", "advantage_stats")]
+        return [("fork", None), *head_,
+                ("run", q_fwd1, S), ("sum", lambda: st["pipe"].stats1, S, "critic_ln1_fwd_stats"),
+                ("run", q_fwd2, S), ("sum", lambda: st["pipe"].stats2, S, "critic_ln2_fwd_stats"),
+                ("run", p_main),
+                ("sum", lambda: self.gbuf[:self._rec + na], "m", "flat_gradient_actor+loss_records"),
+                ("run", q_fwd3, S), ("sum", lambda: st["pipe"].bst2, S, "critic_ln2_bwd_stats"),
+                ("run", q_bwd2, S), ("sum", lambda: st["pipe"].bst1, S, "critic_ln1_bwd_stats"),
+                ("run", p_tail),
+                ("run", q_bwd1, S), ("sum", lambda: self.gflat[na:], S, "flat_gradient_critic"), ("sum", lambda: st["vl"], S, "loss_critic_sum"),
+                ("run", q_tail, S),
+                ("join", None, "m", "join_critic_lane"), ("run_host", lambda: self._finish(st))]
 
     def _critic_stream(self):
         if getattr(self, "_cstream", None) is None:
             # the LOWEST priority the device offers: the critic's small launches take the compute units the actor's kernels leave (heads,
             # tails, the latency-bound loss kernel) instead of displacing their workgroups (DESIGN.md finding 33)
             prio = 0
-            if os.environ.get("GRL_CRITIC_PRIO", "1") != "0" and hasattr(torch.cuda.Stream, "priority_range"):
+            if hasattr(torch.cuda.Stream, "priority_range"):
                 try:
                     prio = max(torch.cuda.Stream.priority_range())
                 except Exception:
@@ -742,32 +577,15 @@ class PolicyUpdater:
         return out
 
     def _reduce(self, kind, t, label=None, lane="m"):
+        """A collective of the program: "sum" all-reduce of ``t`` on the lane's communicator (the critic's lane: ``group_c``)."""
         import torch.distributed as dist
-        group = self.group_c if (lane == "s" and self.group_c is not None) else self.group
-        if kind == "wait":
-            with self._log_span(label):
-                for w in self._pending:
-                    w.wait()
-            self._pending = []
-            return
         if t is None:
             return
-        if kind == "gather":   # t = (out [world, n], in [n])
-            out_t, in_t = t
-            with self._log_span(label or kind, in_t.numel() * in_t.element_size()):
-                if dist.get_backend(group) == "nccl":
-                    dist.all_gather_into_tensor(out_t, in_t, group=group)
-                else:   # (gloo: the list form; rows of out_t are contiguous views)
-                    dist.all_gather(list(out_t.unbind(0)), in_t, group=group)
-            return
-        nbytes = t.numel() * t.element_size()
-        if kind in ("sum_async", "max_async"):
-            op = dist.ReduceOp.SUM if kind == "sum_async" else dist.ReduceOp.MAX
-            with self._log_span((label or kind) + " (issue only: asynchronous)", nbytes):
-                self._pending.append(dist.all_reduce(t, op=op, group=group, async_op=True))
-            return
-        with self._log_span(label or kind, nbytes):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == "sum" else dist.ReduceOp.MAX, group=group)
+        if kind != "sum":
+            raise ValueError(f"unknown program entry '{kind}'")
+        group = self.group_c if (lane == "s" and self.group_c is not None) else self.group
+        with self._log_span(label or kind, t.numel() * t.element_size()):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     def _compile(self, batch):
         """Record the plan's segments into hipGraphs (adjacent segments without a reduction between them share one graph)."""
@@ -898,7 +716,23 @@ class PolicyUpdater:
         if not self.use_graph or B not in seen:     # the first step of a minibatch size always runs eagerly: it builds the
             seen.add(B)                             # cached topology of that size and the kernels' one-time attributes
             st = {}
-            self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m", e[3] if len(e) > 3 else None) for e in self._plan(batch, st)])
+            hooks, torch_fed = [], []
+            if not self._overwrite_checked:
+                # overwrite mode (no zeroing launch) is only right while NO leaf gradient arrives through torch's AccumulateGrad, which would
+                # add into a never-zeroed .grad: a hook on a leaf fires exactly for such a gradient (ops' backward functions hand None to
+                # autograd for the leaves whose slabs they queue).  Checked once, on the first eager step.
+                hooks = [p.register_hook(lambda g, i=i: torch_fed.append(i)) for i, p in enumerate(self.params)]
+            try:
+                self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m", e[3] if len(e) > 3 else None) for e in self._plan(batch, st)])
+            finally:
+                for h in hooks:
+                    h.remove()
+            if hooks:
+                self._overwrite_checked = True
+                if torch_fed:
+                    raise RuntimeError(f"{len(set(torch_fed))} parameter(s) received their gradient from torch autograd instead of the fold queue "
+                                       "while PolicyUpdater runs in overwrite mode (their .grad is never zeroed): this model must be added to "
+                                       "the exceptions of PolicyUpdater._fold_overwrite")
             return st["out"]
         if self._program is not None and (any(self._static[k].shape != batch[k].shape for k in self._static if k in batch)
                                           or ("adv_stats" in batch) != ("adv_stats" in self._static)):
@@ -923,34 +757,10 @@ class PolicyUpdater:
         self._execute(self._program)
         return self._st["out"]
 
-    def _actor_stream(self):
-        """One rank, two lanes: the actor's lane runs on a stream of its own with the HIGHEST priority the device offers (the critic's lane
-        keeps the default): when both lanes have workgroups to place, the actor's go first, and the critic's small launches take what the
-        actor's kernels leave -- their heads and tails, the latency-bound loss kernel -- instead of sitting on compute units the first edge
-        convolution then finds occupied (DESIGN.md finding 33: 319 -> 382 us for that launch at 4096 frames with both lanes at one priority)."""
-        if getattr(self, "_astream", None) is None:
-            prio = 0
-            # MEASURED round 4 (tools/prio_ab.sh, one box) and left OFF: 32 / 512 frames 0.370 -> 0.409 / 0.705 -> 0.736 ms per step, 4096
-            # frames 3.195 -> 3.196, cloth 5.42 -> 5.48, EMPN 4.80 -> 4.91: the two extra stream hand-overs per step (caller -> own stream
-            # -> caller) cost more than the priority buys -- the critic's resident workgroups are not evicted by it
-            if os.environ.get("GRL_ACTOR_PRIO", "0") != "0" and hasattr(torch.cuda.Stream, "priority_range"):
-                try:
-                    prio = min(torch.cuda.Stream.priority_range())
-                except Exception:
-                    prio = 0
-            self._astream = torch.cuda.Stream(priority=prio) if prio != 0 else False
-            self._astream_priority = prio
-        return self._astream or None
-
     def _execute(self, program):
-        """Run a program: ("run" closure | "graph" replay | collective | "fork" | "join" | "wait", item, lane).  Lane "m" is the
-        caller's stream (one rank with two lanes: a high-priority stream of the updater's, joined back into the caller's at the end), lane
-        "s" the critic stream; "fork": the side lane waits for the main lane, "join": the reverse."""
-        caller = torch.cuda.current_stream()
-        own = self._actor_stream() if (self._lanes and self.group is None and self.overlap_critic) else None   # (off by default)
-        main = own or caller
-        if own is not None:
-            own.wait_stream(caller)
+        """Run a program: ("run" closure | "graph" replay | "sum" collective | "fork" | "join", item, lane, label).  Lane "m" is the
+        caller's stream, lane "s" the critic's stream; "fork": the side lane waits for the main lane, "join": the reverse."""
+        main = torch.cuda.current_stream()
         side = None
         for kind, item, lane, label in program:
             if kind in ("fork", "join"):
@@ -965,13 +775,8 @@ class PolicyUpdater:
                 side = side or self._critic_stream()
                 with torch.cuda.stream(side):
                     self._do(kind, item, label, lane)
-            elif own is not None:
-                with torch.cuda.stream(own):
-                    self._do(kind, item, label)
             else:
                 self._do(kind, item, label)
-        if own is not None:
-            caller.wait_stream(own)
 
     def _do(self, kind, item, label=None, lane="m"):
         if kind in ("run", "run_host"):

@@ -521,191 +521,6 @@ __global__ __launch_bounds__(TRPL_FPB * L) void trpl_lanes_kernel(TrplCfg cfg, T
   trpl_lanes_body<L, PROJ, TRPL_FPB * L>(cfg, q_, B, (int)blockIdx.x, (int)threadIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------ read-out + loss + read-out backward, ONE launch
-// (round 4).  readout_fwd -> trpl_lanes -> readout_bwd were three launches on the step's chain (8 + 12 + 12 us at 32
-// frames: latency, not work).  A workgroup of 16 waves takes the 16 frames of one TRPL slot record: (1) a wave per actuator node: decoder,
-// orientation pooling, std head -> the frames' loc / sigma rows in LDS (and to the caller's arrays); (2) the first 16 L threads run the
-// loss body on the LDS rows, d loc / d sigma stay in LDS; (3) a wave per node again: the read-out backward, the waves' weight-gradient
-// sums folded in a fixed order into ONE partial row per workgroup (layout of readout_bwd_kernel).  Same arithmetic per node and per frame as
-// the three kernels (bitwise the same loc / sigma / d lat; the weight gradients differ by the grouping of their partial rows).
-constexpr int HF_WAVES = 16;
-struct HeadParams {
-  const float *lat, *grid, *Wd, *bd, *Ws, *bs;
-  float shift, min_std;
-  float *mean_out, *sigma_out, *dlat, *partial;
-  int n_nodes, od, ov, npf;   // npf: actuator nodes per frame (node n = frame * npf + g)
-};
-template <int L, int PROJ>
-__global__ __launch_bounds__(64 * HF_WAVES) void head_fused_kernel(HeadParams hp, TrplCfg cfg, TrplPtrs tq, int B) {
-  __shared__ float ms[4][TRPL_FPB * 16];                     // loc, sigma, d loc, d sigma of this workgroup's frames: [frame][A]
-  __shared__ float red[HF_WAVES / 2][2 * (JMAX + APER_MAX)][C];
-  const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;
-  const int od = hp.od, ov = hp.ov, J = od + ov, aper = 3 * ov;
-  const int node0 = (int)blockIdx.x * TRPL_FPB * hp.npf;
-  const int nn = min(TRPL_FPB * hp.npf, hp.n_nodes - node0);
-  const float* __restrict__ grid = hp.grid;
-  float wd[JMAX], ws[APER_MAX], bdv[JMAX], bsv[APER_MAX];
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) { wd[j] = j < J ? hp.Wd[j * C + c] : 0.f; bdv[j] = j < J ? hp.bd[j] : 0.f; }
-#pragma unroll
-  for (int a = 0; a < APER_MAX; ++a) { ws[a] = a < aper ? hp.Ws[a * C + c] : 0.f; bsv[a] = a < aper ? hp.bs[a] : 0.f; }
-  float sgx = 0.f, sgy = 0.f, sgz = 0.f;
-#pragma unroll
-  for (int o = 0; o < O; ++o) { sgx += grid[3 * o]; sgy += grid[3 * o + 1]; sgz += grid[3 * o + 2]; }
-  // ---- (1) read-out forward (readout_fwd_kernel's node, line by line)
-  for (int q = wave; q < nn; q += HF_WAVES) {
-    const int n = node0 + q;
-    const float* l = hp.lat + (size_t)n * O * C + c;
-    float hsum = 0.f, lgx = 0.f, lgy = 0.f, lgz = 0.f;
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-      const float v = l[o * C];
-      hsum += v;
-      lgx += v * grid[3 * o]; lgy += v * grid[3 * o + 1]; lgz += v * grid[3 * o + 2];
-    }
-    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f}, vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f}, vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      if (j < od) sc[j] = wave_sum(hsum * wd[j]) + O * bdv[j];
-      else if (j < J) {
-        vx[j - od] = wave_sum(lgx * wd[j]) + bdv[j] * sgx;
-        vy[j - od] = wave_sum(lgy * wd[j]) + bdv[j] * sgy;
-        vz[j - od] = wave_sum(lgz * wd[j]) + bdv[j] * sgz;
-      }
-    }
-    const float hid = hsum * (1.f / O);
-#pragma unroll
-    for (int a = 0; a < APER_MAX; ++a) {
-      if (a < aper) {
-        const float pre = wave_sum(hid * ws[a]) + bsv[a];
-        if (c == 0) {
-          const float sg = softplus_f(pre + hp.shift) + hp.min_std;
-          ms[1][q * aper + a] = sg;
-          hp.sigma_out[(size_t)n * aper + a] = sg;
-        }
-      }
-    }
-    if (c == 0) {
-      for (int v = 0; v < ov; ++v) {
-        const float s_ = sc[v] * (1.f / O);
-        const float m0 = vx[v] * (1.f / O) * s_, m1 = vy[v] * (1.f / O) * s_, m2 = vz[v] * (1.f / O) * s_;
-        ms[0][q * aper + 3 * v] = m0; ms[0][q * aper + 3 * v + 1] = m1; ms[0][q * aper + 3 * v + 2] = m2;
-        float* mo = hp.mean_out + ((size_t)n * ov + v) * 3;
-        mo[0] = m0; mo[1] = m1; mo[2] = m2;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- (2) the loss on the LDS rows
-  TrplPtrs t2 = tq;
-  t2.mean = ms[0]; t2.sigma = ms[1]; t2.dmean = ms[2]; t2.dsigma = ms[3];
-  t2.ms_row0 = (int)blockIdx.x * TRPL_FPB;
-  trpl_lanes_body<L, PROJ, 64 * HF_WAVES>(cfg, t2, B, (int)blockIdx.x, tid);
-  __syncthreads();
-  // ---- (3) read-out backward (readout_bwd_kernel's node, line by line; no external hidden gradient on this path)
-  float dwd[JMAX], dws[APER_MAX], dbd[JMAX], dbs[APER_MAX];
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) { dwd[j] = 0.f; dbd[j] = 0.f; }
-#pragma unroll
-  for (int a = 0; a < APER_MAX; ++a) { dws[a] = 0.f; dbs[a] = 0.f; }
-  for (int q = wave; q < nn; q += HF_WAVES) {
-    const int n = node0 + q;
-    const float* l = hp.lat + (size_t)n * O * C + c;
-    float lv[O], hsum = 0.f, lgx = 0.f, lgy = 0.f, lgz = 0.f;
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-      lv[o] = l[o * C];
-      hsum += lv[o];
-      lgx += lv[o] * grid[3 * o]; lgy += lv[o] * grid[3 * o + 1]; lgz += lv[o] * grid[3 * o + 2];
-    }
-    float sc[JMAX] = {0.f, 0.f, 0.f, 0.f}, vx[JMAX] = {0.f, 0.f, 0.f, 0.f}, vy[JMAX] = {0.f, 0.f, 0.f, 0.f}, vz[JMAX] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      if (j < od) sc[j] = wave_sum(hsum * wd[j]) + O * bdv[j];
-      else if (j < J) {
-        vx[j - od] = wave_sum(lgx * wd[j]) + bdv[j] * sgx;
-        vy[j - od] = wave_sum(lgy * wd[j]) + bdv[j] * sgy;
-        vz[j - od] = wave_sum(lgz * wd[j]) + bdv[j] * sgz;
-      }
-    }
-    const float hid = hsum * (1.f / O);
-    float dhid = 0.f;
-#pragma unroll
-    for (int a = 0; a < APER_MAX; ++a) {
-      if (a < aper) {
-        const float pre = wave_sum(hid * ws[a]) + bsv[a];
-        const float dpre = ms[3][q * aper + a] * sigmoid_f(pre + hp.shift);
-        dws[a] += dpre * hid;
-        dbs[a] += dpre;
-        dhid += dpre * ws[a];
-      }
-    }
-    float ds[JMAX] = {0.f, 0.f, 0.f, 0.f}, dvx[JMAX], dvy[JMAX], dvz[JMAX];
-#pragma unroll
-    for (int v = 0; v < JMAX; ++v) {
-      dvx[v] = dvy[v] = dvz[v] = 0.f;
-      if (v < ov) {
-        const float s_ = sc[v] * (1.f / O);
-        const float* dm = ms[2] + q * aper + 3 * v;
-        ds[v] = (dm[0] * vx[v] + dm[1] * vy[v] + dm[2] * vz[v]) * (1.f / O);
-        dvx[v] = dm[0] * s_; dvy[v] = dm[1] * s_; dvz[v] = dm[2] * s_;
-      }
-    }
-    float* dl = hp.dlat + (size_t)n * O * C + c;
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-      const float gx = grid[3 * o], gy = grid[3 * o + 1], gz = grid[3 * o + 2];
-      float g = dhid * (1.f / O);
-#pragma unroll
-      for (int j = 0; j < JMAX; ++j) {
-        if (j < J) {
-          const float dy = (j < od) ? ds[j] * (1.f / O) : (dvx[j - od] * gx + dvy[j - od] * gy + dvz[j - od] * gz) * (1.f / O);
-          g += dy * wd[j];
-          dwd[j] += dy * lv[o];
-          dbd[j] += dy;
-        }
-      }
-      dl[o * C] = g;
-    }
-  }
-  // the sixteen waves' sums, fixed order: 8..15 onto 0..7, 4..7 onto 0..3, then 1, 2, 3 onto 0
-  auto put = [&](int slot_) {
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) { red[slot_][j][c] = dwd[j]; red[slot_][JMAX + j][c] = dbd[j]; }
-#pragma unroll
-    for (int a = 0; a < APER_MAX; ++a) { red[slot_][2 * JMAX + a][c] = dws[a]; red[slot_][2 * JMAX + APER_MAX + a][c] = dbs[a]; }
-  };
-  auto add = [&](int slot_) {
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) { dwd[j] += red[slot_][j][c]; dbd[j] += red[slot_][JMAX + j][c]; }
-#pragma unroll
-    for (int a = 0; a < APER_MAX; ++a) { dws[a] += red[slot_][2 * JMAX + a][c]; dbs[a] += red[slot_][2 * JMAX + APER_MAX + a][c]; }
-  };
-  if (wave >= 8) put(wave - 8);
-  __syncthreads();
-  if (wave < 8) add(wave);
-  __syncthreads();
-  if (wave >= 4 && wave < 8) put(wave - 4);
-  __syncthreads();
-  if (wave < 4) add(wave);
-  __syncthreads();
-  if (wave >= 1 && wave < 4) put(wave);
-  __syncthreads();
-  if (wave != 0) return;
-  add(1); add(2); add(3);
-  float* out = hp.partial + (size_t)blockIdx.x * RO_PARTIAL;
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) out[j * C + c] = dwd[j];
-#pragma unroll
-  for (int a = 0; a < APER_MAX; ++a) out[JMAX * C + JMAX + a * C + c] = dws[a];
-  if (c == 0) {
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) out[JMAX * C + j] = dbd[j];
-#pragma unroll
-    for (int a = 0; a < APER_MAX; ++a) out[JMAX * C + JMAX + APER_MAX * C + a] = dbs[a];
-  }
-}
-
 // slots [n_blocks][14] -> sums[12] (written, not accumulated) and maxes[2] (float bits); fixed order (grl_report.h trpl_fold_columns)
 constexpr int FOLD_NT = 256;
 __global__ __launch_bounds__(FOLD_NT) void trpl_fold_kernel(const double* __restrict__ slots, int n_blocks, double* __restrict__ sums,
@@ -928,41 +743,6 @@ int grl_trpl_fwd_bwd(const double* cfg9, int action_dim, const float* mean, cons
                      unsigned int* maxes, double* slots, int batch, hipStream_t stream) {
   return trpl_launch(cfg9, action_dim, mean, sigma, action, old_mean, old_var, old_logp, advantage, value, old_value, value_target,
                      dmean, dsigma, dvalue, proj_mean, proj_var, adv_stats, sums, maxes, slots, nullptr, nullptr, batch, stream);
-}
-
-// Read-out forward + fused loss (actor terms) + read-out backward in ONE launch (head_fused_kernel): lat [n_nodes,16,64] with
-// n_nodes = batch * nodes_per_frame and action_dim = nodes_per_frame * 3 * ov.  Writes mean [n_nodes, ov, 3] (= loc [batch, A]), sigma
-// [n_nodes, 3 ov], d lat, one partial row of grl_readout_partial_size() floats per 16 frames (grl_head_fused_rows(batch) rows) and the
-// loss kernel's slot records.  cfg9 / adv_stats as grl_trpl_fwd_bwd (no value terms: the critic's share is grl_value_loss).
-int grl_head_fused_rows(int batch) { return trpl_blocks(batch) < 1 ? 1 : trpl_blocks(batch); }
-int grl_head_fused(const double* cfg9, int action_dim, const float* lat, const float* grid, const float* Wd, const float* bd,
-                   const float* Ws, const float* bs, float shift, float min_std, int n_nodes, int od, int ov, int nodes_per_frame,
-                   const float* action, const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
-                   const double* adv_stats, float* mean_out, float* sigma_out, float* dlat, float* partial, double* slots, int batch,
-                   hipStream_t stream) {
-  if (batch < 1 || nodes_per_frame < 1 || n_nodes != batch * nodes_per_frame || action_dim != nodes_per_frame * 3 * ov) return -2;
-  if (action_dim > 16 || od + ov > JMAX || 3 * ov > APER_MAX || od < 1 || ov < 1 || !slots || !partial || !dlat) return -2;
-  TrplCfg c{cfg9[0], cfg9[1], cfg9[2], cfg9[3], cfg9[4], cfg9[5], cfg9[6], cfg9[7], action_dim, (int)cfg9[9]};
-  const int proj = (int)cfg9[8];
-  if (proj < 0 || proj > 2) return -3;
-  const HeadParams hp{lat, grid, Wd, bd, Ws, bs, shift, min_std, mean_out, sigma_out, dlat, partial, n_nodes, od, ov, nodes_per_frame};
-  const TrplPtrs tp{nullptr, nullptr, action, old_mean, old_var, old_logp, advantage, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                    nullptr, nullptr, adv_stats, slots, nullptr, nullptr, 0};
-#define GRL_HEAD_LAUNCH(LL, PJ) \
-  hipLaunchKernelGGL((head_fused_kernel<LL, PJ>), dim3(trpl_blocks(batch)), dim3(64 * HF_WAVES), 0, stream, hp, c, tp, batch)
-#define GRL_HEAD_WIDTH(PJ)                                        \
-  do {                                                            \
-    if (action_dim <= 4) GRL_HEAD_LAUNCH(4, PJ);                  \
-    else if (action_dim <= 8) GRL_HEAD_LAUNCH(8, PJ);             \
-    else GRL_HEAD_LAUNCH(16, PJ);                                 \
-  } while (0)
-  if (proj == 0) GRL_HEAD_WIDTH(0);
-  else if (proj == 1) GRL_HEAD_WIDTH(1);
-  else GRL_HEAD_WIDTH(2);
-#undef GRL_HEAD_WIDTH
-#undef GRL_HEAD_LAUNCH
-  GRL_CHECK_LAUNCH();
-  return 0;
 }
 
 // Boundary methods of the projection layer (base_projection_layer.py:292-327 get_trust_region_loss, :332-384 compute_metrics) for

@@ -684,9 +684,6 @@ int GRL_ENTRY(grl_node_mlp_fwd)(const st_t* x2, const st_t* x_dst, const float* 
 int GRL_ENTRY(grl_node_mlp_bwd16_launch)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4,
                                          const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, int blocks,
                                          const void* wimg, hipStream_t stream);
-int GRL_ENTRY(grl_node_mlp_bwd16w8_launch)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4,
-                                           const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, int blocks,
-                                           const void* wimg, hipStream_t stream);
 int GRL_ENTRY(grl_node_mlp_bwd_img)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, st_t* dx2, float* partial, int n_rows, const void* wimg, hipStream_t stream);
 int GRL_ENTRY(grl_node_mlp_bwd)(const st_t* x2, const st_t* dout, const float* W3, const float* b3, const float* W4, const float* b4,
@@ -703,14 +700,6 @@ int GRL_ENTRY(grl_node_mlp_bwd_img)(const st_t* x2, const st_t* dout, const floa
   }
   if (GRL_MLP_BWD16 && n_rows % 16 == 0) {
     grl_prof_begin_replay("node_mlp_bwd16_kernel", stream);
-    // GRL_MLP_BWD_W8=1: the eight-wave form (node_mlp16w8.hip; two waves per SIMD).  Correct, and SLOWER in both builds (DESIGN.md
-    // finding 47: 0.77 -> 2.50 ms per step split-bf16, 1.69 -> 2.29 ms plain bf16): kept as the reproducible half of that finding
-    static const bool w8 = getenv("GRL_MLP_BWD_W8") && atoi(getenv("GRL_MLP_BWD_W8")) != 0;
-    if (w8) {
-      const int rc8 = GRL_ENTRY(grl_node_mlp_bwd16w8_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), wimg, stream);
-      grl_prof_end_replay(stream);
-      return rc8;
-    }
     const int rc = GRL_ENTRY(grl_node_mlp_bwd16_launch)(x2, dout, W3, b3, W4, gamma, beta, dx2, partial, n_rows, grl_node_mlp_bwd_blocks(n_rows), wimg, stream);
     grl_prof_end_replay(stream);
     return rc;

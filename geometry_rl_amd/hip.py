@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
 ABI_VERSION = 203   # include/grl_hip.h GRL_HIP_VERSION
-SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "node_mlp16w8.hip", "head_ops.hip",
+SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "head_ops.hip",
            "critic_ops.hip", "train_ops.hip", "weight_images.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
@@ -31,7 +31,6 @@ FILE_FLAGS = {"edge_conv16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-
               "node_mlp.hip": ["-fno-slp-vectorize", "-DGRL_GELU4_SCALAR=1"]}
 VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_mlp.hip", ["-DGRL_PREC=1"], ".bf16"), ("node_mlp16.hip", ["-DGRL_PREC=1"], ".bf16"),
-            ("node_mlp16w8.hip", ["-DGRL_PREC=1"], ".bf16"),
             ("node_ops.hip", ["-DGRL_PREC=1"], ".bf16"), ("weight_images.hip", ["-DGRL_PREC=1"], ".bf16")]
 
 
@@ -48,45 +47,72 @@ def build(verbose: bool = True, force: bool = False) -> str:
         raise RuntimeError("GRL_DIAG (timing knock-outs: wrong results) must never be built into libgrl_hip.so -- use tools/build_variants.sh")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
-    def info(mode, rebuilt):
+    def info(mode, rebuilt, lint=None):
         try:
             with open(BUILD_INFO, "w") as f:
-                json.dump({"build_mode": mode, "objects_rebuilt": rebuilt, "objects_total": len(srcs) + len(VARIANTS), "library": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)),
+                json.dump({"build_mode": mode, "objects_rebuilt": rebuilt, "isa_lint": lint, "objects_total": len(srcs) + len(VARIANTS), "library": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)),
                            "library_bytes": os.path.getsize(LIB_PATH) if os.path.exists(LIB_PATH) else None, "abi_version": ABI_VERSION,
                            "forced": bool(force), "time": time.strftime("%Y-%m-%dT%H:%M:%S")}, f, indent=1)
         except OSError:
             pass
-    headers = [os.path.join(CSRC, h) for h in ("grl_common.h", "grl_tile16.h", "grl_wimg.h")]
+    headers = [os.path.join(CSRC, h) for h in ("grl_common.h", "grl_tile16.h", "grl_wimg.h", "grl_report.h")]
+    headers.append(os.path.join(os.path.dirname(_HERE), "include", "grl_hip.h"))   # (the export list is read from it)
     deps = srcs + headers + [os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         info("prebuilt (library newer than every source: nothing compiled)", [])
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    from . import isa_lint
     objs = []
     procs = []
     rebuilt = []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    lint_jobs = []   # (label, assembly file) of every object compiled NOW from a source with asm MFMAs
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
     jobs = [(s, [], "") for s in srcs] + [(os.path.join(CSRC, s), fl, sfx) for s, fl, sfx in VARIANTS]
     for s, flags, sfx in jobs:
-        o = os.path.join(CSRC, "build", os.path.basename(s) + sfx + ".o")
+        base = os.path.basename(s)
+        lint = base in isa_lint.FILES
+        # sources with asm MFMAs are compiled with -save-temps into a directory of their own: the assembly the REAL compile leaves behind
+        # is what the ISA lint reads (a different hipcc or different flags must not get past the hazard check)
+        odir = os.path.join(bdir, base + sfx + ".d") if lint else bdir
+        os.makedirs(odir, exist_ok=True)
+        o = os.path.join(odir, base + sfx + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d)
                                                     for d in [s] + headers + [os.path.abspath(__file__)]):
             continue
-        cmd = ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + FILE_FLAGS.get(os.path.basename(s), [])
-               + flags + ["-c", s, "-o", o])
+        cmd = ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + FILE_FLAGS.get(base, [])
+               + flags + (["-save-temps=obj"] if lint else []) + ["-c", s, "-o", o])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         rebuilt.append(os.path.basename(o))
-        procs.append((cmd, subprocess.Popen(cmd)))
+        if lint:
+            lint_jobs.append((base + sfx, os.path.join(odir, os.path.splitext(base)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s"), o))
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.DEVNULL if (lint and not verbose) else None)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    lint_report = {}
+    for label, asm, o in lint_jobs:
+        n, n_asm, bad = isa_lint.lint_assembly(asm)
+        lint_report[label] = {"kernels": n, "kernels_with_asm_mfma": n_asm, "findings": bad}
+        if bad or n_asm == 0:
+            os.remove(o)   # never leave an object behind that a later incremental build would link unchecked
+            raise RuntimeError(f"ISA lint of {label} failed (geometry_rl_amd/isa_lint.py): "
+                               + ("; ".join(bad) if bad else "no kernel with asm MFMAs found in the assembly -- the lint saw nothing"))
+    # exports = exactly the entry points include/grl_hip.h declares (cross-file helpers such as grl_edge16_launch stay internal)
+    import re
+    header = os.path.join(os.path.dirname(_HERE), "include", "grl_hip.h")
+    names = sorted(set(re.findall(r"\bint\s+(grl_[a-z0-9_]+)\s*\(", open(header).read())))
+    vs = os.path.join(bdir, "exports.map")
+    with open(vs, "w") as f:
+        f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in names) + "  local: *;\n};\n")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    info("compiled from source" if len(rebuilt) == len(objs) else "incremental (objects newer than their sources were kept)", rebuilt)
+    info("compiled from source" if len(rebuilt) == len(objs) else "incremental (objects newer than their sources were kept)", rebuilt, lint_report)
     return LIB_PATH
 
 

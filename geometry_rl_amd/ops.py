@@ -7,7 +7,6 @@ forward/backward kernel pair into autograd so the modules in ``geometry_rl_amd.m
 from dataclasses import dataclass
 from typing import Optional
 
-import os
 
 import torch
 
@@ -60,7 +59,6 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
     # step, -5.5 % at 1024 frames); in the forward 13 108 five-node chunks over 3 072 slots leave some waves five chunks, others four.
     # Functions of the topology alone: results stay reproducible.
     E = int(src.numel())
-    force = os.environ.get("GRL_EDGE_SPLIT_ALWAYS")
 
     def balanced_split(rowptr, n_anchor, slots, npw, tol):
         """Node boundaries [slots + 1] with ~E / slots edges per slot, or None where the slowest wave slot of the kernel's round-robin deal
@@ -69,11 +67,9 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         n_chunks = (n_anchor + npw - 1) // npw
         cb = (torch.arange(n_chunks + 1, device=dev, dtype=torch.int64) * npw).clamp_(max=n_anchor)
         load = torch.zeros(slots, device=dev, dtype=torch.int64).scatter_add_(0, torch.arange(n_chunks, device=dev) % slots, rp[cb[1:]] - rp[cb[:-1]])
-        if float(load.max()) * slots / E <= tol and not force:
+        if float(load.max()) * slots / E <= tol:
             return None
-        # cost of a node = its edges (one pass each) + NODE_COST passes for its own row loads / stores (the per-node part of a wave's work)
-        nc = float(os.environ.get("GRL_SPLIT_NODE_COST", "0"))
-        cum = rp.double() + nc * torch.arange(n_anchor + 1, device=dev, dtype=torch.float64)
+        cum = rp.double()   # cost of a node = its edges (one pass each)
         targets = torch.arange(slots + 1, device=dev, dtype=torch.float64) * (float(cum[-1]) / slots)
         split = torch.searchsorted(cum, targets).clamp_(max=n_anchor)
         split[0], split[-1] = 0, n_anchor
@@ -102,16 +98,9 @@ def _reduce(partial: torch.Tensor, out: torch.Tensor):
 
 # Deferred folding: while a list is installed here (PolicyUpdater does, around the backward), folds whose destinations are all
 # existing leaf ``.grad`` buffers are queued and executed by ONE launch (flush_deferred_grads) instead of one launch each.
-SPLIT_BACKWARD = os.environ.get("GRL_EDGE_SPLIT", "1") != "0"   # edge-balanced wave partition in the fused edge backward (EdgeSet.split_s)
-SPLIT_FORWARD = os.environ.get("GRL_EDGE_SPLIT_FWD", os.environ.get("GRL_EDGE_SPLIT", "1")) != "0"   # ... and in the forward (EdgeSet.split_d)
+SPLIT_BACKWARD = True   # edge-balanced wave partition in the fused edge backward (EdgeSet.split_s); module attributes, not environment
+SPLIT_FORWARD = True    # ... and in the forward (EdgeSet.split_d): tools flip them in-process for A/B runs
 DEFERRED = None
-# FOLD_STREAM (set by PolicyUpdater for one-rank steps): when not None, the queued folds of a backward op are launched at once on this side
-# stream, behind an event of the producing kernel, instead of waiting for the single launch at the end of the backward pass -- the
-# fold of a 34 MB partial slab then runs in the heads / tails of the following kernels (and beside the HBM-rate ones), and only the
-# last producer's fold is left on the critical path (the one launch at the end was a constant ~45 us per step at any batch size).
-# Folds into one destination are issued in program order on ONE stream: the summation order is fixed, the result reproducible.
-FOLD_STREAM = None
-_FOLD_KEEP = []   # partial slabs whose fold is in flight (kept alive until flush_deferred_grads joins the side stream)
 
 
 def _launch_folds(jobs, overwrite=False):
@@ -152,7 +141,7 @@ def fold_adam_report(overwrite, adam=None, report=None):
     import ctypes
     global DEFERRED
     jobs = DEFERRED or []
-    if len(jobs) > 64 or FOLD_STREAM is not None:
+    if len(jobs) > 64:
         return False
     by_dst = {}
     for j in jobs:
@@ -189,12 +178,6 @@ def flush_deferred_grads(overwrite=False, only=None):
         jobs = [j for j in jobs if only(j[3])]
     if DEFERRED is not None:
         DEFERRED = keep
-    if FOLD_STREAM is not None:
-        if jobs:
-            _launch_folds(jobs)
-        torch.cuda.current_stream().wait_stream(FOLD_STREAM)   # join: every fold has landed in the flat gradient
-        _FOLD_KEEP.clear()
-        return
     if jobs:
         _launch_folds(jobs, overwrite)
 
@@ -225,13 +208,7 @@ def _emit_grads(partial: torch.Tensor, segments):
     if DEFERRED is not None:
         jobs = [(partial, st, ln, d) for st, ln, d, f in zip(starts, lens, dsts, fresh_flags) if not f]
         now = [i for i, f in enumerate(fresh_flags) if f]
-        if FOLD_STREAM is not None and jobs:   # fold now, on the side stream, behind the kernel that has just been queued on this stream
-            FOLD_STREAM.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(FOLD_STREAM):
-                _launch_folds(jobs)
-            _FOLD_KEEP.append(partial)
-        else:
-            DEFERRED.extend(jobs)   # keeps `partial` alive until the flush
+        DEFERRED.extend(jobs)   # keeps `partial` alive until the flush
     for i0 in range(0, len(now), 8):
         idx = now[i0:i0 + 8]
         n = len(idx)
@@ -254,7 +231,7 @@ class WeightImages:
 
 
 WIMG_EDGE16, WIMG_EDGE32, WIMG_MLP_FWD, WIMG_MLP_BWD16 = 0, 1, 2, 3
-USE_WEIGHT_IMAGES = os.environ.get("GRL_WEIGHT_IMAGES", "1") != "0"   # A/B switch: 0 = every launch stages its weights itself (round 3)
+USE_WEIGHT_IMAGES = True   # module attribute (tests/test_gpu_weight_images.py flips it): False = every launch stages its weights itself
 
 
 @torch.no_grad()
@@ -379,10 +356,6 @@ class LiftEncodeMulti(torch.autograd.Function):
         return (None, dw, None) + (None,) * (2 * T)
 
 
-# One-shot hook(n_source_nodes) run in front of the NEXT edge convolution's launch (PolicyUpdater: join the critic's forward there -- see agent.py).
-PRE_EDGE_HOOK = None
-
-
 class EdgeConv(torch.autograd.Function):
     """x1[d] = sum_{e->d} Wk(basis_mlp(invariants_e)) * x_src[src(e)]   (reference hepi.py:145-157, conv.py:79-86,115-149)."""
 
@@ -394,10 +367,6 @@ class EdgeConv(torch.autograd.Function):
         ``wimg``: the block's pre-split weight images of this pass (``weight_images``), reused by the backward."""
         hip.check_f32(pos_src, pos_dst, grid3, w1, b1, w2, b2, wk)
         hip.check_latent(prec, x_src)
-        global PRE_EDGE_HOOK
-        if PRE_EDGE_HOOK is not None:
-            hook, PRE_EDGE_HOOK = PRE_EDGE_HOOK, None
-            hook(int(x_src.shape[0]))
         x1 = torch.empty(edges.n_dst, 16, 64, device=x_src.device, dtype=x_src.dtype)  # every row is written by the kernel
         args = [a.contiguous() for a in (w1, b1, w2, b2, wk)]
         sd = edges.split_d if SPLIT_FORWARD else None
@@ -842,47 +811,6 @@ def trpl_fwd_bwd(loc, sigma, batch, value, *, mean_bound, cov_bound, trust_regio
         fold.slots, fold.batch, fold.sums, fold.maxes = slots, B, sums, maxes   # (for a caller that folds and reports in one launch)
         return fold, maxes, dloc, dsigma, dvalue, pm, pv
     return sums, maxes, dloc, dsigma, dvalue, pm, pv
-
-
-def head_fused(lat, grid3, wd, bd, ws, bs, shift: float, min_std: float, od: int, ov: int, batch, *, mean_bound, cov_bound,
-               trust_region_coeff, entropy_coef, global_batch: int, adv_stats: Optional[torch.Tensor], sums, maxes, proj_type: int = 0,
-               adv_local: bool = False):
-    """Read-out forward + fused loss kernel (actor terms) + read-out backward in ONE launch (grl_head_fused): the three launches
-    ``Readout.forward`` -> ``trpl_fwd_bwd`` -> ``Readout.backward`` sat on the step's chain with ~10 us of latency each.  ``lat``
-    [B * G, 16, 64] (detached), parameters of the decoder / std head as the leaves that own ``.grad``: their partial rows go through
-    ``_emit_grads`` (queued while a DEFERRED list is installed).  Returns (fold, loc [B, A], sigma [B, A], dlat): ``fold`` as
-    ``trpl_fwd_bwd(defer_fold=True)`` returns it."""
-    import ctypes
-    hip.check_f32(lat, grid3, wd, bd, ws, bs)
-    n = lat.shape[0]
-    B = batch["action"].shape[0]
-    G = n // B
-    A = G * 3 * ov
-    dev = lat.device
-    cfg = (ctypes.c_double * 10)(mean_bound, cov_bound, trust_region_coeff, entropy_coef, 0.0, 0.0, 1.0 / global_batch, float(global_batch),
-                                 float(proj_type), 1.0 if adv_local else 0.0)
-    loc = torch.empty(B, A, device=dev, dtype=torch.float32)
-    sigma = torch.empty(B, A, device=dev, dtype=torch.float32)
-    dlat = torch.empty_like(lat)
-    rows, psize = hip.query("grl_head_fused_rows", B), hip.query("grl_readout_partial_size")
-    partial = torch.empty(rows, psize, device=dev, dtype=torch.float32)
-    slots = torch.empty(hip.query("grl_trpl_slot_doubles", B), device=dev, dtype=torch.float64)
-    f = lambda t: t.reshape(B, -1).contiguous() if t.dim() > 1 else t.contiguous()
-    hip.call("grl_head_fused", cfg, A, lat.contiguous(), grid3, wd.contiguous(), bd.contiguous(), ws.contiguous(), bs.contiguous(),
-             ctypes.c_float(float(shift)), ctypes.c_float(float(min_std)), n, od, ov, G, f(batch["action"]), f(batch["loc"]), f(batch["var"]),
-             batch["sample_log_prob"].reshape(B).contiguous(), batch["advantage"].reshape(B).contiguous(), adv_stats, loc, sigma, dlat,
-             partial, slots, B)
-    J, aper = od + ov, 3 * ov
-    outs = _emit_grads(partial, [(0, J * 64, (J, 64), wd), (256, J, (J,), bd), (260, aper * 64, (aper, 64), ws), (260 + 384, aper, (aper,), bs)])
-    for t, g in zip((wd, bd, ws, bs), outs):   # (leaves without a .grad view: eager callers outside PolicyUpdater)
-        if g is not None:
-            t.grad = g if t.grad is None else t.grad + g
-
-    def fold(sums=sums, maxes=maxes, slots=slots):
-        hip.call("grl_trpl_fold", slots, B, sums, maxes)
-        return sums, maxes
-    fold.slots, fold.batch, fold.sums, fold.maxes = slots, B, sums, maxes
-    return fold, loc, sigma, dlat
 
 
 def trpl_target_terms(loc, sigma, tgt_mean, tgt_S, *, mean_bound, cov_bound, trust_region_coeff, global_batch: int, proj_type: int = 0):

@@ -98,16 +98,6 @@ class GNNGaussianPolicyDiag(nn.Module):
                                            gnn.output_dim_vec)
         return mean.reshape(B, -1), sigma.reshape(B, -1)
 
-    def latent_diag(self, *args, train=True) -> torch.Tensor:
-        """``forward_diag`` up to the read-out: the actuator nodes' latents [B * G, 16, 64] (node n = frame * G + g).  For callers that
-        run read-out, loss and read-out backward as one launch (trpl.head_launch)."""
-        assert not self.post_fc
-        self.train(train)
-        if train and not self._calib_checked:
-            self._maybe_calibrate(args)
-        graph, u = self.hyper_data.build_data(*args, train=train)
-        return self.gnn.latent_step(graph, u)
-
     def forward(self, *args, train=True):
         loc, sigma = self.forward_diag(*args, train=train)
         return loc, sigma.diag_embed() ** 2

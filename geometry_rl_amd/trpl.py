@@ -184,20 +184,6 @@ def trpl_launch(m, loc, sigma, value, batch, adv_stats, sums=None, maxes=None, d
     return sums, maxes, dloc, dsigma, dvalue
 
 
-def head_launch(m, policy, lat, batch, adv_stats, sums, maxes, adv_local=False):
-    """``policy``'s read-out, the fused loss kernel (actor terms) and the read-out's backward as ONE launch on the pre-read-out latents
-    ``lat`` (ops.head_fused): -> (fold, loc, sigma, dlat).  The decoder's and the std head's gradients are queued / folded like
-    ``ops.Readout.backward`` does."""
-    p = m.projection
-    gnn, dec = policy.gnn, policy.gnn.decoder
-    B = batch["action"].shape[0]
-    return ops.head_fused(lat.detach(), gnn.grid3, dec.weight, dec.bias, policy._pre_std.weight, policy._pre_std.bias,
-                          float(policy._pre_activation_shift), float(policy.minimal_std), gnn.output_dim, gnn.output_dim_vec, batch,
-                          mean_bound=p.mean_bound, cov_bound=p.cov_bound, trust_region_coeff=p.trust_region_coeff,
-                          entropy_coef=m.entropy_coef if m.entropy_bonus else 0.0, global_batch=B * m.world_size, adv_stats=adv_stats,
-                          sums=sums, maxes=maxes, proj_type=getattr(p, "proj_code", 0), adv_local=adv_local)
-
-
 def value_loss(m, value, batch):
     """The critic's share of the loss on its own (clipped l2 value loss, trpl.py:213-228): -> (dvalue [B], loss_critic float32 0-d, sums
     fp64[2] = summed loss and its mean over the global batch).  One launch; one rank (nothing is all-reduced)."""

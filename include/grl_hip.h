@@ -49,8 +49,8 @@ int grl_lift_encode_bwd_multi(int n_types, const float* const* scal, const float
  *           partial [grl_edge_bwd_blocks(n_edges)][grl_edge_partial_size()] = [dW1 64x14 | db1 64 | dW2 64x64 | db2 64 | dWk 64x64]
  *           (one row per workgroup: its four waves are folded through LDS at the end of the launch).
  *           Since round 2 the backward is ONE launch (d x_src and the five weight gradients share one recompute of the basis MLP).
- * libgrl_hip.so also exports grl_edge16_launch / grl_edge_bwd16_launch (and their _bf16 twins): cross-file entry points of the 16-row
- * kernels used by the functions below -- internal, NOT part of this ABI. */
+ * (libgrl_hip.so exports EXACTLY the functions this header declares: the link uses a version script generated from it; cross-file
+ * helpers of the 16-row kernels -- grl_edge16_launch, grl_edge_bwd16_launch, grl_node_mlp_bwd16_launch -- are internal symbols.) */
 int grl_edge_conv_fwd(const float* x_src, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                       const int* e_dst, int n_dst, const float* grid, int dim, const float* W1, const float* b1,
                       const float* W2, const float* b2, const float* Wk, float* x1, hipStream_t stream);
@@ -237,18 +237,6 @@ int grl_readout_bwd(const float* lat, const float* grid, const float* Wd, const 
  *               adv_local: 1 = the advantage statistics are summed inside the kernel from this launch's batch (one rank), 0 = adv_stats}
  * sums fp64[12]: loss_objective, loss_trust_region, entropy(dist), loss_critic, sum w, sum w^2, mean_constraint,
  *               cov_constraint, entropy(p), entropy_diff, count, kl  (per-frame sums; divide by count);  maxes u32[2] (float bits) */
-/* (ABI 203) read-out forward (hepi.py:173-190, gnn_gaussian_policy_diag.py:65-87) + fused loss kernel (actor terms) + read-out backward in ONE
- * launch: lat [n_nodes,16,64], n_nodes = batch * nodes_per_frame (node n = frame * nodes_per_frame + g), action_dim = nodes_per_frame * 3 ov <= 16.
- * Writes mean [n_nodes,ov,3] (= loc [batch, action_dim]), sigma [n_nodes,3 ov], dlat [n_nodes,16,64], partial [grl_head_fused_rows(batch)]
- * [grl_readout_partial_size()] (one row per 16 frames, layout of grl_readout_bwd) and slots (grl_trpl_slot_doubles(batch) doubles).  cfg9 /
- * adv_stats as grl_trpl_fwd_bwd; no value terms (grl_value_loss), no external hidden gradient.  Same arithmetic per node / frame as the
- * three launches it replaces. */
-int grl_head_fused_rows(int batch);
-int grl_head_fused(const double* cfg9, int action_dim, const float* lat, const float* grid, const float* Wd, const float* bd,
-                   const float* Ws, const float* bs, float shift, float min_std, int n_nodes, int od, int ov, int nodes_per_frame,
-                   const float* action, const float* old_mean, const float* old_var, const float* old_logp, const float* advantage,
-                   const double* adv_stats, float* mean_out, float* sigma_out, float* dlat, float* partial, double* slots, int batch,
-                   hipStream_t stream);
 /* (ABI 203) the critic's share of the loss on its own: clipped l2 value loss (trpl.py:213-228, objectives/utils.py:5-28) and d loss / d V per
  * frame (already scaled by critic_coef / B_global) -- elementwise, so the critic's lane needs nothing from the fused actor kernel (which is
  * then called with value = NULL).  out2 fp64[2] = {sum over the frames of critic_coef * loss, that sum * inv_batch}; one workgroup */

@@ -22,6 +22,12 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/grl_hip.h but not exported by libgrl_hip.so"
+    # ... and nothing else: the link uses a version script generated from the header (hip.build), so cross-file helpers
+    # (grl_edge16_launch, grl_node_mlp_bwd16_launch, ...) and extern "C" kernels stay internal
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == names, (sorted(set(exported) - set(names)), sorted(set(names) - set(exported)))
     # host-only queries are callable without a GPU
     lib.grl_edge_partial_size.restype = ctypes.c_int
     assert lib.grl_edge_partial_size() == 64 * 14 + 64 + 4096 + 64 + 4096

@@ -372,13 +372,3 @@ def test_fixed_order_sums_are_repeatable():
         assert abs(outs[0][0] - ref2) <= 1e-13 * ref2 and abs(outs[0][3] - ref2) <= 1e-13 * ref2, (lo, n)
         assert abs(outs[0][2] - float(v.double().sum())) <= 1e-10 * max(1.0, n ** 0.5), (lo, n)
         assert abs(outs[0][1] - min(1.0, 0.5 / (ref2 ** 0.5 + 1e-6))) <= 1e-6
-
-
-def test_node_mlp_eight_wave_form_in_a_child_process():
-    """GRL_MLP_BWD_W8=1 (the two-waves-per-SIMD form of the fused ConvNeXt backward, node_mlp16w8.hip: correct and slower, DESIGN.md
-    finding 47) is read once per process: the node-MLP parity tests are re-run in a child process with it set."""
-    import os, subprocess, sys
-    env = dict(os.environ, GRL_MLP_BWD_W8="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_node_mlp and not eight_wave"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

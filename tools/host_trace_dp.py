@@ -6,7 +6,7 @@ from geometry_rl_amd import agent, synthetic as syn
 from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
 dev = torch.device("cuda:0")
 s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), GRL_FORCE_DP_PLAN="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_))
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 group = dist.group.WORLD
@@ -18,7 +18,7 @@ A = spec.num_actuators * cfg.output_dim_vec * 3
 pool = []
 for i in range(4):
     b = dict(make_obs(mb, 100 + i, 0)); b.update(syn.make_ppo_fields(mb, A, seed=i)); pool.append({k: v.to(dev) for k, v in b.items()})
-upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True, group=group)
+upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True, group=group, force_dp_plan=group is not None)
 data = {k: torch.stack([f[k] for f in pool], dim=1) for k in pool[0]}
 buf = RolloutBuffer(data)
 drv = RolloutDriver(upd, spec, ppo_epochs=5, seed=0)
