@@ -149,21 +149,28 @@ def cpu_baseline_and_parity(wl_name, minibatch, dev, steps=3, max_threads=32):
             worst, worst_key = e, k
     p_err, p_ratio = None, None
     if ptol is not None:
-        # post-Adam parameters: the first Adam step turns an absolute gradient error dg into lr * dg / (|g| + eps) -- up to lr / eps = 30 x for
-        # entries whose gradient is small beside eps -- so the allowance follows from the gradient tolerance (2e-4 of the tensor's own largest
-        # reference gradient entry, at least 1e-4 of the network's), not from a flat number: tests/parity_util.py has the derivation
+        # post-Adam parameters, the tests' rule (oracle/parity_util.py): the first Adam step turns an absolute gradient error dg into
+        # lr * dg * eps / (|g| + eps)^2 -- entries with a large gradient are saturated and held to fp32 rounding, only entries near zero get
+        # the lr * dg / eps allowance -- with dg = 2e-4 of the tensor's own largest reference gradient entry (at least 1e-4 of the network's).
+        # ENTRY-WISE wherever nothing rescales the gradient; per tensor under clip_grad_norm (the clip coefficient carries the relative
+        # error of the norm on top).  (the per-tensor form saturates at 2 lr for every tensor with max |g| >= 0.1.)
+        from oracle import parity_util as pu
         p_err, p_ratio = 0.0, 0.0
         for mod, ref_p, ref_g, strip in ((actor, ag.actor, ref_grads["actor"], 0), (critic, ag.critic, ref_grads["critic"], len("_network1."))):
-            net_max = max((float(v.abs().max()) for v in ref_g.values() if v.numel()), default=0.0)
+            scales = pu.grad_scales(ref_g)
             for k, p in mod.named_parameters():
                 kk = k[strip:]
-                sc = max(float(ref_g[kk].abs().max()) if kk in ref_g and ref_g[kk].numel() else 0.0, 1e-4 * net_max)
-                allowed = cfg.lr * min(2.0, 2e-4 * sc * (2.0 if cfg.clip_grad_norm else 1.0) / 1e-5) + 3e-7
+                if kk not in ref_g:   # no gradient reaches it (the unused `_mean` head): untouched by both optimizers
+                    allowed = pu.P_ROUND * max(1.0, float(ref_p[kk].abs().max()))
+                elif cfg.clip_grad_norm:
+                    allowed = pu.adam_first_step_bound(cfg.lr, 1e-5, scales[kk], clip=True, p_ref=ref_p[kk])
+                else:
+                    allowed = pu.adam_first_step_bound_elem(cfg.lr, 1e-5, ref_g[kk], scales[kk], ref_p[kk])
                 e = (p.detach().cpu() - ref_p[kk]).abs().max().item()
-                p_err, p_ratio = max(p_err, e), max(p_ratio, e / allowed)
+                p_err, p_ratio = max(p_err, e), max(p_ratio, pu.param_excess(p, ref_p[kk], allowed))
         ok = ok and p_ratio <= 1.0
     gate = {"passed": bool(ok), "workload": wl_name, "frames": sample,
-            "tolerance": f"{tol:g} * max(1, |ref|) on loc / var / state_value / 13 loss entries" + ("; post-Adam parameters within lr * min(2, 2e-4 * max|g_tensor| / eps) + 3e-7 (what the gradient tolerance implies through Adam's first step)" if ptol else
+            "tolerance": f"{tol:g} * max(1, |ref|) on loc / var / state_value / 13 loss entries" + ("; post-Adam parameters ENTRY-WISE within lr * min(2, dg eps / (max(|g_i| - dg, 0) + eps)^2) + 4e-7 max(1, |p|), dg = 2e-4 * max|g_tensor| (oracle/parity_util.py; per tensor under clip_grad_norm)" if ptol else
                          " (relative down to 1e-2 for the scalar entries; parameters not compared: bf16 build against the fp32 oracle)"),
             "worst_value_err_over_scale": worst, "worst_key": worst_key, "post_adam_param_err": p_err,
             "post_adam_param_err_over_allowed": p_ratio}
@@ -211,6 +218,49 @@ def determinism_selfcheck(dev, prec=""):
     return {"passed": not bad, "differing_outputs": bad, "shape": f"{n} nodes, {E} edges, edge conv + ConvNeXt block forward / backward twice"}
 
 
+# Reference box for `value_normalised`: the calibration figures of the box the round-5 target table was measured on.
+# value_normalised = value * REF_BOX["mfma_tflops"] / this box's mfma_tflops -- the 4096-frame step is 84 % MFMA kernels whose rate follows
+# the clock the chip holds under matrix load (DESIGN.md finding 32), which is what the MFMA calibration loop measures.
+REF_BOX = {"mfma_tflops": 1500.0, "copy_tb_per_s": 5.0}
+
+
+def box_calibration(dev, mfma_iters=6000, reps=9, copy_bytes=1 << 30):
+    """Two FIXED kernels (csrc/calib.hip), timed with HIP events in this process before anything else runs: a bare v_mfma_f32_32x32x16_bf16
+    loop on random register operands on every SIMD, and a 1 GiB float4 copy.  They identify the box: the pool's boxes span several per
+    cent for one build, more than the changes of a round.  Median over ``reps`` back-to-back launches after two untimed ones."""
+    from geometry_rl_amd import hip
+    out = torch.empty(256 * 256, device=dev, dtype=torch.float32)
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+
+    def timed(fn, n):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in ev]
+
+    f_mfma = lambda: hip.call("grl_calib_mfma", mfma_iters, out)
+    timed(f_mfma, 2)
+    t_m = timed(f_mfma, reps)
+    flops = 1024.0 * mfma_iters * 16 * 32768
+    src = torch.empty(copy_bytes // 4, device=dev, dtype=torch.float32).normal_()
+    dst = torch.empty_like(src)
+    import ctypes
+    f_copy = lambda: hip.call("grl_calib_copy", src, dst, ctypes.c_longlong(copy_bytes))
+    timed(f_copy, 2)
+    t_c = timed(f_copy, reps)
+    del src, dst
+    torch.cuda.empty_cache()
+    mf, cp = flops / (med(t_m) * 1e-3) / 1e12, 2.0 * copy_bytes / (med(t_c) * 1e-3) / 1e12
+    return {"mfma_tflops": mf, "mfma_tflops_min_max": [flops / (max(t_m) * 1e-3) / 1e12, flops / (min(t_m) * 1e-3) / 1e12],
+            "mfma_ms_per_launch": med(t_m), "copy_tb_per_s": cp, "copy_ms_per_launch": med(t_c),
+            "reference_box": REF_BOX, "mfma_vs_reference": mf / REF_BOX["mfma_tflops"], "copy_vs_reference": cp / REF_BOX["copy_tb_per_s"],
+            "what": f"grl_calib_mfma: 1024 waves x {mfma_iters} x 16 v_mfma_f32_32x32x16_bf16 on random register operands (dense bf16 peak 2500); "
+                    f"grl_calib_copy: {copy_bytes >> 20} MiB float4 copy, read + write bytes; medians of {reps} launches, HIP events"}
+
+
 def syn_fields(B, A):
     from geometry_rl_amd import synthetic as syn
     return syn.make_ppo_fields(B, A, seed=1)
@@ -221,6 +271,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=7, help="the timed region of --steps steps is repeated this many times back to back; "
+                    "`value` is the MEDIAN repeat (every repeat is listed in the line)")
     ap.add_argument("--workload", default="rigid_hepi")
     ap.add_argument("--minibatch", type=int, default=4096, help="global frames per policy update (= num_envs)")
     ap.add_argument("--pool", type=int, default=128, help="time steps of the synthetic device-resident rollout the minibatches are "
@@ -279,6 +331,7 @@ def main():
 
     from geometry_rl_amd import agent, hip, synthetic as syn
     spec, cfg, make_obs, cfg_name = workload(args.workload)
+    calib = box_calibration(dev) if rank == 0 else None   # before anything else has warmed or loaded the chip
     det = None
     if rank == 0 and not os.environ.get("GRL_BENCH_NO_SELFCHECK"):   # (the override is for timing knock-out builds, whose results are garbage)
         det = determinism_selfcheck(dev, "_bf16" if cfg.precision == "bf16" else "")
@@ -339,22 +392,32 @@ def main():
         upd.step_from(buf, next(mb))  # hipGraph(s), the third is the first replay
     for i in range(args.warmup):
         upd.step_from(buf, next(mb))
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = upd.step_from(buf, next(mb))
-    barrier()
-    dt = time.perf_counter() - t0
+    # R repeats of the timed region, each EXACTLY --steps steps between a barrier + device synchronisation on both sides; the repeat's
+    # time is the MAX over the ranks; `value` is the median repeat (one 65 ms shot could not resolve a 1 % change)
+    rep_dt = []
+    for r_ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = upd.step_from(buf, next(mb))
+        barrier()
+        rep_dt.append(time.perf_counter() - t0)
+    if world > 1:
+        import torch.distributed as dist
+        t_all = torch.tensor(rep_dt, device=dev, dtype=torch.float64)
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        rep_dt_global = [float(x) for x in t_all.tolist()]
+    else:
+        rep_dt_global = list(rep_dt)
+    dt_own = sorted(rep_dt)[len(rep_dt) // 2]
+    dt = sorted(rep_dt_global)[len(rep_dt_global) // 2]
     dp_info = None
     if world > 1 or args.dp_plan:
         import torch.distributed as dist
-        own = torch.tensor([dt], device=dev, dtype=torch.float64)
+        own = torch.tensor([dt_own], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(own) for _ in range(world)]
         dist.all_gather(every, own)
-        per_rank = [1e3 * float(x.item()) / args.steps for x in every]
-        t = own.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        per_rank = [1e3 * float(x.item()) / args.steps for x in every]   # every rank's own median repeat
         # the first hardware run must describe itself: which backend carried the collectives, how many ranks it saw,
         # every collective of the step by name with its payload and the time its lane was held by it (HIP events on the lane's stream around
         # the call: waiting for the other ranks + transfer), how long the main lane stood at the two joins with the critic's lane, and the
@@ -568,6 +631,12 @@ def main():
         line = {
             "metric": "policy-update steps/sec, HEPi 4096 envs x 128 steps", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "repeats": len(rep_dt_global), "repeats_ms_per_step": [1e3 * x / args.steps for x in rep_dt_global],
+            "ms_per_step_min_max": [1e3 * min(rep_dt_global) / args.steps, 1e3 * max(rep_dt_global) / args.steps],
+            "value_note": "value = steps / (median over the repeats of the time of one timed region of exactly `steps` steps, max over ranks)",
+            "box_calibration": calib,
+            "value_normalised": (args.steps / dt) / calib["mfma_vs_reference"] if calib else None,
+            "value_normalised_note": "value x reference box's MFMA calibration / this box's (BASELINE.md section 4): compare lines of different boxes by this",
             "scaling": "strong", "vs_baseline": None,
             "dtype": ("bf16 latent storage and MFMA operands (one bf16 MFMA per product), f32 accumulate / weights / loss" if cfg.precision == "bf16" else
                       "f32 storage/accumulate, bf16x3 products (three bf16 MFMAs per f32 product)"), "data": "synthetic",

@@ -533,6 +533,24 @@ class PolicyUpdater:
                 ("run", q_tail, S),
                 ("join", None, "m", "join_critic_lane"), ("run_host", lambda: self._finish(st))]
 
+    def program_outline(self, published: bool = True):
+        """The data-parallel program as data, without running anything: [(kind, lane, label, communicator)] in HOST (enqueue) order, where
+        communicator is "group" / "group_c" for collectives and None otherwise.  ``published``: the minibatch carries the epoch's advantage
+        statistics (rollout.RolloutDriver.publish_advantage_stats) -- otherwise the lane starts with one more graph and collective.
+        Needs no GPU (the closures are built, not called): tests/test_dp_program_order.py checks on four gloo ranks that every rank
+        enqueues the same sequence per communicator and that the program has no dependency cycle across communicators -- the property the
+        device-side RCCL run of two concurrently driven communicators rests on."""
+        plan = self._plan_dp({"adv_stats": None} if published else {}, {})
+        out = []
+        for e in plan:
+            kind, lane = e[0], (e[2] if len(e) > 2 else "m")
+            label = e[3] if len(e) > 3 else None
+            comm = None
+            if kind == "sum":
+                comm = "group_c" if (lane == "s" and self.group_c is not None) else "group"
+            out.append((kind, lane, label, comm))
+        return out
+
     def _critic_stream(self):
         if getattr(self, "_cstream", None) is None:
             # the LOWEST priority the device offers: the critic's small launches take the compute units the actor's kernels leave (heads,

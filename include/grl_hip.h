@@ -383,6 +383,14 @@ int grl_prof_enable(int on);
 int grl_prof_count(void);
 int grl_prof_get(int i, char* name, int cap, float* ms);
 
+/* ---- measurement support (bench.py `box_calibration`; not part of the policy-update path, nothing in the package calls them) -------------
+ * Two FIXED kernels that identify the speed of the box a bench line was taken on (the pool's boxes hold different clocks under load):
+ * grl_calib_mfma: 1024 waves (one per SIMD) issue v_mfma_f32_32x32x16_bf16 back to back on random register operands; FLOPs per call =
+ *                1024 * iters * 16 * 32768; out: 65536 floats (written).
+ * grl_calib_copy: float4 grid-stride copy, bytes a multiple of 16; bytes moved per call = 2 * bytes. */
+int grl_calib_mfma(int iters, float* out, hipStream_t stream);
+int grl_calib_copy(const void* src, void* dst, long long bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,146 @@
+"""The data-parallel step drives TWO communicators concurrently from two streams (agent.PolicyUpdater._plan_dp: the actor's lane on
+``group``, the critic's lane on ``group_c``).  On RCCL that is deadlock-free if (a) every rank enqueues the SAME sequence of collectives on
+each communicator and (b) the program has no dependency cycle once the k-th collective of a communicator is one rendezvous of all ranks.
+Neither needs a GPU to check: the program is data (``PolicyUpdater.program_outline``).  Four gloo ranks on CPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _has_cycle(nodes, edges):
+    indeg = {n: 0 for n in nodes}
+    out = {n: [] for n in nodes}
+    for a, b in edges:
+        out[a].append(b)
+        indeg[b] += 1
+    ready = [n for n in nodes if indeg[n] == 0]
+    seen = 0
+    while ready:
+        n = ready.pop()
+        seen += 1
+        for b in out[n]:
+            indeg[b] -= 1
+            if indeg[b] == 0:
+                ready.append(b)
+    return seen != len(nodes)
+
+
+def dependency_graph(outlines):
+    """nodes: (rank, position) of every program entry, except that the k-th collective of a communicator is ONE node ("c", comm, k) shared
+    by all ranks; edges: program order inside a lane, fork (main -> side lane's first entry behind it), join (side lane's last entry -> the
+    join), and a communicator's own issue order (RCCL runs a communicator's collectives in order on one internal stream)."""
+    nodes, edges = set(), []
+    for rank, prog in enumerate(outlines):
+        counters = {}
+        last = {"m": None, "s": None}
+        pending_fork = None
+        for pos, (kind, lane, label, comm) in enumerate(prog):
+            if kind == "sum":
+                k = counters.get(comm, 0)
+                counters[comm] = k + 1
+                node = ("c", comm, k)
+                if k > 0:
+                    edges.append((("c", comm, k - 1), node))
+            else:
+                node = (rank, pos)
+            nodes.add(node)
+            if kind == "fork":
+                if last["m"] is not None:
+                    edges.append((last["m"], node))
+                last["m"] = node
+                pending_fork = node
+                continue
+            if kind == "join":
+                for l in ("m", "s"):
+                    if last[l] is not None:
+                        edges.append((last[l], node))
+                last["m"], last["s"] = node, None
+                continue
+            if lane == "s" and last["s"] is None and pending_fork is not None:
+                edges.append((pending_fork, node))
+            if last[lane] is not None:
+                edges.append((last[lane], node))
+            last[lane] = node
+    return nodes, edges
+
+
+def test_cycle_detector_sees_a_crossed_order():
+    """two ranks that enqueue two communicators' collectives so that each waits for the other's: the checker must object"""
+    a = [("sum", "m", "x", "A"), ("run", "m", None, None), ("sum", "m", "y", "B")]
+    b = [("sum", "m", "y", "B"), ("run", "m", None, None), ("sum", "m", "x", "A")]
+    nodes, edges = dependency_graph([a, b])
+    assert _has_cycle(nodes, edges)
+    nodes, edges = dependency_graph([a, a])
+    assert not _has_cycle(nodes, edges)
+
+
+def _worker(rank, world, port, one_comm, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if one_comm:
+        os.environ["GRL_DP_ONE_COMM"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from geometry_rl_amd import agent, graph
+    spec = graph.rigid_spec()
+    cfg = agent.AgentConfig(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)
+    torch.manual_seed(rank)   # different initial weights per rank: sync_replicas must make them rank 0's
+    actor, critic, proj, loss = agent.build_agent(spec, cfg, device="cpu", group=dist.group.WORLD)
+    upd = agent.PolicyUpdater(loss, lr=cfg.lr, group=dist.group.WORLD)
+    assert (upd.group_c is None) == bool(one_comm)
+    outlines = {pub: upd.program_outline(published=pub) for pub in (True, False)}
+    # replicas start from rank 0's parameters
+    ref = upd.flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(ref, upd.flat)
+    # the collective skeleton really runs in this order on these communicators (gloo: a hang detector for mismatched sequences)
+    for kind, lane, label, comm in outlines[True]:
+        if kind == "sum":
+            t = torch.full((4,), float(rank + 1))
+            dist.all_reduce(t, group=upd.group_c if comm == "group_c" else upd.group)
+            assert float(t[0]) == world * (world + 1) / 2
+    gathered = [None] * world
+    dist.all_gather_object(gathered, outlines)
+    if rank == 0:
+        ret["outlines"] = gathered
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("one_comm", [False, True])
+def test_four_ranks_enqueue_one_sequence_per_communicator_and_no_cycle(one_comm):
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), one_comm, ret), nprocs=world, join=True)
+    per_rank = ret["outlines"]
+    for pub in (True, False):
+        progs = [r[pub] for r in per_rank]
+        assert all(p == progs[0] for p in progs), "ranks built different programs"
+        prog = progs[0]
+        colls = [(label, comm) for kind, lane, label, comm in prog if kind == "sum"]
+        # 7 collectives per update with published advantage statistics, 8 without; the actor's lane carries exactly one (two)
+        assert len(colls) == (7 if pub else 8)
+        on_main = [c for (kind, lane, label, comm), c in zip([e for e in prog if e[0] == "sum"], colls) if lane == "m"]
+        assert [l for l, _ in on_main] == ([] if pub else ["advantage_stats"]) + ["flat_gradient_actor+loss_records"]
+        if one_comm:
+            assert {c for _, c in colls} == {"group"}
+        else:
+            # lanes and communicators coincide: nothing of the critic's ever sits on the actor's communicator
+            assert all((comm == "group") == (lane == "m") for kind, lane, label, comm in prog if kind == "sum")
+        # between fork and join no entry waits for the other lane
+        kinds = [e[0] for e in prog]
+        assert kinds.count("fork") == 1 and kinds.count("join") == 1 and kinds.index("fork") == 0 and kinds.index("join") == len(kinds) - 2
+        nodes, edges = dependency_graph(progs)
+        assert not _has_cycle(nodes, edges)

@@ -11,8 +11,12 @@ magnitude shows up in exp_avg, exp_avg_sq and the parameters.  Both sides run fi
   * parameters   within  K * (the first-step bound of parity_util.adam_first_step_bound) -- the trajectories are compared, not re-synchronised:
                  the bound is what a gradient error of 2e-4 per step can accumulate to through Adam
 
-Cases: rigid HEPi B = 64, cloth HEPi B = 16 (25 particles), two-agent EMPN B = 32; the recorded (hipGraph) step is what runs from the third
-update on, so the comparison also covers replayed launches.  Reference semantics: examples/torchrl/train.py:264-316."""
+Cases: rigid HEPi B = 64, cloth HEPi B = 16 (25 particles), two-agent EMPN B = 32 -- and, since round 5, the sizes
+BASELINE.json names: rigid HEPi at config 2's exact minibatch (B = 1024, P = 32, K = 5: ~15 s of oracle time on the GPU box) and cloth with
+225 particles / 10 hole points / 4 grippers at B = 256 (K = 3).  The recorded (hipGraph) step is what runs from the third update on, so the
+comparison also covers replayed launches.  Reference semantics: examples/torchrl/train.py:264-316."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,7 +26,6 @@ from geometry_rl_amd import synthetic as syn
 from parity_util import NET_FLOOR, adam_first_step_bound, grad_scales
 
 pytestmark = pytest.mark.gpu
-K = 5
 M_TOL, V_TOL = 5e-4, 1e-3
 
 
@@ -31,15 +34,22 @@ def _obs(name, B, seed):
         return syn.make_rigid_obs(B, seed=seed)
     if name == "cloth":
         return syn.make_cloth_obs(B, n_particles=25, E_cloth=40, seed=seed)
+    if name == "cloth_full":   # 225 particles, 10 hole points, 4 grippers
+        return syn.make_cloth_obs(B, seed=seed)
     return syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=seed)
 
 
-@pytest.mark.parametrize("name,B", [("rigid_g1", 64), ("cloth", 16), ("empn_g2", 32)])
-def test_five_updates_match_the_oracle(name, B):
-    from geometry_rl_amd import agent
+@pytest.mark.parametrize("name,B,K", [("rigid_g1", 64, 5), ("cloth", 16, 5), ("empn_g2", 32, 5), ("rigid_g1", 1024, 5), ("cloth_full", 256, 3)])
+def test_five_updates_match_the_oracle(name, B, K):
+    from geometry_rl_amd import agent, graph
+    from oracle import graph as ogr
     from test_gpu_step import load_params, make_case
     dev = torch.device("cuda:0")
-    o_spec, spec, kw, _ = make_case(name, B)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))   # the oracle: more intra-op threads than this only slow its small CPU ops down
+    if name == "cloth_full":
+        o_spec, spec, kw = ogr.cloth_spec(), graph.cloth_spec(), dict(trust_region_coeff=4.0, cov_bound=0.001)
+    else:
+        o_spec, spec, kw, _ = make_case(name, B)
     o_cfg, cfg = ost.AgentConfig(**kw), agent.AgentConfig(**kw)
     a_par, c_par = ost.init_agent_params(o_spec, o_cfg, seed=21)
     oracle = ost.OracleAgent(o_spec, o_cfg, a_par, c_par)
