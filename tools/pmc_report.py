@@ -11,6 +11,10 @@ def load(d):
             seen.add(r["Dispatch_Id"]); n[k] += 1
     return acc, n
 A, nA = load("pmcA"); B, nB = load("pmcB"); C, nC = load("pmcC"); D, nD = load("pmcD")
+try:
+    E, nE = load("pmcE")   # round 5: co-execution and per-class issue activity (optional pass)
+except Exception:
+    E, nE = None, None
 print("kernel | launches | wave-cycle shares: active / wait(waitcnt,barrier) / issue-stall | VALU active | MFMA busy/(4 wave cyc) | VALU per MFMA | LDS insts | LDS conflict | fetch MB (x2 corr.) | write MB")
 for k in A:
     if not any(s in k for s in ("edge_conv", "edge16", "edge_bwd16", "node_mlp", "fiber", "lift", "ds_", "readout", "trpl", "reduce_partials")):
@@ -20,6 +24,20 @@ for k in A:
     print(f"{k:40s} {n:3d}  act {a['SQ_ACTIVE_INST_ANY']/wc:.2f} wait {a['SQ_WAIT_ANY']/wc:.2f} stall {a['SQ_WAIT_INST_ANY']/wc:.2f} | valu {a['SQ_ACTIVE_INST_VALU']/wc:.2f} | mfma {a['SQ_VALU_MFMA_BUSY_CYCLES']/(4*wc):.2f} | "
           f"valu/mfma {b['SQ_INSTS_VALU']/max(b['SQ_INSTS_MFMA'],1):6.1f} | lds {b['SQ_INSTS_LDS']/n:.3g} conf {b['SQ_LDS_BANK_CONFLICT']/max(b['SQ_ACTIVE_INST_LDS'],1):.2f} | "
           f"rd {2*C[k]['FETCH_SIZE']*1024/max(nC[k],1)/1e6:8.1f} wr {D[k]['WRITE_SIZE']*1024/max(nD[k],1)/1e6:8.1f}")
+if E is not None:
+    print()
+    print("where the cycles go (shares of SQ_WAVE_CYCLES; pass A: issue stall on LDS = SQ_WAIT_INST_LDS, a sub-bucket of the issue stall; pass E: per-class issue activity, "
+          "MFMA / VALU co-execution = SQ_VALU_MFMA_COEXEC_CYCLES / (4 x wave cycles), as a share of MFMA busy in brackets, MFMA mops per MFMA)")
+    for k in A:
+        if not any(s in k for s in ("edge_conv", "edge16", "edge_bwd16", "node_mlp")) or k not in E:
+            continue
+        a, e, b = A[k], E[k], B[k]
+        wc, wce = a["SQ_WAVE_CYCLES"] or 1, e["SQ_WAVE_CYCLES"] or 1
+        co = e["SQ_VALU_MFMA_COEXEC_CYCLES"] / (4 * wce)
+        mb = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc)
+        print(f"{k:40s} stall {a['SQ_WAIT_INST_ANY']/wc:.2f} of which LDS-issue {a['SQ_WAIT_INST_LDS']/wc:.3f} | wait {a['SQ_WAIT_ANY']/wc:.2f} | active: valu {a['SQ_ACTIVE_INST_VALU']/wc:.2f} "
+              f"lds {e['SQ_ACTIVE_INST_LDS']/wce:.3f} vmem {e.get('SQ_ACTIVE_INST_VMEM', 0)/wce:.3f} scalar {e.get('SQ_ACTIVE_INST_SCA', 0)/wce:.3f} misc {e.get('SQ_ACTIVE_INST_MISC', 0)/wce:.3f} | "
+              f"mfma busy {mb:.2f} coexec {co:.3f} ({co/max(mb,1e-9):.2f} of busy) | mops/mfma {e['SQ_INSTS_VALU_MFMA_MOPS']/max(b['SQ_INSTS_MFMA'],1)*nB[k]/max(nE[k],1):.1f}")
 
 # ---- JSON summary (profiles/r01_pmc_summary_*.json; bench.py reads hbm_*_bytes_per_launch of the dominant kernel from it)
 if len(sys.argv) > 2:
@@ -41,7 +59,13 @@ if len(sys.argv) > 2:
                "wave_issue_stall": round(a["SQ_WAIT_INST_ANY"] / wc, 3), "valu_active": round(a["SQ_ACTIVE_INST_VALU"] / wc, 3),
                "mfma_busy_per_wave_cycle": round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc), 3),
                "valu_per_mfma": round(b["SQ_INSTS_VALU"] / b["SQ_INSTS_MFMA"], 2) if b["SQ_INSTS_MFMA"] else None,
-               "lds_bank_conflict_ratio": round(b["SQ_LDS_BANK_CONFLICT"] / max(b["SQ_ACTIVE_INST_LDS"], 1), 3)}
+               "lds_bank_conflict_ratio": round(b["SQ_LDS_BANK_CONFLICT"] / max(b["SQ_ACTIVE_INST_LDS"], 1), 3),
+               "issue_stall_on_lds": round(a["SQ_WAIT_INST_LDS"] / wc, 4)}
+        if E is not None and k in E:
+            e_ = E[k]
+            wce = e_["SQ_WAVE_CYCLES"] or 1
+            rec.update(lds_active=round(e_["SQ_ACTIVE_INST_LDS"] / wce, 4), mfma_valu_coexec_per_wave_cycle=round(e_["SQ_VALU_MFMA_COEXEC_CYCLES"] / (4 * wce), 4),
+                       vmem_active=round(e_.get("SQ_ACTIVE_INST_VMEM", 0) / wce, 4), scalar_active=round(e_.get("SQ_ACTIVE_INST_SCA", 0) / wce, 4))
         if e is None or rec["launches"] > e["launches"]:   # template instances of one kernel: keep the one launched most
             out["kernels"][name] = rec
     json.dump(out, open(sys.argv[2], "w"), indent=1)
