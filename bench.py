@@ -432,7 +432,13 @@ def main():
             lib_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
         except Exception:
             lib_version = None
+        gname = lambda g_: getattr(g_, "group_name", None) if g_ is not None else None
         dp_info = {"collective_backend": dist.get_backend(), "collective_library_version": lib_version, "ranks_seen": dist.get_world_size(),
+                   # which communicator carries which lane, and every NCCL_* / RCCL_* setting of the run (algorithm / protocol sweeps of
+                   # tools/first_multigpu_run.sh are told apart by these)
+                   "communicators": {"actor_lane": gname(upd.group), "critic_lane": gname(upd.group_c) or gname(upd.group),
+                                     "two_communicators": upd.group_c is not None},
+                   "collective_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "GRL_DP_"))},
                    "per_rank_ms_per_step": per_rank, "rank_spread_max_over_min": max(per_rank) / max(min(per_rank), 1e-9),
                    "collectives_per_step": sum(v["per_step"] for k, v in coll.items() if not k.startswith(("join", "wait"))),
                    "collectives": coll,

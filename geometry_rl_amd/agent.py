@@ -739,7 +739,7 @@ class PolicyUpdater:
                 # overwrite mode (no zeroing launch) is only right while NO leaf gradient arrives through torch's AccumulateGrad, which would
                 # add into a never-zeroed .grad: a hook on a leaf fires exactly for such a gradient (ops' backward functions hand None to
                 # autograd for the leaves whose slabs they queue).  Checked once, on the first eager step.
-                hooks = [p.register_hook(lambda g, i=i: torch_fed.append(i)) for i, p in enumerate(self.params)]
+                hooks = [p.register_hook(lambda g, i=i: torch_fed.append(i) if g is not None else None) for i, p in enumerate(self.params)]   # (autograd calls a leaf hook with None when a backward function returned no gradient for it)
             try:
                 self._execute([(e[0], e[1], e[2] if len(e) > 2 else "m", e[3] if len(e) > 3 else None) for e in self._plan(batch, st)])
             finally:
