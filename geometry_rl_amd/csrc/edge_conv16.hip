@@ -255,7 +255,74 @@ GRL_DEVINL void chain16(const ChainW16& w, float a, float b, int r, int g, KEpi&
                [&](const f32x4v& acc) { k_epi(nt, v4(acc)); });
 }
 
-#if GRL_E16_REGIONS
+#if GRL_PREC
+// Plain-bf16 build (round 5): a lane's weight fragments depend on (row, k-group, n-tile, K-step) only -- the SAME 20 operand registers for
+// every pass -- and without lo halves they fit: W2 8 + Wk 8 fragments = 64 registers, resident for the whole launch (W1's four would push the
+// kernel over the 168 registers of three waves per SIMD: they are requested with the biases at the head of the pass).  The pass loop
+// then has no fragment read inside the chain at all (the fenced groups exposed one LDS round trip per group: 12 per pass, wave cycles wait 0.41 + issue
+// stall 0.23 at three waves per SIMD, profiles/r05_pmc_table_rope_hepi_bf16_a.txt); the only LDS reads left are the two layers' biases,
+// requested at the head of the pass behind a scheduling barrier (no MFMA of this wave is in flight there: the previous pass's last
+// accumulators have been consumed).  Same products in the same order per accumulator: bit-identical results.
+struct ChainRegs {
+  bf16x8 w2[4][2], wk[4][2];
+};
+GRL_DEVINL void chain_regs_load(ChainRegs& cr, const ChainW16& w, int r, int g) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      cr.w2[nt][s] = *reinterpret_cast<const bf16x8*>(w.W2h + (16 * nt + r) * LD2 + 8 * g + 32 * s);
+      cr.wk[nt][s] = *reinterpret_cast<const bf16x8*>(w.Wkh + (16 * nt + r) * LD2 + 8 * g + 32 * s);
+    }
+  }
+}
+template <class KEpi>
+GRL_DEVINL void chain16_resident(const ChainRegs& cr, const ChainW16& w, float a, float b, int r, int g, KEpi&& k_epi) {
+  __builtin_amdgcn_sched_barrier(0);
+  float4 b1q[4], b2q[4];
+  bf16x8 w1[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    w1[nt] = *reinterpret_cast<const bf16x8*>(w.W1h + (16 * nt + r) * LD1 + 8 * g);
+    b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
+    b2q[nt] = *reinterpret_cast<const float4*>(w.b2s + 16 * nt + 4 * g);
+  }
+  const float aa = a * a, ab = a * b, bb = b * b;
+  float4 phi;
+  if (g == 0) phi = make_float4(a, b, aa, ab);
+  else if (g == 1) phi = make_float4(ab, bb, aa * a, aa * b);
+  else if (g == 2) phi = make_float4(ab * a, ab * b, ab * a, ab * b);
+  else phi = make_float4(bb * a, bb * b, 0.f, 0.f);
+  bf16x8 ph, pl;
+  split_pair(phi, make_float4(0.f, 0.f, 0.f, 0.f), ph, pl);
+  f32x4v c[4];
+  float4 g1[4], g2[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1[nt], ph, f32x4v{b1q[nt].x, b1q[nt].y, b1q[nt].z, b1q[nt].w});
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) g1[nt] = GELU16(v4(c[nt]));
+  bf16x8 xh[2], xl[2];
+  split_pair(g1[0], g1[1], xh[0], xl[0]);
+  split_pair(g1[2], g1[3], xh[1], xl[1]);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2[nt][0], xh[0], f32x4v{b2q[nt].x, b2q[nt].y, b2q[nt].z, b2q[nt].w});
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2[nt][1], xh[1], c[nt]);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) g2[nt] = GELU16(v4(c[nt]));
+  bf16x8 yh[2], yl[2];
+  split_pair(g2[0], g2[1], yh[0], yl[0]);
+  split_pair(g2[2], g2[3], yh[1], yl[1]);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wk[nt][0], yh[0], f32x4v{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wk[nt][1], yh[1], c[nt]);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) k_epi(nt, v4(c[nt]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define E16_CHAIN(S, A, B, R, G, EPI) chain16_resident(cregs, S, A, B, R, G, EPI)
+#elif GRL_E16_REGIONS
 #define E16_CHAIN chain16_regions
 #else
 #define E16_CHAIN chain16
@@ -273,6 +340,10 @@ __global__ __launch_bounds__(E16_THREADS, GRL_E16_WGS) void edge16_kernel(Edge16
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const float gx = s.grid_s[3 * r], gy = s.grid_s[3 * r + 1], gz = s.grid_s[3 * r + 2];
+#if GRL_PREC
+  ChainRegs cregs;
+  chain_regs_load(cregs, s, r, g);
+#endif
   const int* e_other = p.anchor_is_dst ? p.e_src : p.e_dst;
   const float* pos_anchor = p.anchor_is_dst ? p.pos_dst : p.pos_src;
   const float* pos_other = p.anchor_is_dst ? p.pos_src : p.pos_dst;
@@ -488,6 +559,26 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   const ChainW16& w = sm.img.w;
   const float gx = w.grid_s[3 * r], gy = w.grid_s[3 * r + 1], gz = w.grid_s[3 * r + 2];
   const bool g0 = g == 0, g1_ = g == 1, g2_ = g == 2;
+#if GRL_PREC
+  // Plain-bf16 build (round 5): a 64-deep group is TWO MFMAs here (fp32 build: six), so a group's region is too short to hide the LDS
+  // latency of the next group's fragments behind it -- the K / dZ2 / dZ1 layers (four multiply-adds of epilogue per group) stood at
+  // s_waitcnt lgkmcnt in front of every MFMA (wave cycles: wait 0.29, profiles/r05_pmc_table_rope_hepi_bf16_a.txt).  The four groups' fragments of a WHOLE layer
+  // (8 ds_read_b128 = 32 registers; no lo halves in this build) are therefore requested one layer ahead into two alternating buffers:
+  //   bufA: W2 (layer 2) -> Wk^T (dZ2) -> W2 of the NEXT pass;   bufB: Wk (K) -> W2^T (dZ1) -> Wk of the next pass
+  // each refilled in the tail of the layer that has just consumed it, i.e. a full layer before its next use; inside a layer the eight
+  // MFMAs run as four independent two-deep chains (a0 a1 a2 a3 b0 b1 b2 b3) and the compiler places the epilogues.  Same products in the
+  // same order per accumulator as before: results are bit-identical.
+  struct LayerFrags { bf16x8 h[4][2]; };
+  auto lf_load = [&](LayerFrags& f, const unsigned short* img) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) f.h[nt][s_] = *reinterpret_cast<const bf16x8*>(img + (16 * nt + r) * LD2 + 8 * g + 32 * s_);
+  };
+  LayerFrags bufA, bufB;
+  lf_load(bufA, w.W2h);
+  lf_load(bufB, w.Wkh);
+#endif
 
   f32x16 accK[2][2], accA[2][2], accB[2][1];   // dWk, dW2, dW1 (| db1 in column 14)
 #pragma unroll
@@ -607,7 +698,13 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
           b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
         }
+#if GRL_PREC
+        float4 b2q[4];   // layer 2's biases (its fragments are resident in bufA)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) b2q[nt] = *reinterpret_cast<const float4*>(w.b2s + 16 * nt + 4 * g);
+#else
         wf_load(wf[0], w.W2h + r * LD2 + 8 * g, w.W2l + r * LD2 + 8 * g, w.b2s + 4 * g);
+#endif
         // dW1 (| db1) of the PREVIOUS pass: its operands were staged at that pass's end (zero tiles before a wave's first pass); the six
         // MFMAs run beside this pass's first GELU instead of standing alone behind an exposed LDS round trip
         RFrags<1> rf1;
@@ -645,6 +742,27 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #define BAR() __builtin_amdgcn_sched_barrier(0)
         auto wptr_h = [&](int i) { const unsigned short* m = i < 4 ? w.W2h : i < 8 ? w.Wkh : i < 12 ? sm.img.WkTh : sm.img.W2Th; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
         auto wptr_l = [&](int i) { const unsigned short* m = i < 4 ? w.W2l : i < 8 ? w.Wkl : i < 12 ? sm.img.WkTl : sm.img.W2Tl; return m + (16 * (i & 3) + r) * LD2 + 8 * g; };
+#if GRL_PREC
+        // a 64-deep layer from a resident buffer: four independent two-deep MFMA chains, then the epilogues, then the tail (which refills
+        // the buffer for its next use -- behind a scheduling barrier, so every MFMA that reads the buffer has delivered its result first)
+        auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
+          (void)il;
+          LayerFrags& f = (base == 0 || base == 8) ? bufA : bufB;
+          f32x4v c[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[nt] = base == 0 ? f32x4v{b2q[nt].x, b2q[nt].y, b2q[nt].z, b2q[nt].w} : f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(f.h[nt][s_], ih[s_], c[nt]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) epi(nt, c[nt]);
+          BAR();
+          lf_load(f, base == 0 ? sm.img.WkTh : base == 4 ? sm.img.W2Th : base == 8 ? w.W2h : w.Wkh);
+          tail();
+          BAR();
+        };
+#else
         // a 64-deep layer: groups base .. base + 3 (wf[base & 1] already requested); epi(nt, c) consumes tile nt one region later
         auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
           f32x4v c[4];
@@ -662,6 +780,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           tail();
           BAR();
         };
+#endif
         {
           float4 g1[4];
           BAR();
@@ -905,8 +1024,8 @@ int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const 
   return 0;
 }
 
-#if defined(GRL_B16_PHASE) && !GRL_PREC
-int grl_edge_bwd16_phase_read(unsigned long long* out16, int reset) {
+#if defined(GRL_B16_PHASE)   // (each precision twin has its own counters: grl_edge_bwd16_phase_read / ..._bf16)
+int GRL_ENTRY(grl_edge_bwd16_phase_read)(unsigned long long* out16, int reset) {
   hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_b16phase), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_b16phase), z, sizeof(z)); }
   return 0;

@@ -9,6 +9,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmcD -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcD.log 2>&1
 # pass E (round 5: where the wait + stall cycles go): MFMA / VALU co-execution, LDS / VMEM / scalar / misc issue activity.  If a counter name is
 # unknown to this rocprofv3 the pass fails as a whole: pass F is the short list.
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d $R/gpurun_out/pmcE -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcE.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT --output-format csv -d $R/gpurun_out/pmcE -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcE.log 2>&1
 ls $R/gpurun_out/pmcE/*/*counter_collection.csv > /dev/null 2>&1 || { rm -rf $R/gpurun_out/pmcE; rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/pmcE -- python3 $R/tools/profile_step.py > $R/gpurun_out/pmcE.log 2>&1; }
 echo done

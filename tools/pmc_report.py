@@ -37,7 +37,7 @@ if E is not None:
         mb = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * wc)
         print(f"{k:40s} stall {a['SQ_WAIT_INST_ANY']/wc:.2f} of which LDS-issue {a['SQ_WAIT_INST_LDS']/wc:.3f} | wait {a['SQ_WAIT_ANY']/wc:.2f} | active: valu {a['SQ_ACTIVE_INST_VALU']/wc:.2f} "
               f"lds {e['SQ_ACTIVE_INST_LDS']/wce:.3f} vmem {e.get('SQ_ACTIVE_INST_VMEM', 0)/wce:.3f} scalar {e.get('SQ_ACTIVE_INST_SCA', 0)/wce:.3f} | "
-              f"mfma busy {mb:.2f} coexec {co:.3f} ({co/max(mb,1e-9):.2f} of busy) | LDS in flight (avg, per wave) {e.get('SQ_INST_LEVEL_LDS', 0)/wce:.2f} = {e.get('SQ_INST_LEVEL_LDS', 0)/max(b['SQ_INSTS_LDS'],1)*nB[k]/max(nE[k],1)*4:.0f} cyc per LDS inst | VMEM in flight {e.get('SQ_INST_LEVEL_VMEM', 0)/wce:.2f} = {e.get('SQ_INST_LEVEL_VMEM', 0)/max(b['SQ_INSTS_VMEM_RD']+b['SQ_INSTS_VMEM_WR'],1)*nB[k]/max(nE[k],1)*4:.0f} cyc per VMEM inst")
+              f"mfma busy {mb:.2f} coexec {co:.3f} ({co/max(mb,1e-9):.2f} of busy)")
 
 # ---- JSON summary (profiles/r01_pmc_summary_*.json; bench.py reads hbm_*_bytes_per_launch of the dominant kernel from it)
 if len(sys.argv) > 2:
