@@ -559,15 +559,16 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   const ChainW16& w = sm.img.w;
   const float gx = w.grid_s[3 * r], gy = w.grid_s[3 * r + 1], gz = w.grid_s[3 * r + 2];
   const bool g0 = g == 0, g1_ = g == 1, g2_ = g == 2;
+
 #if GRL_PREC
   // Plain-bf16 build (round 5): a 64-deep group is TWO MFMAs here (fp32 build: six), so a group's region is too short to hide the LDS
-  // latency of the next group's fragments behind it -- the K / dZ2 / dZ1 layers (four multiply-adds of epilogue per group) stood at
-  // s_waitcnt lgkmcnt in front of every MFMA (wave cycles: wait 0.29, profiles/r05_pmc_table_rope_hepi_bf16_a.txt).  The four groups' fragments of a WHOLE layer
-  // (8 ds_read_b128 = 32 registers; no lo halves in this build) are therefore requested one layer ahead into two alternating buffers:
+  // latency of the next group's fragments -- the K / dZ2 / dZ1 layers (four multiply-adds of epilogue per group) stood at s_waitcnt
+  // lgkmcnt in front of every MFMA.  The four groups' fragments of a WHOLE layer (8 ds_read_b128 = 32 registers; no lo halves in this
+  // build) are therefore requested one layer ahead into two alternating buffers:
   //   bufA: W2 (layer 2) -> Wk^T (dZ2) -> W2 of the NEXT pass;   bufB: Wk (K) -> W2^T (dZ1) -> Wk of the next pass
-  // each refilled in the tail of the layer that has just consumed it, i.e. a full layer before its next use; inside a layer the eight
-  // MFMAs run as four independent two-deep chains (a0 a1 a2 a3 b0 b1 b2 b3) and the compiler places the epilogues.  Same products in the
-  // same order per accumulator as before: results are bit-identical.
+  // each refilled in the tail of the layer that has just consumed it, a full layer before its next use; inside a layer the eight MFMAs
+  // run as four independent two-deep chains.  Measured against fragments two groups ahead in three rotating slots (24 registers): 2.66
+  // vs 2.82 ms per step for the three launches of the rope workload.  Same products in the same order per accumulator.
   struct LayerFrags { bf16x8 h[4][2]; };
   auto lf_load = [&](LayerFrags& f, const unsigned short* img) {
 #pragma unroll
@@ -579,7 +580,6 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   lf_load(bufA, w.W2h);
   lf_load(bufB, w.Wkh);
 #endif
-
   f32x16 accK[2][2], accA[2][2], accB[2][1];   // dWk, dW2, dW1 (| db1 in column 14)
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   for (int t = 0; t < 4; ++t) db2[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #ifdef GRL_B16_PHASE
-  unsigned long long ph_[8] = {0}, tl_ = __builtin_amdgcn_s_memtime();
+  unsigned long long ph_[12] = {0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
   // The chunks of this wave.  Round-robin chunks of npw nodes are balanced when every chunk carries the same number of edges (whole frames
   // of a large minibatch); for small graphs the OUT-degrees of a kNN graph vary (mean 3, up to ~10) and a wave with a few more edges than
@@ -623,12 +623,88 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
     int node = 0;
     int node_end = __builtin_amdgcn_readlane(rp, 1);
     float4 acc[4], xv[4];
+    // `dres ? load : 0` written on the load EXPRESSION compiles to a branch around every load with an s_waitcnt vmcnt(0) at its end (the
+    // value merges with a constant): four serialised memory round trips per node change -- 22 % of the bf16 build's pass, 7 % of the fp32
+    // build's (profiles/r05_edge_bwd16_phases_*.txt).  The loads are therefore unconditional -- from x_src when there is no dres: the rows
+    // the same node loads anyway, so no extra traffic where it matters -- and the SELECT is on the loaded value.
+    const st_t* dres_b = bp.dres ? bp.dres : bp.x_src;
+    const unsigned dmask = bp.dres ? 0xFFFFFFFFu : 0u;   // the select as a bit mask (a ?: on a wave-uniform bool becomes branches again)
+    auto keep = [&](const float4& v) {
+      return make_float4(__uint_as_float(__float_as_uint(v.x) & dmask), __uint_as_float(__float_as_uint(v.y) & dmask),
+                         __uint_as_float(__float_as_uint(v.z) & dmask), __uint_as_float(__float_as_uint(v.w) & dmask));
+    };
+#ifndef GRL_B16_ROWS
+#define GRL_B16_ROWS 0   // plain-bf16 build, how the source node's own rows are fetched: 0 = at the node change, widened at the first consumer;
+#endif                   // 1 = "uniform passes" (below).  A/B on one box (tools/r05_ab_rows.sh): 0 wins, see the comment at the #else
+#if GRL_PREC && GRL_B16_ROWS
+    // Plain-bf16 build ("uniform passes", round 5).  The rows arrive as bf16 bits and are widened in registers, a ~2.6 us pass is shorter
+    // than a row gather under load, and s_waitcnt vmcnt counts loads AND stores in issue order: any load or store whose presence depends
+    // on the pass (a node change's row loads) makes the compiler wait for the smallest count over all paths, i.e. for operations that have
+    // only just been issued (phase stamps: 22 % of the pass at the node change, then 41 % at the first consumer when the widening was
+    // merely deferred; knock-out without gathers: -20 % of the launch).  Here EVERY pass issues the same twelve loads at its top -- for the
+    // NEXT edge: its dM row, the x_src row and the dres row of its source node (the node's rows again for each of its edges: L1 / L2 hits)
+    // -- and takes last pass's twelve over right before: one vmcnt(0) per pass, at a point where everything outstanding is a full pass
+    // old.  No row load is tied to a node change; the dres row stays raw (aq) and is added by flush(), the accumulator starts at zero.
+    struct RawRows { uint2 d[4], x[4], a[4]; };
+    RawRows nq;
+    uint2 aq[4];
+    auto widen = [](const uint2& u) {
+      return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    };
+    auto flush = [&](int j) {
+      st_t* o = bp.dx_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st4(o + 16 * t, f4_add(acc[t], widen(make_uint2(aq[t].x & dmask, aq[t].y & dmask))));
+    };
+#elif GRL_PREC
+    // Plain-bf16 build, rows at the node change (the form that measured best: 2.66 ms per step for the rope workload's three launches
+    // against 2.82-2.9 for the uniform passes above and for rows requested a node ahead -- the extra loads, copies and per-pass widenings
+    // cost more than the residual wait): the raw rows are kept as loaded (xq, aq) and widened by materialise() in front of the K layer of
+    // the node's first pass; a widening right behind the load would be a use that waits for it (node_begin stood a memory round trip at
+    // every node change: 22 % of the pass).  dM rows are gathered two edges ahead (dq1, dq2).
+    uint2 xq[4], aq[4];
+    bool fresh = false;
+    auto widen = [](const uint2& u) {
+      return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    };
+    auto node_begin = [&](int j) {
+      const st_t* xs = bp.x_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
+      const st_t* ds = dres_b + ((size_t)(n0 + j) * O + r) * C + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#ifdef GRL_B16_NOGATHER
+        xq[t] = aq[t] = make_uint2(0x3f003e80u, 0xbf003f80u);
+#else
+        xq[t] = *reinterpret_cast<const uint2*>(xs + 16 * t);
+        aq[t] = *reinterpret_cast<const uint2*>(ds + 16 * t);
+#endif
+      }
+      fresh = true;
+    };
+    auto materialise = [&]() {
+      if (fresh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          xv[t] = widen(xq[t]);
+          acc[t] = widen(make_uint2(aq[t].x & dmask, aq[t].y & dmask));
+        }
+        fresh = false;
+      }
+    };
+    auto flush = [&](int j) {
+      materialise();
+      st_t* o = bp.dx_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st4(o + 16 * t, acc[t]);
+    };
+#else
     auto node_begin = [&](int j) {   // the source node's own row: the same for all of its edges
       const st_t* xs = bp.x_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {   // the accumulator starts from the other branch's gradient row (dres), long before it is needed
         xv[t] = B16_LD(xs + 16 * t);
-        acc[t] = bp.dres ? B16_LD(bp.dres + ((size_t)(n0 + j) * O + r) * C + 4 * g + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 dr = B16_LD(dres_b + ((size_t)(n0 + j) * O + r) * C + 4 * g + 16 * t);   // UNCONDITIONAL load, then a select (below)
+        acc[t] = keep(dr);
       }
     };
     auto flush = [&](int j) {
@@ -636,34 +712,104 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) st4(o + 16 * t, acc[t]);
     };
+#endif
     // nodes [from, to) have no out-edges (padded points come in runs): their rows are dres or zero.  Four nodes per round trip --
     // a load -> store per node would expose an HBM latency each (indices are clamped, not branched on: duplicates are harmless)
     auto skip_empty_run = [&](int from, int to) {
 #pragma unroll 1
       for (int j = from; j < to; j += 4) {
+#if GRL_PREC
+        uint2 v[4][4];   // (bf16 rows are copied as they are: no widening / rounding round trip)
+#else
         float4 v[4][4];
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const size_t row = ((size_t)(n0 + min(j + u, to - 1)) * O + r) * C + 4 * g;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) v[u][t] = bp.dres ? B16_LD(bp.dres + row + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int t = 0; t < 4; ++t) {
+#if GRL_PREC
+            const uint2 dr = *reinterpret_cast<const uint2*>(dres_b + row + 16 * t);
+            v[u][t] = make_uint2(dr.x & dmask, dr.y & dmask);
+#else
+            const float4 dr = B16_LD(dres_b + row + 16 * t);
+            v[u][t] = keep(dr);
+#endif
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const size_t row = ((size_t)(n0 + min(j + u, to - 1)) * O + r) * C + 4 * g;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) st4(bp.dx_src + row + 16 * t, v[u][t]);
+          for (int t = 0; t < 4; ++t)
+#if GRL_PREC
+            *reinterpret_cast<uint2*>(bp.dx_src + row + 16 * t) = v[u][t];
+#else
+            st4(bp.dx_src + row + 16 * t, v[u][t]);
+#endif
         }
       }
     };
+#if GRL_PREC && GRL_B16_ROWS
+    if (E0 < E1) {   // the leading nodes without edges are copied; the first node WITH edges becomes the current one
+      while (__builtin_amdgcn_readlane(rp, node + 1) <= E0) ++node;
+      skip_empty_run(0, node);
+      node_end = __builtin_amdgcn_readlane(rp, node + 1);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int pnode = node, pnode_end = node_end;   // the node of the edge whose rows are requested next (runs one edge ahead of `node`)
+#else
     node_begin(0);
+#endif
     for (int eb = E0; eb < E1; eb += 64) {
       const int ee = min(eb + lane, E1 - 1);
       const int oth = p.e_dst[ee];
       const int xrow = p.per_edge ? (p.erow ? p.erow[ee] : ee) : oth;
       const float pox = p.pos_dst[3 * oth], poy = p.pos_dst[3 * oth + 1], poz = p.pos_dst[3 * oth + 2];
       const int nb = min(64, E1 - eb);
-      // dM rows are gathered ONE EDGE AHEAD (a single wave per SIMD cannot hide an HBM round trip behind another wave)
+      // dM rows are gathered AHEAD of their pass (a single wave per SIMD cannot hide an HBM round trip behind another wave): one edge ahead
+      // in the fp32 build (a pass is ~4.3 us), TWO edges ahead in the plain-bf16 build, whose ~2.6 us pass is shorter than a gather under
+      // load -- the one-ahead form stood ~0.5 us per pass at the loop tail's vmcnt (profiles/r05_edge_bwd16_phases_rope_bf16.txt: 22 % of
+      // the pass; knock-out without gathers: -20 % of the launch).  The prefetched row is TAKEN OVER BEFORE the node change below: vmcnt
+      // counts in issue order, and with the node change's stores and loads issued in front of the take-over the wait for the old gather
+      // would also wait for the row loads that have only just been requested.
+#if GRL_PREC && GRL_B16_ROWS
+      auto rows_issue = [&](int kk) {   // the twelve loads of edge eb + kk (pnode: its source node)
+        const int en = eb + kk;
+        while (en >= pnode_end) { ++pnode; pnode_end = __builtin_amdgcn_readlane(rp, pnode + 1); }
+        const int row_in = __builtin_amdgcn_readlane(xrow, kk);
+        const st_t* dm = p.x_in + ((size_t)row_in * O + r) * C + 4 * g;
+        const st_t* xs = bp.x_src + ((size_t)(n0 + pnode) * O + r) * C + 4 * g;
+        const st_t* ds = dres_b + ((size_t)(n0 + pnode) * O + r) * C + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#ifdef GRL_B16_NOGATHER
+          nq.d[t] = nq.x[t] = nq.a[t] = make_uint2(0x3f003e80u, 0xbf003f80u);
+#else
+          nq.d[t] = *reinterpret_cast<const uint2*>(dm + 16 * t);
+          nq.x[t] = *reinterpret_cast<const uint2*>(xs + 16 * t);
+          nq.a[t] = *reinterpret_cast<const uint2*>(ds + 16 * t);
+#endif
+        }
+      };
+      rows_issue(0);
+#elif GRL_PREC
+      uint2 dq1[4], dq2[4];   // raw bf16 dM rows of the next two edges (widened when taken over)
+      auto dq_issue = [&](uint2 (&q)[4], int kk) {
+        const int row_in = __builtin_amdgcn_readlane(xrow, kk);
+        const st_t* dm = p.x_in + ((size_t)row_in * O + r) * C + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#ifdef GRL_B16_NOGATHER
+          q[t] = make_uint2(0x3f003e80u, 0xbf003f80u);
+#else
+          q[t] = *reinterpret_cast<const uint2*>(dm + 16 * t);
+#endif
+      };
+      dq_issue(dq1, 0);
+      dq_issue(dq2, min(1, nb - 1));
+#else
       float4 dvn[4];
       auto dv_issue = [&](int kk) {
         const int row_in = __builtin_amdgcn_readlane(xrow, kk);
@@ -672,9 +818,32 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         for (int t = 0; t < 4; ++t) dvn[t] = B16_LD(dm + 16 * t);
       };
       dv_issue(0);
+#endif
 #pragma unroll 1
       for (int k = 0; k < nb; ++k) {
         const int e = eb + k;
+        B16_PH(7);   // (diagnostic build) loop tail of the previous pass
+        float4 dv[4];
+#if GRL_PREC && GRL_B16_ROWS
+        // take-over of the twelve rows requested by the previous pass, PINNED here (the empty asm statements are uses the compiler
+        // cannot sink): the one vmcnt wait of the pass, with nothing younger than a pass in flight
+        uint2 dq[4], xq[4], an[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          dq[t] = nq.d[t]; xq[t] = nq.x[t]; an[t] = nq.a[t];
+          asm volatile("" : "+v"(dq[t].x), "+v"(dq[t].y), "+v"(xq[t].x), "+v"(xq[t].y), "+v"(an[t].x), "+v"(an[t].y));
+        }
+#elif GRL_PREC
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // taken over BEFORE the node change below (vmcnt counts in issue order)
+          dv[t] = widen(dq1[t]);
+          dq1[t] = dq2[t];
+        }
+#else
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dv[t] = dvn[t];
+#endif
+        B16_PH(8);   // this edge's prefetched rows taken over (vmcnt wait)
         if (e >= node_end) {            // the edge belongs to a later node of the chunk
           flush(node);
           int m = node + 1;
@@ -682,12 +851,27 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           skip_empty_run(node + 1, m);
           node = m;
           node_end = __builtin_amdgcn_readlane(rp, m + 1);
-          node_begin(m);
-        }
-        float4 dv[4];
+#if GRL_PREC && GRL_B16_ROWS
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dv[t] = dvn[t];
+          for (int t = 0; t < 4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+          node_begin(m);
+#endif
+        }
+#if GRL_PREC && GRL_B16_ROWS
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // (behind the flush, which adds the OLD node's dres row)
+          aq[t] = an[t];
+          dv[t] = widen(dq[t]);
+          xv[t] = widen(xq[t]);
+        }
+        rows_issue(min(k + 1, nb - 1));
+#elif GRL_PREC
+        dq_issue(dq2, min(k + 2, nb - 1));
+#else
         dv_issue(min(k + 1, nb - 1));
+#endif
+        B16_PH(10);  // node change (flush, skip of empty nodes, node_begin), next gather issued
         // layer 1's weight fragments and biases, and the first 64-deep group: requested before the invariants are computed
         bf16x8 w1h[4], w1l[4];
         float4 b1q[4];
@@ -710,6 +894,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
         RFrags<1> rf1;
         rowred_load<1>(st, lane, rf1);
         __builtin_amdgcn_sched_barrier(0);
+        B16_PH(9);   // layer 1's fragments / biases and the transposed dW1 operands requested (the stamp itself waits for them: LDS latency)
         // rel = pos_src - pos_dst (hepi.py:109-117); the source is the anchor here
         float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pax), node)) -
                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pox), k));
@@ -810,6 +995,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
                   });
         }
         B16_PH(2);   // layer 2 (24 MFMA, GELU + derivative, split)
+#if GRL_PREC && !GRL_B16_ROWS
+        materialise();   // the node's own rows, requested at the node change, are widened here -- first use below
+#endif
         // ---- K = Wk g2: d x_src row += K * dM;  dK = dM * x_src, staged with g2 for dWk += dK^T g2 (consumed after the dZ2 groups)
         bf16x8 kh[2], kl[2];
         RFrags<2> rf;
@@ -870,8 +1058,13 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #undef BAR
       }
     }
+#if GRL_PREC && GRL_B16_ROWS
+    if (E0 < E1) { flush(node); skip_empty_run(node + 1, nn); }   // the last node with edges, then the trailing nodes without
+    else skip_empty_run(0, nn);
+#else
     flush(node);                  // the last node with edges (or node 0 of a chunk without any), then the trailing nodes without
     skip_empty_run(node + 1, nn);
+#endif
   }
 
   {   // dW1 of the wave's last pass
@@ -881,7 +1074,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   }
 #ifdef GRL_B16_PHASE
   if (lane == 0 && wave == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_b16phase[i], ph_[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(&g_b16phase[i], ph_[i]);
 #endif
   // ---- fold the four waves through LDS (images dead): 1 -> 0 and 3 -> 2, then 2 -> 0; fixed order, one partial row per workgroup
   constexpr int NACC = 10 * 16 + 16;

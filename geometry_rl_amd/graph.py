@@ -12,7 +12,6 @@ Differences from the reference that do not change any output:
 The topology is built once per batch size and reused for every later batch of that size, like the reference cache
 (rigid_tasks_data.py:254-255).
 """
-import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -151,7 +150,7 @@ class HyperData:
             self.node_type_list = list(spec.node_types)
         self._cache = {}
         self.bump_next = None   # one-shot: a device int32[1] the NEXT build_data's feature launch advances by one (PolicyUpdater: step count)
-        self.check_topology_always = bool(int(os.environ.get("GRL_CHECK_TOPOLOGY", "0")))
+        self.check_topology_always = False   # debugging: True = every eager build_data re-validates the cached topology (one device sync each)
 
     # ---- cached topology: invariant and guards
     def reset_cache(self):
@@ -166,7 +165,7 @@ class HyperData:
         """Raise if the batch's per-row valid point counts differ from those the cached topology of this batch size was built
         from (padded points are DROPPED from the actor graph according to the cached counts, so a mismatch silently mis-assigns
         nodes).  One device->host sync: called by PolicyUpdater when it records the step, by every eager build when
-        GRL_CHECK_TOPOLOGY=1, never inside a replayed graph."""
+        ``check_topology_always`` is set, never inside a replayed graph."""
         obs = dict(zip(self.spec.in_features, args))
         B = obs["scalars"].shape[0]
         topo = self._cache.get(B)

@@ -20,10 +20,13 @@ torch.cuda.synchronize()
 READ(buf, ctypes.c_int(1))
 upd.step(b); torch.cuda.synchronize()
 READ(buf, ctypes.c_int(1))
-names = ["pass top: node change, gathers issued, invariants, phi", "layer 1: 12 MFMA, GELU + derivative, split", "layer 2: 24 MFMA, GELU + derivative, split",
+names = ["pass top, rest: invariants, phi, split", "layer 1: 12 MFMA, GELU + derivative, split", "layer 2: 24 MFMA, GELU + derivative, split",
          "K: 24 MFMA, d x_src, dK, staging dK | g2, transposed reads", "dZ2: 24 MFMA, dWk: 12 MFMA 32x32, split", "staging dZ2 | g1, dZ1: 24 MFMA, dW2: 12 MFMA 32x32, split",
-         "staging dZ1 | phi, dW1: 6 MFMA 32x32"]
-v = [buf[i] for i in range(7)]
+         "staging dZ1 | phi, dW1: 6 MFMA 32x32",
+         "pass top: loop tail of the previous pass", "pass top: prefetched dM row taken over (vmcnt wait)",
+         "pass top: layer-1 fragments + transposed dW1 operands requested (stamp waits for the LDS reads)",
+         "pass top: node change (flush, skip of empty nodes, node_begin), next gather issued"]
+v = [buf[i] for i in range(11)]
 tot = sum(v) or 1
 print(f"== edge_bwd16_kernel, workload {WL}: {tot / 1e6:.1f} Mticks over wave 0 of every workgroup")
 for n, x in zip(names, v):
