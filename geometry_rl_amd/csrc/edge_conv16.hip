@@ -20,6 +20,7 @@
 // 32-block: position 8 g + j <-> feature 16 (j >> 2) + 4 g + (j & 3); the weight images are staged in that order), so the chain stays
 // in registers exactly as in the 32-row kernels.  Three waves per SIMD: every MFMA group is fenced (all fragment loads, then the
 // MFMAs, then a read of the accumulator: DESIGN.md finding 3).
+#define GRL_PK_F4 1   // (plain-bf16 build only: packed f32 pairs for the element-wise products, grl_common.h)
 #include "grl_tile16.h"
 #include "grl_wimg.h"
 #include <cstdlib>
@@ -498,7 +499,8 @@ GRL_DEVINL void rowred_mma(const RFrags<NTK>& f, f32x16 (&acc)[2][NTK]) {
 
 #ifdef GRL_B16_NOGELU
 #define B16_GELU(x, gv, gpv) ((gv) = (x), (gpv) = (x))
-#elif !defined(GRL_B16_SCALAR_GELU)   // packed pairs: one wave per SIMD issues a v_pk_* in the time of a scalar op (A/B: -5 %)
+#elif !defined(GRL_B16_SCALAR_GELU) || GRL_PREC   // packed pairs: one wave per SIMD issues a v_pk_* in the time of a scalar op; the plain-bf16
+                                                  // build always (its MFMAs come in bursts, not between the epilogue's instructions)
 GRL_DEVINL void gelu_both4_pk(const float4& x, float4& gv, float4& gpv) {
   v2f g0, g1, d0, d1;
   gelu_pair<true>(v2f{x.x, x.y}, g0, d0);

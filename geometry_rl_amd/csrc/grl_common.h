@@ -137,18 +137,41 @@ GRL_DEVINL v2f splat2(float a) { return v2f{a, a}; }
 #ifndef GRL_GELU_V2
 #define GRL_GELU_V2 1
 #endif
+// Packed form of the logistic GELU (round 5, plain-bf16 build): the same operations as gelu_logistic / gelu_logistic_both on TWO elements per
+// instruction.  A lone wave issues a v_pk_mul_f32 / v_pk_fma_f32 in ~5.2 cycles (profiles/r02_valu_rates.txt) -- the cost of ONE plain
+// instruction -- so the ten plain operations per element become ten per PAIR (66 -> 43 cycles per element with the two transcendentals).
+// Packed f32 does not overlap with an MFMA of the same wave (+20 cycles per instruction inside a dependent-MFMA gap,
+// profiles/r05_valu16_rates.txt): in the bf16 build that does not matter, its layers issue their few MFMAs as one burst and the
+// epilogues behind it; the fp32 build (MFMAs between the epilogue's instructions) keeps the scalar forms (DESIGN.md finding 23).
+GRL_DEVINL void gelu_logistic_pair(v2f x, v2f& g) {
+  const v2f w = x * fma2(x * x, splat2(-0.07056f * 1.44269504088896f), splat2(-1.5976f * 1.44269504088896f));
+  v2f a;
+  a.x = __builtin_amdgcn_exp2f(w.x);
+  a.y = __builtin_amdgcn_exp2f(w.y);
+  a = a + splat2(1.f);
+  v2f s_;
+  s_.x = __builtin_amdgcn_rcpf(a.x);
+  s_.y = __builtin_amdgcn_rcpf(a.y);
+  g = x * s_;
+}
+GRL_DEVINL void gelu_logistic_both_pair(v2f x, v2f& g, v2f& gp) {
+  const v2f x2 = x * x;
+  const v2f w = x * fma2(x2, splat2(-0.07056f * 1.44269504088896f), splat2(-1.5976f * 1.44269504088896f));
+  v2f a;
+  a.x = __builtin_amdgcn_exp2f(w.x);
+  a.y = __builtin_amdgcn_exp2f(w.y);
+  a = a + splat2(1.f);
+  v2f s_;
+  s_.x = __builtin_amdgcn_rcpf(a.x);
+  s_.y = __builtin_amdgcn_rcpf(a.y);
+  g = x * s_;
+  gp = fma2(s_ * (splat2(1.f) - s_), x * fma2(x2, splat2(3.f * 0.07056f), splat2(1.5976f)), s_);
+}
 template <bool WITH_GRAD>
 GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
 #if GRL_GELU_LOGISTIC
-  if (WITH_GRAD) {
-    float g0, g1, d0, d1;
-    gelu_logistic_both(x.x, g0, d0);
-    gelu_logistic_both(x.y, g1, d1);
-    g = v2f{g0, g1};
-    gp = v2f{d0, d1};
-  } else {
-    g = v2f{gelu_logistic(x.x), gelu_logistic(x.y)};
-  }
+  if (WITH_GRAD) gelu_logistic_both_pair(x, g, gp);
+  else gelu_logistic_pair(x, g);
   return;
 #endif
   const float kp = 0.3275911f * 0.70710678118654752440f;
@@ -294,8 +317,19 @@ GRL_DEVINL float4 load_nt4(const float* p) {
 GRL_DEVINL void store_nt4(float* p, const float4& v) {
   __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(p));
 }
+#if GRL_PREC && defined(GRL_PK_F4)   // plain-bf16 build of a file that asks for it: element-wise products and sums as packed pairs (see gelu_logistic_pair)
+GRL_DEVINL float4 f4_mul(float4 a, float4 b) {
+  const v2f lo = v2f{a.x, a.y} * v2f{b.x, b.y}, hi = v2f{a.z, a.w} * v2f{b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+GRL_DEVINL float4 f4_add(float4 a, float4 b) {
+  const v2f lo = v2f{a.x, a.y} + v2f{b.x, b.y}, hi = v2f{a.z, a.w} + v2f{b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+#else
 GRL_DEVINL float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 GRL_DEVINL float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+#endif
 GRL_DEVINL float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
 // copy a row-major [rows][K] fp32 matrix from global into an LDS image with leading dim ld (pads untouched)

@@ -71,8 +71,8 @@ GRL_DEVINL void split4(const float4& v, uint2& hi, uint2& lo) {
 }
 // GRL_M16_SCALAR (default): plain f32 vector instructions only in this kernel (scalar GELU, file compiled with -fno-slp-vectorize)
 #ifndef GRL_M16_SCALAR
-#define GRL_M16_SCALAR 1
-#endif
+#define GRL_M16_SCALAR (!GRL_PREC)   // the plain-bf16 build takes the packed logistic GELU (grl_common.h gelu_logistic_both_pair): +1.3 % on the
+#endif                               // rope workload's step, A/B profiles/r05_ab_mlp_pk.txt; the fp32 build stays scalar (finding 23)
 GRL_DEVINL void gelu_both4_pk(const float4& x, float4& gv, float4& gpv) {
 #if GRL_M16_SCALAR
   gelu_both4(x, gv, gpv);
