@@ -20,7 +20,10 @@
 // 32-block: position 8 g + j <-> feature 16 (j >> 2) + 4 g + (j & 3); the weight images are staged in that order), so the chain stays
 // in registers exactly as in the 32-row kernels.  Three waves per SIMD: every MFMA group is fenced (all fragment loads, then the
 // MFMAs, then a read of the accumulator: DESIGN.md finding 3).
-#define GRL_PK_F4 1   // (plain-bf16 build only: packed f32 pairs for the element-wise products, grl_common.h)
+#ifndef GRL_B16_BURST
+#define GRL_B16_BURST 1   // fp32 build: MFMA bursts per layer + packed epilogues in the fused backward (see edge_bwd16_kernel; 0 = the grouped form of rounds 2-4)
+#endif
+#define GRL_PK_F4 1   // (plain-bf16 build, or the fp32 burst experiment: packed f32 pairs for the element-wise products, grl_common.h)
 #include "grl_tile16.h"
 #include "grl_wimg.h"
 #include <cstdlib>
@@ -499,7 +502,7 @@ GRL_DEVINL void rowred_mma(const RFrags<NTK>& f, f32x16 (&acc)[2][NTK]) {
 
 #ifdef GRL_B16_NOGELU
 #define B16_GELU(x, gv, gpv) ((gv) = (x), (gpv) = (x))
-#elif !defined(GRL_B16_SCALAR_GELU) || GRL_PREC   // packed pairs: one wave per SIMD issues a v_pk_* in the time of a scalar op; the plain-bf16
+#elif !defined(GRL_B16_SCALAR_GELU) || GRL_PREC || GRL_B16_BURST   // packed pairs: one wave per SIMD issues a v_pk_* in the time of a scalar op; the plain-bf16
                                                   // build always (its MFMAs come in bursts, not between the epilogue's instructions)
 GRL_DEVINL void gelu_both4_pk(const float4& x, float4& gv, float4& gpv) {
   v2f g0, g1, d0, d1;
@@ -581,6 +584,27 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
   LayerFrags bufA, bufB;
   lf_load(bufA, w.W2h);
   lf_load(bufB, w.Wkh);
+#elif GRL_B16_BURST
+  // fp32 build (round 5; GRL_B16_BURST=0 restores the grouped form): a layer's 24 MFMAs as ONE burst of four independent six-deep chains from a layer-wide fragment
+  // buffer (hi + lo: 64 registers, ONE buffer: it is refilled for the next layer right behind the burst -- in-order issue, one wave per
+  // SIMD: every MFMA of the burst has been issued, i.e. has read its operands, before the first of these reads is issued -- and the
+  // reads land during the epilogue), and the epilogues as PACKED f32 pairs behind it (no MFMA between their instructions: a lone wave issues a
+  // v_pk_* in the time of a plain instruction, but not inside an MFMA's shadow).  Bitwise the grouped form's results (same products in the
+  // same order per accumulator).  A/B on one box, three alternating rounds: 310.4-312.8 -> 312.2-313.7 steps/s (+0.5 %), edge_bwd16 1.19 ->
+  // 1.17 ms per step (profiles/r05_ab_burst.txt): the packed epilogues save ~12 % of the pass's vector issue, the burst gives back the
+  // little MFMA / VALU overlap the grouped form had (finding 18: the kernel is additive either way).
+  struct LayerFrags { bf16x8 h[4][2], l[4][2]; };
+  auto lf_load = [&](LayerFrags& f, const unsigned short* imh, const unsigned short* iml) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        f.h[nt][s_] = *reinterpret_cast<const bf16x8*>(imh + (16 * nt + r) * LD2 + 8 * g + 32 * s_);
+        f.l[nt][s_] = *reinterpret_cast<const bf16x8*>(iml + (16 * nt + r) * LD2 + 8 * g + 32 * s_);
+      }
+  };
+  LayerFrags buf;
+  lf_load(buf, w.W2h, w.W2l);
 #endif
   f32x16 accK[2][2], accA[2][2], accB[2][1];   // dWk, dW2, dW1 (| db1 in column 14)
 #pragma unroll
@@ -884,7 +908,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
           b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
         }
-#if GRL_PREC
+#if GRL_PREC || GRL_B16_BURST
         float4 b2q[4];   // layer 2's biases (its fragments are resident in bufA)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) b2q[nt] = *reinterpret_cast<const float4*>(w.b2s + 16 * nt + 4 * g);
@@ -949,6 +973,31 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           tail();
           BAR();
         };
+#elif GRL_B16_BURST
+        auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
+          f32x4v c[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[nt] = base == 0 ? f32x4v{b2q[nt].x, b2q[nt].y, b2q[nt].z, b2q[nt].w} : f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_) {   // (per accumulator the same six products in the same order as the grouped form: bitwise equal)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(buf.h[nt][s_], ih[s_], c[nt]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(buf.l[nt][s_], ih[s_], c[nt]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(buf.h[nt][s_], il[s_], c[nt]);
+          }
+          BAR();
+          if (base == 0) lf_load(buf, w.Wkh, w.Wkl);
+          else if (base == 4) lf_load(buf, sm.img.WkTh, sm.img.WkTl);
+          else if (base == 8) lf_load(buf, sm.img.W2Th, sm.img.W2Tl);
+          else lf_load(buf, w.W2h, w.W2l);
+          BAR();
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) epi(nt, c[nt]);
+          tail();
+          BAR();
+        };
 #else
         // a 64-deep layer: groups base .. base + 3 (wf[base & 1] already requested); epi(nt, c) consumes tile nt one region later
         auto layer64 = [&](int base, const bf16x8 (&ih)[2], const bf16x8 (&il)[2], auto&& epi, auto&& tail) {
@@ -968,6 +1017,28 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           BAR();
         };
 #endif
+#if GRL_B16_BURST && !GRL_PREC
+        {
+          float4 g1[4];
+          BAR();
+          f32x4v c[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[nt] = f32x4v{b1q[nt].x, b1q[nt].y, b1q[nt].z, b1q[nt].w};
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1h[nt], ph[0], c[nt]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1l[nt], ph[0], c[nt]);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1h[nt], pl[0], c[nt]);
+          rowred_mma<1>(rf1, accB);
+          BAR();
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) B16_GELU(v4(c[nt]), g1[nt], gp1[nt]);
+          split_pair(g1[0], g1[1], xh[0], xl[0]);
+          split_pair(g1[2], g1[3], xh[1], xl[1]);
+          BAR();
+        }
+#else
         {
           float4 g1[4];
           BAR();
@@ -987,6 +1058,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           split_pair(g1[2], g1[3], xh[1], xl[1]);
           BAR();
         }
+#endif
         B16_PH(1);   // layer 1 (12 MFMA, GELU + derivative, split)
         {
           float4 g2[4];

@@ -317,7 +317,7 @@ GRL_DEVINL float4 load_nt4(const float* p) {
 GRL_DEVINL void store_nt4(float* p, const float4& v) {
   __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(p));
 }
-#if GRL_PREC && defined(GRL_PK_F4)   // plain-bf16 build of a file that asks for it: element-wise products and sums as packed pairs (see gelu_logistic_pair)
+#if (GRL_PREC || (defined(GRL_B16_BURST) && GRL_B16_BURST)) && defined(GRL_PK_F4)   // plain-bf16 build of a file that asks for it: element-wise products and sums as packed pairs (see gelu_logistic_pair)
 GRL_DEVINL float4 f4_mul(float4 a, float4 b) {
   const v2f lo = v2f{a.x, a.y} * v2f{b.x, b.y}, hi = v2f{a.z, a.w} * v2f{b.z, b.w};
   return make_float4(lo.x, lo.y, hi.x, hi.y);
