@@ -724,13 +724,20 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
       for (int t = 0; t < 4; ++t) st4(o + 16 * t, acc[t]);
     };
 #else
+#ifndef GRL_B16_FP32_ROWS
+#define GRL_B16_FP32_ROWS 0   // fp32 build: 0 = round 4's node rows (dres ? load : 0 on the load expression, node change in front of the dM take-over),
+#endif                        // 1 = unconditional loads + bit-mask select + take-over first (what the bf16 build needs).  See the A/B note below.
     auto node_begin = [&](int j) {   // the source node's own row: the same for all of its edges
       const st_t* xs = bp.x_src + ((size_t)(n0 + j) * O + r) * C + 4 * g;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {   // the accumulator starts from the other branch's gradient row (dres), long before it is needed
         xv[t] = B16_LD(xs + 16 * t);
-        const float4 dr = B16_LD(dres_b + ((size_t)(n0 + j) * O + r) * C + 4 * g + 16 * t);   // UNCONDITIONAL load, then a select (below)
+#if GRL_B16_FP32_ROWS
+        const float4 dr = B16_LD(dres_b + ((size_t)(n0 + j) * O + r) * C + 4 * g + 16 * t);   // UNCONDITIONAL load, then a select
         acc[t] = keep(dr);
+#else
+        acc[t] = bp.dres ? B16_LD(bp.dres + ((size_t)(n0 + j) * O + r) * C + 4 * g + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
       }
     };
     auto flush = [&](int j) {
@@ -758,8 +765,12 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
             const uint2 dr = *reinterpret_cast<const uint2*>(dres_b + row + 16 * t);
             v[u][t] = make_uint2(dr.x & dmask, dr.y & dmask);
 #else
+#if GRL_B16_FP32_ROWS
             const float4 dr = B16_LD(dres_b + row + 16 * t);
             v[u][t] = keep(dr);
+#else
+            v[u][t] = bp.dres ? B16_LD(bp.dres + row + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 #endif
           }
         }
@@ -865,7 +876,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
           dv[t] = widen(dq1[t]);
           dq1[t] = dq2[t];
         }
-#else
+#elif GRL_B16_FP32_ROWS
 #pragma unroll
         for (int t = 0; t < 4; ++t) dv[t] = dvn[t];
 #endif
@@ -895,6 +906,10 @@ __global__ __launch_bounds__(256, 1) void edge_bwd16_kernel(Bwd16Params bp) {
 #elif GRL_PREC
         dq_issue(dq2, min(k + 2, nb - 1));
 #else
+#if !GRL_B16_FP32_ROWS
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dv[t] = dvn[t];
+#endif
         dv_issue(min(k + 1, nb - 1));
 #endif
         B16_PH(10);  // node change (flush, skip of empty nodes, node_begin), next gather issued

@@ -327,6 +327,16 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
   }
   __syncthreads();
 
+#ifndef GRL_M16_BURST
+#define GRL_M16_BURST GRL_PREC   // plain-bf16 build: z and dH of a chunk as ONE burst of sixteen MFMAs (the W4^T fragments resident in registers:
+#endif                           // no lo halves, they fit), the GELUs and dZ as packed f32 pairs behind it -- the edge backward's recipe (round 5)
+#if GRL_M16_BURST
+  bf16x8 w4r[4][2];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) w4r[nt][s] = __builtin_bit_cast(bf16x8, sm.W4F[wave][nt][s][0][lane]);
+#endif
 #ifdef GRL_M16_PHASE
   unsigned long long ph_[12] = {0}, tl_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -388,7 +398,25 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
         dz[nt] = f4_mul(v4(e[nt]), gp[nt]);
         db3[nt] = f4_add(db3[nt], dz[nt]);
       };
-#if GRL_M16_PAIRS
+#if GRL_M16_BURST
+      static_assert(GRL_PREC, "the burst form keeps W4^T resident: plain-bf16 build only");
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { c[nt] = f32x4v{b3q[nt].x, b3q[nt].y, b3q[nt].z, b3q[nt].w}; e[nt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w3f.h[nt][s], ah[s], c[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) e[nt] = mfma16(w4r[nt][s], dh_[s], e[nt]);
+      }
+      BAR();
+      M16_PH(2);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) gelu_both4_pk(v4(c[nt]), hv[nt], gp[nt]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dz_tile(nt);
+      split_pair(dz[0], dz[1], zh[0], zl[0]);
+#elif GRL_M16_PAIRS
       z_tile(0); z_tile(1); w4_load(0); w4_load(1);
       BAR();
       z_tile(2); z_tile(3);

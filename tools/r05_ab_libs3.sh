@@ -1,0 +1,9 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for round in 1 2; do
+  for lib in r04 now; do
+    GRL_BENCH_NO_SELFCHECK=1 GRL_ALLOW_DIAG_LIB=1 GRL_LIB=$PWD/_variants/lib_$lib.so python bench.py --no-cpu-baseline --no-parity-gate --repeats 3 2>/dev/null | tail -1 | python -c "
+import sys,json; l=json.loads(sys.stdin.read()); k=l['roofline']['replayed_launches']
+print('newpy+$lib', round(l['value'],2), round(l['ms_per_step'],4), 'replayed:', ' '.join('%s %.4f' % (n.replace('_kernel','')[:16], v['ms_per_step']) for n,v in k.items()), 'sum %.4f' % sum(v['ms_per_step'] for v in k.values()))"
+  done
+done
