@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 203
+#define GRL_HIP_VERSION 204   /* 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
 int grl_version(void);
 
 /* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
