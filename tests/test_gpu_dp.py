@@ -118,6 +118,23 @@ def test_two_ranks_with_graph_segments_match_single_rank(n_steps):
         assert (flat - ref_flat).abs().max().item() <= (4e-6 if n_steps == 2 else 3e-5)
 
 
+def test_two_ranks_on_one_communicator_fallback(monkeypatch):
+    """GRL_DP_ONE_COMM=1 -- both lanes on the actor's communicator, the documented fallback of PolicyUpdater._plan_dp (what
+    tools/first_multigpu_run.sh switches to after a hang): same results as one rank, recorded graph segments included."""
+    monkeypatch.setenv("GRL_DP_ONE_COMM", "1")   # (inherited by the spawned workers)
+    B, world, n_steps = 16, 2, 3
+    ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
+    assert all(r in ret for r in range(world))
+    for r in range(world):
+        losses, flat = ret[r]
+        for k, v in ref_losses.items():
+            assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (r, k, losses[k], v)
+        assert (flat - ref_flat).abs().max().item() <= 3e-5
+
+
 def test_two_ranks_with_published_advantage_statistics():
     """The epoch-level advantage statistics (one all-reduce per epoch, carried as a per-frame column): the update has no
     ``advantage_stats`` collective any more and still equals the single-rank update of the whole minibatch."""

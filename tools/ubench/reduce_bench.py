@@ -53,3 +53,11 @@ run("whole fold, 512-frame shard", slabs, segs)
 run("  only the two MLP slabs", slabs, [s_ for s_ in segs if s_[0] in (0, 2)])
 run("  only the two edge slabs", slabs, [s_ for s_ in segs if s_[0] in (1, 3)])
 run("  the rest", slabs, [s_ for s_ in segs if s_[0] >= 4])
+
+# ---- round 5: would a COLUMN-BLOCKED slab ([64-column block][row][64]: a block's rows contiguous, 256 B each) fold faster than the
+#      row-major one (rows 133 KB apart)?  A blocked slab's block is a row-major [rows][64] matrix of its own, so the existing kernel can
+#      read 64 of them as 64 segments: the same 4096 columns x 256 rows both ways.
+run("row-major: 4096 cols of a 256 x 33216 slab", [(256, M)], [(0, 0, 4096, "a")])
+run("blocked:   64 blocks of [256][64]", [(256, 64)] * 64, [(i, 0, 64, f"k{i}") for i in range(64)])
+run("row-major: 4096 cols of a 1024 x 33216 slab", [(1024, M)], [(0, 0, 4096, "a")])
+run("blocked:   64 blocks of [1024][64]", [(1024, 64)] * 64, [(i, 0, 64, f"k{i}") for i in range(64)])
