@@ -259,16 +259,21 @@ GRL_DEVINL void chain16(const ChainW16& w, float a, float b, int r, int g, KEpi&
                [&](const f32x4v& acc) { k_epi(nt, v4(acc)); });
 }
 
-#if GRL_PREC
-// Plain-bf16 build (round 5): a lane's weight fragments depend on (row, k-group, n-tile, K-step) only -- the SAME 20 operand registers for
-// every pass -- and without lo halves they fit: W2 8 + Wk 8 fragments = 64 registers, resident for the whole launch (W1's four would push the
-// kernel over the 168 registers of three waves per SIMD: they are requested with the biases at the head of the pass).  The pass loop
-// then has no fragment read inside the chain at all (the fenced groups exposed one LDS round trip per group: 12 per pass, wave cycles wait 0.41 + issue
-// stall 0.23 at three waves per SIMD, profiles/r05_pmc_table_rope_hepi_bf16_a.txt); the only LDS reads left are the two layers' biases,
-// requested at the head of the pass behind a scheduling barrier (no MFMA of this wave is in flight there: the previous pass's last
-// accumulators have been consumed).  Same products in the same order per accumulator: bit-identical results.
+#ifndef GRL_E16_RESIDENT
+#define GRL_E16_RESIDENT GRL_PREC   // forward: weight fragments resident in registers (bf16 build: always; fp32 build: with GRL_E16_WGS=2, experiment)
+#endif
+#if GRL_E16_RESIDENT
+// Resident weight fragments (round 5): a lane's weight fragments depend on (row, k-group, n-tile, K-step) only -- the SAME operand registers
+// for every pass.  Plain-bf16 build: W2 8 + Wk 8 fragments = 64 registers at three waves per SIMD (W1's four would push the kernel over 168
+// registers: they are requested with the biases at the head of the pass).  fp32 build: hi + lo = 128 registers, two waves per SIMD
+// (GRL_E16_WGS=2).  The pass loop then has no fragment read inside the chain at all (the fenced groups exposed one LDS round trip per
+// group: 12 per pass, wave cycles wait 0.41 + issue stall 0.23 at three waves per SIMD in the bf16 build, profiles/r05_pmc_table_rope_hepi_bf16_a.txt);
+// the only LDS reads left are W1's fragments and the two layers' biases, requested at the head of the pass behind a scheduling barrier
+// (no MFMA of this wave is in flight there: the previous pass's last accumulators have been consumed).  A layer's MFMAs run as four
+// independent chains, round-robin.  Same products in the same order per accumulator: bit-identical results.
 struct ChainRegs {
   bf16x8 w2[4][2], wk[4][2];
+  GRL_LO(bf16x8 w2l[4][2]; bf16x8 wkl[4][2];)
 };
 GRL_DEVINL void chain_regs_load(ChainRegs& cr, const ChainW16& w, int r, int g) {
 #pragma unroll
@@ -277,6 +282,8 @@ GRL_DEVINL void chain_regs_load(ChainRegs& cr, const ChainW16& w, int r, int g) 
     for (int s = 0; s < 2; ++s) {
       cr.w2[nt][s] = *reinterpret_cast<const bf16x8*>(w.W2h + (16 * nt + r) * LD2 + 8 * g + 32 * s);
       cr.wk[nt][s] = *reinterpret_cast<const bf16x8*>(w.Wkh + (16 * nt + r) * LD2 + 8 * g + 32 * s);
+      GRL_LO(cr.w2l[nt][s] = *reinterpret_cast<const bf16x8*>(w.W2l + (16 * nt + r) * LD2 + 8 * g + 32 * s);)
+      GRL_LO(cr.wkl[nt][s] = *reinterpret_cast<const bf16x8*>(w.Wkl + (16 * nt + r) * LD2 + 8 * g + 32 * s);)
     }
   }
 }
@@ -285,9 +292,11 @@ GRL_DEVINL void chain16_resident(const ChainRegs& cr, const ChainW16& w, float a
   __builtin_amdgcn_sched_barrier(0);
   float4 b1q[4], b2q[4];
   bf16x8 w1[4];
+  GRL_LO(bf16x8 w1l[4];)
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     w1[nt] = *reinterpret_cast<const bf16x8*>(w.W1h + (16 * nt + r) * LD1 + 8 * g);
+    GRL_LO(w1l[nt] = *reinterpret_cast<const bf16x8*>(w.W1l + (16 * nt + r) * LD1 + 8 * g);)
     b1q[nt] = *reinterpret_cast<const float4*>(w.b1s + 16 * nt + 4 * g);
     b2q[nt] = *reinterpret_cast<const float4*>(w.b2s + 16 * nt + 4 * g);
   }
@@ -303,24 +312,48 @@ GRL_DEVINL void chain16_resident(const ChainRegs& cr, const ChainW16& w, float a
   float4 g1[4], g2[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1[nt], ph, f32x4v{b1q[nt].x, b1q[nt].y, b1q[nt].z, b1q[nt].w});
+#if !GRL_PREC
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1l[nt], ph, c[nt]);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(w1[nt], pl, c[nt]);
+#endif
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) g1[nt] = GELU16(v4(c[nt]));
   bf16x8 xh[2], xl[2];
   split_pair(g1[0], g1[1], xh[0], xl[0]);
   split_pair(g1[2], g1[3], xh[1], xl[1]);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2[nt][0], xh[0], f32x4v{b2q[nt].x, b2q[nt].y, b2q[nt].z, b2q[nt].w});
+  for (int nt = 0; nt < 4; ++nt) c[nt] = f32x4v{b2q[nt].x, b2q[nt].y, b2q[nt].z, b2q[nt].w};
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2[nt][1], xh[1], c[nt]);
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2[nt][s], xh[s], c[nt]);
+#if !GRL_PREC
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2l[nt][s], xh[s], c[nt]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.w2[nt][s], xl[s], c[nt]);
+#endif
+  }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) g2[nt] = GELU16(v4(c[nt]));
   bf16x8 yh[2], yl[2];
   split_pair(g2[0], g2[1], yh[0], yl[0]);
   split_pair(g2[2], g2[3], yh[1], yl[1]);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wk[nt][0], yh[0], f32x4v{0.f, 0.f, 0.f, 0.f});
+  for (int nt = 0; nt < 4; ++nt) c[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wk[nt][1], yh[1], c[nt]);
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wk[nt][s], yh[s], c[nt]);
+#if !GRL_PREC
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wkl[nt][s], yh[s], c[nt]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) c[nt] = mfma16(cr.wk[nt][s], yl[s], c[nt]);
+#endif
+  }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) k_epi(nt, v4(c[nt]));
   __builtin_amdgcn_sched_barrier(0);
@@ -344,7 +377,7 @@ __global__ __launch_bounds__(E16_THREADS, GRL_E16_WGS) void edge16_kernel(Edge16
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const float gx = s.grid_s[3 * r], gy = s.grid_s[3 * r + 1], gz = s.grid_s[3 * r + 2];
-#if GRL_PREC
+#if GRL_E16_RESIDENT
   ChainRegs cregs;
   chain_regs_load(cregs, s, r, g);
 #endif
