@@ -313,10 +313,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
+        # a collective that never completes must end the run, not hold the node: the watchdog aborts after three minutes (the default is ten
+        # to thirty) -- nothing of the N > 1 path has ever run on more than one GPU
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("GRL_BENCH_COLLECTIVE_TIMEOUT_S", "180")))
         if os.environ.get("GRL_BENCH_ONE_GPU"):
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         group = dist.group.WORLD
     elif args.dp_plan:
         import socket
