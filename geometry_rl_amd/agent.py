@@ -104,6 +104,7 @@ class PolicyUpdater:
         self.loss_module, self.group = loss_module, group
         self.overlap_critic = overlap_critic   # one rank: False = everything on the caller's stream (_plan_one_stream)
         self.force_dp_plan = force_dp_plan     # a process group of ONE rank runs the data-parallel program (bench.py --dp-plan)
+        self.critic_delay_us = 0               # experiment knob (tools/critic_delay_ab.py): microseconds the critic's lane idles before it starts
         self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
         self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
         self._hyper = dict(eps=eps, betas=tuple(betas), clip=clip_grad_norm, max_norm=max_grad_norm)
@@ -404,6 +405,8 @@ class PolicyUpdater:
         def critic_all():
             ops.DEFERRED = []
             with torch.no_grad():
+                if self.critic_delay_us:   # (experiment knob, default 0: an idle one-wave kernel in front of the critic's lane)
+                    hip.call("grl_calib_spin", int(self.critic_delay_us))
                 if not ow:
                     self.gflat[na:].zero_()   # on THIS lane, in front of its folds (never from the actor's lane)
                 vf.train(True)

@@ -53,6 +53,11 @@ __global__ __launch_bounds__(256, 1) void calib_mfma_kernel(int iters, float* __
   out[gid] = s;
 }
 
+// one wave that does nothing for `us` microseconds (s_memrealtime: 100 MHz), sleeping between polls: a delay node for lane-placement experiments
+__global__ __launch_bounds__(64) void calib_spin_kernel(int us) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < 100LL * us) __builtin_amdgcn_s_sleep(32);
+}
 __global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
@@ -64,6 +69,12 @@ extern "C" {
 int grl_calib_mfma(int iters, float* out, hipStream_t stream) {
   if (iters < 1 || !out) return -2;
   hipLaunchKernelGGL(calib_mfma_kernel, dim3(256), dim3(256), 0, stream, iters, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// a one-wave kernel that idles for `us` microseconds (experiments with where the critic's lane starts relative to the actor's kernels)
+int grl_calib_spin(int us, hipStream_t stream) {
+  if (us <= 0) return 0;
+  hipLaunchKernelGGL(calib_spin_kernel, dim3(1), dim3(64), 0, stream, us);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // bytes: a multiple of 16.  Bytes moved by one call: 2 * bytes.

@@ -390,6 +390,8 @@ int grl_prof_get(int i, char* name, int cap, float* ms);
  * grl_calib_copy: float4 grid-stride copy, bytes a multiple of 16; bytes moved per call = 2 * bytes. */
 int grl_calib_mfma(int iters, float* out, hipStream_t stream);
 int grl_calib_copy(const void* src, void* dst, long long bytes, hipStream_t stream);
+/* one wave that idles for `us` microseconds (s_memrealtime): a delay node for lane-placement experiments (tools/critic_delay_ab.sh) */
+int grl_calib_spin(int us, hipStream_t stream);
 
 #ifdef __cplusplus
 }
