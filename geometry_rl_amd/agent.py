@@ -100,11 +100,17 @@ class PolicyUpdater:
     case (``_plan_one_stream`` / ``_plan_lanes`` / ``_plan_dp``): see the comment above ``_plan``."""
 
     def __init__(self, loss_module: TRPLLoss, lr=3e-4, eps=1e-5, betas=(0.9, 0.999), clip_grad_norm=False, max_grad_norm=1.0,
-                 group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False, force_dp_plan=False):
+                 group=None, use_graph=False, overlap_critic=True, allow_eager_fallback=False, force_dp_plan=False,
+                 critic_after_first_conv=True):
         self.loss_module, self.group = loss_module, group
         self.overlap_critic = overlap_critic   # one rank: False = everything on the caller's stream (_plan_one_stream)
         self.force_dp_plan = force_dp_plan     # a process group of ONE rank runs the data-parallel program (bench.py --dp-plan)
         self.critic_delay_us = 0               # experiment knob (tools/critic_delay_ab.py): microseconds the critic's lane idles before it starts
+        # one rank, two lanes: the critic's lane starts when the actor's FIRST edge convolution has finished (a stream wait on a flag that a
+        # 4-byte copy behind that launch sets to the step count: _plan_lanes).  Beside that launch the critic's kernels cost it 60-90 us at 4096
+        # frames (DESIGN.md finding 42); beside the HBM-bound kernels that follow they cost less: -1.6 % on the step (finding 55).
+        self.critic_after_first_conv = critic_after_first_conv
+
         self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
         self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
         self._hyper = dict(eps=eps, betas=tuple(betas), clip=clip_grad_norm, max_norm=max_grad_norm)
@@ -138,6 +144,7 @@ class PolicyUpdater:
         self.steps = 0
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)  # optimizer step, device side (graph replays)
         self.step_dev_c = torch.zeros(1, device=dev, dtype=torch.int32)  # the same count kept by the critic's lane
+        self.lane_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # step count of the last "first edge convolution finished" signal
         # learning rate, device side: the recorded Adam launches read it, so an annealed rate (train.py:264-271 writes
         # ``group["lr"] = lr * alpha`` before every iteration; configs/algorithm/optim/default.yaml:5) takes effect under replay
         self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
@@ -379,11 +386,28 @@ class PolicyUpdater:
         # the one-launch tail needs every leaf gradient of the lane in the fold queue (overwrite mode) and no clipping (which needs the
         # finished gradient norm before Adam)
         fuse_tail = not self.clip and ow
+        gate = bool(self.critic_after_first_conv)
+
+        def copy4(dst, src):   # dst[0] = src[0] (int32) on the current stream: one tiny launch
+            import ctypes
+            hip.call("grl_copy_many", (ctypes.c_void_p * 1)(dst.data_ptr()), (ctypes.c_void_p * 1)(src.data_ptr()), (ctypes.c_longlong * 1)(4), 1)
 
         def main_all():
             self._prep(batch, st, zero=self.gflat[:na])
             actor.hyper_data.bump_next = self.step_dev   # the step count rides on the lane's first launch (grl_build_features_bump)
-            fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
+            fired = []
+            if gate:   # the critic's lane starts on this signal: flag = the step count, written right behind the first edge convolution
+                def signal():
+                    if actor.hyper_data.bump_next is not None:   # the step count has not been advanced yet (a calibrating pass in front of
+                        return False                             # the step's own forward): not this edge convolution
+                    fired.append(1)
+                    copy4(self.lane_flag, self.step_dev)
+                    return True
+                ops.AFTER_EDGE_HOOK = signal
+            try:
+                fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
+            finally:
+                ops.AFTER_EDGE_HOOK = None
             assert actor.hyper_data.bump_next is None, "the actor's feature launch did not take the step count"
             with torch.no_grad():
                 done = False
@@ -400,6 +424,8 @@ class PolicyUpdater:
                     self._adam(st, 0, na, 0)
                     a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
                 ops.DEFERRED = None
+                if gate:   # ... and once more at the lane's end, whatever happened above (an actor without an edge convolution; a signal that
+                    copy4(self.lane_flag, self.step_dev)   # carried a stale count): the critic's lane can be late, it can never be stuck
                 st.update(sums=fold_.sums, maxes=fold_.maxes, lv_main=(a_loss, mt))
 
         def critic_all():
@@ -426,7 +452,8 @@ class PolicyUpdater:
                 ops.DEFERRED = None
                 st["c_loss"] = c_loss
 
-        return [("fork", None), ("run", main_all), ("run", critic_all, "s"), ("join", None), ("run_host", lambda: self._finish(st))]
+        wait = [("wait_flag", None, "s", "critic_lane_start")] if gate else []
+        return [("fork", None), ("run", main_all), *wait, ("run", critic_all, "s"), ("join", None), ("run_host", lambda: self._finish(st))]
 
     def _plan_dp(self, batch, st):
         """Several ranks: the same two lanes, graph segments between the collectives (which stay eager torch.distributed calls).
@@ -800,6 +827,9 @@ class PolicyUpdater:
                 self._do(kind, item, label)
 
     def _do(self, kind, item, label=None, lane="m"):
+        if kind == "wait_flag":   # (current stream = the critic's) until the actor's lane has signalled THIS step (host count = device count)
+            hip.stream_wait_value32(self.lane_flag, self.steps)
+            return
         if kind in ("run", "run_host"):
             item()
         elif kind == "graph":

@@ -228,3 +228,20 @@ def check_latent(prec: str, *tensors: torch.Tensor):
     for t in tensors:
         if t is not None and (t.dtype != want or not t.is_cuda):
             raise TypeError(f"expected a CUDA {want} latent tensor for the '{prec or 'fp32'}' kernels, got {t.dtype} on {t.device}")
+
+
+_hiprt = None
+
+
+def stream_wait_value32(value_tensor: torch.Tensor, value: int) -> None:
+    """The CURRENT stream waits (in the command processor: no wave, no compute unit is held) until the int32 at ``value_tensor`` is >=
+    ``value`` (hipStreamWaitValue32, flag hipStreamWaitValueGte).  The location must be written by work already enqueued on another
+    stream -- the caller owns that ordering."""
+    global _hiprt
+    if _hiprt is None:
+        _hiprt = ctypes.CDLL("libamdhip64.so")
+        _hiprt.hipStreamWaitValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint, ctypes.c_uint32]
+        _hiprt.hipStreamWaitValue32.restype = ctypes.c_int
+    rc = _hiprt.hipStreamWaitValue32(stream_ptr(), ctypes.c_void_p(value_tensor.data_ptr()), ctypes.c_uint32(int(value) & 0xFFFFFFFF), 0, 0xFFFFFFFF)
+    if rc != 0:
+        raise RuntimeError(f"hipStreamWaitValue32 failed with status {rc}")

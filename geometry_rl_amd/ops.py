@@ -356,6 +356,10 @@ class LiftEncodeMulti(torch.autograd.Function):
         return (None, dw, None) + (None,) * (2 * T)
 
 
+# One-shot hook run right behind the NEXT edge convolution's forward launch (set by PolicyUpdater._plan_lanes, cleared when it fires).
+AFTER_EDGE_HOOK = None
+
+
 class EdgeConv(torch.autograd.Function):
     """x1[d] = sum_{e->d} Wk(basis_mlp(invariants_e)) * x_src[src(e)]   (reference hepi.py:145-157, conv.py:79-86,115-149)."""
 
@@ -373,6 +377,10 @@ class EdgeConv(torch.autograd.Function):
         hip.call("grl_edge_conv_fwd_balanced" + prec, x_src, pos_src, pos_dst, edges.rowptr_d, edges.src_d, edges.dst_d, edges.n_dst, grid3,
                  dim, *args, x1, sd, (sd.numel() - 1) if sd is not None else 0, wimg.e16 if wimg else None, wimg.e32 if wimg else None,
                  rows=edges.n_edges * 16)
+        global AFTER_EDGE_HOOK
+        if AFTER_EDGE_HOOK is not None:   # behind the launch (PolicyUpdater: the signal the critic's lane starts on -- agent.py); the hook
+            if AFTER_EDGE_HOOK():         # returns True once it has fired (it declines during the calibrating pass in front of the step's own)
+                AFTER_EDGE_HOOK = None
         ctx.save_for_backward(x_src, pos_src, pos_dst, grid3, *args)
         ctx.edges, ctx.dim, ctx.residual, ctx.prec, ctx.wimg = edges, dim, residual, prec, wimg
         ctx.params = (w1, b1, w2, b2, wk)
