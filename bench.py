@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the 1024-frame oracle comparison (and the CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--critic-gate", default=None, help="A/B: where the critic's lane starts: edge0 (default) | fwd_end")
     ap.add_argument("--no-critic-gate", action="store_true", help="A/B: the critic's lane starts with the step instead of behind the actor's first edge convolution")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the recorded hipGraph(s)")
     ap.add_argument("--dp-plan", action="store_true", help="one GPU, but the DATA-PARALLEL program of the step: a one-rank RCCL process group, "
@@ -359,7 +360,7 @@ def main():
     # the natural order: the updater is built first; the data-dependent calibration (conv.py:104-105) happens inside its first step,
     # from statistics summed over the ranks (every replica computes the factors of the whole minibatch)
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group,
-                              use_graph=not args.no_graph, force_dp_plan=args.dp_plan, critic_after_first_conv=not args.no_critic_gate)
+                              use_graph=not args.no_graph, force_dp_plan=args.dp_plan, critic_after_first_conv=(False if args.no_critic_gate else (args.critic_gate or True)))
     if world > 1:
         import torch.distributed as dist
         assert dist.get_world_size() == world

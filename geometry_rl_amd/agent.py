@@ -283,6 +283,9 @@ class PolicyUpdater:
         sums, maxes = zw[10:22], zw[22:23].view(torch.int32)
         ops.DEFERRED = []   # leaf-gradient folds of this backward are queued and executed by one launch at the lane's end
         loc, sigma = actor.forward_diag(*st["obs"], train=True)
+        after_fwd = st.pop("after_forward", None)
+        if after_fwd is not None:
+            after_fwd()
         with torch.no_grad():
             fold_, _mx, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], adv, sums=sums, maxes=maxes, defer_fold=True,
                                                       adv_local=adv_local)
@@ -386,7 +389,14 @@ class PolicyUpdater:
         # the one-launch tail needs every leaf gradient of the lane in the fold queue (overwrite mode) and no clipping (which needs the
         # finished gradient norm before Adam)
         fuse_tail = not self.clip and ow
-        gate = bool(self.critic_after_first_conv)
+        # Gate the critic's lane behind the actor's first edge convolution?  It pays where the critic then finishes inside the actor's FORWARD
+        # (its kernels cost the one-wave-per-SIMD backward launches far more than the forward ones: gated at the forward's END the step is 6 %
+        # slower): measured on rigid HEPi +1.1 % at 4096 frames, +3 % at 512, +1 % at 32, 0 at 2048, -1.5 % at 1024, where a forward of
+        # 0.35 ms is too short for it (profiles/r05_ab_critic_gate.txt, r05_ab_critic_gate_points.txt).  True (default) = that table.
+        frames = next(int(v.shape[0]) for v in batch.values() if torch.is_tensor(v))
+        mode = self.critic_after_first_conv
+        gate = bool(mode) and (isinstance(mode, str) or not (768 <= frames < 2048))
+        gate_point = mode if isinstance(mode, str) else "edge0"   # "edge0" | "fwd_end" (experiment: bench.py --critic-gate)
 
         def copy4(dst, src):   # dst[0] = src[0] (int32) on the current stream: one tiny launch
             import ctypes
@@ -396,7 +406,7 @@ class PolicyUpdater:
             self._prep(batch, st, zero=self.gflat[:na])
             actor.hyper_data.bump_next = self.step_dev   # the step count rides on the lane's first launch (grl_build_features_bump)
             fired = []
-            if gate:   # the critic's lane starts on this signal: flag = the step count, written right behind the first edge convolution
+            if gate and gate_point == "edge0":   # the critic's lane starts on this signal: flag = the step count, written right behind the first edge convolution
                 def signal():
                     if actor.hyper_data.bump_next is not None:   # the step count has not been advanced yet (a calibrating pass in front of
                         return False                             # the step's own forward): not this edge convolution
@@ -404,6 +414,8 @@ class PolicyUpdater:
                     copy4(self.lane_flag, self.step_dev)
                     return True
                 ops.AFTER_EDGE_HOOK = signal
+            if gate and gate_point == "fwd_end":
+                st["after_forward"] = lambda: copy4(self.lane_flag, self.step_dev)
             try:
                 fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
             finally:
