@@ -448,6 +448,15 @@ GRL_DEVINL void st4(st_t* p, const float4& v) {
 }
 GRL_DEVINL float4 ld4_nt(const st_t* p) { return ld4(p); }
 GRL_DEVINL void st4_nt(st_t* p, const float4& v) { st4(p, v); }
+// A prefetched quad stays RAW until it is used: widened where it is loaded, the shift is the load's first use and the compiler puts the
+// s_waitcnt of every prefetch directly behind it (round 5: lift_encode_bwd's four loads per node ran one after the other, 270 us where
+// the bytes need 60).
+typedef uint2 raw4_t;
+GRL_DEVINL raw4_t ld4_raw(const st_t* p) { return *reinterpret_cast<const uint2*>(p); }
+GRL_DEVINL float4 widen4(const raw4_t& u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
 #else
 typedef float st_t;
 GRL_DEVINL float ld1(const st_t* p) { return *p; }
@@ -456,6 +465,9 @@ GRL_DEVINL float4 ld4(const st_t* p) { return *reinterpret_cast<const float4*>(p
 GRL_DEVINL void st4(st_t* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 GRL_DEVINL float4 ld4_nt(const st_t* p) { return load_nt4(p); }
 GRL_DEVINL void st4_nt(st_t* p, const float4& v) { store_nt4(p, v); }
+typedef float4 raw4_t;
+GRL_DEVINL raw4_t ld4_raw(const st_t* p) { return load_nt4(p); }
+GRL_DEVINL float4 widen4(const raw4_t& u) { return u; }
 #endif
 
 // LDS leading dimension (in bf16 elements) of a [rows][K] split-weight image: +8 elements (16 B) keeps ds_read_b128 conflict-free

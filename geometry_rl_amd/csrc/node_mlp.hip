@@ -83,13 +83,38 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int n_tiles = (n_rows + 31) >> 5;
   float sink = 0.f;
+#if GRL_PREC
+  // plain-bf16 build (184 registers of 256): the tile's x2 row arrives a tile ahead and its residual row is requested before the MLP
+  // chain, both RAW (grl_common.h raw4_t) -- loaded where they were used, each cost the wave a full HBM round trip per tile (round 5:
+  // 0.36 of the kernel's wave cycles in s_waitcnt).  The fp32 build has no registers left for it.
+  raw4_t xr[8], rres[8];
+  {
+    const int tile0 = blockIdx.x * 8 + wave, row0 = tile0 * 32 + r;
+    const size_t rr0 = (tile0 < n_tiles && row0 < n_rows) ? row0 : 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xr[t] = ld4_raw(x2 + rr0 * C + 4 * h + 8 * t);
+  }
+#endif
   for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
     const int row = tile * 32 + r;
     const bool valid = row < n_rows;
     const size_t rr = valid ? row : 0;
     float4 x[8], xh[8], a[8];
     float rstd;
+#if GRL_PREC
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = widen4(xr[t]);
+    {
+      const int tile_n = tile + gridDim.x * 8, row_n = tile_n * 32 + r;
+      const size_t rn = (tile_n < n_tiles && row_n < n_rows) ? row_n : rr;   // (clamped: no branch around the loads)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) rres[t] = ld4_raw(x_dst + rr * C + 4 * h + 8 * t);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xr[t] = ld4_raw(x2 + rn * C + 4 * h + 8 * t);
+    }
+#else
     load_row(x2, rr, h, x);
+#endif
     {  // LayerNorm over the 64 channels of the row, split across the lane pair (l, l^32)
       float sum = 0.f;
 #pragma unroll
@@ -212,7 +237,12 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
     }
 #endif
     float4 res[8], y[8];
+#if GRL_PREC
+#pragma unroll
+    for (int t = 0; t < 8; ++t) res[t] = widen4(rres[t]);
+#else
     load_row(x_dst, rr, h, res);
+#endif
     if (accumulate) {
       load_row(out, rr, h, y);
 #pragma unroll

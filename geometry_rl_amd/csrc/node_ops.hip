@@ -164,42 +164,52 @@ GRL_DEVINL void lift_encode_bwd_body(const float* __restrict__ scal, const float
 #pragma unroll
     for (int k = 0; k < KF_MAX; ++k) dwa[j][k] = dwb[j][k] = 0.f;
   const LiftLane L = lift_lane(scal, vec, S, V);
-  float cur = 0.f, nxt;
-  float4 dcur[4], dnxt[4];
-  if (wave < N) {
-    cur = lift_fetch(L, wave);
+  // LB nodes per iteration: their loads (four storage quads + one input dword each) are issued in one burst and kept RAW until used
+  // (grl_common.h raw4_t), 8 KB in flight per wave.  The former form -- node n + 1 loaded while node n is computed, handed over in
+  // registers at the loop end -- did not survive the compiler: the loads were sunk behind the back-edge to their first use, and in the
+  // bf16 build each of the four waited for the one before it (270 us for the rope minibatch's 180 MB, round 5).
+  // Slots past N re-read the iteration's first node with their input zeroed (no branch around a load).
+#ifndef GRL_LIFT_LB
+#define GRL_LIFT_LB (GRL_PREC ? 4 : 2)
+#endif
+  constexpr int LB = GRL_LIFT_LB;
+  for (long long n0 = wave; n0 < N; n0 += (long long)n_waves * LB) {
+    raw4_t dq[LB][4];
+    float in[LB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dcur[i] = ld4_nt(dx + (size_t)wave * (O * C) + (4 * i + o4) * C + 4 * c4);
-  }
-  for (int n = wave; n < N; n += n_waves) {
-    const int nn = n + n_waves < N ? n + n_waves : n;      // (the last iteration re-reads its own node: no branch around the loads)
-    nxt = lift_fetch(L, nn);
+    for (int b = 0; b < LB; ++b) {
+      const long long nb = n0 + (long long)b * n_waves;
+      const int nn = nb < N ? (int)nb : (int)n0;
+      in[b] = lift_fetch(L, nn);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dnxt[i] = ld4_nt(dx + (size_t)nn * (O * C) + (4 * i + o4) * C + 4 * c4);
-    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f}, d3[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float dv[4] = {dcur[i].x, dcur[i].y, dcur[i].z, dcur[i].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        d0[j] += dv[j];
-        d1[j] = fmaf(g[i][0], dv[j], d1[j]);
-        d2[j] = fmaf(g[i][1], dv[j], d2[j]);
-        d3[j] = fmaf(g[i][2], dv[j], d3[j]);
-      }
+      for (int i = 0; i < 4; ++i) dq[b][i] = ld4_raw(dx + (size_t)nn * (O * C) + (4 * i + o4) * C + 4 * c4);
     }
 #pragma unroll
-    for (int k = 0; k < KF_MAX; ++k) {
-      const float sv = LIFT_S(cur, k), vx = LIFT_V(cur, k, 0), vy = LIFT_V(cur, k, 1), vz = LIFT_V(cur, k, 2);
+    for (int b = 0; b < LB; ++b) {
+      const float cur = n0 + (long long)b * n_waves < N ? in[b] : 0.f;
+      float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f}, d3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dwa[j][k] = fmaf(sv, d0[j], dwa[j][k]);
-        dwb[j][k] += vx * d1[j] + vy * d2[j] + vz * d3[j];
+      for (int i = 0; i < 4; ++i) {
+        const float4 dw = widen4(dq[b][i]);
+        const float dv[4] = {dw.x, dw.y, dw.z, dw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          d0[j] += dv[j];
+          d1[j] = fmaf(g[i][0], dv[j], d1[j]);
+          d2[j] = fmaf(g[i][1], dv[j], d2[j]);
+          d3[j] = fmaf(g[i][2], dv[j], d3[j]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KF_MAX; ++k) {
+        const float sv = LIFT_S(cur, k), vx = LIFT_V(cur, k, 0), vy = LIFT_V(cur, k, 1), vz = LIFT_V(cur, k, 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dwa[j][k] = fmaf(sv, d0[j], dwa[j][k]);
+          dwb[j][k] += vx * d1[j] + vy * d2[j] + vz * d3[j];
+        }
       }
     }
-    cur = nxt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dcur[i] = dnxt[i];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -244,21 +254,29 @@ __global__ __launch_bounds__(256) void lift_encode_bwd_multi_kernel(LiftMulti m,
 #ifndef GRL_FIBER_NT
 #define GRL_FIBER_NT 0   // bit 0: non-temporal loads, bit 1: non-temporal stores
 #endif
+#ifndef GRL_FIBER_CLAMP
+#define GRL_FIBER_CLAMP 1   // prefetch of the last trip clamped instead of skipped (no branch in the main loops)
+#endif
 constexpr int FB = GRL_FIBER_FB;                  // nodes per batch
 constexpr int FB_E = FB * O * C;                  // elements per batch
-template <int NT> struct FiberRegs { float4 r[FB_E / 4 / NT]; };   // 16-byte pieces per thread and batch (NT threads per workgroup)
+template <int NT> struct FiberRegs { raw4_t r[FB_E / 4 / NT]; };   // four-element pieces per thread and batch (NT threads per workgroup), RAW:
+// widened where they go to LDS -- widened at the load (bf16 build) every prefetch was waited for before the batch in LDS was computed (round 5)
 // Full batches only (the main loops are free of guards and branches: a conditional store or load in there makes the compiler's vmcnt
 // bookkeeping assume the worst, and the wait for the prefetched loads becomes a wait for every store of the iteration as well).
 template <int NT> GRL_DEVINL void fiber_load(FiberRegs<NT>& R, const st_t* __restrict__ src, long long batch) {
 #pragma unroll
   for (int i = 0; i < FB_E / 4 / NT; ++i) {
     const st_t* p = src + batch * FB_E + 4 * (threadIdx.x + NT * i);
+#if GRL_PREC
+    R.r[i] = ld4_raw(p);
+#else
     R.r[i] = (GRL_FIBER_NT & 1) ? ld4_nt(p) : ld4(p);
+#endif
   }
 }
 template <int NT> GRL_DEVINL void fiber_put(const FiberRegs<NT>& R, float* tile) {
 #pragma unroll
-  for (int i = 0; i < FB_E / 4 / NT; ++i) *reinterpret_cast<float4*>(tile + 4 * (threadIdx.x + NT * i)) = R.r[i];
+  for (int i = 0; i < FB_E / 4 / NT; ++i) *reinterpret_cast<float4*>(tile + 4 * (threadIdx.x + NT * i)) = widen4(R.r[i]);
 }
 template <int NT> GRL_DEVINL void fiber_store(st_t* __restrict__ dst, long long batch, const float* tile) {
 #pragma unroll
@@ -311,11 +329,16 @@ __global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const st_t* __restr
   __syncthreads();
   for (; batch < nb; batch += gridDim.x) {
     const long long next = batch + gridDim.x;
+#if GRL_FIBER_CLAMP
+    fiber_load(R, x1, next < nb ? next : batch);   // (clamped, not skipped: the last trip re-reads its own batch -- a branch around the
+                                                   //  loads makes the compiler wait for them before the batch in LDS is computed, round 5)
+#else
     if (next < nb) fiber_load(R, x1, next);
+#endif
     fiber_fwd_batch(tin, to, k, b, c, q);
     __syncthreads();
     fiber_store<256>(x2, batch, to);
-    if (next < nb) fiber_put(R, tin);
+    if (GRL_FIBER_CLAMP || next < nb) fiber_put(R, tin);
     __syncthreads();
   }
   if (N % FB != 0 && blockIdx.x == nb % gridDim.x) {
@@ -334,7 +357,15 @@ constexpr int FIBER_PARTIAL = O * O * C + C;
 // its own and cost 1-2 % of the step on every workload: sixteen resident waves per CU starve the critic's backward next to it.)
 constexpr int FBW = 4;                       // waves per workgroup
 constexpr int FBR = O / FBW;                 // orientations per thread
-GRL_DEVINL void fiber_bwd_batch(const float* tx, const float* td, float* to, const float (&kq)[FBR][O], float (&dk)[O][FBR], float& db,
+// Two forms of the backward batch.  GRL_FIBER_BWD_PK = 1 (the plain-bf16 build, where the kernel is instruction-bound: 656 -> 404 us on the
+// rope minibatch's large layer): packed pairs, the own quad re-read from LDS.  0 (the fp32 build, HBM-bound either way: 154 us for 728 MB):
+// round 4's form -- with the packed form the kernel itself is 10 % faster and the REPLAYED step 1.7 % slower on two boxes
+// (profiles/r05_ab_nodeops.txt: 324.8 / 325.1 with this form, 319.1 / 319.4 with the packed one), so it stays.
+#ifndef GRL_FIBER_BWD_PK
+#define GRL_FIBER_BWD_PK GRL_PREC
+#endif
+#if !GRL_FIBER_BWD_PK
+GRL_DEVINL void fiber_bwd_batch_sel(const float* tx, const float* td, float* to, const float (&kq)[FBR][O], float (&dk)[O][FBR], float& db,
                                 int c, int q) {
 #pragma unroll 1
   for (int i = 0; i < FB; ++i) {
@@ -359,6 +390,40 @@ GRL_DEVINL void fiber_bwd_batch(const float* tx, const float* td, float* to, con
     }
   }
 }
+#endif
+// The thread's own quad of dx2 (orientations FBR q .. FBR q + 3) is read from LDS a second time: picked out of the register array dv[] by
+// the (wave-uniform, but not to the compiler) index q it cost 120 v_cmp / v_cndmask per node beside 128 FMAs (round 5: the bf16 build of
+// this kernel is instruction-bound).  Both products run as packed pairs over the quad (v_pk_fma_f32: 64 per node).
+GRL_DEVINL void fiber_bwd_batch(const float* tx, const float* td, float* to, const v2f (&kq)[O][FBR / 2], v2f (&dk)[O][FBR / 2], float& db,
+                                int c, int q) {
+#pragma unroll 1
+  for (int i = 0; i < FB; ++i) {
+    v2f dq[FBR / 2], acc[FBR / 2];
+#pragma unroll
+    for (int h = 0; h < FBR / 2; ++h) {
+      dq[h] = v2f{td[(i * O + FBR * q + 2 * h) * C + c], td[(i * O + FBR * q + 2 * h + 1) * C + c]};
+      acc[h] = v2f{0.f, 0.f};
+      db += dq[h][0] + dq[h][1];
+    }
+#pragma unroll
+    for (int p = 0; p < O; ++p) {
+      const v2f dv = splat2(td[(i * O + p) * C + c]);
+#pragma unroll
+      for (int h = 0; h < FBR / 2; ++h) acc[h] = fma2(dv, kq[p][h], acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < FBR / 2; ++h) {
+      to[(i * O + FBR * q + 2 * h) * C + c] = acc[h][0];
+      to[(i * O + FBR * q + 2 * h + 1) * C + c] = acc[h][1];
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const v2f xv = splat2(tx[(i * O + o) * C + c]);
+#pragma unroll
+      for (int h = 0; h < FBR / 2; ++h) dk[o][h] = fma2(xv, dq[h], dk[o][h]);
+    }
+  }
+}
 __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
                                                                      const st_t* __restrict__ dx2, st_t* __restrict__ dx1,
                                                                      float* __restrict__ partial, int N) {
@@ -368,16 +433,31 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
   __shared__ __attribute__((aligned(16))) float to[FB_E];   // dx1 of the batch: leaves as 16-byte stores
   __shared__ float red[FBW * C];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  float kq[FBR][O];   // fk[o = FBR q + j][p][c] / 16   (rows this thread back-propagates to)
-  float dk[O][FBR];   // d fk[o][p = FBR q + j][c]
+#if !GRL_FIBER_BWD_PK
+#define FIBER_DK_OLD(o, j) dk_[o][j]
+  float kq_[FBR][O], dk_[O][FBR];
 #pragma unroll
   for (int j = 0; j < FBR; ++j)
 #pragma unroll
-    for (int p = 0; p < O; ++p) kq[j][p] = fk[((FBR * q + j) * O + p) * C + c] * (1.f / O);
+    for (int p = 0; p < O; ++p) kq_[j][p] = fk[((FBR * q + j) * O + p) * C + c] * (1.f / O);
 #pragma unroll
   for (int o = 0; o < O; ++o)
 #pragma unroll
-    for (int j = 0; j < FBR; ++j) dk[o][j] = 0.f;
+    for (int j = 0; j < FBR; ++j) dk_[o][j] = 0.f;
+#define fiber_bwd_batch(tx, td, to, kq, dk, db, c, q) fiber_bwd_batch_sel(tx, td, to, kq_, dk_, db, c, q)
+#else
+#define FIBER_DK_OLD(o, j) 0.f
+#endif
+  v2f kq[O][FBR / 2];   // [p][j]: fk[o = FBR q + j][p][c] / 16   (rows this thread back-propagates to), pairs over j
+  v2f dk[O][FBR / 2];   // d fk[o][p = FBR q + j][c], pairs over j
+#pragma unroll
+  for (int p = 0; p < O; ++p)
+#pragma unroll
+    for (int j = 0; j < FBR; ++j) kq[p][j >> 1][j & 1] = fk[((FBR * q + j) * O + p) * C + c] * (1.f / O);
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int h = 0; h < FBR / 2; ++h) dk[o][h] = v2f{0.f, 0.f};
   float db = 0.f;
   const long long nb = N / FB;               // full batches
   FiberRegs<NT> RX, RD;
@@ -386,11 +466,11 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
   __syncthreads();
   for (; batch < nb; batch += gridDim.x) {
     const long long next = batch + gridDim.x;
-    if (next < nb) { fiber_load(RX, x1, next); fiber_load(RD, dx2, next); }
+    if (GRL_FIBER_CLAMP || next < nb) { const long long nx = next < nb ? next : batch; fiber_load(RX, x1, nx); fiber_load(RD, dx2, nx); }   // (clamped: see the forward)
     fiber_bwd_batch(tx, td, to, kq, dk, db, c, q);
     __syncthreads();
     fiber_store<NT>(dx1, batch, to);
-    if (next < nb) { fiber_put(RX, tx); fiber_put(RD, td); }
+    if (GRL_FIBER_CLAMP || next < nb) { fiber_put(RX, tx); fiber_put(RD, td); }
     __syncthreads();
   }
   if (N % FB != 0 && blockIdx.x == nb % gridDim.x) {
@@ -405,7 +485,7 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
 #pragma unroll
   for (int o = 0; o < O; ++o)
 #pragma unroll
-    for (int j = 0; j < FBR; ++j) out[(o * O + FBR * q + j) * C + c] = dk[o][j] * (1.f / O);
+    for (int j = 0; j < FBR; ++j) out[(o * O + FBR * q + j) * C + c] = (GRL_FIBER_BWD_PK ? dk[o][j >> 1][j & 1] : FIBER_DK_OLD(o, j)) * (1.f / O);
   red[q * C + c] = db;
   __syncthreads();
   if (q == 0) {
