@@ -254,9 +254,6 @@ __global__ __launch_bounds__(256) void lift_encode_bwd_multi_kernel(LiftMulti m,
 #ifndef GRL_FIBER_NT
 #define GRL_FIBER_NT 0   // bit 0: non-temporal loads, bit 1: non-temporal stores
 #endif
-#ifndef GRL_FIBER_CLAMP
-#define GRL_FIBER_CLAMP 1   // prefetch of the last trip clamped instead of skipped (no branch in the main loops)
-#endif
 constexpr int FB = GRL_FIBER_FB;                  // nodes per batch
 constexpr int FB_E = FB * O * C;                  // elements per batch
 template <int NT> struct FiberRegs { raw4_t r[FB_E / 4 / NT]; };   // four-element pieces per thread and batch (NT threads per workgroup), RAW:
@@ -329,16 +326,12 @@ __global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const st_t* __restr
   __syncthreads();
   for (; batch < nb; batch += gridDim.x) {
     const long long next = batch + gridDim.x;
-#if GRL_FIBER_CLAMP
-    fiber_load(R, x1, next < nb ? next : batch);   // (clamped, not skipped: the last trip re-reads its own batch -- a branch around the
-                                                   //  loads makes the compiler wait for them before the batch in LDS is computed, round 5)
-#else
-    if (next < nb) fiber_load(R, x1, next);
-#endif
+    if (next < nb) fiber_load(R, x1, next);   // (clamped instead of guarded -- a branch-free loop -- measured: no gain in the bf16 step,
+                                              //  -0.6 % in the fp32 one, profiles/r05_ab_nodeops.txt call 5)
     fiber_fwd_batch(tin, to, k, b, c, q);
     __syncthreads();
     fiber_store<256>(x2, batch, to);
-    if (GRL_FIBER_CLAMP || next < nb) fiber_put(R, tin);
+    if (next < nb) fiber_put(R, tin);
     __syncthreads();
   }
   if (N % FB != 0 && blockIdx.x == nb % gridDim.x) {
@@ -466,11 +459,11 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
   __syncthreads();
   for (; batch < nb; batch += gridDim.x) {
     const long long next = batch + gridDim.x;
-    if (GRL_FIBER_CLAMP || next < nb) { const long long nx = next < nb ? next : batch; fiber_load(RX, x1, nx); fiber_load(RD, dx2, nx); }   // (clamped: see the forward)
+    if (next < nb) { fiber_load(RX, x1, next); fiber_load(RD, dx2, next); }
     fiber_bwd_batch(tx, td, to, kq, dk, db, c, q);
     __syncthreads();
     fiber_store<NT>(dx1, batch, to);
-    if (GRL_FIBER_CLAMP || next < nb) { fiber_put(RX, tx); fiber_put(RD, td); }
+    if (next < nb) { fiber_put(RX, tx); fiber_put(RD, td); }
     __syncthreads();
   }
   if (N % FB != 0 && blockIdx.x == nb % gridDim.x) {
