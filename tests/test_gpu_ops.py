@@ -188,6 +188,55 @@ def test_fiber_conv_and_lift(n):
         check(f"lift dW dim{dim}", wd.grad, wl.grad, 2e-4)
 
 
+# The plain-bf16 build of the same kernels (entry points *_bf16: bf16 storage, fp32 arithmetic -- round 5 gave them their own inner loops:
+# packed backward batch, bursts of raw quads in the lift backward, raw prefetch registers).  Inputs are rounded to bf16 FIRST, so the fp32
+# torch reference sees exactly the values the kernels load: what is left is the summation order (weight gradients: fp32 partial sums,
+# 2e-4 of the tensor's largest entry as for the fp32 build) and ONE rounding of each stored latent to nearest bf16 (2^-8 relative).
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 77, 9001, 70001])
+def test_fiber_conv_and_lift_bf16_build(n):
+    from geometry_rl_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(100 + n)
+    r16 = lambda t: t.to(torch.bfloat16)
+    x1 = r16(torch.randn(n, 16, 64, generator=g))
+    fk = torch.randn(16, 16, 64, generator=g)
+    bias = torch.randn(64, generator=g)
+    R = r16(torch.randn(n, 16, 64, generator=g))
+    leaves = [x1.float().requires_grad_(True), fk.clone().requires_grad_(True), bias.clone().requires_grad_(True)]
+    ref = torch.einsum("boc,opc->bpc", leaves[0], leaves[1]) / 16 + leaves[2]
+    (ref * R.float()).sum().backward()
+    dl = [x1.to(d).requires_grad_(True), fk.clone().to(d).requires_grad_(True), bias.clone().to(d).requires_grad_(True)]
+    out = ops.FiberConv.apply(*dl, "_bf16")
+    assert out.dtype == torch.bfloat16
+
+    def close16(name, got, want):   # a stored latent: nearest bf16 of an fp32 value that itself differs in the last fp32 bits
+        err = (got.float().cpu() - want).abs()
+        tol = 2.0 ** -8 * want.abs() + 1e-5 * float(want.abs().max())
+        assert bool((err <= tol).all()), (name, float((err - tol).max()))
+
+    close16("x2", out.detach(), ref.detach())
+    (out.float() * R.to(d).float()).sum().backward()   # d out = R (bf16-exact), handed to the kernel as bf16
+    close16("dx1", dl[0].grad, leaves[0].grad)
+    check("dfk", dl[1].grad, leaves[1].grad, 2e-4)
+    check("dbias", dl[2].grad, leaves[2].grad, 2e-4)
+
+    for dim in (3, 2):
+        grid = eq.make_grid(dim, 16)
+        grid3 = F.pad(grid, (0, 3 - grid.shape[1]))
+        scal = torch.zeros(n, 3)
+        scal[:, n % 3] = 1
+        vec = torch.randn(n, 4, 3, generator=g)
+        w = torch.randn(64, 7, generator=g)
+        wl = w.clone().requires_grad_(True)
+        ref = F.linear(eq.lift_features(scal, vec.reshape(n, -1), grid, dim), wl)
+        (ref * R.float()).sum().backward()
+        wd = w.clone().to(d).requires_grad_(True)
+        out = ops.LiftEncode.apply(scal.to(d), vec.to(d), grid3.to(d), wd, "_bf16")
+        close16(f"lift dim{dim}", out.detach(), ref.detach())
+        (out.float() * R.to(d).float()).sum().backward()
+        check(f"lift dW dim{dim}", wd.grad, wl.grad, 2e-4)
+
+
 def test_reduce_partials_multi_all_paths():
     """Gradient folding in one launch: float4 path (aligned slabs), scalar path (odd lengths / offsets), several slabs feeding one
     destination, accumulation into non-zero destinations, row counts around the unroll depths."""
