@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256, 1) void node_mlp_bwd16_kernel(const st_t* __re
   raw4_t px = raw4_t{}, pd = px, pxn = px, pdn = px;
   float4 pxw = make_float4(0.f, 0.f, 0.f, 0.f), pdw = pxw;
   auto fetch = [&](int i, raw4_t& fx, raw4_t& fd) {   // this thread's quad of chunk i (clamped: the loads of a non-existent chunk are never used)
+#if defined(GRL_M16_KNOCK) && (GRL_M16_KNOCK & 1)   // timing knock-out (GRL_DIAG builds only): no row loads behind the first two chunks
+    if (i >= 2) return;
+#endif
     const size_t gofs = ((size_t)chunk_of(i < n_mine ? i : n_mine - 1) * 16 + srow) * C + 4 * cq;
     fx = ld4_raw(x2 + gofs);
     fd = ld4_raw(dout + gofs);
