@@ -358,7 +358,7 @@ constexpr int FBR = O / FBW;                 // orientations per thread
 #define GRL_FIBER_BWD_PK GRL_PREC
 #endif
 #if !GRL_FIBER_BWD_PK
-GRL_DEVINL void fiber_bwd_batch_sel(const float* tx, const float* td, float* to, const float (&kq)[FBR][O], float (&dk)[O][FBR], float& db,
+GRL_DEVINL void fiber_bwd_batch(const float* tx, const float* td, float* to, const float (&kq)[FBR][O], float (&dk)[O][FBR], float& db,
                                 int c, int q) {
 #pragma unroll 1
   for (int i = 0; i < FB; ++i) {
@@ -384,6 +384,7 @@ GRL_DEVINL void fiber_bwd_batch_sel(const float* tx, const float* td, float* to,
   }
 }
 #endif
+#if GRL_FIBER_BWD_PK
 // The thread's own quad of dx2 (orientations FBR q .. FBR q + 3) is read from LDS a second time: picked out of the register array dv[] by
 // the (wave-uniform, but not to the compiler) index q it cost 120 v_cmp / v_cndmask per node beside 128 FMAs (round 5: the bf16 build of
 // this kernel is instruction-bound).  Both products run as packed pairs over the quad (v_pk_fma_f32: 64 per node).
@@ -417,6 +418,7 @@ GRL_DEVINL void fiber_bwd_batch(const float* tx, const float* td, float* to, con
     }
   }
 }
+#endif
 __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
                                                                      const st_t* __restrict__ dx2, st_t* __restrict__ dx1,
                                                                      float* __restrict__ partial, int N) {
@@ -426,21 +428,7 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
   __shared__ __attribute__((aligned(16))) float to[FB_E];   // dx1 of the batch: leaves as 16-byte stores
   __shared__ float red[FBW * C];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-#if !GRL_FIBER_BWD_PK
-#define FIBER_DK_OLD(o, j) dk_[o][j]
-  float kq_[FBR][O], dk_[O][FBR];
-#pragma unroll
-  for (int j = 0; j < FBR; ++j)
-#pragma unroll
-    for (int p = 0; p < O; ++p) kq_[j][p] = fk[((FBR * q + j) * O + p) * C + c] * (1.f / O);
-#pragma unroll
-  for (int o = 0; o < O; ++o)
-#pragma unroll
-    for (int j = 0; j < FBR; ++j) dk_[o][j] = 0.f;
-#define fiber_bwd_batch(tx, td, to, kq, dk, db, c, q) fiber_bwd_batch_sel(tx, td, to, kq_, dk_, db, c, q)
-#else
-#define FIBER_DK_OLD(o, j) 0.f
-#endif
+#if GRL_FIBER_BWD_PK
   v2f kq[O][FBR / 2];   // [p][j]: fk[o = FBR q + j][p][c] / 16   (rows this thread back-propagates to), pairs over j
   v2f dk[O][FBR / 2];   // d fk[o][p = FBR q + j][c], pairs over j
 #pragma unroll
@@ -451,6 +439,20 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
   for (int o = 0; o < O; ++o)
 #pragma unroll
     for (int h = 0; h < FBR / 2; ++h) dk[o][h] = v2f{0.f, 0.f};
+  auto dk_at = [&](int o, int j) { return dk[o][j >> 1][j & 1]; };
+#else
+  float kq[FBR][O];   // fk[o = FBR q + j][p][c] / 16   (rows this thread back-propagates to)
+  float dk[O][FBR];   // d fk[o][p = FBR q + j][c]
+#pragma unroll
+  for (int j = 0; j < FBR; ++j)
+#pragma unroll
+    for (int p = 0; p < O; ++p) kq[j][p] = fk[((FBR * q + j) * O + p) * C + c] * (1.f / O);
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int j = 0; j < FBR; ++j) dk[o][j] = 0.f;
+  auto dk_at = [&](int o, int j) { return dk[o][j]; };
+#endif
   float db = 0.f;
   const long long nb = N / FB;               // full batches
   FiberRegs<NT> RX, RD;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(64 * FBW, 2) void fiber_conv_bwd_kernel(const st_t*
 #pragma unroll
   for (int o = 0; o < O; ++o)
 #pragma unroll
-    for (int j = 0; j < FBR; ++j) out[(o * O + FBR * q + j) * C + c] = (GRL_FIBER_BWD_PK ? dk[o][j >> 1][j & 1] : FIBER_DK_OLD(o, j)) * (1.f / O);
+    for (int j = 0; j < FBR; ++j) out[(o * O + FBR * q + j) * C + c] = dk_at(o, j) * (1.f / O);
   red[q * C + c] = db;
   __syncthreads();
   if (q == 0) {
