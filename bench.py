@@ -422,6 +422,23 @@ def main():
         rep_dt_global = list(rep_dt)
     dt_own = sorted(rep_dt)[len(rep_dt) // 2]
     dt = sorted(rep_dt_global)[len(rep_dt_global) // 2]
+    # The same MFMA calibration once more, HOT, directly behind the timed region: a box that throttles under sustained load reads its normal
+    # figure at process start and loses 20 % a few seconds into the workload (round 5 met one: profiles/r05_sizes_and_workloads_v6_throttled_box.txt).
+    calib_after = None
+    if rank == 0 and calib is not None:
+        from geometry_rl_amd import hip as _hip
+        _out = torch.empty(256 * 256, device=dev, dtype=torch.float32)
+        _ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a_, b_ in _ev:
+            a_.record()
+            _hip.call("grl_calib_mfma", 6000, _out)
+            b_.record()
+        torch.cuda.synchronize()
+        _t = sorted(a_.elapsed_time(b_) for a_, b_ in _ev)[2]
+        _mf = 1024.0 * 6000 * 16 * 32768 / (_t * 1e-3) / 1e12
+        calib_after = {"mfma_tflops": _mf, "vs_start_of_process": _mf / calib["mfma_tflops"],
+                       "box_throttled": bool(_mf < 0.93 * calib["mfma_tflops"]),
+                       "what": "grl_calib_mfma again, median of 5 launches directly behind the timed region; box_throttled: below 0.93 of the figure at process start"}
     dp_info = None
     if world > 1 or args.dp_plan:
         import torch.distributed as dist
@@ -651,7 +668,7 @@ def main():
             "repeats": len(rep_dt_global), "repeats_ms_per_step": [1e3 * x / args.steps for x in rep_dt_global],
             "ms_per_step_min_max": [1e3 * min(rep_dt_global) / args.steps, 1e3 * max(rep_dt_global) / args.steps],
             "value_note": "value = steps / (median over the repeats of the time of one timed region of exactly `steps` steps, max over ranks)",
-            "box_calibration": calib,
+            "box_calibration": calib, "box_calibration_after": calib_after,
             "value_normalised": (args.steps / dt) / calib["mfma_vs_reference"] if calib else None,
             "value_normalised_note": "value x reference box's MFMA calibration / this box's (BASELINE.md section 4): compare lines of different boxes by this",
             "scaling": "strong", "vs_baseline": None,
