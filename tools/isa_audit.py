@@ -22,7 +22,7 @@ def audit(path):
         body = [l for l in body if l]
         labels = {l[:-1]: i for i, l in enumerate(body) if re.match(r'^\.LBB\w+:$', l)}
         for i, l in enumerate(body):
-            m = re.match(r's_cbranch\S+\s+(\.LBB\w+)', l)
+            m = re.match(r's_c?branch\S*\s+(\.LBB\w+)', l)
             if not (m and m.group(1) in labels and labels[m.group(1)] < i):
                 continue
             loop = [x.split()[0] for x in body[labels[m.group(1)]:i] if not x.endswith(':') and not x.startswith('.')]
