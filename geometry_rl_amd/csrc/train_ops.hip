@@ -393,7 +393,7 @@ extern "C" {
 
 // ABI version of this library: major * 10000 + minor * 100 + patch.  Bumped whenever a declared signature changes
 // (include/grl_hip.h GRL_HIP_VERSION must agree: geometry_rl_amd/hip.py checks it at load time).
-int grl_version(void) { return 204; }
+int grl_version(void) { return 205; }
 
 // step = 1-based Adam step count.  scale_dev: optional device scalar multiplied into the gradient (clip coefficient).
 int grl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,

@@ -56,6 +56,14 @@ def _written(t):
 
 
 def lint_kernel(name, lines):
+    """-> [findings] (see lint_kernel_ex)"""
+    return lint_kernel_ex(name, lines)[0]
+
+
+def lint_kernel_ex(name, lines):
+    """-> ([findings], number of MFMAs found INSIDE ;;#ASMSTART / ;;#ASMEND regions).  Only those count as "asm MFMAs": empty pin
+    statements (asm volatile("" : "+v"(x))) emit ASMSTART blocks too, and a kernel whose asm MFMAs vanished (or whose mnemonic changed so
+    that nothing below matches) must not pass as "linted, no findings" (ADVICE r5)."""
     findings = []
     insts = []            # (text, in_asm) -- labels are kept as ("<label>:", False)
     in_asm = False
@@ -77,7 +85,7 @@ def lint_kernel(name, lines):
     is_label = lambda i: insts[i][0].endswith(":")
     asm_mfma = [(i, t) for i, (t, a) in enumerate(insts) if a and t.startswith("v_mfma")]
     if not asm_mfma:
-        return findings
+        return findings, 0
     tiles = set()
     for i, t in asm_mfma:
         m = re.match(r"v_mfma\S+\s+a\[(\d+):(\d+)\]", t)
@@ -95,30 +103,46 @@ def lint_kernel(name, lines):
             return _regs(t.split(",")[-1], "a")
         return []
 
-    # (1) reads shortly after an asm MFMA writing the same tile
-    for i, t in asm_mfma:
-        m = re.match(r"v_mfma\S+\s+a\[(\d+):(\d+)\]", t)
-        if not m:
-            continue
-        tile = (int(m.group(1)), int(m.group(2)))
-        n = 0
-        for j in range(i + 1, len(insts)):
-            tj, aj = insts[j]
-            if is_label(j):
-                continue
-            n += 1
-            if n > WINDOW or tj.startswith("s_nop 15"):
-                break
-            if not aj and any(tile_of(r) == tile for r in acc_read(tj)):
-                findings.append(f"{name}: '{tj}' {n} instructions after asm '{t[:60]}'")
-
-    # (3) operands written less than two wait states before an asm MFMA, across basic-block boundaries
     branches = {}   # label -> [instruction index of every branch to it]
+    label_at = {}   # label -> its instruction index
     for i, (t, _) in enumerate(insts):
         m = re.match(r"s_c?branch\S*\s+(\.?\w+)", t)
         if m:
             branches.setdefault(m.group(1) + ":", []).append(i)
+        if is_label(i):
+            label_at[t] = i
 
+    # (1) reads shortly after an asm MFMA writing the same tile -- along the fall-through path AND through every branch inside the window
+    def scan_down(j, n, tile, mfma_text, seen):
+        while j < len(insts) and n < WINDOW:
+            if (j, n) in seen:
+                return
+            seen.add((j, n))
+            tj, aj = insts[j]
+            if is_label(j):
+                j += 1
+                continue
+            n += 1
+            if tj.startswith("s_nop 15") or tj.startswith(("s_endpgm", "s_setpc")):
+                return
+            if not aj and any(tile_of(r) == tile for r in acc_read(tj)):
+                findings.append(f"{name}: '{tj}' {n} instructions after asm '{mfma_text[:60]}'")
+            mb = re.match(r"s_(c?)branch\S*\s+(\.?\w+)", tj)
+            if mb:
+                tgt = label_at.get(mb.group(2) + ":")
+                if tgt is not None:
+                    scan_down(tgt, n, tile, mfma_text, seen)
+                if not mb.group(1):
+                    return              # unconditional: no fall-through
+            j += 1
+
+    for i, t in asm_mfma:
+        m = re.match(r"v_mfma\S+\s+a\[(\d+):(\d+)\]", t)
+        if not m:
+            continue
+        scan_down(i + 1, 0, (int(m.group(1)), int(m.group(2))), t, set())
+
+    # (3) operands written less than two wait states before an asm MFMA, across basic-block boundaries
     def scan_up(j, ws, src_v, src_a, mfma_text, seen):
         """walk upward from instruction j (inclusive) with ``ws`` wait states already between it and the MFMA"""
         while j >= 0 and ws < 2:
@@ -153,15 +177,24 @@ def lint_kernel(name, lines):
     drain = next((j for j in range(last, len(insts)) if insts[j][0].startswith("s_nop 15") and insts[j][1]), None)
     if drain is None:
         findings.append(f"{name}: asm MFMAs but no drain (s_nop 15) behind the last one")
-    return findings
+    return findings, len(asm_mfma)
 
 
-def lint_assembly(path):
-    """-> (number of kernels scanned, number of kernels with asm MFMAs, [findings]) for one gfx950 assembly file"""
-    bad, n, n_asm = [], 0, 0
+# kernels that MUST show up with asm MFMAs (substring of the mangled name), per source: a build in which one of them has none fails
+EXPECTED = {"edge_conv16.hip": ("edge_bwd16_kernel",), "node_mlp16.hip": ("node_mlp_bwd16_kernel",)}
+
+
+def lint_assembly(path, expected=()):
+    """-> (number of kernels scanned, number of kernels with asm MFMAs, [findings]) for one gfx950 assembly file.  ``expected``: kernel
+    names (substrings of the mangled names) that must be among the kernels with asm MFMAs -- a missing one is a finding."""
+    bad, n, asm_names = [], 0, []
     for name, lines in kernels(path):
         n += 1
-        if any("v_mfma" in l for l in lines) and any(";;#ASMSTART" in l for l in lines):
-            n_asm += 1
-        bad += lint_kernel(name, lines)
-    return n, n_asm, bad
+        f, n_mfma = lint_kernel_ex(name, lines)
+        if n_mfma:
+            asm_names.append(name)
+        bad += f
+    for want in expected:
+        if not any(want in k for k in asm_names):
+            bad.append(f"{want}: expected a kernel with asm MFMAs of that name in {path}, found {asm_names or 'none'}")
+    return n, len(asm_names), bad

@@ -21,8 +21,11 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 204   /* 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
+#define GRL_HIP_VERSION 205   /* 205 (round 6): grl_source_hash added; 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
 int grl_version(void);
+/* The hash of the sources this binary was built from (16 hex digits + NUL into buf; returns the length).  geometry_rl_amd/hip.py
+   source_hash() recomputes it from csrc/, this header and the build's flag tables and refuses a library that disagrees. */
+int grl_source_hash(char* buf, int cap);
 
 /* ---- lift + node encoder: geometry_rl/modules/pyg_models/hepi.py:136-143, ponita/utils/to_from_sphere.py:4-9 ------------
  * x[n,o,:] = [scal[n,:] | vec[n,v,:] . grid[o,:]] W_enc^T ;  scal [N,S], vec [N,V,3], grid [16,3] (z = 0 for S1), W_enc [64,S+V] */

@@ -110,3 +110,38 @@ def test_knockout_switches_need_grl_diag_and_the_product_library_is_not_a_diag_b
     assert not hasattr(lib, "grl_diag_build")
     info = __import__("json").load(open(os.path.join(ROOT, "BUILD_INFO.json")))
     assert info["abi_version"] == hip.ABI_VERSION and "build_mode" in info and isinstance(info["objects_rebuilt"], list)
+
+
+def test_library_is_tied_to_its_sources_by_hash_not_mtime(tmp_path):
+    """a tree whose modification times say nothing (all equal, as after a copy to another box) with ONE edited
+    source must refuse its stale library until it is rebuilt -- and the rebuild recompiles exactly the object whose source changed."""
+    import json
+    import shutil
+    from geometry_rl_amd import hip
+    hip.build(verbose=False)
+    root = tmp_path / "tree"
+    pkg = root / "geometry_rl_amd"
+    shutil.copytree(os.path.join(ROOT, "geometry_rl_amd", "csrc"), pkg / "csrc")           # (objects + their recorded hashes included)
+    shutil.copy(os.path.join(ROOT, "geometry_rl_amd", "isa_lint.py"), pkg / "isa_lint.py")
+    shutil.copy(os.path.join(ROOT, "geometry_rl_amd", "libgrl_hip.so"), pkg / "libgrl_hip.so")
+    os.makedirs(root / "include")
+    shutil.copy(os.path.join(ROOT, "include", "grl_hip.h"), root / "include" / "grl_hip.h")
+    lib = str(pkg / "libgrl_hip.so")
+    h0 = hip.check_library(lib, root=str(root))
+    assert h0 == hip.source_hash() == hip.embedded_hash(lib) and len(h0) == 16
+    buf = ctypes.create_string_buffer(32)
+    assert ctypes.CDLL(lib).grl_source_hash(buf, 32) == 16 and buf.value.decode() == h0
+    with open(pkg / "csrc" / "calib.hip", "a") as f:
+        f.write("\n// edited\n")
+    for d, _, files in os.walk(root):                      # every modification time equal: mtimes must not matter
+        for fn in files:
+            os.utime(os.path.join(d, fn), (1_700_000_000, 1_700_000_000))
+    assert hip.source_hash(str(root)) != h0
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        hip.check_library(lib, root=str(root))
+    hip.build(verbose=False, root=str(root))
+    info = json.load(open(root / "BUILD_INFO.json"))
+    assert info["objects_rebuilt"] == ["calib.hip.o"], info["objects_rebuilt"]
+    assert info["source_hash"] == info["library_source_hash"] == hip.check_library(lib, root=str(root)) != h0
+    hip.build(verbose=False, root=str(root))               # and now nothing is left to do
+    assert json.load(open(root / "BUILD_INFO.json"))["objects_rebuilt"] == []

@@ -66,7 +66,7 @@ def test_missing_drain_is_caught():
 
 
 def test_build_lints_the_objects_it_compiles(tmp_path):
-    """touch the two sources' common header dependency path: force only the objects of the linted files to rebuild and read the report"""
+    """remove the objects of the linted files (and the library): exactly those are recompiled, linted, and the report is written"""
     from geometry_rl_amd import hip, isa_lint
     for f in isa_lint.FILES:
         for sfx in ("", ".bf16"):
@@ -75,12 +75,32 @@ def test_build_lints_the_objects_it_compiles(tmp_path):
                 os.remove(o)
     lib = hip.LIB_PATH
     if os.path.exists(lib):
-        os.utime(lib, (0, 0))   # older than every source: build() goes through its object loop
+        os.remove(lib)          # no library whose embedded hash could say "prebuilt": build() goes through its object loop
     hip.build(verbose=False)
     info = json.load(open(hip.BUILD_INFO))
     rep = info["isa_lint"]
     assert set(rep) == {f + sfx for f in isa_lint.FILES for sfx in ("", ".bf16")}, rep
     assert all(v["kernels_with_asm_mfma"] >= 1 and v["findings"] == [] for v in rep.values()), rep
+    assert sorted(info["objects_rebuilt"]) == sorted(f + sfx + ".o" for f in isa_lint.FILES for sfx in ("", ".bf16")), info["objects_rebuilt"]
+
+
+def test_kernel_without_asm_mfma_is_not_counted_and_expected_names_are_enforced(tmp_path):
+    """an ASMSTART block that is only an empty pin statement beside a builtin MFMA is NOT an asm-MFMA kernel; a build in which
+    an expected kernel shows no asm MFMA fails."""
+    from geometry_rl_amd import isa_lint
+    asm = tmp_path / "k.s"
+    asm.write_text("\n".join(["_Z17edge_bwd16_kernelv:", "\t;;#ASMSTART", "\t;;#ASMEND", MFMA, "\ts_endpgm", ""]))
+    n, n_asm, bad = isa_lint.lint_assembly(str(asm), ("edge_bwd16_kernel",))
+    assert (n, n_asm) == (1, 0) and len(bad) == 1 and "expected a kernel with asm MFMAs" in bad[0]
+    asm.write_text("\n".join(["_Z17edge_bwd16_kernelv:", *_asm(MFMA), *DRAIN, ""]))
+    assert isa_lint.lint_assembly(str(asm), ("edge_bwd16_kernel",)) == (1, 1, [])
+
+
+def test_read_behind_a_branch_inside_the_window_is_caught():
+    body = [*_asm(MFMA), "\ts_cbranch_scc1 .LBB0_2", "\tv_mov_b32 v1, v2", *DRAIN[:-1], "\ts_branch .LBB0_3", ".LBB0_2:", "\tv_accvgpr_read_b32 v3, a7",
+            ".LBB0_3:"]
+    f = _lint(body)
+    assert len(f) == 1 and "v_accvgpr_read_b32" in f[0]
 
 
 def test_command_line_form_is_clean():
