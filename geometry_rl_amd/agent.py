@@ -110,6 +110,9 @@ class PolicyUpdater:
         # 4-byte copy behind that launch sets to the step count: _plan_lanes).  Beside that launch the critic's kernels cost it 60-90 us at 4096
         # frames (DESIGN.md finding 42); beside the HBM-bound kernels that follow they cost less: -1.6 % on the step (finding 55).
         self.critic_after_first_conv = critic_after_first_conv
+        # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
+        self.critic_first = os.environ.get("GRL_CRITIC_FIRST", "0") == "1"
+        self.critic_prio = os.environ.get("GRL_CRITIC_PRIO", "low")
 
         self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
         self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
@@ -290,7 +293,14 @@ class PolicyUpdater:
             fold_, _mx, dloc, dsigma, _ = trpl_launch(m, loc, sigma, None, st["b"], adv, sums=sums, maxes=maxes, defer_fold=True,
                                                       adv_local=adv_local)
         st.update(loc=loc.detach(), sigma=sigma.detach())
-        torch.autograd.backward([loc, sigma], [dloc, dsigma])
+        # the lift's and the fiber basis' backward launches only feed the tail's fold: the first of the two waits for the other and they
+        # share ONE launch (ops._tail_pre_offer)
+        ops.TAIL_PRE = {} if ops.FUSE_TAIL_PRE else None
+        try:
+            torch.autograd.backward([loc, sigma], [dloc, dsigma])
+            ops.flush_tail_pre()
+        finally:
+            ops.TAIL_PRE = None
         return fold_
 
     @staticmethod
@@ -411,7 +421,12 @@ class PolicyUpdater:
                     if actor.hyper_data.bump_next is not None:   # the step count has not been advanced yet (a calibrating pass in front of
                         return False                             # the step's own forward): not this edge convolution
                     fired.append(1)
-                    copy4(self.lane_flag, self.step_dev)
+                    # the signal rides on the NEXT launch of the lane (the fiber convolution behind this edge convolution writes the flag
+                    # when it starts, ops.FiberConv): no 4-us copy launch on the step's chain
+                    if ops.SIGNAL_IN_KERNEL:
+                        ops.PENDING_SIGNAL = (self.lane_flag, self.step_dev)
+                    else:
+                        copy4(self.lane_flag, self.step_dev)
                     return True
                 ops.AFTER_EDGE_HOOK = signal
             if gate and gate_point == "fwd_end":
@@ -420,15 +435,19 @@ class PolicyUpdater:
                 fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
             finally:
                 ops.AFTER_EDGE_HOOK = None
+                unsent, ops.PENDING_SIGNAL = ops.PENDING_SIGNAL, None
+            if unsent is not None:   # (no fiber convolution followed the edge convolution: send the signal by itself)
+                copy4(*unsent)
             assert actor.hyper_data.bump_next is None, "the actor's feature launch did not take the step count"
             with torch.no_grad():
                 done = False
                 if fuse_tail:   # fold + Adam + reported values: ONE launch at the lane's end (ops.fold_adam_report)
                     o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
                     ent = m.entropy_coef if m.entropy_bonus else 0.0
+                    # (gated: the lane's closing signal -- see below -- rides on this launch)
                     done = ops.fold_adam_report(ow, self._tail_args(0, na, self.step_dev),
                                                 dict(slots=fold_.slots, batch=fold_.batch, sums=fold_.sums, maxes=fold_.maxes,
-                                                     ent_coef=ent, out14=o14))
+                                                     ent_coef=ent, out14=o14), signal=(self.lane_flag, self.step_dev) if (gate and ops.SIGNAL_IN_KERNEL) else None)
                     if done:
                         a_loss, mt = report_dict(o14)
                 if not done:
@@ -436,8 +455,8 @@ class PolicyUpdater:
                     self._adam(st, 0, na, 0)
                     a_loss, _c, mt = report_values(m, fold_.slots, fold_.batch, fold_.sums, fold_.maxes)
                 ops.DEFERRED = None
-                if gate:   # ... and once more at the lane's end, whatever happened above (an actor without an edge convolution; a signal that
-                    copy4(self.lane_flag, self.step_dev)   # carried a stale count): the critic's lane can be late, it can never be stuck
+                if gate and not (done and ops.SIGNAL_IN_KERNEL):   # ... and once more at the lane's end, whatever happened above (an actor without an edge convolution; a
+                    copy4(self.lane_flag, self.step_dev)   # signal that carried a stale count): the critic's lane can be late, it can never be stuck
                 st.update(sums=fold_.sums, maxes=fold_.maxes, lv_main=(a_loss, mt))
 
         def critic_all():
@@ -448,12 +467,13 @@ class PolicyUpdater:
                 if not ow:
                     self.gflat[na:].zero_()   # on THIS lane, in front of its folds (never from the actor's lane)
                 vf.train(True)
-                _, x = vf.hyper_data.build_data(*st["cobs"], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
+                # (inputs straight from the batch: this lane depends on nothing the actor's lane prepares, so it can be enqueued first)
+                _, x = vf.hyper_data.build_data(*[batch[k] for k in m.critic_in_features], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
                 pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                 pipe.fwd1()
                 pipe.fwd2()
                 value = st["value"] = pipe.fwd3()
-                dvalue, c_loss, _ = value_loss(m, value, st["b"])
+                dvalue, c_loss, _ = value_loss(m, value, batch)
                 pipe.bwd3(dvalue)
                 pipe.bwd2()
                 grads = pipe.bwd1(leaves)
@@ -465,6 +485,8 @@ class PolicyUpdater:
                 st["c_loss"] = c_loss
 
         wait = [("wait_flag", None, "s", "critic_lane_start")] if gate else []
+        if self.critic_first:   # host order only: the critic's wait + graph are handed to the device BEFORE the actor's graph
+            return [("fork", None), *wait, ("run", critic_all, "s"), ("run", main_all), ("join", None), ("run_host", lambda: self._finish(st))]
         return [("fork", None), ("run", main_all), *wait, ("run", critic_all, "s"), ("join", None), ("run_host", lambda: self._finish(st))]
 
     def _plan_dp(self, batch, st):
@@ -598,7 +620,7 @@ class PolicyUpdater:
             # the LOWEST priority the device offers: the critic's small launches take the compute units the actor's kernels leave (heads,
             # tails, the latency-bound loss kernel) instead of displacing their workgroups (DESIGN.md finding 33)
             prio = 0
-            if hasattr(torch.cuda.Stream, "priority_range"):
+            if self.critic_prio == "low" and hasattr(torch.cuda.Stream, "priority_range"):
                 try:
                     prio = max(torch.cuda.Stream.priority_range())
                 except Exception:
@@ -769,6 +791,17 @@ class PolicyUpdater:
                 actor.forward_diag(*[batch[k] for k in m.in_features], train=True)   # calibrates on this rank's shard
             self.sync_replicas()                                                       # ... and rank 0's factors win everywhere
         self.steps += 1
+        try:
+            return self._step(batch)
+        except BaseException:
+            # the critic lane's gate waits until the DEVICE-side step count (advanced by the actor's feature launch) reaches the HOST's: a
+            # step that raised before that launch was enqueued must not leave the host one ahead for good -- the next step's wait would
+            # never be satisfied and the process would hang on the device instead of raising.  After a failure the host count
+            # is at most the device's: the gate may then release early, it can never be stuck.
+            self.steps -= 1
+            raise
+
+    def _step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         B = next(v.shape[0] for v in batch.values() if torch.is_tensor(v))
         seen = getattr(self, "_eager_sizes", None)
         if seen is None:
@@ -811,8 +844,7 @@ class PolicyUpdater:
                 print(f"[geometry_rl_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches "
                       "(allow_eager_fallback=True)", file=sys.stderr)
                 self.use_graph, self._program, self._static, self.mode = False, None, None, "eager (graph capture failed)"
-                self.steps -= 1
-                return self.step(batch)
+                return self._step(batch)
         self._refresh_static(batch)
         self._execute(self._program)
         return self._st["out"]

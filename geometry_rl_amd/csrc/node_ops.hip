@@ -5,6 +5,8 @@
 // All are streaming kernels: one coalesced pass over [N,16,64] fp32 node tensors, weights held in registers / LDS.
 #include "grl_common.h"
 #include "grl_report.h"
+#include "grl_feat.h"
+#include "grl_wimg_kernel.h"
 
 namespace {
 
@@ -308,8 +310,17 @@ GRL_DEVINL void fiber_fwd_batch(const float* tin, float* to, const float (&k)[O]
   }
 }
 
+// ``flag_dst`` (optional): one thread copies ``flag_src[0]`` there when the launch STARTS, i.e. when everything in front of it on the
+// stream has finished -- the signal another lane's hipStreamWaitValue32 waits for (PolicyUpdater: "the first edge convolution is done"),
+// without a 4-us copy launch of its own on the step's chain.  System scope: the store must not linger in this XCD's L2.
+GRL_DEVINL void lane_signal(int* flag_dst, const int* flag_src) {
+  if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(flag_dst, flag_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(256) void fiber_conv_fwd_kernel(const st_t* __restrict__ x1, const float* __restrict__ fk,
-                                                             const float* __restrict__ bias, st_t* __restrict__ x2, int N) {
+                                                             const float* __restrict__ bias, st_t* __restrict__ x2, int N,
+                                                             int* flag_dst, const int* flag_src) {
+  lane_signal(flag_dst, flag_src);
   __shared__ __attribute__((aligned(16))) float tin[FB_E];   // the next batch waits in registers
   __shared__ __attribute__((aligned(16))) float to[FB_E];    // x2 of the batch: leaves as 16-byte stores
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -564,58 +575,69 @@ GRL_DEVINL void fb_stage(float* dst /*[64][65]*/, const float* __restrict__ src 
     d[0] = q[u].x; d[1] = q[u].y; d[2] = q[u].z; d[3] = q[u].w;
   }
 }
-__global__ __launch_bounds__(256) void fiber_basis_fwd_kernel(const float* __restrict__ poly, const float* __restrict__ W1,
-                                                              const float* __restrict__ b1, const float* __restrict__ W2,
-                                                              const float* __restrict__ b2, FiberWfs wf, float* __restrict__ saved,
-                                                              FiberFks fk) {
-  extern __shared__ float fb_smem[];
+// LDS of the two bodies (static, so that they can ride in merged launches beside other roles: grl_step_head, grl_lift_fiber_basis_bwd):
+// W2 | ONE Wf matrix at a time (round 5 staged all n of them: 17 KB each, dynamic LDS) | the row buffers
+constexpr int FB_SMEM_FLOATS = 2 * 64 * 65 + FB_MAXC * FB_RPB * 64 + 4 * FB_RPB * 64;
+struct FbFwd { const float *poly, *W1, *b1, *W2, *b2; FiberWfs wf; float* saved; FiberFks fk; };   // wf.n == 0: nothing to do
+struct FbBwd { const float *poly, *W2; FiberWfs wf; const float* saved; FiberDfks dfk; float* partial; int partial_ld; };
+GRL_DEVINL void fiber_basis_fwd_body(const FbFwd& A, int blk, float* fb_smem) {
+  const FiberWfs& wf = A.wf;
   float* W2s = fb_smem;                    // [64][65]
-  float* Wfs = W2s + 64 * 65;              // [n_conv][64][65]
-  float* hs = Wfs + wf.n * 64 * 65;        // [2][FB_RPB][64]  h1 | h2
-  fb_stage(W2s, W2);
-  for (int i = 0; i < wf.n; ++i) fb_stage(Wfs + i * 64 * 65, wf.w[i]);
-  const int rl = threadIdx.x >> 6, c = threadIdx.x & 63, r = blockIdx.x * FB_RPB + rl;
-  float z1 = b1[c];
+  float* Wfs = W2s + 64 * 65;              // [64][65]: the convolution in progress
+  float* hs = Wfs + 64 * 65;               // [2][FB_RPB][64]  h1 | h2
+  fb_stage(W2s, A.W2);
+  fb_stage(Wfs, wf.w[0]);
+  const int rl = threadIdx.x >> 6, c = threadIdx.x & 63, r = blk * FB_RPB + rl;
+  float z1 = A.b1[c];
 #pragma unroll
-  for (int k = 0; k < FB_P; ++k) z1 += W1[c * FB_P + k] * poly[r * FB_P + k];
+  for (int k = 0; k < FB_P; ++k) z1 += A.W1[c * FB_P + k] * A.poly[r * FB_P + k];
   const float h1 = gelu_f(z1);
   hs[rl * 64 + c] = h1;
   __syncthreads();
-  float z2 = b2[c];
+  float z2 = A.b2[c];
 #pragma unroll 16
   for (int k = 0; k < 64; ++k) z2 += W2s[c * 65 + k] * hs[rl * 64 + k];
   const float h2 = gelu_f(z2);
   hs[(FB_RPB + rl) * 64 + c] = h2;
   // saved for the backward: [z1 | h1 | z2 | h2] each [256][64]
-  saved[(0 * FB_ROWS + r) * 64 + c] = z1;
-  saved[(1 * FB_ROWS + r) * 64 + c] = h1;
-  saved[(2 * FB_ROWS + r) * 64 + c] = z2;
-  saved[(3 * FB_ROWS + r) * 64 + c] = h2;
+  A.saved[(0 * FB_ROWS + r) * 64 + c] = z1;
+  A.saved[(1 * FB_ROWS + r) * 64 + c] = h1;
+  A.saved[(2 * FB_ROWS + r) * 64 + c] = z2;
+  A.saved[(3 * FB_ROWS + r) * 64 + c] = h2;
   __syncthreads();
   for (int i = 0; i < wf.n; ++i) {
-    const float* w = Wfs + i * 64 * 65 + c * 65;
+    if (i > 0) {
+      __syncthreads();          // every thread has finished with the previous matrix
+      fb_stage(Wfs, wf.w[i]);
+      __syncthreads();
+    }
+    const float* w = Wfs + c * 65;
     float acc = 0.f;
 #pragma unroll 16
     for (int k = 0; k < 64; ++k) acc += w[k] * hs[(FB_RPB + rl) * 64 + k];
-    fk.p[i][r * 64 + c] = acc;
+    A.fk.p[i][r * 64 + c] = acc;
   }
 }
+__global__ __launch_bounds__(256) void fiber_basis_fwd_kernel(FbFwd A) {
+  __shared__ float fb_smem[FB_SMEM_FLOATS];
+  fiber_basis_fwd_body(A, (int)blockIdx.x, fb_smem);
+}
 
-__global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __restrict__ poly, const float* __restrict__ W2,
-                                                              FiberWfs wf, const float* __restrict__ saved, FiberDfks dfk,
-                                                              float* __restrict__ partial, int partial_ld) {
-  extern __shared__ float fb_smem[];
+GRL_DEVINL void fiber_basis_bwd_body(const FbBwd& A, int blk, float* fb_smem) {
+  const FiberWfs& wf = A.wf;
   float* W2s = fb_smem;                          // [64][65]
-  float* Wfs = W2s + 64 * 65;                    // [n][64][65]
-  float* dfs = Wfs + wf.n * 64 * 65;             // [n][FB_RPB][64]   dfk rows
-  float* h2s = dfs + wf.n * FB_RPB * 64;         // [FB_RPB][64]
+  float* Wfs = W2s + 64 * 65;                    // [64][65]: the convolution in progress
+  float* dfs = Wfs + 64 * 65;                    // [n][FB_RPB][64]   dfk rows
+  float* h2s = dfs + FB_MAXC * FB_RPB * 64;      // [FB_RPB][64]
   float* h1s = h2s + FB_RPB * 64;
   float* dz2s = h1s + FB_RPB * 64;
   float* dz1s = dz2s + FB_RPB * 64;
-  fb_stage(W2s, W2);
-  for (int i = 0; i < wf.n; ++i) fb_stage(Wfs + i * 64 * 65, wf.w[i]);
-  const int rl = threadIdx.x >> 6, c = threadIdx.x & 63, r = blockIdx.x * FB_RPB + rl;
-  for (int i = 0; i < wf.n; ++i) dfs[(i * FB_RPB + rl) * 64 + c] = dfk.p[i] ? dfk.p[i][r * 64 + c] : 0.f;
+  const float* poly = A.poly;
+  const float* saved = A.saved;
+  fb_stage(W2s, A.W2);
+  fb_stage(Wfs, wf.w[0]);
+  const int rl = threadIdx.x >> 6, c = threadIdx.x & 63, r = blk * FB_RPB + rl;
+  for (int i = 0; i < wf.n; ++i) dfs[(i * FB_RPB + rl) * 64 + c] = A.dfk.p[i] ? A.dfk.p[i][r * 64 + c] : 0.f;
   const float z1 = saved[(0 * FB_ROWS + r) * 64 + c], h1 = saved[(1 * FB_ROWS + r) * 64 + c];
   const float z2 = saved[(2 * FB_ROWS + r) * 64 + c], h2 = saved[(3 * FB_ROWS + r) * 64 + c];
   h2s[rl * 64 + c] = h2;
@@ -624,7 +646,12 @@ __global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __res
   // dPhi[r][k = c] = sum_i sum_c' dfk_i[r][c'] Wf_i[c'][k]
   float dphi = 0.f;
   for (int i = 0; i < wf.n; ++i) {
-    const float* w = Wfs + i * 64 * 65 + c;
+    if (i > 0) {
+      __syncthreads();
+      fb_stage(Wfs, wf.w[i]);
+      __syncthreads();
+    }
+    const float* w = Wfs + c;
     const float* d = dfs + (i * FB_RPB + rl) * 64;
 #pragma unroll 16
     for (int k = 0; k < 64; ++k) dphi += d[k] * w[k * 65];
@@ -639,7 +666,7 @@ __global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __res
   dz1s[rl * 64 + c] = dz1;
   __syncthreads();
   // ---- this workgroup's partial row (sums over its FB_RPB rows)
-  float* out = partial + (size_t)blockIdx.x * partial_ld;
+  float* out = A.partial + (size_t)blk * A.partial_ld;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int cc = e >> 6, k = e & 63;
     for (int i = 0; i < wf.n; ++i) {
@@ -658,7 +685,7 @@ __global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __res
     float t2 = 0.f, t1 = 0.f, tw[FB_P] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < FB_RPB; ++q) {
-      const int rr = blockIdx.x * FB_RPB + q;
+      const int rr = blk * FB_RPB + q;
       t2 += dz2s[q * 64 + c];
       t1 += dz1s[q * 64 + c];
 #pragma unroll
@@ -669,6 +696,38 @@ __global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < FB_P; ++k) oW1[c * FB_P + k] = tw[k];
   }
+}
+__global__ __launch_bounds__(256) void fiber_basis_bwd_kernel(FbBwd A) {
+  __shared__ float fb_smem[FB_SMEM_FLOATS];
+  fiber_basis_bwd_body(A, (int)blockIdx.x, fb_smem);
+}
+
+// ---- merged launches of the recorded step (round 6): roles that do not depend on each other share ONE launch, told apart by block range.
+// Head of the actor's lane: node features (+ the step count) | fiber basis + fiber kernels | weight images -- three ~5 us launches of the
+// step's serial chain (build_features -> lift needs only the first; the other two are parameter-only) become one.
+__global__ __launch_bounds__(256) void step_head_kernel(FeatDescs feat, int n_desc, int nfx, int* __restrict__ bump, FbFwd fb, WimgJobs jobs) {
+  __shared__ float fb_smem[FB_SMEM_FLOATS];
+  const int nfb = fb.wf.n > 0 ? FB_ROWS / FB_RPB : 0, nwi = WIMG_PARTS * jobs.n;
+  int b = (int)blockIdx.x;
+  if (b < nfb) { fiber_basis_fwd_body(fb, b, fb_smem); return; }   // (the long roles first: they are the launch's critical path)
+  b -= nfb;
+  if (b < nwi) { weight_images_body(jobs, b / WIMG_PARTS, b % WIMG_PARTS); return; }
+  b -= nwi;
+  build_features_body(feat, bump, b % nfx, nfx, b / nfx, b == 0);
+}
+// End of the actor's backward: the lift's weight gradient (all node types) | the fiber basis backward -- both only feed the tail's fold.
+__global__ __launch_bounds__(256) void lift_fiber_basis_bwd_kernel(LiftMulti m, const float* __restrict__ grid, float* __restrict__ partial,
+                                                                   int S, int V, FbBwd fb) {
+  __shared__ float smem[FB_SMEM_FLOATS];   // (the lift's [4][C * KF_MAX] reduction buffer aliases its head)
+  static_assert(4 * C * KF_MAX <= FB_SMEM_FLOATS, "LDS of the lift backward must fit the shared block");
+  const int nfb = fb.wf.n > 0 ? FB_ROWS / FB_RPB : 0;
+  int b = (int)blockIdx.x;
+  if (b < nfb) { fiber_basis_bwd_body(fb, b, smem); return; }
+  b -= nfb;
+  int t = 0;
+  while (t + 1 < m.n_types && b >= m.blk0[t + 1]) ++t;
+  lift_encode_bwd_body(m.scal[t], m.vec[t], grid, m.x[t], partial + (size_t)b * C * (S + V), m.N[t], S, V, b - m.blk0[t],
+                       m.blk0[t + 1] - m.blk0[t], reinterpret_cast<float (*)[C * KF_MAX]>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------ slab reduce
@@ -782,6 +841,8 @@ struct FoldTail {
   unsigned int* maxes;
   float ent_coef;
   float* out14;
+  int* flag_dst;                   // optional lane signal written when the launch starts (lane_signal)
+  const int* flag_src;
 };
 GRL_DEVINL void adam_apply(float g, float* __restrict__ gp, const FoldTail& t, float lr, float bc1, float bc2_sqrt) {
   float* p = gp + t.d_param;
@@ -852,6 +913,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(R
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float lr = 0.f, bc1 = 1.f, bc2_sqrt = 1.f;
   if (TAIL) {
+    lane_signal(tail.flag_dst, tail.flag_src);
     if (tail.report && (int)blockIdx.x == m.blk0[m.n_dst]) {   // the extra workgroup: reported values (its first 64 threads)
       __shared__ double sh[16], part[64 * RED_WAVES];
       trpl_report_body<64 * RED_WAVES>(tail.slots, tail.n_slot_blocks, tail.sums, tail.maxes, tail.ent_coef, tail.out14, sh, part);
@@ -995,10 +1057,18 @@ int GRL_ENTRY(grl_lift_encode_bwd)(const float* scal, const float* vec, const fl
   return 0;
 }
 
+int GRL_ENTRY(grl_fiber_conv_fwd_sig)(const st_t* x1, const float* fk, const float* bias, st_t* x2, int n_nodes, int* flag_dst,
+                                      const int* flag_src, hipStream_t stream);
 int GRL_ENTRY(grl_fiber_conv_fwd)(const st_t* x1, const float* fk, const float* bias, st_t* x2, int n_nodes, hipStream_t stream) {
-  if (n_nodes <= 0) return 0;
+  return GRL_ENTRY(grl_fiber_conv_fwd_sig)(x1, fk, bias, x2, n_nodes, nullptr, nullptr, stream);
+}
+// the same; flag_dst (device int[1] or NULL) := flag_src[0] when the launch starts (see lane_signal)
+int GRL_ENTRY(grl_fiber_conv_fwd_sig)(const st_t* x1, const float* fk, const float* bias, st_t* x2, int n_nodes, int* flag_dst,
+                                      const int* flag_src, hipStream_t stream) {
+  if (n_nodes <= 0) return flag_dst ? -2 : 0;   // (a signal needs a launch to ride on)
+  if (flag_dst && !flag_src) return -2;
   hipLaunchKernelGGL(fiber_conv_fwd_kernel, dim3(cap_blocks(n_nodes, FB, 1024)), dim3(256), 0, stream, x1, fk, bias, x2,
-                     n_nodes);
+                     n_nodes, flag_dst, flag_src);
   GRL_CHECK_LAUNCH();
   return 0;
 }
@@ -1031,39 +1101,95 @@ int GRL_ENTRY(grl_softmax_aggregate_bwd)(const float* gate, const st_t* msg, con
   return 0;
 }
 
+static int fb_fwd_fill(FbFwd& A, const float* poly, const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* const* wf, int n_conv, float* saved, float* const* fk) {
+  if (n_conv < 1 || n_conv > FB_MAXC) return -2;
+  A.poly = poly; A.W1 = W1; A.b1 = b1; A.W2 = W2; A.b2 = b2; A.saved = saved;
+  A.wf.n = n_conv;
+  for (int i = 0; i < n_conv; ++i) { A.wf.w[i] = wf[i]; A.fk.p[i] = fk[i]; }
+  return 0;
+}
 #if !GRL_PREC   // parameter-only and reduction entry points exist once (fp32)
 // poly [256,3]; W1 [64,3]; W2 [64,64]; wf: HOST array of n_conv <= 4 device pointers to fiber_kernel weights [64 channels, 64];
 // fk: HOST array of n_conv device pointers to outputs [256,64]; saved: scratch [4,256,64] kept for the backward
 int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, const float* W2, const float* b2, const float* const* wf,
                         int n_conv, float* saved, float* const* fk, hipStream_t stream) {
-  if (n_conv < 1 || n_conv > FB_MAXC) return -2;
-  FiberWfs w{};
-  FiberFks f{};
-  w.n = n_conv;
-  for (int i = 0; i < n_conv; ++i) { w.w[i] = wf[i]; f.p[i] = fk[i]; }
-  const size_t smem = sizeof(float) * (64 * 65 * (1 + n_conv) + 2 * FB_RPB * 64);
-  GRL_ONCE(hipFuncSetAttribute((const void*)fiber_basis_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); hipFuncSetAttribute((const void*)fiber_basis_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-  hipLaunchKernelGGL(fiber_basis_fwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), smem, stream, poly, W1, b1, W2, b2, w, saved, f);
+  FbFwd A{};
+  if (const int rc = fb_fwd_fill(A, poly, W1, b1, W2, b2, wf, n_conv, saved, fk)) return rc;
+  hipLaunchKernelGGL(fiber_basis_fwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), 0, stream, A);
   GRL_CHECK_LAUNCH();
   return 0;
 }
 int grl_fiber_basis_partial_size(int n_conv) { return (n_conv + 1) * 4096 + 64 + 64 * FB_P + 64; }
 int grl_fiber_basis_blocks() { return FB_ROWS / FB_RPB; }
+static int fb_bwd_fill(FbBwd& A, const float* poly, const float* W2, const float* const* wf, int n_conv, const float* saved,
+                       const float* const* dfk, float* partial) {
+  if (n_conv < 1 || n_conv > FB_MAXC) return -2;
+  A.poly = poly; A.W2 = W2; A.saved = saved; A.partial = partial; A.partial_ld = grl_fiber_basis_partial_size(n_conv);
+  A.wf.n = n_conv;
+  for (int i = 0; i < n_conv; ++i) { A.wf.w[i] = wf[i]; A.dfk.p[i] = dfk[i]; }
+  return 0;
+}
 // dfk: HOST array of n_conv device pointers [256,64] (NULL = no gradient); partial [grl_fiber_basis_blocks()][partial_size(n_conv)]
 int grl_fiber_basis_bwd(const float* poly, const float* W2, const float* const* wf, int n_conv, const float* saved,
                         const float* const* dfk, float* partial, hipStream_t stream) {
-  if (n_conv < 1 || n_conv > FB_MAXC) return -2;
-  FiberWfs w{};
-  FiberDfks d{};
-  w.n = n_conv;
-  for (int i = 0; i < n_conv; ++i) { w.w[i] = wf[i]; d.p[i] = dfk[i]; }
-  const size_t smem = sizeof(float) * (64 * 65 * (1 + n_conv) + n_conv * FB_RPB * 64 + 4 * FB_RPB * 64);
-  hipLaunchKernelGGL(fiber_basis_bwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), smem, stream, poly, W2, w, saved, d, partial,
-                     grl_fiber_basis_partial_size(n_conv));
+  FbBwd A{};
+  if (const int rc = fb_bwd_fill(A, poly, W2, wf, n_conv, saved, dfk, partial)) return rc;
+  hipLaunchKernelGGL(fiber_basis_bwd_kernel, dim3(FB_ROWS / FB_RPB), dim3(256), 0, stream, A);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+#endif   // !GRL_PREC
+
+// ---- merged launches (round 6).  grl_step_head: grl_build_features_bump (descs, n_desc, bump) + grl_fiber_basis_fwd (n_conv may be 0:
+// role absent) + grl_weight_images (n_img may be 0) in ONE launch; arguments as in those three entry points.  The images depend on the
+// build's precision, hence the _bf16 twin.
+int GRL_ENTRY(grl_step_head)(const long long* descs, int n_desc, int* bump, const float* poly, const float* W1, const float* b1,
+                             const float* W2, const float* b2, const float* const* wf, int n_conv, float* saved, float* const* fk,
+                             int n_img, const int* kinds, const float* const* srcs, void* const* outs, hipStream_t stream) {
+  if (n_desc < 0 || n_desc > FEAT_MAX || n_img < 0) return -2;
+  FeatDescs feat{};
+  const int max_nodes = n_desc > 0 ? feat_fill(feat, descs, n_desc) : 1;
+  FbFwd A{};
+  if (n_conv > 0)
+    if (const int rc = fb_fwd_fill(A, poly, W1, b1, W2, b2, wf, n_conv, saved, fk)) return rc;
+  WimgJobs jobs{};
+  if (n_img > 0)
+    if (const int rc = wimg_fill(jobs, n_img, kinds, srcs, outs)) return rc;
+  // feature workgroups: grid-stride over the nodes, at most 64 per descriptor (their 41 KB of static LDS -- the fiber-basis role's -- allows
+  // four workgroups per compute unit)
+  int nfx = (max_nodes + 255) / 256;
+  if (nfx > 64) nfx = 64;
+  const int blocks = (n_conv > 0 ? FB_ROWS / FB_RPB : 0) + WIMG_PARTS * jobs.n + nfx * n_desc;
+  if (blocks <= 0) return 0;
+  hipLaunchKernelGGL(step_head_kernel, dim3(blocks), dim3(256), 0, stream, feat, n_desc, nfx, bump, A, jobs);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+// grl_lift_encode_bwd_multi + grl_fiber_basis_bwd in ONE launch (n_conv may be 0: the lift alone); arguments as in those two entry points
+int GRL_ENTRY(grl_lift_fiber_basis_bwd)(int n_types, const float* const* scal, const float* const* vec, const float* grid,
+                                        const st_t* const* dx, float* lift_partial, const int* n_nodes, int n_scal, int n_vec,
+                                        const float* poly, const float* W2, const float* const* wf, int n_conv, const float* saved,
+                                        const float* const* dfk, float* fb_partial, hipStream_t stream) {
+  if (n_scal + n_vec > KF_MAX) return -2;
+  LiftMulti m{};
+  if (n_types > 0)
+    if (const int rc = lift_multi_fill(m, n_types, scal, vec, const_cast<st_t* const*>(dx), n_nodes)) return rc;
+  FbBwd A{};
+  if (n_conv > 0) {
+    A.poly = poly; A.W2 = W2; A.saved = saved; A.partial = fb_partial; A.partial_ld = (n_conv + 1) * 4096 + 64 + 64 * FB_P + 64;
+    if (n_conv > FB_MAXC) return -2;
+    A.wf.n = n_conv;
+    for (int i = 0; i < n_conv; ++i) { A.wf.w[i] = wf[i]; A.dfk.p[i] = dfk[i]; }
+  }
+  const int blocks = (n_conv > 0 ? FB_ROWS / FB_RPB : 0) + (m.n_types > 0 ? m.blk0[m.n_types] : 0);
+  if (blocks <= 0) return 0;
+  hipLaunchKernelGGL(lift_fiber_basis_bwd_kernel, dim3(blocks), dim3(256), 0, stream, m, grid, lift_partial, n_scal, n_vec, A);
   GRL_CHECK_LAUNCH();
   return 0;
 }
 
+#if !GRL_PREC   // (the reductions exist once)
 // out[j] += sum over the n_rows partial rows (out must be initialised by the caller)
 int grl_reduce_partials(const float* partial, float* out, int n_rows, int n, hipStream_t stream) {
   if (n_rows <= 0 || n <= 0) return 0;
@@ -1119,10 +1245,24 @@ int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const i
 // launch produces -- grads / params / exp_avg / exp_avg_sq are parallel flat buffers (every dst lies inside grads; entries no slab feeds
 // keep their zero gradient: Adam would not move them either), lr_dev float[1], step_dev int[1] = the count of THIS step --
 // PLUS (slots != NULL) one extra workgroup doing grl_trpl_report's work.  Gradient clipping needs the finished norm first: not here.
+int grl_fold_adam_report_sig(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                             float* const* dst, int overwrite, int adam, const float* grads, float* params, float* exp_avg, float* exp_avg_sq,
+                             const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev, const double* slots, int batch,
+                             double* sums, unsigned int* maxes, float entropy_coef, float* out14, int* flag_dst, const int* flag_src,
+                             hipStream_t stream);
 int grl_fold_adam_report(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
                          float* const* dst, int overwrite, int adam, const float* grads, float* params, float* exp_avg, float* exp_avg_sq,
                          const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev, const double* slots, int batch,
                          double* sums, unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
+  return grl_fold_adam_report_sig(n_seg, partial, n_rows, ld, start, len, dst, overwrite, adam, grads, params, exp_avg, exp_avg_sq, lr_dev,
+                                  beta1, beta2, eps, step_dev, slots, batch, sums, maxes, entropy_coef, out14, nullptr, nullptr, stream);
+}
+// the same; flag_dst (device int[1] or NULL) := flag_src[0] when the launch starts (a lane signal riding on the tail: lane_signal)
+int grl_fold_adam_report_sig(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                             float* const* dst, int overwrite, int adam, const float* grads, float* params, float* exp_avg, float* exp_avg_sq,
+                             const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev, const double* slots, int batch,
+                             double* sums, unsigned int* maxes, float entropy_coef, float* out14, int* flag_dst, const int* flag_src,
+                             hipStream_t stream) {
   ReduceMulti m{};
   if (n_seg > 0)
     if (const int rc = fold_fill(m, n_seg, partial, n_rows, ld, start, len, dst, overwrite)) return rc;
@@ -1138,8 +1278,10 @@ int grl_fold_adam_report(int n_seg, const float* const* partial, const int* n_ro
     t.report = 1;
     t.slots = slots; t.n_slot_blocks = trpl_blocks(batch); t.sums = sums; t.maxes = maxes; t.ent_coef = entropy_coef; t.out14 = out14;
   }
+  if (flag_dst && !flag_src) return -2;
+  t.flag_dst = flag_dst; t.flag_src = flag_src;
   const int blocks = m.blk0[m.n_dst] + (t.report ? 1 : 0);
-  if (blocks <= 0) return 0;
+  if (blocks <= 0) return flag_dst ? -2 : 0;
   hipLaunchKernelGGL(reduce_partials_multi_kernel<true>, dim3(blocks), dim3(64 * RED_WAVES), 0, stream, m, t);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -394,7 +394,11 @@ class HyperData:
             bump = kw.get("bump")
             if bump is None and self.bump_next is not None:
                 bump, self.bump_next = self.bump_next, None
-            hip.call("grl_build_features_bump", (ctypes.c_longlong * len(words))(*words), n_desc, bump)
+            from . import ops
+            if ops.HEAD is not None and ops.HEAD.feat is None:   # rides in the merged head launch of this forward (ops.HeadLaunch)
+                ops.HEAD.feat = ((ctypes.c_longlong * len(words))(*words), n_desc, bump)
+            else:
+                hip.call("grl_build_features_bump", (ctypes.c_longlong * len(words))(*words), n_desc, bump)
             self._keepalive = obs  # the launch reads these buffers asynchronously
             graph = GraphBatch(B, list(self.node_type_list), {t: (topo["n_main"] if t == main else B * topo["n_per"][t])
                                                               for t in self.node_type_list}, graph_pos,

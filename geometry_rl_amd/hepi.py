@@ -100,6 +100,8 @@ class HeteroFiberConv(nn.Module):
 
 
 class HEPi(nn.Module):
+    supports_head = True   # latent_step issues the merged head launch (ops.HeadLaunch) before its first consumer
+
     def __init__(self, input_dim_node, input_dim_edge, hidden_dim, latent_dim, output_dim, output_dim_vec, node_encoder_layers=2,
                  edge_encoder_layers=2, node_decoder_layers=2, node_type_mapping=None, edge_type_mapping=None,
                  edge_level_mapping=None, message_passing=None, num_messages=2, concat_global=False, shared_processor=False,
@@ -212,13 +214,17 @@ class HEPi(nn.Module):
         scalar_dict, vector_dict = u_dict
         grid3 = self.grid3
         types = self._needed_types(graph)
+        # parameter-only work of the pass (fiber kernels, pre-split weight images) is issued FIRST: with a head collector installed
+        # (ops.HEAD, policy.forward_diag) it shares ONE launch with the node features that build_data has handed over
+        fks = self._fiber_kernels(graph)
+        wimgs = self._weight_images(graph)
+        if ops.HEAD is not None:
+            ops.HEAD.launch(self._prec)
         if 1 < len(types) <= 4:   # every node type in ONE lift launch (each way)
             xs = ops.LiftEncodeMulti.apply(grid3, self.node_encoder.weight, self._prec, *[a for t in types for a in (scalar_dict[t], vector_dict[t])])
             x = dict(zip(types, xs))
         else:
             x = {t: ops.LiftEncode.apply(scalar_dict[t], vector_dict[t], grid3, self.node_encoder.weight, self._prec) for t in types}
-        fks = self._fiber_kernels(graph)
-        wimgs = self._weight_images(graph)
         for rnd in self.processor:
             outs = {}
             for et, conv in rnd.items():

@@ -36,7 +36,6 @@ VARIANTS = [("edge_conv.hip", ["-DGRL_PREC=1"], ".bf16"), ("edge_conv16.hip", ["
 
 BUILD_INFO = os.path.join(os.path.dirname(_HERE), "BUILD_INFO.json")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-HEADERS = ("grl_common.h", "grl_tile16.h", "grl_wimg.h", "grl_report.h")
 HASH_TAG = b"GRL_SOURCE_HASH="
 
 
@@ -126,7 +125,7 @@ def build(verbose: bool = True, force: bool = False, root=None) -> str:
         return lib_path
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     from . import isa_lint
-    header_bytes = [_read(os.path.join(csrc, h)) for h in HEADERS]
+    header_bytes = [_read(os.path.join(csrc, h)) for h in sorted(f for f in os.listdir(csrc) if f.endswith(".h"))]   # every header feeds every object
     lint_bytes = _read(lint_py)
     objs = []
     procs = []

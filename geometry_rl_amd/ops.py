@@ -133,7 +133,7 @@ def _launch_folds(jobs, overwrite=False):
                  (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in part]), 1 if overwrite else 0)
 
 
-def fold_adam_report(overwrite, adam=None, report=None):
+def fold_adam_report(overwrite, adam=None, report=None, signal=None):
     """The queued folds, the Adam update of the parameters they feed and the reported loss values in ONE launch
     (grl_fold_adam_report).  ``adam``: dict(grads, params, exp_avg, exp_avg_sq, lr_dev, betas, eps, step_dev) or None; ``report``:
     dict(slots, batch, sums, maxes, ent_coef, out14) or None.  Returns False (nothing launched, queue untouched) when the queue does not fit
@@ -153,14 +153,15 @@ def fold_adam_report(overwrite, adam=None, report=None):
         lo, hi = a["grads"].data_ptr(), a["grads"].data_ptr() + 4 * a["grads"].numel()
         if any(not (lo <= j[3].data_ptr() and j[3].data_ptr() + 4 * j[2] <= hi) for j in part):
             return False
-    hip.call("grl_fold_adam_report", n, (ctypes.c_void_p * max(n, 1))(*[j[0].data_ptr() for j in part]),
+    sig = list(signal) if signal is not None else [None, None]   # (flag_dst, flag_src): a lane signal written when the launch starts
+    hip.call("grl_fold_adam_report_sig", n, (ctypes.c_void_p * max(n, 1))(*[j[0].data_ptr() for j in part]),
              (ctypes.c_int * max(n, 1))(*[j[0].shape[0] for j in part]), (ctypes.c_int * max(n, 1))(*[j[0].shape[1] for j in part]),
              (ctypes.c_int * max(n, 1))(*[j[1] for j in part]), (ctypes.c_int * max(n, 1))(*[j[2] for j in part]),
              (ctypes.c_void_p * max(n, 1))(*[j[3].data_ptr() for j in part]), 1 if overwrite else 0, 1 if adam is not None else 0,
              a.get("grads"), a.get("params"), a.get("exp_avg"), a.get("exp_avg_sq"), a.get("lr_dev"),
              float(a["betas"][0]) if adam else 0.0, float(a["betas"][1]) if adam else 0.0, float(a["eps"]) if adam else 0.0,
              a.get("step_dev"), r.get("slots"), int(r.get("batch", 0)), r.get("sums"), r.get("maxes"), float(r.get("ent_coef", 0.0)),
-             r.get("out14"))
+             r.get("out14"), *sig)
     if DEFERRED is not None:
         DEFERRED = []
     return True
@@ -219,6 +220,89 @@ def _emit_grads(partial: torch.Tensor, segments):
     return outs
 
 
+# ---- merged launches of the recorded step (round 6; csrc/node_ops.hip step_head_kernel / lift_fiber_basis_bwd_kernel) ---------------------
+import os as _os
+# module attributes (tests flip them in-process; the A/B scripts through the environment): False = every role is its own launch, as in round 5
+FUSE_HEAD = _os.environ.get("GRL_FUSE_HEAD", "1") == "1"
+FUSE_TAIL_PRE = _os.environ.get("GRL_FUSE_TAIL_PRE", "1") == "1"
+SIGNAL_IN_KERNEL = _os.environ.get("GRL_SIGNAL_IN_KERNEL", "1") == "1"   # False: lane signals as 4-byte copy launches of their own
+HEAD = None            # a HeadLaunch while an actor forward that supports it is being issued (policy.GNNGaussianPolicyDiag.forward_diag)
+TAIL_PRE = None        # a dict while PolicyUpdater issues the actor's backward: the first of {lift backward, fiber-basis backward} waits here
+PENDING_SIGNAL = None  # (flag_dst, flag_src) int32 tensors: the next FiberConv forward launch writes flag_dst[0] = flag_src[0] when it starts
+
+
+class HeadLaunch:
+    """The three mutually independent launches at the head of an actor forward -- node features (+ the optimizer's step count), fiber basis
+    + fiber kernels, pre-split weight images -- collected and issued as ONE (grl_step_head).  Each producer hands over its argument set
+    instead of launching (graph.HyperData.build_data, FiberKernels.forward, weight_images); ``launch`` must run before the first consumer
+    (the lift reads the features)."""
+
+    def __init__(self):
+        self.feat = self.fiber = self.wimg = None
+        self.keep = []
+
+    def launch(self, prec: str = ""):
+        import ctypes
+        if self.feat is None and self.fiber is None and self.wimg is None:
+            return
+        words, n_desc, bump = self.feat if self.feat is not None else (None, 0, None)
+        if self.fiber is not None:
+            poly2, P, W, saved, fks = self.fiber
+            n = len(W)
+            fargs = [poly2, *P, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved, (ctypes.c_void_p * n)(*[t.data_ptr() for t in fks])]
+        else:
+            fargs = [None, None, None, None, None, None, 0, None, None]
+        if self.wimg is not None:
+            kinds, ptrs, outs = self.wimg
+            n_img = len(kinds)
+            wargs = [n_img, (ctypes.c_int * n_img)(*kinds), (ctypes.c_void_p * (6 * n_img))(*ptrs), (ctypes.c_void_p * n_img)(*outs)]
+        else:
+            wargs = [0, None, None, None]
+        hip.call("grl_step_head" + prec, words, n_desc, bump, *fargs, *wargs)
+        self.feat = self.fiber = self.wimg = None
+
+
+def _tail_pre_launch(lift, fiber):
+    """lift = (prec, T, scal, vec, grid3, dxs, partial, ns, s, v) or None; fiber = (poly2, w2, W, saved, d, partial) or None: ONE launch."""
+    import ctypes
+    prec = lift[0] if lift is not None else ""
+    if lift is not None:
+        _, T, scal, vec, grid3, dxs, lpart, ns, s_, v_ = lift
+        largs = [T, (ctypes.c_void_p * T)(*[a.data_ptr() for a in scal]), (ctypes.c_void_p * T)(*[b.data_ptr() for b in vec]), grid3,
+                 (ctypes.c_void_p * T)(*[(d.data_ptr() if d is not None else 0) for d in dxs]), lpart, ns, s_, v_]
+    else:
+        largs = [0, None, None, None, None, None, None, 0, 0]
+    if fiber is not None:
+        poly2, w2, W, saved, d, fpart = fiber
+        n = len(W)
+        fargs = [poly2, w2, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
+                 (ctypes.c_void_p * n)(*[(g.data_ptr() if g is not None else 0) for g in d]), fpart]
+    else:
+        fargs = [None, None, None, 0, None, None, None]
+    hip.call("grl_lift_fiber_basis_bwd" + prec, *largs, *fargs)
+
+
+def _tail_pre_offer(kind, job):
+    """Called by the two backward functions while TAIL_PRE is installed: the first one parks its launch, the second issues both as one."""
+    other = "fiber" if kind == "lift" else "lift"
+    if other in TAIL_PRE:
+        pair = {kind: job, other: TAIL_PRE.pop(other)}
+        _tail_pre_launch(pair["lift"], pair["fiber"])
+    else:
+        TAIL_PRE[kind] = job
+
+
+def flush_tail_pre():
+    """Issue whatever is still parked (a backward in which only one of the two roles ran)."""
+    if TAIL_PRE:
+        _tail_pre_launch(TAIL_PRE.pop("lift", None), TAIL_PRE.pop("fiber", None))
+
+
+def _all_leaf_grads(tensors):
+    return all(t is not None and t.is_leaf and getattr(t, "grad", None) is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32
+               for t in tensors)
+
+
 class WeightImages:
     """Pre-split weight images of ONE convolution block for one forward pass (csrc/grl_wimg.h, grl_weight_images): device byte buffers
     whose contents are the MFMA kernels' LDS structs.  ``e16``: edge chain for the 16-row kernels (forward prefix + the backward's
@@ -270,6 +354,14 @@ def weight_images(blocks, grid3, basis, prec: str = "", with_backward: bool = Tr
         setattr(out[i], member, v)
         views.append(v)
     cap = hip.query("grl_wimg_max_jobs")
+    if HEAD is not None and HEAD.wimg is None and 0 < len(jobs) <= cap:   # rides in the merged head launch (HeadLaunch)
+        ptrs = []
+        for kind, srcs, _, _ in jobs:
+            ptrs += [t.data_ptr() for t in srcs] + [0] * (6 - len(srcs))
+            HEAD.keep += list(srcs)
+        HEAD.wimg = ([j[0] for j in jobs], ptrs, [v.data_ptr() for v in views])
+        HEAD.keep.append(buf)
+        return out
     for j0 in range(0, len(jobs), cap):
         part = jobs[j0:j0 + cap]
         n = len(part)
@@ -349,9 +441,13 @@ class LiftEncodeMulti(torch.autograd.Function):
         if blocks == 0:
             return (None,) * (3 + 2 * T)
         partial = torch.empty(blocks, 64 * ctx.kf, device=grid3.device, dtype=torch.float32)
-        hip.call("grl_lift_encode_bwd_multi" + ctx.prec, T, (ctypes.c_void_p * T)(*[a.data_ptr() for a in scal]),
-                 (ctypes.c_void_p * T)(*[b.data_ptr() for b in vec]), grid3,
-                 (ctypes.c_void_p * T)(*[(d.data_ptr() if d is not None else 0) for d in dxs]), partial, ns, s, v)
+        if TAIL_PRE is not None and DEFERRED is not None and _all_leaf_grads([ctx.w_enc]):
+            # (the fold of this slab is queued for the lane's tail anyway: the launch may wait for the fiber-basis backward and share its launch)
+            _tail_pre_offer("lift", (ctx.prec, T, list(scal), list(vec), grid3, dxs, partial, ns, s, v))
+        else:
+            hip.call("grl_lift_encode_bwd_multi" + ctx.prec, T, (ctypes.c_void_p * T)(*[a.data_ptr() for a in scal]),
+                     (ctypes.c_void_p * T)(*[b.data_ptr() for b in vec]), grid3,
+                     (ctypes.c_void_p * T)(*[(d.data_ptr() if d is not None else 0) for d in dxs]), partial, ns, s, v)
         (dw,) = _emit_grads(partial, [(0, 64 * ctx.kf, (64, ctx.kf), ctx.w_enc)])
         return (None, dw, None) + (None,) * (2 * T)
 
@@ -474,7 +570,12 @@ class FiberConv(torch.autograd.Function):
         hip.check_latent(prec, x1)
         x2 = torch.empty_like(x1)
         fk = fk.contiguous()
-        hip.call("grl_fiber_conv_fwd" + prec, x1, fk, bias.contiguous(), x2, x1.shape[0])
+        global PENDING_SIGNAL
+        if PENDING_SIGNAL is not None and x1.shape[0] > 0:   # a lane signal rides on this launch (written when it starts: PolicyUpdater._plan_lanes)
+            (fd, fs), PENDING_SIGNAL = PENDING_SIGNAL, None
+            hip.call("grl_fiber_conv_fwd_sig" + prec, x1, fk, bias.contiguous(), x2, x1.shape[0], fd, fs)
+        else:
+            hip.call("grl_fiber_conv_fwd" + prec, x1, fk, bias.contiguous(), x2, x1.shape[0])
         ctx.save_for_backward(x1, fk)
         ctx.bias, ctx.prec = bias, prec
         return x2
@@ -508,8 +609,11 @@ class FiberKernels(torch.autograd.Function):
         W = [t.contiguous() for t in wfs]
         saved = torch.empty(4, 256, 64, device=dev, dtype=torch.float32)
         fks = [torch.empty(16, 16, 64, device=dev, dtype=torch.float32) for _ in range(n)]
-        hip.call("grl_fiber_basis_fwd", poly2, *P, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
-                 (ctypes.c_void_p * n)(*[t.data_ptr() for t in fks]))
+        if HEAD is not None and HEAD.fiber is None:   # rides in the merged head launch (HeadLaunch)
+            HEAD.fiber = (poly2, P, W, saved, fks)
+        else:
+            hip.call("grl_fiber_basis_fwd", poly2, *P, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
+                     (ctypes.c_void_p * n)(*[t.data_ptr() for t in fks]))
         ctx.save_for_backward(poly2, P[2], saved, *W)
         ctx.params = (w1, b1, w2, b2) + tuple(wfs)
         return tuple(fks)
@@ -523,8 +627,11 @@ class FiberKernels(torch.autograd.Function):
         d = [g.contiguous() if g is not None else None for g in dfks]
         partial = torch.empty(hip.query("grl_fiber_basis_blocks"), hip.query("grl_fiber_basis_partial_size", n), device=dev,
                               dtype=torch.float32)
-        hip.call("grl_fiber_basis_bwd", poly2, w2, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
-                 (ctypes.c_void_p * n)(*[(g.data_ptr() if g is not None else 0) for g in d]), partial)
+        if TAIL_PRE is not None and DEFERRED is not None and _all_leaf_grads(ctx.params):
+            _tail_pre_offer("fiber", (poly2, w2, list(W), saved, d, partial))
+        else:
+            hip.call("grl_fiber_basis_bwd", poly2, w2, (ctypes.c_void_p * n)(*[t.data_ptr() for t in W]), n, saved,
+                     (ctypes.c_void_p * n)(*[(g.data_ptr() if g is not None else 0) for g in d]), partial)
         pw1, pb1, pw2, pb2, *pwf = ctx.params
         o = n * 4096
         segs = [(i * 4096, 4096, (64, 64), pwf[i]) for i in range(n)]

@@ -89,9 +89,16 @@ class GNNGaussianPolicyDiag(nn.Module):
             return mean.reshape(B, -1), sigma.reshape(B, -1)
         if train and not self._calib_checked:
             self._maybe_calibrate(args)
-        graph, u = self.hyper_data.build_data(*args, train=train)
         gnn = self.gnn
-        lat = gnn.latent_step(graph, u)
+        # node features + fiber kernels + weight images of this pass as ONE launch (ops.HeadLaunch) where the GNN issues it
+        ops.HEAD = ops.HeadLaunch() if (ops.FUSE_HEAD and getattr(gnn, "supports_head", False)) else None
+        try:
+            graph, u = self.hyper_data.build_data(*args, train=train)
+            lat = gnn.latent_step(graph, u)
+            if ops.HEAD is not None and (ops.HEAD.feat is not None or ops.HEAD.fiber is not None or ops.HEAD.wimg is not None):
+                raise RuntimeError("the merged head launch was not issued by latent_step")
+        finally:
+            ops.HEAD = None
         dec = gnn.decoder
         mean, sigma, _ = ops.Readout.apply(lat, gnn.grid3, dec.weight, dec.bias, self._pre_std.weight, self._pre_std.bias,
                                            float(self._pre_activation_shift), float(self.minimal_std), gnn.output_dim,

@@ -360,6 +360,45 @@ int grl_gae_scan(const float* reward, const unsigned char* done, const unsigned 
 int grl_build_features(const long long* descs, int n_desc, hipStream_t stream);
 /* (ABI 203) the same; bump (device int[1] or NULL) is advanced by one by the launch: the optimizer's step count of a recorded step */
 int grl_build_features_bump(const long long* descs, int n_desc, int* bump, hipStream_t stream);
+
+/* ---- (ABI 205, round 6) merged launches of the recorded policy-update step and lane signals -----------------------------------------
+ * Replaces nothing of the reference (it has no launches to merge: examples/torchrl/train.py:279-316 runs eager PyTorch); these shorten the
+ * serial chain of a shard-sized step, where ~35 dependent launches of 5-15 us each are the cost.
+ *
+ * grl_step_head: the three mutually independent launches at the head of the actor's lane in ONE -- grl_build_features_bump (descs, n_desc,
+ * bump), grl_fiber_basis_fwd (poly .. fk; n_conv = 0: role absent) and grl_weight_images (n_img, kinds, srcs, outs; n_img = 0: absent).
+ * Arguments exactly as in those entry points; the results are bitwise theirs (the same device functions). */
+int grl_step_head(const long long* descs, int n_desc, int* bump, const float* poly, const float* W1, const float* b1, const float* W2,
+                  const float* b2, const float* const* wf, int n_conv, float* saved, float* const* fk, int n_img, const int* kinds,
+                  const float* const* srcs, void* const* outs, hipStream_t stream);
+int grl_step_head_bf16(const long long* descs, int n_desc, int* bump, const float* poly, const float* W1, const float* b1, const float* W2,
+                       const float* b2, const float* const* wf, int n_conv, float* saved, float* const* fk, int n_img, const int* kinds,
+                       const float* const* srcs, void* const* outs, hipStream_t stream);
+/* grl_lift_fiber_basis_bwd: grl_lift_encode_bwd_multi (n_types .. n_vec; n_types = 0: absent) + grl_fiber_basis_bwd (poly .. fb_partial;
+ * n_conv = 0: absent) in ONE launch at the end of the actor's backward; arguments and results as in those two entry points. */
+int grl_lift_fiber_basis_bwd(int n_types, const float* const* scal, const float* const* vec, const float* grid, const float* const* dx,
+                             float* lift_partial, const int* n_nodes, int n_scal, int n_vec, const float* poly, const float* W2,
+                             const float* const* wf, int n_conv, const float* saved, const float* const* dfk, float* fb_partial,
+                             hipStream_t stream);
+int grl_lift_fiber_basis_bwd_bf16(int n_types, const float* const* scal, const float* const* vec, const float* grid,
+                                  const grl_bf16* const* dx, float* lift_partial, const int* n_nodes, int n_scal, int n_vec,
+                                  const float* poly, const float* W2, const float* const* wf, int n_conv, const float* saved,
+                                  const float* const* dfk, float* fb_partial, hipStream_t stream);
+/* Lane signals riding on a launch: flag_dst[0] := flag_src[0] (device int32, system-scope store) by one thread when the launch STARTS,
+ * i.e. when everything in front of it on the stream has finished -- what another stream's hipStreamWaitValue32 waits for, without a copy
+ * launch of its own on the chain.  grl_fiber_conv_fwd_sig = grl_fiber_conv_fwd (+ signal: "the edge convolution in front is done");
+ * grl_fold_adam_report_sig = grl_fold_adam_report (+ signal at the lane's end). */
+int grl_fiber_conv_fwd_sig(const float* x1, const float* fk, const float* bias, float* x2, int n_nodes, int* flag_dst, const int* flag_src,
+                           hipStream_t stream);
+int grl_fiber_conv_fwd_sig_bf16(const grl_bf16* x1, const float* fk, const float* bias, grl_bf16* x2, int n_nodes, int* flag_dst,
+                                const int* flag_src, hipStream_t stream);
+int grl_fold_adam_report_sig(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                             float* const* dst, int overwrite, int adam, const float* grads, float* params, float* exp_avg,
+                             float* exp_avg_sq, const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev,
+                             const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
+                             int* flag_dst, const int* flag_src, hipStream_t stream);
+/* 1 if the current device supports hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue), else 0 (host query, no stream). */
+int grl_can_stream_wait_value(void);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */
 int grl_copy_many(void* const* dst, const void* const* src, const long long* bytes, int n, hipStream_t stream);
 /* minibatch assembly from a device-resident rollout (train.py:120,128,258-261): dst[k][i,:] = src[k][idx[i],:] for k < n <= 24
