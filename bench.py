@@ -405,12 +405,13 @@ def main():
         upd.step_from(buf, next(mb))
     # R repeats of the timed region, each EXACTLY --steps steps between a barrier + device synchronisation on both sides; the repeat's
     # time is the MAX over the ranks; `value` is the median repeat (one 65 ms shot could not resolve a 1 % change)
-    rep_dt = []
+    rep_dt, rep_enq = [], []
     for r_ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             out = upd.step_from(buf, next(mb))
+        rep_enq.append(time.perf_counter() - t0)   # the HOST's share: all K steps enqueued (no device synchronisation inside the loop)
         barrier()
         rep_dt.append(time.perf_counter() - t0)
     if world > 1:
@@ -666,6 +667,8 @@ def main():
             "metric": "policy-update steps/sec, HEPi 4096 envs x 128 steps", "value": args.steps / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "repeats": len(rep_dt_global), "repeats_ms_per_step": [1e3 * x / args.steps for x in rep_dt_global],
+            # host time to ENQUEUE a step (median repeat, rank 0): a step whose enqueue time reaches its device time is launch-bound
+            "host_enqueue_ms_per_step": 1e3 * sorted(rep_enq)[len(rep_enq) // 2] / args.steps,
             "ms_per_step_min_max": [1e3 * min(rep_dt_global) / args.steps, 1e3 * max(rep_dt_global) / args.steps],
             "value_note": "value = steps / (median over the repeats of the time of one timed region of exactly `steps` steps, max over ranks)",
             "box_calibration": calib, "box_calibration_after": calib_after,

@@ -180,6 +180,15 @@ class PolicyUpdater:
                 raise ValueError("PolicyUpdater(group=...) must span the default process group (dist.new_group for the critic's lane is "
                                  "collective over WORLD); set GRL_DP_ONE_COMM=1 to run both lanes on a sub-group's own communicator")
             self.group_c = dist.new_group(ranks=ranks)
+        # GRL_DP_ONESHOT=1: the actor lane's one collective (gradient slice + loss records) as a one-shot all-reduce over hipIpc-mapped peer
+        # buffers (geometry_rl_amd/oneshot.py) instead of RCCL.  OFF by default: tested with stand-in ranks on one GPU only
+        # (tests/test_gpu_oneshot.py); DESIGN.md section 5 has the switch-on criterion for a real node.
+        self._oneshot = None
+        if group is not None and n_ranks > 1 and os.environ.get("GRL_DP_ONESHOT", "0") == "1" and self.flat.is_cuda:
+            import torch.distributed as dist
+            if dist.get_backend(group) == "nccl":
+                from . import oneshot
+                self._oneshot = oneshot.ipc_rank(group, self.gbuf[:self._rec + self.n_actor])
         if group is not None:
             self.sync_replicas()
 
@@ -667,7 +676,10 @@ class PolicyUpdater:
             raise ValueError(f"unknown program entry '{kind}'")
         group = self.group_c if (lane == "s" and self.group_c is not None) else self.group
         with self._log_span(label or kind, t.numel() * t.element_size()):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if self._oneshot is not None and lane == "m" and t.data_ptr() == self._oneshot.payload.data_ptr() and t.numel() == self._oneshot.n:
+                self._oneshot.all_reduce()   # (GRL_DP_ONESHOT=1: in place, on this lane's stream; every rank enqueues it at this point of the program)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     def _compile(self, batch):
         """Record the plan's segments into hipGraphs (adjacent segments without a reduction between them share one graph)."""

@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
 ABI_VERSION = 205   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "head_ops.hip",
-           "critic_ops.hip", "train_ops.hip", "weight_images.hip", "calib.hip"]
+           "critic_ops.hip", "train_ops.hip", "weight_images.hip", "calib.hip", "oneshot.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per
 # product instead of three; csrc/grl_common.h GRL_PREC) whose entry points carry the suffix _bf16
 # per-source compiler flags.  edge_conv16.hip: its 512-register backward kernel keeps the chain's MFMA results in VGPRs (the default

@@ -192,7 +192,10 @@ def _emit_grads(partial: torch.Tensor, segments):
     import ctypes
     dev = partial.device
     outs, dsts, starts, lens, fresh_flags = [], [], [], [], []
-    for start, length, shape, t in segments:
+    skip = set()
+    for i_, (start, length, shape, t) in enumerate(segments):
+        if t is not None and t.is_leaf and not t.requires_grad:
+            skip.add(i_)   # a constant (e.g. the zero weight of a state-independent std head): nobody reads this gradient
         g = getattr(t, "grad", None) if (t is not None and t.is_leaf) else None
         if g is not None and g.is_contiguous() and g.dtype == torch.float32:
             outs.append(None)
@@ -205,10 +208,12 @@ def _emit_grads(partial: torch.Tensor, segments):
             fresh_flags.append(1)
         starts.append(start)
         lens.append(length)
-    now = list(range(len(segments)))
+    now = [i for i in range(len(segments)) if i not in skip]
+    for i in skip:
+        outs[i] = None
     if DEFERRED is not None:
-        jobs = [(partial, st, ln, d) for st, ln, d, f in zip(starts, lens, dsts, fresh_flags) if not f]
-        now = [i for i, f in enumerate(fresh_flags) if f]
+        jobs = [(partial, st, ln, d) for i, (st, ln, d, f) in enumerate(zip(starts, lens, dsts, fresh_flags)) if not f and i not in skip]
+        now = [i for i, f in enumerate(fresh_flags) if f and i not in skip]
         DEFERRED.extend(jobs)   # keeps `partial` alive until the flush
     for i0 in range(0, len(now), 8):
         idx = now[i0:i0 + 8]

@@ -35,9 +35,9 @@ class GNNGaussianPolicyDiag(nn.Module):
                  share_weights=False, vf_model=None, minimal_std=1e-5, scale=1e-4, gain=0.01, share_action_dim=True, post_fc=False,
                  **kwargs):
         super().__init__()
-        if not contextual_std or not share_action_dim or isinstance(action_dim, list) or use_tanh_mean:
-            raise NotImplementedError("policy head: contextual_std=True, share_action_dim=True, no tanh mean "
-                                      "(configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:85-99; post_fc either way)")
+        if not share_action_dim or isinstance(action_dim, list) or use_tanh_mean:
+            raise NotImplementedError("policy head: share_action_dim=True, no tanh mean "
+                                      "(configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:85-99; post_fc and contextual_std either way)")
         if init != "orthogonal":
             raise NotImplementedError("only the 'orthogonal' initialisation of configs/algorithm/policy/default.yaml is mirrored")
         self.action_dim, self.num_actuators = action_dim, num_actuators
@@ -47,7 +47,13 @@ class GNNGaussianPolicyDiag(nn.Module):
         a_shared = action_dim // num_actuators
         self._pre_activation_shift = inverse_softplus(self.init_std - self.minimal_std)  # abstract_gaussian_policy.py:124-134
         self._mean = _orthogonal_linear(hidden_sizes[-1], a_shared, gain)  # unused when post_fc=False, kept for state_dict parity
-        self._pre_std = _orthogonal_linear(hidden_sizes[-1], a_shared, gain)
+        if contextual_std:
+            self._pre_std = _orthogonal_linear(hidden_sizes[-1], a_shared, gain)
+        else:   # a state-independent std: one trainable vector (gnn_gaussian_policy_diag.py:17-19, abstract_gnn_gaussian_policy.py:82-85)
+            self._pre_std = nn.Parameter(torch.normal(0.0, 0.01, (a_shared,)))
+            self.register_buffer("_zero_std_weight", torch.zeros(a_shared, hidden_sizes[-1]), persistent=False)
+        if not trainable_std:   # abstract_gnn_gaussian_policy.py:84-85
+            self._pre_std.requires_grad_(False)
         self.hyper_data = hyper_data
         self.gnn = gnn
         self._calib_checked = False  # host-side latch: the per-conv `callibrated` buffers are inspected once, not every step
@@ -85,7 +91,10 @@ class GNNGaussianPolicyDiag(nn.Module):
             hidden = self.gnn.one_step(graph, u)
             mean = self._mean(hidden)
             shift = self._pre_activation_shift.to(hidden.device)
-            sigma = torch.nn.functional.softplus(self._pre_std(hidden) + shift) + self.minimal_std.to(hidden.device)
+            pre = self._pre_std(hidden) if self.contextual_std else self._pre_std
+            sigma = torch.nn.functional.softplus(pre + shift) + self.minimal_std.to(hidden.device)
+            if not self.contextual_std:   # gnn_gaussian_policy_diag.py:73-74
+                sigma = sigma.tile((hidden.shape[0], 1))
             return mean.reshape(B, -1), sigma.reshape(B, -1)
         if train and not self._calib_checked:
             self._maybe_calibrate(args)
@@ -100,7 +109,10 @@ class GNNGaussianPolicyDiag(nn.Module):
         finally:
             ops.HEAD = None
         dec = gnn.decoder
-        mean, sigma, _ = ops.Readout.apply(lat, gnn.grid3, dec.weight, dec.bias, self._pre_std.weight, self._pre_std.bias,
+        # the std head of the fused read-out is softplus(Ws hidden + bs + shift) + minimal_std: a state-independent std is the same head with
+        # Ws = 0 and bs = the trainable vector (gnn_gaussian_policy_diag.py:70-74: ``std = self._pre_std`` tiled over the nodes)
+        ws, bs = (self._pre_std.weight, self._pre_std.bias) if self.contextual_std else (self._zero_std_weight, self._pre_std)
+        mean, sigma, _ = ops.Readout.apply(lat, gnn.grid3, dec.weight, dec.bias, ws, bs,
                                            float(self._pre_activation_shift), float(self.minimal_std), gnn.output_dim,
                                            gnn.output_dim_vec)
         return mean.reshape(B, -1), sigma.reshape(B, -1)
@@ -140,8 +152,29 @@ class GNNGaussianPolicyDiag(nn.Module):
     def precision(self, std):
         return (1 / self.covariance(std).diagonal(dim1=-2, dim2=-1)).diag_embed()
 
-    def set_std(self, std):
-        raise AssertionError("set_std requires a non-contextual std (gnn_gaussian_policy_diag.py:137-142)")
+    def set_std(self, std: torch.Tensor) -> None:
+        """gnn_gaussian_policy_diag.py:137-142: overwrite the state-independent std with the diagonal of ``std`` (a std MATRIX).  Written
+        IN PLACE (the reference rebinds ``.data``): under PolicyUpdater the parameter is a view of the flat buffer and must stay one."""
+        assert not self.contextual_std
+        shifted_min = self.minimal_std + torch.finfo(std.dtype).eps   # avoid 0 on the diagonal: softplus^-1 fails there
+        std_min = std.diagonal().clamp(min=shifted_min.to(std.device)) - self.minimal_std.to(std.device)
+        new = inverse_softplus(std_min) - self._pre_activation_shift.to(std.device)
+        if new.numel() != self._pre_std.numel():
+            raise ValueError(f"set_std: {new.numel()} diagonal entries for a shared std of {self._pre_std.numel()} "
+                             "(share_action_dim=True: one std per action dimension of ONE actuator)")
+        self._pre_std.data.copy_(new.reshape(self._pre_std.shape).to(self._pre_std.device))
+
+
+def get_policy_network(policy_type, proj_type, squash=False, device="cpu", dtype=torch.float32, **kwargs):
+    """policy_factory.py:6-33 -- the call builders/utils_algo_graph.py:125-137 makes: ``policy_type == "gnn_diag"`` ->
+    GNNGaussianPolicyDiag(**kwargs) on ``device``.  (``proj_type`` / ``squash`` are accepted and unused there as well.)"""
+    if policy_type == "gnn_diag":
+        policy = GNNGaussianPolicyDiag(**kwargs)
+    else:
+        raise ValueError(f"Invalid policy type {policy_type}. Select one of 'full', 'diag'.")
+    if dtype not in (torch.float32, None):
+        raise NotImplementedError("the HIP kernels store parameters in float32")
+    return policy.to(device)
 
 
 class _PygLinearNames(nn.Module):
@@ -255,3 +288,14 @@ class BaseCritic(nn.Module):
     @property
     def is_vf(self):
         return True
+
+
+def get_critic(critic_type: str, dim: int = 0, device="cpu", dtype=torch.float32, **kwargs):
+    """critic_factory.py:7-33 -- the call builders/utils_algo_graph.py:180-187 makes: ``critic_type == "gnn"`` ->
+    BaseCritic(GNNVFNet(**kwargs)).  The builder's orthogonal re-initialisation of every Linear (utils_algo_graph.py:195-198) works on the
+    returned module unchanged (its Linear children are ordinary ``nn.Linear`` parameter holders)."""
+    if critic_type == "gnn":
+        if dtype not in (torch.float32, None):
+            raise NotImplementedError("the HIP kernels store parameters in float32")
+        return BaseCritic(GNNVFNet(**kwargs)).to(device)
+    raise ValueError(f"Invalid value_loss type {critic_type}. Select one of 'base', 'double', 'duelling'.")

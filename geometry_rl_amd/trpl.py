@@ -64,6 +64,47 @@ def _diag(t):
     return t.diagonal(dim1=-2, dim2=-1) if t.dim() == 3 else t
 
 
+# ---- entropy control of the projection (base_projection_layer.py:14-68, projection_utils.py:252-280).  Plain tensor arithmetic on the
+#      [B, A, A] "std" matrices of the reference's API (what the policy returns as covariance), differentiable: a host-side step on the
+#      tensors that feed / leave the fused kernel.  Pinned by tests/golden/tier2e_std_entropy.npz (reference code).
+def _entropy_of(p):
+    """gnn_gaussian_policy_diag.py:104-126 on p = (mean, std matrix or its diagonal)."""
+    import math
+    d = _diag(p[1])
+    return 0.5 * (d.shape[-1] * math.log(2 * math.e * math.pi) + 2 * d.log().sum(-1))
+
+
+def entropy_inequality_projection(policy, p, beta):
+    """base_projection_layer.py:14-44: samples whose entropy is below ``beta`` get their std scaled by exp((beta - entropy) / k)."""
+    mean, std = p
+    k = std.shape[-1]
+    ent = policy.entropy(p) if policy is not None else _entropy_of(p)
+    mask = ent < beta
+    if not bool(mask.any()):
+        return p
+    beta = torch.as_tensor(beta, dtype=ent.dtype, device=ent.device).expand_as(ent)
+    alpha = torch.where(mask, ((beta - ent) / k).exp(), torch.ones_like(ent))
+    return mean, std * alpha.reshape(alpha.shape + (1,) * (std.dim() - alpha.dim()))
+
+
+def entropy_equality_projection(policy, p, beta):
+    """base_projection_layer.py:47-68: every sample's std is scaled so that its entropy EQUALS ``beta``."""
+    mean, std = p
+    k = std.shape[-1]
+    ent = policy.entropy(p) if policy is not None else _entropy_of(p)
+    alpha = ((beta - ent) / k).exp()
+    return mean, std * alpha.reshape(alpha.shape + (1,) * (std.dim() - alpha.dim()))
+
+
+def get_entropy_schedule(schedule_type, total_train_steps, dim):
+    """projection_utils.py:252-280: f(initial_entropy, target_entropy, temperature, step) -> entropy bound."""
+    if schedule_type == "linear":
+        return lambda initial, target, temperature, step: step * (target - initial) / total_train_steps + initial
+    if schedule_type == "exp":
+        return lambda initial, target, temperature, step: dim * target + (initial - dim * target) * temperature ** (10 * step / total_train_steps)
+    return lambda initial, target, temperature, step: torch.as_tensor(float("-inf"))
+
+
 class KLProjectionLayer:
     """Hyper-parameter holder with the reference constructor (base_projection_layer.py:123-197; configs/algorithm/projection/kl.yaml).
     ``__call__(policy, p, q, step)`` returns the projected (mean, "std") like the reference layer, for inspection."""
@@ -71,8 +112,16 @@ class KLProjectionLayer:
     def __init__(self, proj_type="kl", mean_bound=0.0, cov_bound=0.0, trust_region_coeff=0.0, scale_prec=True, mean_eq=False,
                  entropy_schedule=None, action_dim=None, total_train_steps=None, target_entropy=0.0, temperature=0.0,
                  entropy_eq=False, entropy_first=False, cpu=False, dtype=torch.float32, **ignored):
-        if entropy_schedule:
-            raise NotImplementedError("entropy_schedule is False in every reference TRPL config (kl.yaml:9)")
+        # entropy control (base_projection_layer.py:176-185): the schedule, the bound and the two projections are here (pinned by the
+        # tier-2e fixture); the FUSED update kernel does not apply them -- TRPLLoss refuses a layer with an active schedule instead of
+        # silently skipping the entropy projection (no reference TRPL config turns it on: configs/algorithm/projection/kl.yaml:9)
+        if entropy_schedule and not (action_dim and total_train_steps):
+            raise AssertionError("entropy_schedule needs action_dim and total_train_steps (base_projection_layer.py:177)")
+        self.entropy_schedule_type = entropy_schedule or None
+        self._entropy_schedule = get_entropy_schedule(self.entropy_schedule_type, total_train_steps, dim=action_dim)
+        self._entropy_proj = entropy_equality_projection if entropy_eq else entropy_inequality_projection
+        self.target_entropy, self.temperature = float(target_entropy), float(temperature)
+        self.entropy_first, self.entropy_eq = bool(entropy_first), bool(entropy_eq)
         kinds = {"kl": 0, "frob": 1, "frobenius": 1, "w2": 2, "wasserstein": 2}
         if proj_type.lower() not in kinds or mean_eq or not scale_prec:
             raise NotImplementedError("projections: kl | frob | w2 (commutative), each with the Mahalanobis (scale_prec) mean bound")
@@ -81,7 +130,27 @@ class KLProjectionLayer:
         self.trust_region_coeff = float(trust_region_coeff)
         self.initial_entropy = None
 
+    def get_entropy_bound(self, step):
+        """base_projection_layer.py:329-330."""
+        init = self.initial_entropy if self.initial_entropy is not None else torch.as_tensor(0.0)
+        return self._entropy_schedule(init, torch.as_tensor(self.target_entropy, dtype=init.dtype, device=init.device), self.temperature, step)
+
+    def entropy_projection(self, policy, p, q, step):
+        """The entropy half of base_projection_layer.py:200-205,266-283 on its own: latches the initial entropy (mean entropy of the OLD
+        distribution at the first call) and projects ``p`` onto the scheduled bound."""
+        if self.initial_entropy is None:
+            self.initial_entropy = (policy.entropy(q) if policy is not None else _entropy_of(q)).mean().detach()
+        return self._entropy_proj(policy, p, self.get_entropy_bound(step) * p[0].new_ones(p[0].shape[0]))
+
     def __call__(self, policy, p, q, step=0, **kw):
+        if self.entropy_schedule_type and self.entropy_first:     # base_projection_layer.py:266-283: entropy first, then the trust region
+            p = self.entropy_projection(policy, p, q, step)
+        out = self._trust_region_call(policy, p, q)
+        if self.entropy_schedule_type and not self.entropy_first:
+            out = self.entropy_projection(policy, out, q, step)
+        return out
+
+    def _trust_region_call(self, policy, p, q):
         mean, S = p
         old_mean, S_old = q
         d = lambda t: t.diagonal(dim1=-2, dim2=-1) if t.dim() == 3 else t
@@ -144,6 +213,25 @@ class WassersteinProjectionLayer(KLProjectionLayer):
 
     def __init__(self, proj_type="w2", **kw):
         super().__init__(proj_type="w2", **kw)
+
+
+def get_projection_layer(proj_type: str = "", **kwargs) -> KLProjectionLayer:
+    """projection_factory.py:9-48 -- the call builders/utils_algo_graph.py:246-253 makes (``action_dim``, ``total_train_steps``, ``cpu``,
+    ``dtype`` + the entries of configs/algorithm/projection/<type>.yaml as keyword arguments).  "kl" / "frob" / "w2": the fused-kernel
+    layers of this module; the reference's other branches are outside the TRPL hot path (PPO objective, PAPI,
+    non-commuting W2) and say so; anything else is the reference's ValueError."""
+    key = (proj_type or "").lower()
+    if key == "kl":
+        return KLProjectionLayer(proj_type, **kwargs)
+    if key == "frob":
+        return FrobeniusProjectionLayer(proj_type, **kwargs)
+    if key == "w2":
+        return WassersteinProjectionLayer(proj_type, **kwargs)
+    if not key or key.isspace() or key in ("ppo", "sac", "td3", "mpo", "vlearn", "vtrace", "awr", "entropy", "w2_non_com", "papi"):
+        raise NotImplementedError(f"projection '{proj_type}': only the TRPL projections kl | frob | w2 are built (the PPO-style "
+                                  "BaseProjectionLayer, PAPI and the non-commuting W2 are outside the policy-update hot path)")
+    raise ValueError(f"Invalid projection type {proj_type}. Choose one of None/' ', 'ppo', 'sac', 'td3', 'mpo', 'vtrace', 'papi', 'w2', "
+                     "'w2_non_com', 'frob', 'kl', or 'entropy'.")
 
 
 class _InjectGrad(torch.autograd.Function):
@@ -300,6 +388,9 @@ class TRPLLoss(_LossBase):
             return m
         actor_network = unwrap(actor_network, "forward_diag")
         critic_network = unwrap(critic_network, "_network1")
+        if getattr(projection, "entropy_schedule_type", None):
+            raise NotImplementedError("an entropy schedule (base_projection_layer.py:266-283) is not applied by the fused update kernel; the "
+                                      "projection layer offers it on its own (KLProjectionLayer.entropy_projection / __call__)")
         self.actor_network, self.critic_network, self.projection = actor_network, critic_network, projection
         self.trust_region_coef = trust_region_coef
         self.entropy_bonus, self.entropy_coef, self.critic_coef = entropy_bonus, float(entropy_coef), float(critic_coef)

@@ -397,6 +397,22 @@ int grl_fold_adam_report_sig(int n_seg, const float* const* partial, const int* 
                              float* exp_avg_sq, const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev,
                              const double* slots, int batch, double* sums, unsigned int* maxes, float entropy_coef, float* out14,
                              int* flag_dst, const int* flag_src, hipStream_t stream);
+/* ---- (ABI 205, round 6) one-shot all-reduce over directly mapped peer buffers (csrc/oneshot.hip) -----------------------------------
+ * For the data-parallel step's one bandwidth-relevant collective, the actor's gradient slice + loss records (the
+ * reference has no distributed code -- the semantics kept are examples/torchrl/train.py:304-316: every replica applies Adam to the same
+ * summed gradient).  Each rank writes its contribution to chunk p into rank p's staging row, rank p sums its chunk in RANK ORDER and writes
+ * the result into every rank's buffer: bitwise identical on all ranks.  bufs / stages / flags: HOST arrays of `world` (<= 8) device
+ * pointers, entry p = rank p's areas as mapped into this process (hipIpcOpenMemHandle for peers; the same pointers in a single-process
+ * test) -- bufs[p]: the n payload floats (n a multiple of 4), stages[p]: grl_oneshot_stage_floats floats, flags[p]:
+ * grl_oneshot_flag_words 32-bit words zeroed ONCE.  seq: the call's number, the same on all ranks, strictly increasing from 1.  status:
+ * device int32 written only on a timeout (1 / 2).  Every rank must enqueue the call; the kernels wait for each other on the device, each
+ * wait bounded by timeout_ms. */
+int grl_oneshot_chunk_floats(int n, int world);
+int grl_oneshot_stage_floats(int n, int world);
+int grl_oneshot_flag_words(int world);
+int grl_oneshot_blocks(void);
+int grl_oneshot_allreduce(float* const* bufs, float* const* stages, unsigned* const* flags, int rank, int world, int n, unsigned seq,
+                          int timeout_ms, int* status, hipStream_t stream);
 /* 1 if the current device supports hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue), else 0 (host query, no stream). */
 int grl_can_stream_wait_value(void);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */

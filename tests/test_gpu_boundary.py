@@ -212,3 +212,61 @@ def test_knn_to_actuators_topology():
                 want.add((off + j, b * G + k))
         off += n
     assert got == want, (len(got), len(want))
+
+
+def test_state_independent_std_head_through_the_factories():
+    """``contextual_std=False`` (abstract_gnn_gaussian_policy.py:82-85, gnn_gaussian_policy_diag.py:70-74) on the fused
+    read-out, built through ``get_policy_network`` / ``get_critic`` / ``get_projection_layer`` with the builders' keyword arguments.  A
+    state-independent std is the contextual head with a zero weight and the trainable vector as its bias: both forms have to give the same
+    distribution, the same loss and the same gradient for that vector -- and PolicyUpdater has to take a step on it (``set_std`` included)."""
+    from geometry_rl_amd import agent
+    from geometry_rl_amd.policy import get_critic, get_policy_network
+    from geometry_rl_amd.trpl import TRPLLoss, get_projection_layer
+    B = 10
+    spec, actor_c, critic, _, _ = _build(seed=3)
+    proj = get_projection_layer(proj_type="kl", action_dim=6, total_train_steps=100, cpu=False, dtype=torch.float32, mean_bound=0.05,
+                                cov_bound=0.0025, trust_region_coeff=1.0, scale_prec=True, entropy_schedule=False, target_entropy=0.0,
+                                temperature=0.5, entropy_eq=False, entropy_first=False)
+    actor_n = get_policy_network(policy_type="gnn_diag", proj_type="kl", squash=False, device=DEV, dtype=torch.float32, action_dim=6,
+                                 num_actuators=2, vf_model=None, gnn=actor_c.gnn, hyper_data=actor_c.hyper_data, init="orthogonal",
+                                 minimal_std=1e-5, init_std=1.0, contextual_std=False, hidden_sizes=[64, 64], activation="elu",
+                                 share_action_dim=True, post_fc=False)
+    critic2 = get_critic(critic_type="gnn", dim=0, device=DEV, gnn=critic._network1.gnn, hyper_data=critic._network1.hyper_data,
+                         hidden_sizes=[64, 64], activation="elu")
+    batch = dict(syn.make_rigid_obs(B, G=2, angular_velocity=False, object_velocity=False, seed=4))
+    batch.update(syn.make_ppo_fields(B, 6, seed=4))
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    obs = [batch[k] for k in spec.in_features]
+    with torch.no_grad():
+        actor_n(*obs)                                               # first training call: calibration (shared GNN)
+        actor_c._calib_checked = True
+        actor_n._pre_std.copy_(torch.tensor([0.3, -0.2, 0.1], device=DEV))
+        actor_c._pre_std.weight.zero_()
+        actor_c._pre_std.bias.copy_(actor_n._pre_std)
+    grads = {}
+    for name, act in (("n", actor_n), ("c", actor_c)):
+        loss_m = TRPLLoss(act, critic2, projection=proj, entropy_coef=0.005, critic_coef=0.5, clip_value=0.2, loss_critic_type="l2")
+        for p_ in list(act.parameters()) + list(critic2.parameters()):
+            p_.grad = None
+        out = loss_m(batch)
+        (out["loss_objective"] + out["loss_entropy"] + out["loss_trust_region"]).backward()
+        grads[name] = (out["sigma"].detach().clone(), out["loc"].detach().clone(), float(out["loss_trust_region"]), float(out["entropy"]),
+                       (act._pre_std.grad if name == "n" else act._pre_std.bias.grad).detach().clone())
+    assert torch.equal(grads["n"][0], grads["c"][0]) and torch.equal(grads["n"][1], grads["c"][1])
+    sig = torch.nn.functional.softplus(actor_n._pre_std.detach() + actor_n._pre_activation_shift.to(DEV)) + 1e-5
+    assert torch.allclose(grads["n"][0], sig.tile((B, 2)), rtol=1e-6, atol=1e-7)      # the same std for every frame and actuator
+    assert grads["n"][2] == grads["c"][2] and grads["n"][3] == grads["c"][3]
+    assert grads["n"][4].abs().max() > 0 and torch.allclose(grads["n"][4], grads["c"][4], rtol=1e-6, atol=1e-9)
+    # ... and the fused driver steps on it: eager (its overwrite-coverage check must accept the constant zero weight), then recorded
+    loss_m = TRPLLoss(actor_n, critic2, projection=proj, entropy_coef=0.005, critic_coef=0.5, clip_value=0.2, loss_critic_type="l2")
+    upd = agent.PolicyUpdater(loss_m, lr=3e-4, use_graph=True)
+    before = actor_n._pre_std.detach().clone()
+    for _ in range(4):
+        out = upd.step(batch)
+    assert upd.mode.startswith("graph") and not torch.equal(actor_n._pre_std.detach(), before)
+    assert torch.isfinite(out["loss_trust_region"]) and (actor_n._pre_std.detach() - before).abs().max() < 4 * 3.1e-4   # four Adam steps
+    ptr = actor_n._pre_std.data_ptr()
+    actor_n.set_std((torch.tensor([0.5, 0.6, 0.7], device=DEV)).diag_embed())
+    assert actor_n._pre_std.data_ptr() == ptr                                        # still the flat buffer's view
+    out = upd.step(batch)
+    assert torch.allclose(out["sigma"][0, :3], torch.tensor([0.5, 0.6, 0.7], device=DEV), rtol=1e-5, atol=1e-6)

@@ -35,20 +35,25 @@ CASES = {
     "cloth_hepi_225p": (256, 8),
     "rope_hepi_80l": (128, 8),
     "empn_g2_b512": (512, 16),
+    # round 6 (VERDICT r5 "weak" 1): the size the metric is quoted on -- 4096-frame minibatches, the whole update against the oracle
+    # (~20 GB and ~1 min of host work per case for the fp32 + fp64 oracle runs: the weight gradients sum over 4 M edge rows)
+    "rigid_hepi_b4096": (4096, 16),
+    "cloth_hepi_225p_b4096": (4096, 8),
+    "empn_g2_b4096": (4096, 16),
 }
 
 
 def _case(name, B):
     from geometry_rl_amd import graph
-    if name == "rigid_hepi_b1024":
+    if name.startswith("rigid_hepi"):
         o_spec, spec = ogr.rigid_spec(), graph.rigid_spec()
         kw = dict(only_upper_hemisphere=True, output_dim=2, output_dim_vec=2)   # configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:110-116
         obs = syn.make_rigid_obs(B, seed=3)
-    elif name == "cloth_hepi_225p":
+    elif name.startswith("cloth_hepi"):
         o_spec, spec = ogr.cloth_spec(), graph.cloth_spec()
         kw = dict(trust_region_coeff=4.0, cov_bound=0.001)                       # configs/cloth_hanging_multi_hepi_trpl_cfg.yaml:130-133
         obs = syn.make_cloth_obs(B, seed=5)
-    elif name == "rope_hepi_80l":
+    elif name.startswith("rope_hepi"):
         o_spec, spec = ogr.rope_spec(), graph.rope_spec()
         kw = dict(dim=2, clip_grad_norm=True)                                    # configs/rope_shaping_hepi_trpl_cfg.yaml
         obs = syn.make_rope_obs(B, seed=6)

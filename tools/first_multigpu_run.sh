@@ -36,5 +36,12 @@ for algo in Ring Tree; do
     run_line sweep_rigid_hepi_n${N}_${algo}_${proto} $N rigid_hepi NCCL_ALGO=$algo NCCL_PROTO=$proto || true
   done
 done
+# (4) the one-shot all-reduce over hipIpc-mapped peer buffers for that collective (geometry_rl_amd/oneshot.py; OFF by default, never run on
+#     more than one GPU before this call): the line's `flat_gradient_actor+loss_records` lane time against the best of the sweep above decides
+#     DESIGN.md section 5's go / no-go
+for n in 2 $N; do
+  [ $n -le $NMAX ] || continue
+  run_line oneshot_rigid_hepi_n${n} $n rigid_hepi GRL_DP_ONESHOT=1 || echo "  -> one-shot all-reduce failed at n=$n: see $O/oneshot_rigid_hepi_n${n}.err"
+done
 python tools/dp_table.py $O > $O/table.txt
 cat $O/table.txt

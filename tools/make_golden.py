@@ -441,9 +441,94 @@ def tier2d():
     print("tier2d: ", len(rec), "arrays;", sum(p_.numel() for p_ in policy.parameters()), "parameters; loc", tuple(loc.shape))
 
 
+# ----------------------------------------------------------------------------------------------- tier 2e (round 6)
+def tier2e():
+    """State-independent std head (contextual_std=False) with set_std, and the entropy projections + schedules of
+    base_projection_layer.py:14-68 / projection_utils.py:252-280 (reference code under the name-only stubs of tier 2)."""
+    from geometry_rl.algorithms.trust_region_projections.projections.base_projection_layer import (
+        BaseProjectionLayer, entropy_equality_projection, entropy_inequality_projection)
+    from geometry_rl.algorithms.trust_region_projections.utils.projection_utils import get_entropy_schedule
+    from geometry_rl.algorithms.trust_region_projections.models.policy.gnn_gaussian_policy_diag import GNNGaussianPolicyDiag
+
+    g = torch.Generator().manual_seed(17)
+    B, A = 7, 6
+
+    class FakeGNN(nn.Module):
+        device = "cpu"
+
+        def one_step(self, data, input_vector):
+            return data
+
+    class FakeData:
+        def build_data(self, *args, train=True):
+            return self.payload, None
+
+    torch.manual_seed(9)
+    fd = FakeData()
+    policy = GNNGaussianPolicyDiag(gnn=FakeGNN(), hyper_data=fd, action_dim=A, num_actuators=1, init="orthogonal",
+                                   hidden_sizes=(64, 64), contextual_std=False, init_std=0.7, minimal_std=1e-5,
+                                   share_action_dim=True, post_fc=False)
+    hidden = torch.randn(B, 64, generator=g)
+    mean_in = torch.randn(B * 2, 3, generator=g)
+    fd.payload = (mean_in, hidden)
+    rec = {"hidden": hidden, "gnn_out": mean_in, "pre_std": policy._pre_std.detach().clone()}
+    loc, cov = policy(torch.zeros(B, 1), train=True)
+    w = torch.rand(B, A, generator=g)
+    (cov.diagonal(dim1=-2, dim2=-1) * w).sum().backward()
+    rec.update({"loc": loc, "cov": cov, "w": w, "grad.pre_std": policy._pre_std.grad.clone()})
+    new_std = (torch.rand(A, generator=g) + 0.2).diag_embed()
+    new_std[0, 0] = 0.0   # below the minimal std: clamped (gnn_gaussian_policy_diag.py:140-143)
+    policy.set_std(new_std)
+    loc2, cov2 = policy(torch.zeros(B, 1), train=True)
+    rec.update({"set_std.arg": new_std, "set_std.pre_std": policy._pre_std.detach().clone(), "set_std.cov": cov2})
+
+    # entropy projections on p = (mean, "std" = what the policy returns as covariance)
+    mean = torch.randn(B, A, generator=g)
+    S = (torch.rand(B, A, generator=g) * 0.6 + 0.05).diag_embed()
+    ent = policy.entropy((mean, S))
+    beta = ent.mean() + torch.linspace(-1.0, 1.0, B)     # some samples below their bound, some above
+    S_g = S.clone().requires_grad_(True)
+    pm, pS = entropy_inequality_projection(policy, (mean, S_g), beta)
+    wS = torch.rand(B, A, generator=g)
+    (pS.diagonal(dim1=-2, dim2=-1) * wS).sum().backward()
+    rec.update({"ent.mean": mean, "ent.S": S, "ent.entropy": ent, "ent.beta": beta, "ent.ineq_S": pS, "ent.wS": wS, "ent.ineq_grad_S": S_g.grad.clone()})
+    S_g2 = S.clone().requires_grad_(True)
+    _, pS2 = entropy_equality_projection(policy, (mean, S_g2), beta)
+    (pS2.diagonal(dim1=-2, dim2=-1) * wS).sum().backward()
+    rec.update({"ent.eq_S": pS2, "ent.eq_grad_S": S_g2.grad.clone()})
+    _, pS3 = entropy_inequality_projection(policy, (mean, S), ent - 1.0)   # nothing to project: returned unchanged
+    rec["ent.ineq_noop_S"] = pS3
+
+    # schedules
+    steps = torch.tensor([0, 1, 10, 50, 100])
+    init_e, target, temp, total = torch.tensor(3.5), torch.tensor(-1.25), 0.5, 100
+    for kind in ("linear", "exp"):
+        f = get_entropy_schedule(kind, total, dim=A)
+        rec[f"sched.{kind}"] = torch.stack([torch.as_tensor(f(init_e, target, temp, int(s_)), dtype=torch.float32) for s_ in steps])
+    rec.update({"sched.steps": steps, "sched.initial": init_e, "sched.target": target, "sched.temperature": torch.tensor(temp),
+                "sched.total": torch.tensor(total)})
+    # the layer's own call with the base (identity) trust-region hook: entropy projection at the scheduled bound, both orders
+    for first in (False, True):
+        layer = BaseProjectionLayer(proj_type="kl", mean_bound=0.05, cov_bound=0.0025, trust_region_coeff=4.0, scale_prec=True,
+                                    entropy_schedule="linear", action_dim=A, total_train_steps=total, target_entropy=float(target),
+                                    temperature=temp, entropy_first=first, cpu=True, dtype=torch.float32)
+        q = (mean + 0.1, (S.diagonal(dim1=-2, dim2=-1) * 1.3).diag_embed())
+        out_m, out_S = layer(policy, (mean, S), q, 40)
+        rec[f"layer.first{int(first)}.S"] = out_S
+        rec[f"layer.first{int(first)}.initial_entropy"] = layer.initial_entropy
+        rec[f"layer.first{int(first)}.bound40"] = torch.as_tensor(layer.get_entropy_bound(40))
+    rec["layer.q_S"] = q[1]
+    np.savez(os.path.join(OUT, "tier2e_std_entropy.npz"), **npd(rec))
+    print("tier2e:", len(rec), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "tier2e":
+        install_stubs()
+        tier2e()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tier2d":   # only the newest tier (the older fixtures stay byte-identical)
         install_stubs()
         tier2d()
@@ -459,5 +544,6 @@ if __name__ == "__main__":
     tier2c()
     tier2d()
     tier2b(attention=True)
+    tier2e()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
