@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--critic-gate", default=None, help="A/B: where the critic's lane starts: edge0 (default) | fwd_end")
     ap.add_argument("--no-critic-gate", action="store_true", help="A/B: the critic's lane starts with the step instead of behind the actor's first edge convolution")
+    ap.add_argument("--one-stream", action="store_true", help="A/B: one rank, everything on ONE stream / in ONE hipGraph (PolicyUpdater(overlap_critic=False)): no cross-stream wait anywhere")
+    ap.add_argument("--unroll", type=int, default=8, help="one rank: minibatch steps per recorded launch (PolicyUpdater.run_minibatches); 1 = one step per launch, as in round 5")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the recorded hipGraph(s)")
     ap.add_argument("--dp-plan", action="store_true", help="one GPU, but the DATA-PARALLEL program of the step: a one-rank RCCL process group, "
                     "every collective issued, graph segments between them -- what a shard's step costs before any inter-GPU latency")
@@ -360,7 +362,7 @@ def main():
     # the natural order: the updater is built first; the data-dependent calibration (conv.py:104-105) happens inside its first step,
     # from statistics summed over the ranks (every replica computes the factors of the whole minibatch)
     upd = agent.PolicyUpdater(loss, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm, max_grad_norm=cfg.max_grad_norm, group=group,
-                              use_graph=not args.no_graph, force_dp_plan=args.dp_plan, critic_after_first_conv=(False if args.no_critic_gate else (args.critic_gate or True)))
+                              use_graph=not args.no_graph, force_dp_plan=args.dp_plan, overlap_critic=not args.one_stream, critic_after_first_conv=(False if args.no_critic_gate else (args.critic_gate or True)))
     if world > 1:
         import torch.distributed as dist
         assert dist.get_world_size() == world
@@ -393,6 +395,12 @@ def main():
                 yield idx[j]
     mb = sampler()
 
+    def take(n):   # the next n minibatches as an [n, B_local] index matrix (what an epoch's sampler hands out, train.py:258-261)
+        return torch.stack([next(mb) for _ in range(n)])
+    # one rank, recorded lanes: the minibatches of a chunk go to the device as several steps per launch (PolicyUpdater.run_minibatches);
+    # every other form (data parallel, eager, one-stream, --unroll 1) takes one step per call
+    chunked = world == 1 and not args.dp_plan and args.unroll > 1
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -401,16 +409,22 @@ def main():
 
     for i in range(3):  # set-up steps (not warmup): the first runs eagerly and builds the cached topology, the second records the
         upd.step_from(buf, next(mb))  # hipGraph(s), the third is the first replay
-    for i in range(args.warmup):
-        upd.step_from(buf, next(mb))
+    if chunked:   # (the warm-up also records the multi-step launch)
+        upd.run_minibatches(buf, take(max(args.warmup, args.unroll)), unroll=args.unroll)
+    else:
+        for i in range(args.warmup):
+            upd.step_from(buf, next(mb))
     # R repeats of the timed region, each EXACTLY --steps steps between a barrier + device synchronisation on both sides; the repeat's
     # time is the MAX over the ranks; `value` is the median repeat (one 65 ms shot could not resolve a 1 % change)
     rep_dt, rep_enq = [], []
     for r_ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = upd.step_from(buf, next(mb))
+        if chunked:
+            out = upd.run_minibatches(buf, take(args.steps), unroll=args.unroll)
+        else:
+            for i in range(args.steps):
+                out = upd.step_from(buf, next(mb))
         rep_enq.append(time.perf_counter() - t0)   # the HOST's share: all K steps enqueued (no device synchronisation inside the loop)
         barrier()
         rep_dt.append(time.perf_counter() - t0)
@@ -478,8 +492,11 @@ def main():
                            "reduced once per epoch ('advantage_stats_epoch', outside the update)"}
     ms = 1e3 * dt / args.steps
     n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
-    upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else
-                                 f" ({'one hipGraph' if n_graphs == 1 else str(n_graphs) + ' single-stream hipGraphs on two lanes' if (world == 1 and not args.dp_plan) else str(n_graphs) + ' hipGraph segments between the collectives'})")
+    if chunked and getattr(upd, "_epoch", None) is not None:
+        upd.mode_timed = f"graph ({upd._epoch['key'][1]} minibatch steps per launch: 2 single-stream hipGraphs on two lanes, in-graph gathers and gate)"
+    else:
+        upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else
+                                     f" ({'one hipGraph' if n_graphs == 1 else str(n_graphs) + ' single-stream hipGraphs on two lanes' if (world == 1 and not args.dp_plan) else str(n_graphs) + ' hipGraph segments between the collectives'})")
 
     # ---- GAE + shifted critic pass over the whole 4096 x 128 rollout (once per 640 updates; outside the timed region)
     gae_ms = None

@@ -111,6 +111,11 @@ class PolicyUpdater:
         # frames (DESIGN.md finding 42); beside the HBM-bound kernels that follow they cost less: -1.6 % on the step (finding 55).
         self.critic_after_first_conv = critic_after_first_conv
         # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
+        self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
+        self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
+        self._epoch = None
+        self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
+        self._copies = []
         self.critic_first = os.environ.get("GRL_CRITIC_FIRST", "0") == "1"
         self.critic_prio = os.environ.get("GRL_CRITIC_PRIO", "low")
 
@@ -387,7 +392,7 @@ class PolicyUpdater:
         return dict(grads=self.gflat[lo:hi], params=self.flat[lo:hi], exp_avg=self.exp_avg[lo:hi], exp_avg_sq=self.exp_avg_sq[lo:hi],
                     lr_dev=self.lr_dev, betas=self.betas, eps=self.eps, step_dev=cnt)
 
-    def _plan_lanes(self, batch, st):
+    def _plan_lanes(self, batch, st, cbatch=None, gate_in_graph=None):
         """One rank as a two-lane PROGRAM of single-stream graphs.  This HIP runtime replays a captured graph with two branches through
         the host (hipGraphLaunch returned after 2/3 of the DEVICE time of a forked step; tools/ubench/graph_branches.py) and every
         cross-branch edge costs a 6-11 us gap; a graph boundary on a lane costs ~15 us as well.  So each lane is ONE graph and the lanes
@@ -405,6 +410,11 @@ class PolicyUpdater:
         leaves = self._critic_leaves()
         ow = self._fold_overwrite
         na, n_all = self.n_actor, self.flat.numel()
+        cb = cbatch if cbatch is not None else batch   # the critic lane's inputs (the epoch program gives each lane a private copy)
+        # the gate as a launch INSIDE the critic's lane (grl_wait_flag_ge: capturable, target read from the lane's own device-side count) or
+        # as a stream operation in front of its graph (hipStreamWaitValue32, round 5; GRL_GATE_STREAMWAIT=1)
+        if gate_in_graph is None:
+            gate_in_graph = self.gate_in_graph
         # the one-launch tail needs every leaf gradient of the lane in the fold queue (overwrite mode) and no clipping (which needs the
         # finished gradient norm before Adam)
         fuse_tail = not self.clip and ow
@@ -473,16 +483,21 @@ class PolicyUpdater:
             with torch.no_grad():
                 if self.critic_delay_us:   # (experiment knob, default 0: an idle one-wave kernel in front of the critic's lane)
                     hip.call("grl_calib_spin", int(self.critic_delay_us))
+                if gate and gate_in_graph:   # until the actor's lane has signalled THIS step: flag >= the steps this lane has finished + 1
+                    hip.call("grl_wait_flag_ge", self.lane_flag, self.step_dev_c, 1, 200000)
+                pre = st.pop("critic_pre", None)
+                if pre is not None:           # (epoch program: the lane's own minibatch gather)
+                    pre()
                 if not ow:
                     self.gflat[na:].zero_()   # on THIS lane, in front of its folds (never from the actor's lane)
                 vf.train(True)
                 # (inputs straight from the batch: this lane depends on nothing the actor's lane prepares, so it can be enqueued first)
-                _, x = vf.hyper_data.build_data(*[batch[k] for k in m.critic_in_features], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
+                _, x = vf.hyper_data.build_data(*[cb[k] for k in m.critic_in_features], train=True, bump=self.step_dev_c)   # (+ the lane's step count)
                 pipe = st["pipe"] = ops.DeepSetsPipeline(x, leaves, 1)
                 pipe.fwd1()
                 pipe.fwd2()
                 value = st["value"] = pipe.fwd3()
-                dvalue, c_loss, _ = value_loss(m, value, batch)
+                dvalue, c_loss, _ = value_loss(m, value, cb)
                 pipe.bwd3(dvalue)
                 pipe.bwd2()
                 grads = pipe.bwd1(leaves)
@@ -493,7 +508,8 @@ class PolicyUpdater:
                 ops.DEFERRED = None
                 st["c_loss"] = c_loss
 
-        wait = [("wait_flag", None, "s", "critic_lane_start")] if gate else []
+        wait = [("wait_flag", None, "s", "critic_lane_start")] if (gate and not gate_in_graph) else []
+        st["lanes"] = (main_all, critic_all)
         if self.critic_first:   # host order only: the critic's wait + graph are handed to the device BEFORE the actor's graph
             return [("fork", None), *wait, ("run", critic_all, "s"), ("run", main_all), ("join", None), ("run_host", lambda: self._finish(st))]
         return [("fork", None), ("run", main_all), *wait, ("run", critic_all, "s"), ("join", None), ("run_host", lambda: self._finish(st))]
@@ -688,6 +704,12 @@ class PolicyUpdater:
         m.actor_network.hyper_data.check_topology(*[batch[k] for k in m.in_features])
         m.critic_network._network1.hyper_data.check_topology(*[batch[k] for k in m.critic_in_features])
         self._static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        self._copies = []
+        for _copy in range(max(1, self.graph_copies)):   # (graph_copies > 1: the same program recorded again, replayed in turn -- an experiment knob)
+            self._compile_one()
+            self._copies.append((self._program, self._st))
+
+    def _compile_one(self):
         st = self._st = {}
         plan = self._plan(self._static, st)
         groups, cur, cur_lane = [], [], None
@@ -774,9 +796,108 @@ class PolicyUpdater:
                  (ctypes.c_longlong * n)(*[j[2] for j in jobs]), n, idx, int(idx.numel()))
         return self.step(self._static)
 
+    # ---- several minibatch steps per launch (round 6).  A shard-sized step is ~35 dependent launches of 5-15 us; what it pays on top of
+    #      them is the boundary of every replay (~13 us between two graph launches on a stream, ~7 us between the eager minibatch gather
+    #      and the graph behind it) and, at 32 frames, the host's ~0.1 ms of enqueue work per step.  The minibatches of an epoch are known
+    #      when it starts (train.py:258-261 iterates a sampler without replacement), so ``unroll`` consecutive steps are recorded into ONE
+    #      graph per lane: the gathers ride inside (fixed rows of a static index matrix), each lane gathers ITS inputs into buffers of its
+    #      own (the lanes share nothing, so no join between the steps of a launch), the critic's gate is a launch of its lane.
+    def _epoch_ok(self) -> bool:
+        m = self.loss_module
+        return bool(self.use_graph and m.world_size == 1 and not (self.group is not None and self.force_dp_plan) and self.overlap_critic
+                    and m.critic_coef and self.gate_in_graph and self.epoch_unroll > 1 and self.graph_copies <= 1)
+
+    def _lane_keys(self, buf):
+        m = self.loss_module
+        var = "var" if "var" in buf.data else "covariance_matrix"
+        a = list(dict.fromkeys(list(m.in_features) + ["action", "loc", var, "sample_log_prob", "advantage"]))
+        c = list(dict.fromkeys(list(m.critic_in_features) + ["state_value", "value_target"]))
+        return a, c
+
+    def _compile_epoch(self, buf, idx0, U):
+        import ctypes
+        m = self.loss_module
+        B = int(idx0.numel())
+        ka, kc = self._lane_keys(buf)
+        sa, sc = buf.rows(idx0, ka), buf.rows(idx0, kc)      # static inputs, one private set per lane
+        m.actor_network.hyper_data.check_topology(*[sa[k] for k in m.in_features])
+        m.critic_network._network1.hyper_data.check_topology(*[sc[k] for k in m.critic_in_features])
+        idx_static = torch.empty(U, B, device=idx0.device, dtype=torch.int64)
+
+        def gather_args(static, keys):
+            n = len(keys)
+            for k in keys:
+                if static[k].dtype != buf.flat(k).dtype or static[k][0].numel() != buf.flat(k).shape[1]:
+                    raise RuntimeError(f"rollout tensor '{k}' cannot be gathered row-wise into the recorded step's inputs")
+            return ((ctypes.c_void_p * n)(*[static[k].data_ptr() for k in keys]), (ctypes.c_void_p * n)(*[buf.flat(k).data_ptr() for k in keys]),
+                    (ctypes.c_longlong * n)(*[buf.flat(k).shape[1] * buf.flat(k).element_size() for k in keys]), n)
+        ga, gc = gather_args(sa, ka), gather_args(sc, kc)
+        sts, mains, critics = [], [], []
+        for j in range(U):
+            st = {}
+            self._plan_lanes(sa, st, cbatch=sc, gate_in_graph=True)
+            main_all, critic_all = st.pop("lanes")
+            row = idx_static[j]
+            mains.append((lambda row=row: hip.call("grl_gather_rows_many", *ga, row, B), main_all))
+            critics.append((st, (lambda row=row: hip.call("grl_gather_rows_many", *gc, row, B)), critic_all))
+            sts.append(st)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ga_graph, gc_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga_graph, stream=side, capture_error_mode="thread_local"):
+            for gather, main_all in mains:
+                gather()
+                main_all()
+        with torch.cuda.graph(gc_graph, stream=side, capture_error_mode="thread_local"):
+            for st, gather, critic_all in critics:
+                st["critic_pre"] = gather          # (behind the lane's gate, in front of its features: critic_all runs it)
+                critic_all()
+        torch.cuda.current_stream().wait_stream(side)
+        for st in sts:
+            self._finish(st)
+        self._epoch = dict(key=(B, U, id(buf)), idx=idx_static, sts=sts, keep=(sa, sc, ga, gc, buf),
+                           program=[("fork", None, "m", None), ("graph", ga_graph, "m", None), ("graph", gc_graph, "s", None),
+                                    ("join", None, "m", None)])
+
+    def run_minibatches(self, buf, idx_rows: torch.Tensor, unroll: Optional[int] = None):
+        """The updates of consecutive minibatches: ``idx_rows`` [M, B] int64 (device), row j = the rollout rows of minibatch j (what
+        ``rollout.RolloutDriver.epoch_minibatches`` hands out).  One rank with recorded lanes: ``unroll`` steps per launch (see above);
+        otherwise, and for the first (eager) step of a size and the remainder, a loop of ``step_from``.  Returns the loss dict of the last
+        step; ``self.last_outs`` holds the dicts of the last launch's steps."""
+        M, B = int(idx_rows.shape[0]), int(idx_rows.shape[1])
+        U = int(unroll or self.epoch_unroll)
+        out, j = None, 0
+        if not self._epoch_ok() or U <= 1:
+            for j in range(M):
+                out = self.step_from(buf, idx_rows[j])
+            return out
+        while j < M and B not in getattr(self, "_eager_sizes", ()):     # the first step of a size runs eagerly (topology, calibration, checks)
+            out = self.step_from(buf, idx_rows[j])
+            j += 1
+        if M - j >= U:
+            if self._epoch is None or self._epoch["key"] != (B, U, id(buf)):
+                self.loss_module._global_steps = self.steps
+                self._compile_epoch(buf, idx_rows[j], U)
+            ep = self._epoch
+            while M - j >= U:
+                ep["idx"].copy_(idx_rows[j:j + U])
+                self.steps += U
+                try:
+                    self._execute(ep["program"])
+                except BaseException:
+                    self.steps -= U
+                    raise
+                j += U
+                self.last_outs = [st["out"] for st in ep["sts"]]
+                out = self.last_outs[-1]
+        while j < M:
+            out = self.step_from(buf, idx_rows[j])
+            j += 1
+        return out
+
     def reset_graph(self):
         """Drop the recorded step (next step re-records): needed when the minibatch size changes."""
-        self._program, self._static = None, None
+        self._program, self._static, self._copies, self._epoch = None, None, [], None
         self._eager_sizes = set()
 
     def _check_calibrated(self):
@@ -858,6 +979,8 @@ class PolicyUpdater:
                 self.use_graph, self._program, self._static, self.mode = False, None, None, "eager (graph capture failed)"
                 return self._step(batch)
         self._refresh_static(batch)
+        if len(self._copies) > 1:
+            self._program, self._st = self._copies[self.steps % len(self._copies)]
         self._execute(self._program)
         return self._st["out"]
 

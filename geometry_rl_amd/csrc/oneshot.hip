@@ -33,9 +33,13 @@ GRL_DEVINL bool os_wait(const unsigned* flag, unsigned seq, unsigned long long d
   return true;
 }
 
-__global__ __launch_bounds__(256) void oneshot_allreduce_kernel(OneShotPeers P, int rank, int W, int n, int chunk, unsigned seq,
+// rank < 0: ALL ranks in this one launch, rank = blockIdx.y (the single-process test of the protocol: W x OS_BLOCKS workgroups that are
+// resident together by construction -- W separate launches on W streams of one process may share a hardware queue and serialise)
+__global__ __launch_bounds__(256) void oneshot_allreduce_kernel(OneShotPeers P, int rank_, int W, int n, int chunk, unsigned seq,
                                                                 unsigned long long timeout_ticks, int* __restrict__ status) {
   __shared__ int ok;
+  const int rank = rank_ >= 0 ? rank_ : (int)blockIdx.y;
+  if (rank_ < 0) status += rank;          // (one status word per stand-in rank)
   const int b = blockIdx.x;
   const unsigned long long deadline = wall_clock64() + timeout_ticks;
   // this workgroup's share of every chunk: [lo, hi) in units of four floats
@@ -107,6 +111,22 @@ int grl_oneshot_allreduce(float* const* bufs, float* const* stages, unsigned* co
   }
   const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull;   // wall_clock64: 100 MHz
   hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(OS_BLOCKS), dim3(256), 0, stream, P, rank, world, n,
+                     grl_oneshot_chunk_floats(n, world), seq, ticks, status);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same protocol with all `world` stand-in ranks in ONE launch (rank = blockIdx.y): the single-process test on one GPU.  status: world ints.
+int grl_oneshot_allreduce_local(float* const* bufs, float* const* stages, unsigned* const* flags, int world, int n, unsigned seq,
+                                int timeout_ms, int* status, hipStream_t stream) {
+  if (world < 1 || world > OS_MAX_WORLD || n <= 0 || (n & 3) || seq == 0 || !status) return -2;
+  OneShotPeers P{};
+  for (int p = 0; p < world; ++p) {
+    if (!bufs[p] || !stages[p] || !flags[p]) return -3;
+    P.buf[p] = bufs[p]; P.stage[p] = stages[p]; P.flags[p] = flags[p];
+  }
+  const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull;
+  hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(OS_BLOCKS, world), dim3(256), 0, stream, P, -1, world, n,
                      grl_oneshot_chunk_floats(n, world), seq, ticks, status);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -173,6 +173,21 @@ __global__ __launch_bounds__(256) void build_features_kernel(FeatDescs all, int*
   build_features_body(all, bump, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, blockIdx.x == 0 && blockIdx.y == 0);
 }
 
+// ---- lane gate as a kernel: one thread waits until flag[0] >= count[0] + add (both device int32), at most timeout_ticks of the 100 MHz wall clock
+// -- what hipStreamWaitValue32 does on this runtime as well (its __amd_rocclr_streamOpsWait is a one-thread kernel), but capturable into a
+// hipGraph, with the target read from DEVICE memory (a recorded step waits for ITS count) and bounded: a gate is a scheduling hint, so on a
+// timeout the lane simply goes on.  One wave on one SIMD; no LDS, a handful of registers.
+__global__ __launch_bounds__(64) void wait_flag_ge_kernel(const int* __restrict__ flag, const int* __restrict__ count, int add,
+                                                          unsigned long long timeout_ticks) {
+  if (threadIdx.x != 0) return;
+  const int target = count[0] + add;
+  const unsigned long long deadline = wall_clock64() + timeout_ticks;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - target < 0) {
+    if (wall_clock64() > deadline) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 // ---- several small device-to-device copies in one launch (refreshing the static input buffers of a recorded step) -------------
 constexpr int COPY_MAX = 24;
 struct CopyJobs {
@@ -358,6 +373,14 @@ extern "C" {
 // ABI version of this library: major * 10000 + minor * 100 + patch.  Bumped whenever a declared signature changes
 // (include/grl_hip.h GRL_HIP_VERSION must agree: geometry_rl_amd/hip.py checks it at load time).
 int grl_version(void) { return 205; }
+// The current stream waits (a one-thread kernel: capturable) until flag[0] >= count[0] + add, at most timeout_us microseconds.
+int grl_wait_flag_ge(const int* flag, const int* count, int add, int timeout_us, hipStream_t stream) {
+  if (!flag || !count) return -2;
+  hipLaunchKernelGGL(wait_flag_ge_kernel, dim3(1), dim3(64), 0, stream, flag, count, add,
+                     (unsigned long long)(timeout_us > 0 ? timeout_us : 200000) * 100ull);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
 int grl_can_stream_wait_value(void) {
   int dev = 0, v = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;

@@ -52,6 +52,19 @@ class OneShotRank:
                                f"arrive within {self.timeout_ms} ms): not every rank enqueued call {self.seq}, or the kernels were not resident together")
 
 
+def all_reduce_local(ranks: List["OneShotRank"]):
+    """All stand-in ranks of ``local_ranks`` in ONE launch (grl_oneshot_allreduce_local): their workgroups are resident together by
+    construction.  (W separate launches on W streams of one process may land on one hardware queue and serialise -- then every wait runs
+    into its timeout: that form is only safe across processes / devices.)"""
+    r0 = ranks[0]
+    seq = max(r.seq for r in ranks) + 1
+    for r in ranks:
+        r.seq = seq
+    status = torch.zeros(len(ranks), device=r0.payload.device, dtype=torch.int32)
+    hip.call("grl_oneshot_allreduce_local", *r0._ptrs, r0.world, r0.n, ctypes.c_uint(seq), r0.timeout_ms, status)
+    return status
+
+
 def _areas(n, world, device):
     stage = torch.empty(hip.query("grl_oneshot_stage_floats", n, world), device=device, dtype=torch.float32)
     flags = torch.zeros(hip.query("grl_oneshot_flag_words", world), device=device, dtype=torch.int32)

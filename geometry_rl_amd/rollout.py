@@ -145,8 +145,16 @@ class RolloutDriver:
         if next_last is not None:
             self.compute_advantages(buf, next_last)
         out = None
-        for idx in self.minibatches(buf):
-            out = self.updater.step_from(buf, idx)
+        dev = next(iter(buf.data.values())).device
+        for _ in range(self.ppo_epochs):
+            idxs = self.epoch_minibatches(buf.N, buf.T, dev)
+            self.publish_advantage_stats(buf, idxs)
+            if idxs and all(i.numel() == idxs[0].numel() for i in idxs) and hasattr(self.updater, "run_minibatches"):
+                # the epoch's minibatches in one call: one rank with recorded lanes takes several steps per launch (PolicyUpdater.run_minibatches)
+                out = self.updater.run_minibatches(buf, torch.stack([i.reshape(-1) for i in idxs]))
+            else:
+                for idx in idxs:
+                    out = self.updater.step_from(buf, idx)
         return out
 
 

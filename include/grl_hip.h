@@ -413,6 +413,12 @@ int grl_oneshot_flag_words(int world);
 int grl_oneshot_blocks(void);
 int grl_oneshot_allreduce(float* const* bufs, float* const* stages, unsigned* const* flags, int rank, int world, int n, unsigned seq,
                           int timeout_ms, int* status, hipStream_t stream);
+/* the same protocol with all `world` stand-in ranks in ONE launch (rank = blockIdx.y; status: world ints): the single-process test */
+int grl_oneshot_allreduce_local(float* const* bufs, float* const* stages, unsigned* const* flags, int world, int n, unsigned seq,
+                                int timeout_ms, int* status, hipStream_t stream);
+/* A lane gate as a launch: the stream waits (one-thread kernel, capturable into a hipGraph) until flag[0] >= count[0] + add -- both read from
+ * DEVICE memory when the kernel runs -- or timeout_us microseconds have passed (a gate is a scheduling hint: the lane then simply goes on). */
+int grl_wait_flag_ge(const int* flag, const int* count, int add, int timeout_us, hipStream_t stream);
 /* 1 if the current device supports hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue), else 0 (host query, no stream). */
 int grl_can_stream_wait_value(void);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */

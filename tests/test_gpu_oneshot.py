@@ -21,10 +21,28 @@ def test_single_process_ranks_agree_bitwise_with_the_rank_ordered_sum(world):
     from geometry_rl_amd import oneshot
     n = 135440 + 28 * world + (-(135440 + 28 * world)) % 4      # the actor's gradient slice + the ranks' loss records (agent.PolicyUpdater)
     ranks = oneshot.local_ranks(world, n, DEV)
-    streams = [torch.cuda.Stream() for _ in range(world)]
     g = torch.Generator(device="cpu").manual_seed(world)
     for call in range(3):                                         # three calls back to back on the same areas: the sequence numbers do their job
         data = [torch.randn(n, generator=g).mul_(10.0 ** (r % 3 - 1)).to(DEV) for r in range(world)]
+        for r, d in zip(ranks, data):
+            r.payload.copy_(d)
+        status = oneshot.all_reduce_local(ranks)                  # all ranks' workgroups in one launch: resident together by construction
+        torch.cuda.synchronize()
+        assert status.tolist() == [0] * world, status.tolist()
+        want = _rank_ordered_sum(data)
+        for r in ranks:
+            assert torch.equal(r.payload, want), (world, call, r.rank, (r.payload - want).abs().max().item())
+
+
+def test_two_ranks_as_two_launches_on_two_streams():
+    """The form a real node runs -- one launch per rank, meeting on the device -- with two stand-in ranks on two streams of this process."""
+    from geometry_rl_amd import oneshot
+    n = 4096 * 33
+    ranks = oneshot.local_ranks(2, n, DEV)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for call in range(3):
+        data = [torch.randn(n, generator=g).to(DEV) for _ in range(2)]
         for r, d in zip(ranks, data):
             r.payload.copy_(d)
         torch.cuda.synchronize()
@@ -35,7 +53,7 @@ def test_single_process_ranks_agree_bitwise_with_the_rank_ordered_sum(world):
         want = _rank_ordered_sum(data)
         for r in ranks:
             r.check()
-            assert torch.equal(r.payload, want), (world, call, r.rank, (r.payload - want).abs().max().item())
+            assert torch.equal(r.payload, want), (call, r.rank)
 
 
 def test_a_missing_rank_times_out_instead_of_hanging():

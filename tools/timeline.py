@@ -8,6 +8,11 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"
 # a step starts at the minibatch gather (bench.py: one grl_gather_rows_many launch per step, outside the recorded graph); older traces
 # without it: at the launch behind an Adam launch (one Adam per step until round 3, two -- critic's lane, actor's lane -- since)
 starts = [i for i, e in enumerate(ev) if "gather_rows_many" in e[2]]
+if any("step_head_kernel" in e[2] for e in ev):
+    # round 6: with several steps per launch each lane gathers its own inputs (two gathers per step, the critic's mid-step): a step then starts
+    # at the actor lane's gather = the gather launch directly in front of the merged head launch
+    heads = [i for i, e in enumerate(ev) if "step_head_kernel" in e[2]]
+    starts = [max([g for g in starts if g < h], default=h) for h in heads]
 if len(starts) < 3:
     starts = [i + 1 for i, e in enumerate(ev) if "adam_dev" in e[2]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) * 2 // 3
