@@ -99,6 +99,10 @@ ORACLE_CASES = {
 }
 
 
+# the committed PMC summaries `roofline.traffic` may be copied from (tools/pmc_passes.sh + tools/pmc_report.py), by workload
+PMC_SUMMARY = {"rigid_hepi": "r06_pmc_summary_rigid_hepi.json", "rope_hepi_bf16": "r06_pmc_summary_rope_hepi_bf16.json"}
+
+
 def cpu_baseline_and_parity(wl_name, minibatch, dev, steps=3, max_threads=32):
     """(1) BASELINE.md section 3's parity gate: one update of a bounded-size minibatch of THIS workload through the HIP path and through
     the oracle (CPU restatement of the reference path) from identical parameters and inputs -- loc, var, state_value and every
@@ -493,7 +497,8 @@ def main():
     ms = 1e3 * dt / args.steps
     n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
     if chunked and getattr(upd, "_epoch", None) is not None:
-        upd.mode_timed = f"graph ({upd._epoch['key'][1]} minibatch steps per launch: 2 single-stream hipGraphs on two lanes, in-graph gathers and gate)"
+        upd.mode_timed = (f"graph ({upd._epoch['key'][1]} minibatch step(s) per launch: 2 single-stream hipGraphs on two lanes, in-graph gathers "
+                          f"{'by device cursor, lanes joined once per call' if upd._epoch['key'][2] else 'of fixed index rows'}, gate as a launch)")
     else:
         upd.mode_timed = upd.mode + ("" if upd.mode != "graph" else
                                      f" ({'one hipGraph' if n_graphs == 1 else str(n_graphs) + ' single-stream hipGraphs on two lanes' if (world == 1 and not args.dp_plan) else str(n_graphs) + ' hipGraph segments between the collectives'})")
@@ -603,14 +608,19 @@ def main():
         # summary of the separate `rocprofv3 --pmc` passes (tools/pmc_passes.sh -> profiles/r01_pmc_summary_*.json), same workload
         traffic, traffic_src = None, None
         try:
-            import glob
-            # the committed PMC summary of THIS workload (rigid_hepi: r0N_pmc_summary_vK.json, the others r0N_pmc_summary_<workload>.json)
-            pat = "r0*_pmc_summary_v*.json" if args.workload == "rigid_hepi" else f"r0*_pmc_summary_{args.workload}*.json"
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]
-            pk = json.load(open(f))["kernels"].get(name)
-            if pk:
-                traffic = pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"]
-                traffic_src = os.path.basename(f)
+            # ONE named file per workload (no glob, no "newest"), and only while it describes the library that is loaded: the summary records
+            # the source hash of the library the passes ran on (tools/pmc_report.py); a mismatch leaves `traffic` null
+            f = os.path.join(ROOT, "profiles", PMC_SUMMARY.get(args.workload, f"pmc_summary_{args.workload}.json"))
+            rec_ = json.load(open(f))
+            from geometry_rl_amd import hip as _hip
+            have = _hip.embedded_hash(_hip.LIB_PATH)
+            if rec_.get("source_hash") and rec_["source_hash"] == have:
+                pk = rec_["kernels"].get(name)
+                if pk:
+                    traffic = pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"]
+                    traffic_src = os.path.basename(f)
+            else:
+                traffic_src = f"{os.path.basename(f)} NOT used: it describes library {rec_.get('source_hash')}, the loaded one is {have}"
         except Exception:
             pass
         # whole-step figures from SURVEY.md section 8(d): algorithmic FLOPs (3 x forward) and bytes of a perfectly fused step

@@ -113,6 +113,8 @@ class PolicyUpdater:
         # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
         self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
         self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
+        self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "1") == "1"    # gated sizes: one step per launch, gathers by device cursor
+        self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64"))   # ... above this many frames
         self._epoch = None
         self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
         self._copies = []
@@ -424,7 +426,7 @@ class PolicyUpdater:
         # 0.35 ms is too short for it (profiles/r05_ab_critic_gate.txt, r05_ab_critic_gate_points.txt).  True (default) = that table.
         frames = next(int(v.shape[0]) for v in batch.values() if torch.is_tensor(v))
         mode = self.critic_after_first_conv
-        gate = bool(mode) and (isinstance(mode, str) or not (768 <= frames < 2048))
+        gate = self._gate_for(frames)
         gate_point = mode if isinstance(mode, str) else "edge0"   # "edge0" | "fwd_end" (experiment: bench.py --critic-gate)
 
         def copy4(dst, src):   # dst[0] = src[0] (int32) on the current stream: one tiny launch
@@ -814,7 +816,12 @@ class PolicyUpdater:
         c = list(dict.fromkeys(list(m.critic_in_features) + ["state_value", "value_target"]))
         return a, c
 
-    def _compile_epoch(self, buf, idx0, U):
+    EPOCH_ROWS = 512   # index rows the cursor form keeps on the device (minibatches per load)
+
+    def _compile_epoch(self, buf, idx0, U, cursor):
+        """Record ``U`` consecutive steps into one graph per lane.  ``cursor`` False: step j of a launch gathers the FIXED row j of a static
+        [U, B] index matrix (filled per launch); True (U = 1): the launch gathers the row the lane's own device-side step count points at in
+        a static [EPOCH_ROWS, B] matrix loaded once per call -- nothing but graph launches per step."""
         import ctypes
         m = self.loss_module
         B = int(idx0.numel())
@@ -822,7 +829,10 @@ class PolicyUpdater:
         sa, sc = buf.rows(idx0, ka), buf.rows(idx0, kc)      # static inputs, one private set per lane
         m.actor_network.hyper_data.check_topology(*[sa[k] for k in m.in_features])
         m.critic_network._network1.hyper_data.check_topology(*[sc[k] for k in m.critic_in_features])
-        idx_static = torch.empty(U, B, device=idx0.device, dtype=torch.int64)
+        rows = self.EPOCH_ROWS if cursor else U
+        idx_static = torch.zeros(rows, B, device=idx0.device, dtype=torch.int64)
+        base_a = torch.zeros(1, device=idx0.device, dtype=torch.int32)
+        base_c = torch.zeros(1, device=idx0.device, dtype=torch.int32)
 
         def gather_args(static, keys):
             n = len(keys)
@@ -832,37 +842,53 @@ class PolicyUpdater:
             return ((ctypes.c_void_p * n)(*[static[k].data_ptr() for k in keys]), (ctypes.c_void_p * n)(*[buf.flat(k).data_ptr() for k in keys]),
                     (ctypes.c_longlong * n)(*[buf.flat(k).shape[1] * buf.flat(k).element_size() for k in keys]), n)
         ga, gc = gather_args(sa, ka), gather_args(sc, kc)
+
+        def gather(args, j, count, base):
+            if cursor:
+                return lambda: hip.call("grl_gather_rows_many_cur", *args, idx_static, B, count, base, rows)
+            row = idx_static[j]
+            return lambda: hip.call("grl_gather_rows_many", *args, row, B)
         sts, mains, critics = [], [], []
         for j in range(U):
             st = {}
             self._plan_lanes(sa, st, cbatch=sc, gate_in_graph=True)
             main_all, critic_all = st.pop("lanes")
-            row = idx_static[j]
-            mains.append((lambda row=row: hip.call("grl_gather_rows_many", *ga, row, B), main_all))
-            critics.append((st, (lambda row=row: hip.call("grl_gather_rows_many", *gc, row, B)), critic_all))
+            mains.append((gather(ga, j, self.step_dev, base_a), main_all))
+            critics.append((st, gather(gc, j, self.step_dev_c, base_c), critic_all))
             sts.append(st)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         ga_graph, gc_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga_graph, stream=side, capture_error_mode="thread_local"):
-            for gather, main_all in mains:
-                gather()
+            for g_, main_all in mains:
+                g_()
                 main_all()
         with torch.cuda.graph(gc_graph, stream=side, capture_error_mode="thread_local"):
-            for st, gather, critic_all in critics:
-                st["critic_pre"] = gather          # (behind the lane's gate, in front of its features: critic_all runs it)
+            for st, g_, critic_all in critics:
+                st["critic_pre"] = g_              # (behind the lane's gate, in front of its features: critic_all runs it)
                 critic_all()
         torch.cuda.current_stream().wait_stream(side)
         for st in sts:
             self._finish(st)
-        self._epoch = dict(key=(B, U, id(buf)), idx=idx_static, sts=sts, keep=(sa, sc, ga, gc, buf),
-                           program=[("fork", None, "m", None), ("graph", ga_graph, "m", None), ("graph", gc_graph, "s", None),
-                                    ("join", None, "m", None)])
+        tail = [] if cursor else [("join", None, "m", None)]   # (cursor form: the lanes are joined once, when the call returns)
+        self._epoch = dict(key=(B, U, cursor, id(buf)), idx=idx_static, base=(base_a, base_c), sts=sts, keep=(sa, sc, ga, gc, buf),
+                           program=[("fork", None, "m", None), ("graph", ga_graph, "m", None), ("graph", gc_graph, "s", None)] + tail)
+
+    def _gate_for(self, frames: int) -> bool:
+        """Is the critic's lane gated behind the actor's first edge convolution at this minibatch size?  (see _plan_lanes)"""
+        mode = self.critic_after_first_conv
+        return bool(mode) and (isinstance(mode, str) or not (768 <= frames < 2048))
 
     def run_minibatches(self, buf, idx_rows: torch.Tensor, unroll: Optional[int] = None):
         """The updates of consecutive minibatches: ``idx_rows`` [M, B] int64 (device), row j = the rollout rows of minibatch j (what
-        ``rollout.RolloutDriver.epoch_minibatches`` hands out).  One rank with recorded lanes: ``unroll`` steps per launch (see above);
-        otherwise, and for the first (eager) step of a size and the remainder, a loop of ``step_from``.  Returns the loss dict of the last
+        ``rollout.RolloutDriver.epoch_minibatches`` hands out).  One rank with recorded lanes takes one of two recorded forms:
+          * ``unroll`` steps per launch where the critic's lane is not gated, or the launches are smaller than the chip (<= 64 frames):
+            no boundary at all between the steps of a launch (-3 % at 32 frames, -1.5 % at 1024);
+          * one step per launch with the gathers inside (index row picked by the lane's device-side step count) where the lane IS gated:
+            a gate waiting inside a multi-step launch is a resident wave during the previous step's one-wave-per-SIMD backward kernels,
+            which then find 255 free compute units for 256 workgroups (+10 % at 512 frames, +20 % at 4096: DESIGN.md, round 6) -- here
+            the lanes are forked per step so that the gate starts with the step, and joined once at the end.
+        Otherwise, and for the first (eager) step of a size and the remainder, a loop of ``step_from``.  Returns the loss dict of the last
         step; ``self.last_outs`` holds the dicts of the last launch's steps."""
         M, B = int(idx_rows.shape[0]), int(idx_rows.shape[1])
         U = int(unroll or self.epoch_unroll)
@@ -874,12 +900,34 @@ class PolicyUpdater:
         while j < M and B not in getattr(self, "_eager_sizes", ()):     # the first step of a size runs eagerly (topology, calibration, checks)
             out = self.step_from(buf, idx_rows[j])
             j += 1
+        cursor = self._gate_for(B) and B > self.epoch_unroll_max_gated_frames and self.epoch_cursor
+        if cursor:
+            U = 1
         if M - j >= U:
-            if self._epoch is None or self._epoch["key"] != (B, U, id(buf)):
+            if self._epoch is None or self._epoch["key"] != (B, U, cursor, id(buf)):
                 self.loss_module._global_steps = self.steps
-                self._compile_epoch(buf, idx_rows[j], U)
+                self._compile_epoch(buf, idx_rows[j], U, cursor)
             ep = self._epoch
-            while M - j >= U:
+            if cursor:
+                main = torch.cuda.current_stream()
+                while j < M:
+                    n = min(M - j, self.EPOCH_ROWS)
+                    main.wait_stream(self._critic_stream())          # every earlier step of BOTH lanes is behind us: the counts are final
+                    ep["idx"][:n].copy_(idx_rows[j:j + n])
+                    ep["base"][0].copy_(self.step_dev)
+                    ep["base"][1].copy_(self.step_dev_c)
+                    for _ in range(n):
+                        self.steps += 1
+                        try:
+                            self._execute(ep["program"])
+                        except BaseException:
+                            self.steps -= 1
+                            raise
+                    j += n
+                main.wait_stream(self._critic_stream())
+                self.last_outs = [ep["sts"][0]["out"]]
+                out = self.last_outs[-1]
+            while not cursor and M - j >= U:
                 ep["idx"].copy_(idx_rows[j:j + U])
                 self.steps += U
                 try:

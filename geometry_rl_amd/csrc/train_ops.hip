@@ -215,7 +215,15 @@ struct GatherJobs {
   const unsigned int* src[COPY_MAX];
   int words[COPY_MAX];   // 4-byte words per row
 };
-__global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherJobs jobs, const long long* __restrict__ idx, int n_rows) {
+// ``count`` (optional): the index row is picked on the DEVICE -- idx points at a matrix [n_idx_rows, n_rows] and this launch reads its row
+// (count[0] - base[0]) mod n_idx_rows: a recorded step gathers "the next minibatch of the epoch" without the host touching its arguments
+__global__ __launch_bounds__(256) void gather_rows_many_kernel(GatherJobs jobs, const long long* __restrict__ idx, int n_rows,
+                                                               const int* __restrict__ count, const int* __restrict__ base, int n_idx_rows) {
+  if (count) {
+    int r = (count[0] - base[0]) % n_idx_rows;
+    if (r < 0) r += n_idx_rows;
+    idx += (long long)r * n_rows;
+  }
   const int k = blockIdx.y;
   const int wpr = jobs.words[k];
   const long long total = (long long)n_rows * wpr;
@@ -469,9 +477,18 @@ int grl_copy_many(void* const* dst, const void* const* src, const long long* byt
 }
 
 // dst[k][i, :] = src[k][idx[i], :] for k < n <= 24 tensors with rows of row_bytes[k] bytes (multiples of 4); idx: DEVICE int64[n_rows]
+int grl_gather_rows_many_cur(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
+                             const int* count, const int* base, int n_idx_rows, hipStream_t stream);
 int grl_gather_rows_many(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
                          hipStream_t stream) {
+  return grl_gather_rows_many_cur(dst, src, row_bytes, n, idx, n_rows, nullptr, nullptr, 1, stream);
+}
+// the same with the index row chosen on the device: idx = a matrix [n_idx_rows, n_rows] (device int64), the launch gathers the rows of its
+// line (count[0] - base[0]) mod n_idx_rows (count, base: device int32[1]; count = NULL: idx is the row itself)
+int grl_gather_rows_many_cur(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
+                             const int* count, const int* base, int n_idx_rows, hipStream_t stream) {
   if (n <= 0 || n_rows <= 0) return 0;
+  if (count && (!base || n_idx_rows < 1)) return -2;
   if (n > COPY_MAX) return -2;
   GatherJobs jobs{};
   long long mx = 0;
@@ -485,7 +502,7 @@ int grl_gather_rows_many(void* const* dst, const void* const* src, const long lo
   long long bx = (mx + 1023) / 1024;
   if (bx < 1) bx = 1;
   if (bx > 512) bx = 512;
-  hipLaunchKernelGGL(gather_rows_many_kernel, dim3((int)bx, n), dim3(256), 0, stream, jobs, idx, n_rows);
+  hipLaunchKernelGGL(gather_rows_many_kernel, dim3((int)bx, n), dim3(256), 0, stream, jobs, idx, n_rows, count, base, n_idx_rows);
   GRL_CHECK_LAUNCH();
   return 0;
 }

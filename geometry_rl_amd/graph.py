@@ -123,6 +123,55 @@ class GraphBatch:
         return list(self.edges.keys())
 
 
+import os as _os
+BALANCE_NODE_ORDER = _os.environ.get("GRL_BALANCE_NODE_ORDER", "1") == "1"   # module attribute: tests / A/B tools flip it
+
+
+def balanced_node_order(src: torch.Tensor, n_nodes: int, slots: int, group: int = 8):
+    """A renumbering of ``n_nodes`` nodes with out-edges ``src`` (node id per edge) and node boundaries ``split`` [slots + 1] of the NEW order
+    such that slot s = nodes split[s] .. split[s+1] carries ~E / slots edges.  The natural order is cut into windows of ``group`` slots'
+    worth of edges (contiguous: a window is a few neighbouring frames, neighbours stay near each other in memory); inside a window the nodes
+    are dealt to its ``group`` slots largest out-degree first, each to the least loaded slot (ties: the lower slot) -- longest-processing-time
+    packing; nodes without out-edges go round-robin.  -> (new_of_old int64 [n_nodes], split int32 [slots + 1]), both on the CPU; a pure
+    function of its arguments."""
+    import heapq
+    deg = torch.bincount(src.reshape(-1).cpu(), minlength=n_nodes).tolist()
+    E = sum(deg)
+    n_groups = max(1, slots // group)
+    per_group = E / n_groups
+    new_of_old = [0] * n_nodes
+    split = [0]
+    nxt, node, cum = 0, 0, 0
+    for g in range(n_groups):
+        n_bins = group if g < n_groups - 1 else slots - group * (n_groups - 1)
+        first = node
+        if g == n_groups - 1:
+            node = n_nodes
+        else:
+            while node < n_nodes and cum + deg[node] <= (g + 1) * per_group + 1e-9:
+                cum += deg[node]
+                node += 1
+        members = list(range(first, node))
+        bins = [[] for _ in range(n_bins)]
+        heap = [(0, b) for b in range(n_bins)]
+        rr = 0
+        for n_ in sorted(members, key=lambda i: (-deg[i], i)):
+            if deg[n_] == 0:
+                bins[rr % n_bins].append(n_)
+                rr += 1
+                continue
+            load, b = heapq.heappop(heap)
+            bins[b].append(n_)
+            heapq.heappush(heap, (load + deg[n_], b))
+        for bin_ in bins:
+            for n_ in sorted(bin_):          # (natural order inside a slot: neighbouring rows stay neighbours)
+                new_of_old[n_] = nxt
+                nxt += 1
+            split.append(nxt)
+    assert nxt == n_nodes and len(split) == slots + 1
+    return torch.tensor(new_of_old, dtype=torch.int64), torch.tensor(split, dtype=torch.int32)
+
+
 class HyperData:
     """Mirror of RigidTasksData / ClothTasksData / RopeTasksData (constructor kwargs of rigid_tasks_data.py:53-67).
 
@@ -242,8 +291,25 @@ class HyperData:
             ok = nb >= 0
             src = (offset[b_of][:, None] + nb)[ok]
             dst = cid[:, None].expand_as(nb)[ok]
+        split_s_int = None
+        if need_edges and et_int[0] in self.node_type_list and self.drop_padding and BALANCE_NODE_ORDER and spec.family != "cloth" and src.numel():
+            # The compact numbering of the main node type is ours to choose (every consumer reads it through gather_main / the edge arrays):
+            # renumber the nodes -- inside windows of a few frames -- so that the wave slots of the fused edge backward, which walk CONTIGUOUS
+            # node ranges of the source-sorted CSR, carry equal numbers of edges.  kNN out-degrees vary 0 .. 10: cutting the natural order at
+            # node boundaries leaves the slowest wave 25 % over the mean at a 512-frame shard (30 passes for 24), and a one-wave-per-SIMD
+            # kernel runs as long as its slowest wave (balanced_node_order).  A function of the topology alone: results stay reproducible.
+            slots = 4 * hip.query("grl_edge_bwd_blocks", int(src.numel()))
+            new_of_old, split_s_int = balanced_node_order(src, n_main, slots)
+            new_of_old = new_of_old.to(dev)
+            src, dst, cid = new_of_old[src], new_of_old[dst], new_of_old[cid]
+            old_of_new = torch.empty_like(new_of_old)
+            old_of_new[new_of_old] = torch.arange(n_main, device=dev)
+            gather_main = gather_main[old_of_new]
+            split_s_int = split_s_int.to(dev)
+        else:
+            new_of_old = None
         if need_edges and et_int[0] in self.node_type_list:
-            edges[et_int] = ops.build_edge_set(torch.stack([src, dst]), n_main, n_main)
+            edges[et_int] = ops.build_edge_set(torch.stack([src, dst]), n_main, n_main, split_s=split_s_int)
         # agent edges: j != k among the actuators of a sample
         if not need_edges:
             pass
@@ -269,6 +335,8 @@ class HyperData:
             order = torch.argsort(d2, dim=-1, stable=True)[..., :kk]                    # ties: lower index first
             ok = torch.gather(d2, -1, order) < float("inf")                             # fewer than k valid points: the valid ones only (as PyG knn)
             src = (offset[:, None, None] + order)[ok]
+            if new_of_old is not None:
+                src = new_of_old[src]
             dst = (torch.arange(B, device=dev)[:, None, None] * G + torch.arange(G, device=dev)[None, :, None]).expand_as(order)[ok]
             edges[et_task] = ops.build_edge_set(torch.stack([src, dst]), n_main, B * G)
         elif need_edges and et_task[0] in self.node_type_list:
@@ -283,7 +351,7 @@ class HyperData:
             oh[:, spec.node_types.index(t)] = 1  # transforms.py:52-66
             one_hot[t] = oh
         topo = dict(n_per=n_per, main=main, gather_main=gather_main, n_main=n_main, edges={k: v for k, v in edges.items() if v is not None},
-                    one_hot=one_hot, G=G, n_valid=n_valid)
+                    one_hot=one_hot, G=G, n_valid=n_valid, permuted=new_of_old is not None)
         self._cache[key] = topo
         return topo
 
@@ -335,7 +403,7 @@ class HyperData:
             elif self.check_topology_always and not torch.cuda.is_current_stream_capturing():
                 self.check_topology(*[obs[k] for k in spec.in_features])
             main, gm = topo["main"], topo["gather_main"]
-            full = topo["n_main"] == B * topo["n_per"][main]
+            full = topo["n_main"] == B * topo["n_per"][main] and not topo.get("permuted", False)   # (identity numbering: no gather needed)
             n_types, n_vec = len(spec.node_types), spec.n_vec
             d = n_types + 3 * n_vec
             n_total = sum(topo["n_per"][t] for t in self.node_type_list)

@@ -32,7 +32,7 @@ class EdgeSet:
     split_d: Optional[torch.Tensor] = None  # the same for the destination-sorted CSR and the forward's wave slots ([n_slots + 1])
 
 
-def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
+def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int, split_s: Optional[torch.Tensor] = None) -> EdgeSet:
     """edge_index [2,E] (row 0 = source, row 1 = destination) -> CSR by destination.  Runs once per cached topology, never under stream
     capture: it synchronises with the host (sort keys, the balance check of the wave partitions)."""
     src, dst = edge_index[0].long(), edge_index[1].long()
@@ -75,12 +75,17 @@ def build_edge_set(edge_index: torch.Tensor, n_src: int, n_dst: int) -> EdgeSet:
         split[0], split[-1] = 0, n_anchor
         return split.int().contiguous()
 
-    split_s = split_d = None
+    given_s, split_s, split_d = split_s, None, None   # (``split_s`` given: the caller numbered the nodes for it -- graph.balanced_node_order)
     if E > 0 and dev.type == "cuda":   # (the launch shapes are the library's: asked for, not copied -- ADVICE r3; CPU tensors: no partitions)
         # backward (csrc/edge_conv16.hip grl_edge_bwd16_launch): 4 waves x grl_edge_bwd_blocks(E) workgroups, chunks of
         # grl_edge_bwd_chunk_nodes(n_src) nodes dealt round-robin (one wave per SIMD: a wave that finishes early leaves its SIMD idle --
         # every per cent of imbalance is a per cent of the launch)
-        split_s = balanced_split(rp_s, n_src, 4 * hip.query("grl_edge_bwd_blocks", E), hip.query("grl_edge_bwd_chunk_nodes", n_src), 1.04)
+        if given_s is not None:
+            if given_s.numel() != 4 * hip.query("grl_edge_bwd_blocks", E) + 1 or int(given_s[-1]) != n_src:
+                raise ValueError("build_edge_set: split_s must hold 4 * grl_edge_bwd_blocks(E) + 1 node boundaries ending at n_src")
+            split_s = given_s.int().contiguous()
+        else:
+            split_s = balanced_split(rp_s, n_src, 4 * hip.query("grl_edge_bwd_blocks", E), hip.query("grl_edge_bwd_chunk_nodes", n_src), 1.04)
         # forward (grl_edge16_launch): grl_edge_fwd_slots(n_dst) wave slots (0: the launch takes the one-workgroup-per-tile kernel of small
         # graphs, which ignores partitions), chunks of grl_edge_fwd_chunk_nodes(n_dst) nodes
         slots_d = hip.query("grl_edge_fwd_slots", n_dst)

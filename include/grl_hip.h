@@ -427,6 +427,11 @@ int grl_copy_many(void* const* dst, const void* const* src, const long long* byt
  * tensors in one launch; dst / src / row_bytes: HOST arrays; idx: DEVICE int64[n_rows]; row_bytes multiples of 4 */
 int grl_gather_rows_many(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
                          hipStream_t stream);
+/* (ABI 205) the same with the index row chosen ON THE DEVICE: idx = a matrix [n_idx_rows, n_rows] (device int64), the launch gathers line
+ * (count[0] - base[0]) mod n_idx_rows (device int32[1] each) -- a recorded step takes "the next minibatch of the epoch"
+ * (examples/torchrl/train.py:258-261) without the host touching its arguments.  count = NULL: idx is the row itself. */
+int grl_gather_rows_many_cur(void* const* dst, const void* const* src, const long long* row_bytes, int n, const long long* idx, int n_rows,
+                             const int* count, const int* base, int n_idx_rows, hipStream_t stream);
 /* ---- collector-side observation transform: NDVecNorm / VecNorm running normalisation + ClipTransform,
  * geometry_rl/torchrl/envs/transforms.py:141-163 (on torchrl's VecNorm), configs/rigid_insertion_multi_hepi_trpl_cfg.yaml:47-72.
  * x [rows, K<=64]; state: device float[2K+1] = [sum | ssq | count], updated in place when update != 0;

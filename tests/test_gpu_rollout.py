@@ -57,7 +57,8 @@ def test_driver_matches_explicit_loop(use_graph):
     assert err <= 1e-7
 
 
-def test_several_steps_per_launch_equal_the_step_by_step_loop():
+@pytest.mark.parametrize("form", ["unrolled", "cursor"])
+def test_several_steps_per_launch_equal_the_step_by_step_loop(form):
     """PolicyUpdater.run_minibatches (round 6): ``unroll`` minibatch steps recorded into ONE graph per lane -- in-graph gathers from a static
     index matrix, private inputs per lane, the critic's gate as a launch of its lane, no join between the steps of a launch.  Ten minibatches
     per epoch with unroll = 4: an eager first step, two 4-step launches, one single step -- the parameters, both Adam moments and every
@@ -66,10 +67,13 @@ def test_several_steps_per_launch_equal_the_step_by_step_loop():
     from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
     N, T = 8, 10
     res = {}
+    want_form = form
     for form in ("loop", "launches"):
         spec, cfg, loss, data, next_last = _make(N, T, seed=33)
         upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True)
         upd.epoch_unroll = 4 if form == "launches" else 1
+        if want_form == "cursor":   # the form of the gated sizes (one step per launch, index row by device cursor), forced at this toy size
+            upd.epoch_unroll_max_gated_frames = 0
         buf = RolloutBuffer(dict(data))
         drv = RolloutDriver(upd, spec, ppo_epochs=2, seed=9)
         drv.compute_advantages(buf, next_last)
@@ -83,8 +87,9 @@ def test_several_steps_per_launch_equal_the_step_by_step_loop():
             for _ in range(2):
                 idxs = drv.epoch_minibatches(buf.N, buf.T, dev)
                 out = upd.run_minibatches(buf, torch.stack(idxs))
-                assert upd._epoch is not None and len(upd.last_outs) == 4
-            kls = [o["kl"].clone() for o in upd.last_outs] + [out["kl"].clone()]
+                assert upd._epoch is not None and upd._epoch["key"][2] == (want_form == "cursor")
+                assert len(upd.last_outs) == (1 if want_form == "cursor" else 4)
+            kls = ([o["kl"].clone() for o in upd.last_outs] if want_form == "unrolled" else []) + [out["kl"].clone()]
         torch.cuda.synchronize()
         assert upd.steps == 2 * T and int(upd.step_dev.item()) == 2 * T and int(upd.step_dev_c.item()) == 2 * T
         res[form] = (upd.flat.detach().clone(), upd.exp_avg.detach().clone(), upd.exp_avg_sq.detach().clone(), kls)
@@ -92,7 +97,7 @@ def test_several_steps_per_launch_equal_the_step_by_step_loop():
         assert torch.equal(a, b), (a - b).abs().max().item()
     # epoch 2 of the launch form: steps 11-14, 15-18 by launches (last_outs = steps 15-18), 19-20 singly (out = step 20)
     loop_kls = res["loop"][3]
-    for got, want in zip(res["launches"][3], loop_kls[14:18] + [loop_kls[19]]):
+    for got, want in zip(res["launches"][3], (loop_kls[14:18] if want_form == "unrolled" else []) + [loop_kls[19]]):
         assert torch.equal(got, want)
 
 

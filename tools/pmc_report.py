@@ -68,4 +68,13 @@ if len(sys.argv) > 2:
                        vmem_active=round(e_.get("SQ_ACTIVE_INST_VMEM", 0) / wce, 4), scalar_active=round(e_.get("SQ_ACTIVE_INST_SCA", 0) / wce, 4))
         if e is None or rec["launches"] > e["launches"]:   # template instances of one kernel: keep the one launched most
             out["kernels"][name] = rec
+    # the sources the profiled library was built from (geometry_rl_amd/hip.py source_hash): bench.py copies `traffic` from this file only
+    # while the loaded library carries the same hash
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from geometry_rl_amd import hip as _hip
+        out["source_hash"] = _hip.embedded_hash(_hip.LIB_PATH)
+    except Exception as e_:
+        out["source_hash"] = None
     json.dump(out, open(sys.argv[2], "w"), indent=1)
