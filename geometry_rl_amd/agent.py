@@ -113,6 +113,7 @@ class PolicyUpdater:
         # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
         self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
         self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
+        self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "16")) << 20   # 0: every slab waits for the tail (round 5)
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "1") == "1"    # gated sizes: one step per launch, gathers by device cursor
         self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64"))   # ... above this many frames
         self._epoch = None
@@ -452,10 +453,13 @@ class PolicyUpdater:
                 ops.AFTER_EDGE_HOOK = signal
             if gate and gate_point == "fwd_end":
                 st["after_forward"] = lambda: copy4(self.lane_flag, self.step_dev)
+            if fuse_tail and self.early_fold_bytes > 0:   # large single-owner slabs are folded (+ Adam) right behind their producers (ops._emit_grads)
+                ops.EARLY_FOLD = dict(adam=self._tail_args(0, na, self.step_dev), overwrite=ow, min_bytes=self.early_fold_bytes, seen=set(), fed=set())
             try:
                 fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
             finally:
                 ops.AFTER_EDGE_HOOK = None
+                ops.EARLY_FOLD = None
                 unsent, ops.PENDING_SIGNAL = ops.PENDING_SIGNAL, None
             if unsent is not None:   # (no fiber convolution followed the edge convolution: send the signal by itself)
                 copy4(*unsent)

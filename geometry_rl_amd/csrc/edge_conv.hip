@@ -405,348 +405,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void edge_conv_fwd_kernel
   pc.flush(0);
 }
 
-// GRL_LEGACY32 (build switch, default 0): the 32-row kernels that the 16-row kernels of edge_conv16.hip superseded in round 2 -- the flat
-// message kernel, the d x_src kernel and the weight-gradient kernel below, and the non-split instance of the forward above.  They are
-// the A/B baselines of DESIGN.md findings 19 / 20 (-DGRL_LEGACY32=1 -DGRL_EDGE16=0 -DGRL_EDGE_BWD16=0) and are NOT compiled into the
-// shipped library: nothing unreachable, nothing the parity / determinism suite does not cover.
+// (The 32-row message / d x_src / weight-gradient kernels of round 1, superseded by edge_conv16.hip in round 2 and compiled out since, were
+// removed in round 6; the A/B figures they served are DESIGN.md findings 19 / 20.)
 constexpr int EDGE_PARTIAL = 64 * 14 + 64 + 64 * 64 + 64 + 64 * 64;   // partial row: [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64]
-#ifndef GRL_LEGACY32
-#define GRL_LEGACY32 0
-#endif
-#if GRL_LEGACY32
-// ------------------------------------------------------------------------------------------------ messages (attention aggregation)
-// FiberBundleConv(aggr="AttentionalAggregation") (conv.py:21-26,58-61,138-139; configs/algorithm/pyg_agent/model/hepi_attention.yaml)
-// gates every message before it is summed, so the messages m_e = K_e * x_src[src(e)] have to exist per edge: this kernel is the forward
-// chain with a store in place of the per-destination sum -- flat passes of two edges in destination-sorted order, row e of
-// msg [E,16,64] = edge e of that order.  The gate, the per-destination softmax and the weighted sum follow in grl_softmax_aggregate_*.
-__global__ __launch_bounds__(256, 2) void edge_msg_fwd_kernel(EdgeParams p, st_t* __restrict__ msg /*[E,16,64]*/, int n_edges) {
-  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
-  load_chain_weights(s, p);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int o = r & 15, el = r >> 4;
-  float sink = 0.f;
-  PhaseClock pc;
-  pc.start();
-  const int n_pass = (n_edges + 1) >> 1;
-  const int stride = gridDim.x * 4;
-  int ps = blockIdx.x * 4 + wave;
-  PassMeta cur;
-  if (ps < n_pass) {
-    meta_indices(p, 2 * ps + el, n_edges, cur);
-    meta_invariants(p, s.grid_s, o, cur);
-  }
-#pragma unroll 1
-  for (; ps < n_pass; ps += stride) {
-    PassMeta nxt;
-    const bool more = ps + stride < n_pass;
-    meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
-    const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
-    float4 xv[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) xv[t] = ld4(xs + 8 * t);
-    float4 g1[8], gp1[8], g2[8], gp2[8];
-    ChainFrags cf;
-    st_t* mrow = msg + ((size_t)(2 * ps + el) * O + o) * C + 4 * h;
-    const bool ok = cur.valid;
-    edge_chain<false, GRL_FENCED_2W>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = 4 * nt + q;
-        const float4 m = f4_mul(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), xv[t]);
-        if (ok) st4(mrow + 8 * t, m);
-      }
-    }, &sink, pc, [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });
-    if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);
-    else if (more) meta_invariants(p, s.grid_s, o, nxt);
-    cur = nxt;
-  }
-  if (sink == 123456.789f) st1(msg, sink);   // never true
-}
-
-// ------------------------------------------------------------------------------------------------ backward
-// Two launches, each recomputing the cheap split-bf16 chain, so that the register file holds one launch's accumulators without
-// spilling (everything in one kernel: 224 accumulator registers + the chain state, 170-220 spilled VGPRs, 30 % slower):
-//   x kernel (edges in SOURCE-sorted order, a wave owns TD = 2 consecutive source nodes, exactly like the forward owns
-//             destination nodes; two waves per SIMD, fenced MFMA groups): dM = d x1[dst]; d x_src[src] += dM * K accumulated in
-//             registers and stored once per node (no per-edge scratch, no second pass, no atomics)
-//   w kernel (destination-sorted order, flat passes of 2 edges x 16 orientations = 32 rows per wave; one wave per SIMD):
-//             dK = dM * x_src; dWk += dK^T g2; dZ2 = (dK Wk) * gelu'(z2); dW2 += dZ2^T g1; db2;
-//             dZ1 = (dZ2 W2) * gelu'(z1); dW1 += dZ1^T phi; db1
-// Weight-gradient accumulators live in registers for the whole launch and leave as one partial row per wave:
-//   partial[block][9216] = [W1 64x14 | b1 64 | W2 64x64 | b2 64 | Wk 64x64]   (the four waves folded through LDS at the end).
-
-
-// p is the SOURCE-anchored view of the edge set (rowptr = rowptr_s, e_src / e_dst in source-sorted order, n_anchor = n_src).
-__global__ __launch_bounds__(256, 2) void edge_conv_bwd_x_kernel(EdgeParams p, const st_t* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                 st_t* __restrict__ dx_src /*[Ns,16,64]*/,
-                                                                 const st_t* __restrict__ dres /*[Ns,16,64] or null*/) {
-  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
-  load_chain_weights(s, p);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int o = r & 15, el = r >> 4;
-  float sink = 0.f;
-  PhaseClock pc;
-  pc.start();
-
-  const int n_tiles = (p.n_anchor + TD - 1) / TD;
-#pragma unroll 1
-  for (int tl = blockIdx.x * 4 + wave; tl < n_tiles; tl += gridDim.x * 4) {
-    const int s0 = tl * TD, s1 = min(s0 + TD, p.n_anchor);
-    const int e0 = p.rowptr[s0], e1 = p.rowptr[s1];
-    float4 accA[8], accB[8];               // d x_src rows of the tile's two source nodes
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { accA[t] = make_float4(0.f, 0.f, 0.f, 0.f); accB[t] = accA[t]; }
-    if (e1 > e0) {
-      PassMeta cur;
-      meta_indices(p, e0 + el, e1, cur);
-      meta_invariants(p, s.grid_s, o, cur);
-#pragma unroll 1
-      for (int e = e0; e < e1; e += 2) {
-        PassMeta nxt;
-        const bool more = e + 2 < e1;
-        meta_indices(p, e + 2 + el, e1, nxt);
-        const st_t* dm = dx1 + ((size_t)cur.grow * O + o) * C + 4 * h;
-        float4 dv[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) dv[t] = ld4(dm + 8 * t);   // in flight behind the chain
-        float4 g1[8], gp1[8], g2[8], gp2[8];
-        ChainFrags cf;
-        const float wa = (cur.valid && cur.src == s0) ? 1.f : 0.f;
-        const float wb = (cur.valid && cur.src != s0) ? 1.f : 0.f;
-        // d x_src row = dM * K, summed into the accumulator of the edge's source node as each K tile leaves the matrix pipe
-        // (two waves share a SIMD: fenced MFMA groups, exactly like the forward kernel)
-        edge_chain<false, GRL_FENCED_2W>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, [&](int nt, const f32x16& acc) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int t = 4 * nt + q;
-            const float4 m = f4_mul(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), dv[t]);
-            accA[t] = make_float4(fmaf(m.x, wa, accA[t].x), fmaf(m.y, wa, accA[t].y), fmaf(m.z, wa, accA[t].z), fmaf(m.w, wa, accA[t].w));
-            accB[t] = make_float4(fmaf(m.x, wb, accB[t].x), fmaf(m.y, wb, accB[t].y), fmaf(m.z, wb, accB[t].z), fmaf(m.w, wb, accB[t].w));
-          }
-        }, &sink, pc, [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });
-        if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);
-        else if (more) meta_invariants(p, s.grid_s, o, nxt);
-        cur = nxt;
-        PHS(8);
-      }
-    }
-    // fold the two edge slots; slot 0 lanes store node A's rows, slot 1 lanes node B's (see the forward kernel)
-    const int node = s0 + el;
-    st_t* dstp = dx_src + ((size_t)node * O + o) * C + 4 * h;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float4 a = accA[t], b = accB[t];
-      a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
-      b.x += __shfl_xor(b.x, 16, 64); b.y += __shfl_xor(b.y, 16, 64); b.z += __shfl_xor(b.z, 16, 64); b.w += __shfl_xor(b.w, 16, 64);
-      const bool is_a = el == 0;
-      float4 v = make_float4(is_a ? a.x : b.x, is_a ? a.y : b.y, is_a ? a.z : b.z, is_a ? a.w : b.w);
-      if (node < s1) {
-        if (dres) v = f4_add(v, ld4(dres + ((size_t)node * O + o) * C + 4 * h + 8 * t));  // + residual branch
-        st4(dstp + 8 * t, v);
-      }
-    }
-  }
-  if (sink == 123456.789f) st1(dx_src, sink);   // never true
-  pc.flush(1);
-}
-
-__global__ __launch_bounds__(256, 1) void edge_conv_bwd_w_kernel(EdgeParams p, const st_t* __restrict__ dx1 /*[Nd,16,64]*/,
-                                                                  float* __restrict__ partial, int n_edges) {
-  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  ChainW& s = *reinterpret_cast<ChainW*>(smem_raw);
-  BwdW& sb = *reinterpret_cast<BwdW*>(smem_raw + sizeof(ChainW) / 4);
-  load_chain_weights(s, p);
-  stage_split_T<256>(sb.W2Th, sb.W2Tl, p.W2, LDB);
-  stage_split_T<256>(sb.WkTh, sb.WkTl, p.Wk, LDB);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int o = r & 15, el = r >> 4;
-  bf16x8 sel0, sel1;
-  make_selectors(sel0, sel1);
-
-  PhaseClock pc;
-  pc.start();
-  f32x16 accA[2][2], accB[2], accK[2][2];  // accA = dW2, accB = dW1, accK = dWk
-#pragma unroll
-  for (int a_ = 0; a_ < 2; ++a_) {
-    accB[a_] = zero16();
-#pragma unroll
-    for (int b_ = 0; b_ < 2; ++b_) { accA[a_][b_] = zero16(); accK[a_][b_] = zero16(); }
-  }
-  float db1[2] = {0.f, 0.f}, db2[2] = {0.f, 0.f};  // column 32*nt + r, summed over this lane half's rows
-
-  const int n_pass = (n_edges + 1) >> 1;
-  const int stride = gridDim.x * 4;
-  int ps = blockIdx.x * 4 + wave;
-  PassMeta cur;
-  if (ps < n_pass) {
-    meta_indices(p, 2 * ps + el, n_edges, cur);
-    meta_invariants(p, s.grid_s, o, cur);
-  }
-#pragma unroll 1
-  for (; ps < n_pass; ps += stride) {
-    PassMeta nxt;
-    const bool more = ps + stride < n_pass;
-    meta_indices(p, 2 * (ps + stride) + el, n_edges, nxt);
-    const st_t* xs = p.x_src + ((size_t)cur.src * O + o) * C + 4 * h;
-    const st_t* dm = dx1 + ((size_t)cur.grow * O + o) * C + 4 * h;
-    float4 xv[8], dv[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { xv[t] = ld4(xs + 8 * t); dv[t] = ld4(dm + 8 * t); }   // in flight behind the chain
-    PHS(1);
-    float4 g1[8], gp1[8], g2[8], gp2[8];
-    ChainFrags cf;
-    edge_chain<true, false>(s, cur.a, cur.b, g1, gp1, g2, gp2, cf, NoK{}, nullptr, pc,
-                            [&]() { if (GRL_POS_EARLY) meta_pos_load(p, nxt); });
-    if (GRL_POS_EARLY) meta_invariants_compute(p, s.grid_s, o, nxt);
-    else if (more) meta_invariants(p, s.grid_s, o, nxt);
-    PHS(8);
-
-    float4 dK[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (!cur.valid) dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      dK[t] = f4_mul(dv[t], xv[t]);
-    }
-    {
-      // ---- dZ2 = (dK Wk) * gelu'(z2)      (split-bf16: rows of Wk^T)
-      float4 dz2[8];
-      {
-        bf16x8 dh_[4], dl_[4];
-        split_frags<64>(dK, dh_, dl_);
-        // ---- dWk[c][k] += sum_r dK[r][c] g2[r][k]   (g2 fragments straight from the chain; consumed first so they die early)
-        {
-          const TTile tg0 = transpose_split(cf.g2h[0], cf.g2h[1], cf.g2l[0], cf.g2l[1], sel0, sel1);
-          const TTile tg1 = transpose_split(cf.g2h[2], cf.g2h[3], cf.g2l[2], cf.g2l[3], sel0, sel1);
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const TTile tk = transpose_split(dh_[2 * ct], dh_[2 * ct + 1], dl_[2 * ct], dl_[2 * ct + 1], sel0, sel1);
-            mma_tn_bf_acc(tk, tg0, accK[ct][0]);
-            mma_tn_bf_acc(tk, tg1, accK[ct][1]);
-          }
-        }
-        GRL_SCHED_BARRIER();
-        PHS(10);  // dK, its split, dWk: 4 transposed tiles (g2 x2, dK x2) + 4 x 6 MFMAs
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          f32x16 acc = zero16();
-          mma_wx_bf<64>(sb.WkTh + (32 * kt + r) * LDB + 8 * h, sb.WkTl + (32 * kt + r) * LDB + 8 * h, dh_, dl_, acc);
-          float4 f0, f1, f2, f3;
-          acc_to_frag(acc, f0, f1, f2, f3);
-          dz2[4 * kt] = f4_mul(f0, gp2[4 * kt]);
-          dz2[4 * kt + 1] = f4_mul(f1, gp2[4 * kt + 1]);
-          dz2[4 * kt + 2] = f4_mul(f2, gp2[4 * kt + 2]);
-          dz2[4 * kt + 3] = f4_mul(f3, gp2[4 * kt + 3]);
-        }
-      }
-      GRL_SCHED_BARRIER();
-      PHS(11);  // dZ2 = (dK Wk) * gelu'(z2): 24 MFMAs from LDS fragments
-      bf16x8 zh[4], zl[4];
-      split_frags<64>(dz2, zh, zl);
-      // ---- dW2 += dZ2^T g1, db2 += column sums of dZ2      (register-level transposes, split-bf16 products)
-      {
-        const TTile tg0 = transpose_split(cf.g1h[0], cf.g1h[1], cf.g1l[0], cf.g1l[1], sel0, sel1);
-        const TTile tg1 = transpose_split(cf.g1h[2], cf.g1h[3], cf.g1l[2], cf.g1l[3], sel0, sel1);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const TTile tz = transpose_split(zh[2 * nt], zh[2 * nt + 1], zl[2 * nt], zl[2 * nt + 1], sel0, sel1, &db2[nt]);
-          mma_tn_bf_acc(tz, tg0, accA[nt][0]);
-          mma_tn_bf_acc(tz, tg1, accA[nt][1]);
-        }
-      }
-      GRL_SCHED_BARRIER();
-      PHS(12);  // split dZ2, dW2: 4 transposed tiles + 24 MFMAs
-      // ---- dZ1 = (dZ2 W2) * gelu'(z1)     (split-bf16: rows of W2^T)
-      float4 dz1[8];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x16 acc = zero16();
-        mma_wx_bf<64>(sb.W2Th + (32 * kt + r) * LDB + 8 * h, sb.W2Tl + (32 * kt + r) * LDB + 8 * h, zh, zl, acc);
-        float4 f0, f1, f2, f3;
-        acc_to_frag(acc, f0, f1, f2, f3);
-        dz1[4 * kt] = f4_mul(f0, gp1[4 * kt]);
-        dz1[4 * kt + 1] = f4_mul(f1, gp1[4 * kt + 1]);
-        dz1[4 * kt + 2] = f4_mul(f2, gp1[4 * kt + 2]);
-        dz1[4 * kt + 3] = f4_mul(f3, gp1[4 * kt + 3]);
-      }
-      GRL_SCHED_BARRIER();
-      PHS(13);  // dZ1: 24 MFMAs
-      // ---- dW1 += dZ1^T phi, db1 += column sums of dZ1      (phi: one 16-column fragment, columns 16..31 of its tile are zero)
-      {
-        bf16x8 yh[4], yl[4];
-        split_frags<64>(dz1, yh, yl);
-        u32x4 z4 = {0u, 0u, 0u, 0u};
-        const bf16x8 zero8 = __builtin_bit_cast(bf16x8, z4);
-        const TTile tp = transpose_split(cf.ph[0], zero8, cf.pl[0], zero8, sel0, sel1);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const TTile ty = transpose_split(yh[2 * nt], yh[2 * nt + 1], yl[2 * nt], yl[2 * nt + 1], sel0, sel1, &db1[nt]);
-          mma_tn_bf_acc(ty, tp, accB[nt]);
-        }
-      }
-      GRL_SCHED_BARRIER();
-      PHS(14);  // split dZ1, dW1: 3 transposed tiles + 12 MFMAs
-    }
-    cur = nxt;
-  }
-  pc.flush(2);
-
-  // ---- fold the four waves' accumulators through LDS (the weight images are dead): pairs (1 -> 0, 3 -> 2), then 2 -> 0; every
-  //      lane reads back exactly the slots its partner lane wrote ([register][lane]: conflict-free, no address arithmetic), so
-  //      the order is fixed and ONE partial row per workgroup leaves (a quarter of the slab the folding launch has to read)
-  constexpr int NACC = 10 * 16 + 4;
-  float* fold = smem_raw;
-  asm_acc_drain();   // the last in-place (asm) MFMAs of the weight-gradient accumulators have finished before they are read
-  auto visit = [&](auto&& f) {
-    int k = 0;
-#pragma unroll
-    for (int a_ = 0; a_ < 2; ++a_) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) accB[a_][i] = f(accB[a_][i], k++);
-#pragma unroll
-      for (int b_ = 0; b_ < 2; ++b_)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { accA[a_][b_][i] = f(accA[a_][b_][i], k++); accK[a_][b_][i] = f(accK[a_][b_][i], k++); }
-      db1[a_] = f(db1[a_], k++);
-      db2[a_] = f(db2[a_], k++);
-    }
-  };
-  __syncthreads();
-  if (wave & 1) visit([&](float v_, int k) { fold[((wave >> 1) * NACC + k) * 64 + lane] = v_; return v_; });
-  __syncthreads();
-  if (!(wave & 1)) visit([&](float v_, int k) { return v_ + fold[((wave >> 1) * NACC + k) * 64 + lane]; });
-  __syncthreads();
-  if (wave == 2) visit([&](float v_, int k) { fold[k * 64 + lane] = v_; return v_; });
-  __syncthreads();
-  if (wave != 0) return;
-  visit([&](float v_, int k) { return v_ + fold[k * 64 + lane]; });
-  // ---- write the workgroup's partial.  acc element rho of lane (j = r, h): D[n = 8q+4h+u][col j]
-  float* out = partial + (size_t)blockIdx.x * EDGE_PARTIAL;
-  float* oW1 = out, *ob1 = out + 64 * 14, *oW2 = ob1 + 64, *ob2 = oW2 + 64 * 64, *oWk = ob2 + 64;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int rho = 0; rho < 16; ++rho) {
-      const int n = 32 * nt + (rho & 3) + 8 * (rho >> 2) + 4 * h;
-      if (r < 14) oW1[n * 14 + r] = accB[nt][rho];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        oW2[n * 64 + 32 * kt + r] = accA[nt][kt][rho];
-        oWk[n * 64 + 32 * kt + r] = accK[nt][kt][rho];
-      }
-    }
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {   // the other 16 rows of every column were summed by lane ^ 32
-    const float v1 = db1[nt] + __shfl_xor(db1[nt], 32, 64), v2 = db2[nt] + __shfl_xor(db2[nt], 32, 64);
-    if (h == 0) { ob1[32 * nt + r] = v1; ob2[32 * nt + r] = v2; }
-  }
-}
-#endif   // GRL_LEGACY32
 
 }  // namespace
 
@@ -777,9 +438,6 @@ int grl_edge_bwd_blocks(int n_edges);
 #endif
 
 // 16-row-tile kernels (edge_conv16.hip): forward, d x_src and messages; the weight-gradient kernel and the few-tile SPLIT forward stay here
-#ifndef GRL_EDGE16
-#define GRL_EDGE16 1
-#endif
 int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                  const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -787,9 +445,6 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
                                  hipStream_t stream);
 
 // fused 16-row backward (edge_conv16.hip edge_bwd16_kernel): d x_src and the weight gradients in one launch, one chain recompute
-#ifndef GRL_EDGE_BWD16
-#define GRL_EDGE_BWD16 1
-#endif
 int GRL_ENTRY(grl_edge_bwd16_launch)(const st_t* x_src, const st_t* dmsg, const float* pos_src, const float* pos_dst, const int* rowptr_s,
                                      const int* src_s, const int* dst_s, const int* erow, int per_edge, int n_src, int n_edges,
                                      const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -827,16 +482,6 @@ int GRL_ENTRY(grl_edge_conv_fwd_balanced)(const st_t* x_src, const float* pos_sr
     GRL_CHECK_LAUNCH();
     return 0;
   }
-#if GRL_LEGACY32
-  if (!GRL_EDGE16) {
-    GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    int blocks = (n_tiles + FWD_WAVES - 1) / FWD_WAVES;
-    if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
-    hipLaunchKernelGGL(edge_conv_fwd_kernel<false>, dim3(blocks), dim3(64 * FWD_WAVES), smem, stream, p, x1);
-    GRL_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
   (void)smem;
   grl_prof_begin_replay("edge_conv_fwd_kernel", stream);
   const int rc16 = GRL_ENTRY(grl_edge16_launch)(0, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, 0, 1, grid, dim, W1, b1, W2,
@@ -880,33 +525,6 @@ int GRL_ENTRY(grl_edge_conv_bwd_balanced)(const st_t* x_src, const float* pos_sr
     return 0;
   }
   const int blocks = grl_edge_bwd_blocks(n_edges);
-#if GRL_LEGACY32
-  if (!GRL_EDGE_BWD16) {
-    EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-    EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
-    const size_t smem_x = sizeof(ChainW);
-    size_t smem_w = smem_x + sizeof(BwdW);
-    if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;   // the end-of-launch fold
-    GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
-    grl_prof_begin("edge_conv_bwd_x_kernel", stream);
-    if (GRL_EDGE16) {
-      GRL_ENTRY(grl_edge16_launch)(1, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2,
-                                   Wk, dx_src, dres, nullptr, 0, nullptr, stream);
-    } else {
-      const int n_tiles_s = (n_src + TD - 1) / TD;
-      int xblocks = (n_tiles_s + 3) / 4;
-      if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;   // two 4-wave workgroups per CU, like the forward
-      hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dx1, dx_src, dres);
-    }
-    grl_prof_end(stream);
-    GRL_CHECK_LAUNCH();
-    grl_prof_begin("edge_conv_bwd_w_kernel", stream);
-    hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dx1, partial, n_edges);
-    grl_prof_end(stream);
-    GRL_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
   (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;   // the destination-sorted view is the legacy weight kernel's
   grl_prof_begin("edge_bwd16_kernel", stream);
   const int rc = GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dx1, pos_src, pos_dst, rowptr_s, src_s, dst_s, nullptr, 0, n_src, n_edges, grid, dim,
@@ -922,18 +540,6 @@ int GRL_ENTRY(grl_edge_messages_fwd)(const st_t* x_src, const float* pos_src, co
                                      const float* b1, const float* W2, const float* b2, const float* Wk, st_t* msg,
                                      hipStream_t stream) {
   if (n_edges <= 0) return 0;
-#if GRL_LEGACY32
-  if (!GRL_EDGE16) {
-    EdgeParams p{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-    const size_t smem = sizeof(ChainW);
-    GRL_ONCE(hipFuncSetAttribute((const void*)edge_msg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW)));
-    int blocks = ((n_edges + 1) / 2 + 3) / 4;
-    if (blocks > GRL_FWD_MAX_BLOCKS) blocks = GRL_FWD_MAX_BLOCKS;
-    hipLaunchKernelGGL(edge_msg_fwd_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), smem, stream, p, msg, n_edges);
-    GRL_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
   return GRL_ENTRY(grl_edge16_launch)(2, x_src, pos_src, pos_dst, rowptr, e_src, e_dst, nullptr, 0, n_dst, n_edges, 1, grid, dim, W1, b1,
                                       W2, b2, Wk, msg, nullptr, nullptr, 0, nullptr, stream);
 }
@@ -952,31 +558,6 @@ int GRL_ENTRY(grl_edge_messages_bwd)(const st_t* x_src, const float* pos_src, co
     return 0;
   }
   const int blocks = grl_edge_bwd_blocks(n_edges);
-#if GRL_LEGACY32
-  if (!GRL_EDGE_BWD16) {
-    EdgeParams pd{x_src, pos_src, pos_dst, rowptr, e_src, e_dst, grid, W1, b1, W2, b2, Wk, n_dst, dim};
-    EdgeParams ps{x_src, pos_src, pos_dst, rowptr_s, src_s, dst_s, grid, W1, b1, W2, b2, Wk, n_src, dim};
-    pd.per_edge = 1;            // the weight kernel walks the destination-sorted order: row = edge position
-    ps.per_edge = 1;
-    ps.erow = s2d;              // the d x_src kernel walks the source-sorted order
-    const size_t smem_x = sizeof(ChainW);
-    size_t smem_w = smem_x + sizeof(BwdW);
-    if (smem_w < sizeof(float) * 2 * (10 * 16 + 4) * 64) smem_w = sizeof(float) * 2 * (10 * 16 + 4) * 64;
-    GRL_ONCE(hipFuncSetAttribute((const void*)edge_conv_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x); hipFuncSetAttribute((const void*)edge_conv_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_w));
-    const int n_tiles_s = (n_src + TD - 1) / TD;
-    int xblocks = (n_tiles_s + 3) / 4;
-    if (xblocks > GRL_FWD_MAX_BLOCKS) xblocks = GRL_FWD_MAX_BLOCKS;
-    if (GRL_EDGE16)
-      GRL_ENTRY(grl_edge16_launch)(1, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, 0, grid, dim, W1, b1, W2, b2, Wk,
-                                   dx_src, dres, nullptr, 0, nullptr, stream);
-    else
-      hipLaunchKernelGGL(edge_conv_bwd_x_kernel, dim3(xblocks < 1 ? 1 : xblocks), dim3(256), smem_x, stream, ps, dmsg, dx_src, dres);
-    GRL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(edge_conv_bwd_w_kernel, dim3(blocks), dim3(256), smem_w, stream, pd, dmsg, partial, n_edges);
-    GRL_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
   (void)rowptr; (void)e_src; (void)e_dst; (void)n_dst;
   return GRL_ENTRY(grl_edge_bwd16_launch)(x_src, dmsg, pos_src, pos_dst, rowptr_s, src_s, dst_s, s2d, 1, n_src, n_edges, grid, dim, W1, b1,
                                           W2, b2, Wk, dres, dx_src, partial, blocks, nullptr, nullptr, stream);

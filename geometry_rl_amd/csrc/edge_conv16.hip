@@ -1278,7 +1278,7 @@ int grl_edge_fwd_chunk_nodes(int n_dst);
 int grl_edge_bwd_chunk_nodes(int n_src);
 #endif
 
-// Internal entry points used by edge_conv.hip's C-ABI functions when the 16-row kernels are selected (GRL_EDGE16).
+// Internal entry points used by edge_conv.hip's C-ABI functions.
 int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_src, const float* pos_dst, const int* rowptr, const int* e_src,
                                  const int* e_dst, const int* erow, int per_edge, int n_anchor, int n_edges, int anchor_is_dst,
                                  const float* grid, int dim, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -1306,14 +1306,7 @@ int GRL_ENTRY(grl_edge16_launch)(int mode, const st_t* x_in, const float* pos_sr
   GRL_ONCE(hipFuncSetAttribute((const void*)edge16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16));
            hipFuncSetAttribute((const void*)edge16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16)));
   if (mode == 0) hipLaunchKernelGGL(edge16_kernel<0>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
-#if defined(GRL_LEGACY32) && GRL_LEGACY32   // the d x_src-alone instance: only the two-launch backward of legacy builds reaches it
-  else if (mode == 1) {
-    GRL_ONCE(hipFuncSetAttribute((const void*)edge16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainW16)));
-    hipLaunchKernelGGL(edge16_kernel<1>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
-  }
-#else
-  else if (mode == 1) return -4;
-#endif
+  else if (mode == 1) return -4;   // (the d x_src-alone instance served round 1's two-launch backward: removed with it in round 6)
   else hipLaunchKernelGGL(edge16_kernel<2>, dim3(blocks), dim3(E16_THREADS), smem, stream, p, out, dres);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -117,6 +117,14 @@ class GraphBatch:
     pos_all: Optional[torch.Tensor] = None      # [N_all, 3]
     vec_all: Optional[torch.Tensor] = None      # [N_all, n_vec, 3]
     scalar_all: Optional[torch.Tensor] = None   # [N_all, n_types] (one-hot node type)
+    # The compact numbering of the main node type is an implementation choice (balanced_node_order renumbers it for the edge backward's load
+    # balance): natural_id[t][i] = the node's index in the NATURAL order (sample after sample, valid points in their order), None = identity.
+    natural_id: Optional[Dict[str, torch.Tensor]] = None
+
+    def natural(self, node_type: str, ids: torch.Tensor) -> torch.Tensor:
+        """Node ids of ``node_type`` in the natural numbering (what the reference's batched graph uses)."""
+        m = (self.natural_id or {}).get(node_type)
+        return ids if m is None else m.to(ids.device)[ids.long()]
 
     @property
     def edge_types(self):
@@ -307,7 +315,7 @@ class HyperData:
             gather_main = gather_main[old_of_new]
             split_s_int = split_s_int.to(dev)
         else:
-            new_of_old = None
+            new_of_old = old_of_new = None
         if need_edges and et_int[0] in self.node_type_list:
             edges[et_int] = ops.build_edge_set(torch.stack([src, dst]), n_main, n_main, split_s=split_s_int)
         # agent edges: j != k among the actuators of a sample
@@ -351,7 +359,8 @@ class HyperData:
             oh[:, spec.node_types.index(t)] = 1  # transforms.py:52-66
             one_hot[t] = oh
         topo = dict(n_per=n_per, main=main, gather_main=gather_main, n_main=n_main, edges={k: v for k, v in edges.items() if v is not None},
-                    one_hot=one_hot, G=G, n_valid=n_valid, permuted=new_of_old is not None)
+                    one_hot=one_hot, G=G, n_valid=n_valid, permuted=new_of_old is not None,
+                    natural_id=({main: old_of_new} if new_of_old is not None else None))
         self._cache[key] = topo
         return topo
 
@@ -471,7 +480,7 @@ class HyperData:
             graph = GraphBatch(B, list(self.node_type_list), {t: (topo["n_main"] if t == main else B * topo["n_per"][t])
                                                               for t in self.node_type_list}, graph_pos,
                                topo["edges"], self._output_mask_key, topo["n_per"], self.drop_padding,
-                               topo.get("all_order"), pos_all, vec_all, topo.get("scalar_all"))
+                               topo.get("all_order"), pos_all, vec_all, topo.get("scalar_all"), topo.get("natural_id"))
             if dense:
                 return graph, x_dense
             return graph, (scalar_dict, vector_dict)

@@ -197,7 +197,7 @@ def test_knn_to_actuators_topology():
     obs["infos"][:, 0] = torch.tensor([1, 2, 3, 5, 8, 32, 4, 6, 20]).float()    # fewer valid points than K for some samples
     g, _ = hd.build_data(*[obs[k].to(DEV) for k in spec.in_features])
     es = g.edges[("object_geometry", "task", "grippers")]
-    got = set(zip(es.src_d.cpu().tolist(), es.dst_d.cpu().tolist()))
+    got = set(zip(g.natural("object_geometry", es.src_d).cpu().tolist(), es.dst_d.cpu().tolist()))   # (natural numbering: GraphBatch.natural)
     # brute force: per sample and actuator the K valid points closest to it (all of them if fewer than K)
     pos = obs["position_vectors"]
     grip = pos[:, :3 * G].reshape(B, G, 3)
