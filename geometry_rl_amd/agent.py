@@ -114,7 +114,9 @@ class PolicyUpdater:
         self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
         self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
         self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "16")) << 20   # 0: every slab waits for the tail (round 5)
-        self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "1") == "1"    # gated sizes: one step per launch, gathers by device cursor
+        # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
+        # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
+        self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
         self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64"))   # ... above this many frames
         self._epoch = None
         self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
@@ -904,9 +906,15 @@ class PolicyUpdater:
         while j < M and B not in getattr(self, "_eager_sizes", ()):     # the first step of a size runs eagerly (topology, calibration, checks)
             out = self.step_from(buf, idx_rows[j])
             j += 1
-        cursor = self._gate_for(B) and B > self.epoch_unroll_max_gated_frames and self.epoch_cursor
+        gated_big = self._gate_for(B) and B > self.epoch_unroll_max_gated_frames
+        cursor = gated_big and self.epoch_cursor
         if cursor:
             U = 1
+        elif gated_big:     # a gate inside a multi-step launch is a resident wave during the previous step's backward: the per-step program
+            while j < M:
+                out = self.step_from(buf, idx_rows[j])
+                j += 1
+            return out
         if M - j >= U:
             if self._epoch is None or self._epoch["key"] != (B, U, cursor, id(buf)):
                 self.loss_module._global_steps = self.steps

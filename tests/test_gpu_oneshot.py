@@ -39,7 +39,10 @@ def test_two_ranks_as_two_launches_on_two_streams():
     from geometry_rl_amd import oneshot
     n = 4096 * 33
     ranks = oneshot.local_ranks(2, n, DEV)
-    streams = [torch.cuda.Stream() for _ in range(2)]
+    # two streams of DIFFERENT priority: distinct hardware queues for certain (two streams of one priority may share a queue in this process,
+    # and launches that wait for each other on one queue would only meet their timeouts)
+    lo, hi = max(torch.cuda.Stream.priority_range()), min(torch.cuda.Stream.priority_range())
+    streams = [torch.cuda.Stream(priority=hi), torch.cuda.Stream(priority=lo)]
     g = torch.Generator(device="cpu").manual_seed(1)
     for call in range(3):
         data = [torch.randn(n, generator=g).to(DEV) for _ in range(2)]
@@ -70,15 +73,11 @@ def test_a_missing_rank_times_out_instead_of_hanging():
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="a result chunk"):
         ranks[1].check()
-    # ... and the group recovers with the next call (a new sequence number on both sides)
-    streams = [torch.cuda.Stream() for _ in range(2)]
+    # ... and the group recovers with the next call (a new sequence number on both sides; both stand-in ranks in one launch)
     ranks[0].payload.fill_(1.0)
     ranks[1].payload.fill_(2.0)
+    status = oneshot.all_reduce_local(ranks)
     torch.cuda.synchronize()
-    for r, s_ in zip(ranks, streams):
-        with torch.cuda.stream(s_):
-            r.all_reduce()
-    torch.cuda.synchronize()
+    assert status.tolist() == [0, 0]
     for r in ranks:
-        r.check()
         assert torch.equal(r.payload, torch.full((4096,), 3.0, device=DEV))
