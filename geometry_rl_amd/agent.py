@@ -113,7 +113,10 @@ class PolicyUpdater:
         # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
         self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
         self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
-        self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "16")) << 20   # 0: every slab waits for the tail (round 5)
+        # large single-owner slabs folded (+ Adam) right behind their producers instead of in the tail: measured SLOWER at every size (a
+        # 33.5 MB slab costs 26 us wherever it is folded -- the fold is not a first-touch problem -- and the tail keeps 16 us of its own:
+        # 0.619 -> 0.623 ms at 512 frames, 0.451 -> 0.468 at 256; profiles/r06_ab_earlyfold.txt): 0 = off
+        self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "0")) << 20
         # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"

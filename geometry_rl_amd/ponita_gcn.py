@@ -152,14 +152,20 @@ class PonitaGCN(nn.Module):
         return ops.NodeMLP.apply(x2, x_dst, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
                                  layer.linear_2.weight, layer.linear_2.bias, None, res, self._prec, wimg)
 
+    supports_head = True   # latent_step issues the merged head launch (ops.HeadLaunch) before its first consumer
+
     def latent_step(self, graph: GraphBatch, u_dict):
         grid3 = self.grid3
         mg = self._merged(graph)
-        x = ops.LiftEncode.apply(graph.scalar_all, graph.vec_all, grid3, self.ponita.x_embedder.weight, self._prec)
+        # parameter-only work first: with a head collector installed (ops.HEAD, policy.forward_diag) the fiber kernels and the weight images
+        # share ONE launch with the node features build_data has handed over; the lift (which reads the features) comes behind it
         fks = self._fiber_kernels()
         layers = list(self.ponita.interaction_layers)
         last = lambda i: i == len(layers) - 1 and self.prune_last_layer
         wimgs = self._weight_images([(l, mg["es_last"] if last(i) else mg["es_all"]) for i, l in enumerate(layers)])
+        if ops.HEAD is not None:
+            ops.HEAD.launch(self._prec)
+        x = ops.LiftEncode.apply(graph.scalar_all, graph.vec_all, grid3, self.ponita.x_embedder.weight, self._prec)
         for i, layer in enumerate(layers):
             if last(i):
                 x = self._layer_merged(layer, x, graph.pos_all, mg["es_last"], grid3, fks[id(layer.conv)], lo=mg["lo"], wimg=wimgs[id(layer)])
