@@ -121,6 +121,7 @@ class PolicyUpdater:
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
         self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64"))   # ... above this many frames
+        self.epoch_gated_from_frames = int(os.environ.get("GRL_EPOCH_GATED_FROM", "3072"))   # run_minibatches: the gated per-step program from here on
         self._epoch = None
         self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
         self._copies = []
@@ -400,7 +401,7 @@ class PolicyUpdater:
         return dict(grads=self.gflat[lo:hi], params=self.flat[lo:hi], exp_avg=self.exp_avg[lo:hi], exp_avg_sq=self.exp_avg_sq[lo:hi],
                     lr_dev=self.lr_dev, betas=self.betas, eps=self.eps, step_dev=cnt)
 
-    def _plan_lanes(self, batch, st, cbatch=None, gate_in_graph=None):
+    def _plan_lanes(self, batch, st, cbatch=None, gate_in_graph=None, gate_override=None):
         """One rank as a two-lane PROGRAM of single-stream graphs.  This HIP runtime replays a captured graph with two branches through
         the host (hipGraphLaunch returned after 2/3 of the DEVICE time of a forked step; tools/ubench/graph_branches.py) and every
         cross-branch edge costs a 6-11 us gap; a graph boundary on a lane costs ~15 us as well.  So each lane is ONE graph and the lanes
@@ -432,7 +433,7 @@ class PolicyUpdater:
         # 0.35 ms is too short for it (profiles/r05_ab_critic_gate.txt, r05_ab_critic_gate_points.txt).  True (default) = that table.
         frames = next(int(v.shape[0]) for v in batch.values() if torch.is_tensor(v))
         mode = self.critic_after_first_conv
-        gate = self._gate_for(frames)
+        gate = self._gate_for(frames) if gate_override is None else bool(gate_override)
         gate_point = mode if isinstance(mode, str) else "edge0"   # "edge0" | "fwd_end" (experiment: bench.py --critic-gate)
 
         def copy4(dst, src):   # dst[0] = src[0] (int32) on the current stream: one tiny launch
@@ -827,7 +828,7 @@ class PolicyUpdater:
 
     EPOCH_ROWS = 512   # index rows the cursor form keeps on the device (minibatches per load)
 
-    def _compile_epoch(self, buf, idx0, U, cursor):
+    def _compile_epoch(self, buf, idx0, U, cursor, gate=None):
         """Record ``U`` consecutive steps into one graph per lane.  ``cursor`` False: step j of a launch gathers the FIXED row j of a static
         [U, B] index matrix (filled per launch); True (U = 1): the launch gathers the row the lane's own device-side step count points at in
         a static [EPOCH_ROWS, B] matrix loaded once per call -- nothing but graph launches per step."""
@@ -860,7 +861,7 @@ class PolicyUpdater:
         sts, mains, critics = [], [], []
         for j in range(U):
             st = {}
-            self._plan_lanes(sa, st, cbatch=sc, gate_in_graph=True)
+            self._plan_lanes(sa, st, cbatch=sc, gate_in_graph=True, gate_override=gate)
             main_all, critic_all = st.pop("lanes")
             mains.append((gather(ga, j, self.step_dev, base_a), main_all))
             critics.append((st, gather(gc, j, self.step_dev_c, base_c), critic_all))
@@ -909,7 +910,13 @@ class PolicyUpdater:
         while j < M and B not in getattr(self, "_eager_sizes", ()):     # the first step of a size runs eagerly (topology, calibration, checks)
             out = self.step_from(buf, idx_rows[j])
             j += 1
-        gated_big = self._gate_for(B) and B > self.epoch_unroll_max_gated_frames
+        # Which form?  Measured on rigid HEPi (profiles/r06_ab_ungated_unroll.txt, r06_ab_unroll.txt): several steps per launch with the critic's
+        # lane UNGATED (it runs ahead inside the launch; the lanes share nothing) beats the gated per-step program up to 2048 frames
+        # (-3.7 % at 128, -1.2 % at 256 / 512, -2 % at 2048) and loses to it at 4096 (+1.7 %), where the critic's 0.25 ms of kernels beside
+        # the wrong launches cost more than the boundaries of a 3 ms step; with the gate INSIDE a multi-step launch it loses everywhere
+        # above 64 frames (a resident waiting wave during the previous step's one-wave-per-SIMD backward kernels).
+        gate_here = self._gate_for(B) and (B <= self.epoch_unroll_max_gated_frames or B >= self.epoch_gated_from_frames)
+        gated_big = gate_here and B > self.epoch_unroll_max_gated_frames
         cursor = gated_big and self.epoch_cursor
         if cursor:
             U = 1
@@ -921,7 +928,7 @@ class PolicyUpdater:
         if M - j >= U:
             if self._epoch is None or self._epoch["key"] != (B, U, cursor, id(buf)):
                 self.loss_module._global_steps = self.steps
-                self._compile_epoch(buf, idx_rows[j], U, cursor)
+                self._compile_epoch(buf, idx_rows[j], U, cursor, gate=gate_here)
             ep = self._epoch
             if cursor:
                 main = torch.cuda.current_stream()

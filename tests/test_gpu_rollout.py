@@ -73,7 +73,7 @@ def test_several_steps_per_launch_equal_the_step_by_step_loop(form):
         upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True)
         upd.epoch_unroll = 4 if form == "launches" else 1
         if want_form == "cursor":   # the form of the gated sizes (one step per launch, index row by device cursor), forced at this toy size
-            upd.epoch_unroll_max_gated_frames, upd.epoch_cursor = 0, True   # (off by default: measured no better than the per-step program)
+            upd.epoch_unroll_max_gated_frames, upd.epoch_gated_from_frames, upd.epoch_cursor = 0, 0, True   # (off by default: measured no better than the per-step program)
         buf = RolloutBuffer(dict(data))
         drv = RolloutDriver(upd, spec, ppo_epochs=2, seed=9)
         drv.compute_advantages(buf, next_last)
