@@ -89,6 +89,9 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
     return actor, critic, projection, loss
 
 
+_CRITIC_GROUPS = {}   # (id of the actor lane's process group, its ranks) -> the critic lane's communicator
+
+
 class PolicyUpdater:
     """One policy-update step = loss forward, actor + critic backward, optional clip_grad_norm_ per network, two Adam(lr,
     eps=1e-5) steps (train.py:279-316).  Parameters of both networks live in ONE flat fp32 buffer (gradients likewise), so a
@@ -111,6 +114,8 @@ class PolicyUpdater:
         # frames (DESIGN.md finding 42); beside the HBM-bound kernels that follow they cost less: -1.6 % on the step (finding 55).
         self.critic_after_first_conv = critic_after_first_conv
         # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
+        # the critic lane's gate: a launch of the lane itself (grl_wait_flag_ge, default) or hipStreamWaitValue32 in front of its graph
+        # (round 5; GRL_GATE_STREAMWAIT=1 -- a BETA API: taken only where the device reports support)
         self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
         self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
         # large single-owner slabs folded (+ Adam) right behind their producers instead of in the tail: measured SLOWER at every size (a
@@ -139,6 +144,8 @@ class PolicyUpdater:
         n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        if not self.gate_in_graph and self.flat.is_cuda and not hip.query("grl_can_stream_wait_value"):
+            self.gate_in_graph = True   # (no hipStreamWaitValue32 on this device: the gate as a launch)
         # the flat gradient, with room IN FRONT of it for the ranks' loss records ([world][14] (hi, lo) float pairs, grl_trpl_fold_record_pairs):
         # data parallel, ``gbuf[:rec + n_actor]`` is ONE all-reduce -- the records ride on the actor's gradient slice
         if group is not None:
@@ -193,7 +200,12 @@ class PolicyUpdater:
             if len(ranks) != dist.get_world_size():
                 raise ValueError("PolicyUpdater(group=...) must span the default process group (dist.new_group for the critic's lane is "
                                  "collective over WORLD); set GRL_DP_ONE_COMM=1 to run both lanes on a sub-group's own communicator")
-            self.group_c = dist.new_group(ranks=ranks)
+            # ONE extra communicator per process group, shared by every updater built on it (a communicator per updater was
+            # never destroyed -- the data-parallel tests leaked one each)
+            key = (id(group), tuple(ranks))
+            if key not in _CRITIC_GROUPS:
+                _CRITIC_GROUPS[key] = dist.new_group(ranks=ranks)
+            self.group_c = _CRITIC_GROUPS[key]
         # GRL_DP_ONESHOT=1: the actor lane's one collective (gradient slice + loss records) as a one-shot all-reduce over hipIpc-mapped peer
         # buffers (geometry_rl_amd/oneshot.py) instead of RCCL.  OFF by default: tested with stand-in ranks on one GPU only
         # (tests/test_gpu_oneshot.py); DESIGN.md section 5 has the switch-on criterion for a real node.
