@@ -233,7 +233,7 @@ class PolicyUpdater:
     def _set_hyper(self, key, value):
         if self._hyper[key] != value:
             self._hyper[key] = value
-            self._program = None   # recorded launches carry the old scalar
+            self._program, self._epoch, self._copies = None, None, []   # recorded launches carry the old scalar
 
     eps = property(lambda self: self._hyper["eps"], lambda self, v: self._set_hyper("eps", v))
     betas = property(lambda self: self._hyper["betas"], lambda self, v: self._set_hyper("betas", tuple(v)))

@@ -734,7 +734,10 @@ __global__ __launch_bounds__(256) void lift_fiber_basis_bwd_kernel(LiftMulti m, 
 // out[j] += sum_w partial[w][j], bitwise reproducible: a workgroup owns 64 columns; its 8 waves sum interleaved row groups
 // (wave g: rows g, g+8, ..., four independent running sums each, combined in a fixed order) and the 8 wave sums are folded
 // through LDS in wave order.  No atomics, so the result does not depend on scheduling.
-constexpr int RED_WAVES = 8;
+#ifndef GRL_RED_WAVES
+#define GRL_RED_WAVES 2   // waves per fold workgroup.  Round 6 A/B (profiles/r06_ab_fold_waves.txt): 8 -> 4 -> 2 waves: 0.320 -> 0.304 -> 0.299 ms at 32 frames, 0.638 -> 0.618 -> 0.614 at 512, 3.113 -> 3.08 at 4096 -- short-lived 512-thread workgroups were the fold's cost, not its bytes
+#endif
+constexpr int RED_WAVES = GRL_RED_WAVES;
 // RED_DEPTH independent loads in flight per wave: the slabs are row-strided, so a wave's walk down its rows is a chain of
 // memory latencies -- with 4 in flight the longest columns (2048 rows: gradients fed by two convolutions) took 64 round trips.
 constexpr int RED_DEPTH = 16;
