@@ -122,6 +122,7 @@ class PolicyUpdater:
         # 33.5 MB slab costs 26 us wherever it is folded -- the fold is not a first-touch problem -- and the tail keeps 16 us of its own:
         # 0.619 -> 0.623 ms at 512 frames, 0.451 -> 0.468 at 256; profiles/r06_ab_earlyfold.txt): 0 = off
         self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "0")) << 20
+        self.dp_gate_from_frames = int(os.environ.get("GRL_DP_GATE_FROM", "0"))   # data parallel: gate the critic's lane from this shard size on (0: never)
         # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
@@ -573,11 +574,36 @@ class PolicyUpdater:
                     st["adv"] = st["zw"][8:10]
                     adv_stats_local(m, st["b"], st["adv"])
 
+        # Large shards: the critic's lane waits (a launch of its own, grl_wait_flag_ge) until the actor's first edge convolution has finished --
+        # beside that launch the critic's kernels cost it 60-170 us at 4096 frames (finding 42; DESIGN round 6).  The wait starts with the step
+        # and ends inside the actor's forward: it is never resident during a backward launch.  GRL_DP_GATE_FROM frames (0 = never).
+        frames_local = next((int(v.shape[0]) for v in batch.values() if torch.is_tensor(v)), 0)
+        gate_dp = bool(self.dp_gate_from_frames) and frames_local >= self.dp_gate_from_frames
+
+        def copy4(dst, src):
+            import ctypes
+            hip.call("grl_copy_many", (ctypes.c_void_p * 1)(dst.data_ptr()), (ctypes.c_void_p * 1)(src.data_ptr()), (ctypes.c_longlong * 1)(4), 1)
+
         def p_main():
             if published:
                 p_stats()
             actor.hyper_data.bump_next = self.step_dev
-            fold_ = self._actor_head(st, st["adv"], False)
+            if gate_dp:
+                def signal():
+                    if actor.hyper_data.bump_next is not None:   # (a calibrating pass in front of the step's own forward: not this convolution)
+                        return False
+                    ops.PENDING_SIGNAL = (self.lane_flag, self.step_dev)   # rides on the fiber convolution behind the edge convolution
+                    return True
+                ops.AFTER_EDGE_HOOK = signal
+            try:
+                fold_ = self._actor_head(st, st["adv"], False)
+            finally:
+                ops.AFTER_EDGE_HOOK = None
+                unsent, ops.PENDING_SIGNAL = ops.PENDING_SIGNAL, None
+            if unsent is not None:
+                copy4(*unsent)
+            if gate_dp:   # ... and once more at the end of the segment: the critic's lane can be late, never stuck (its wait is bounded as well)
+                copy4(self.lane_flag, self.step_dev)
             assert actor.hyper_data.bump_next is None
             with torch.no_grad():
                 # this rank's loss sums / maxes as ONE record of float pairs in front of the flat gradient (own row, zeros in the
@@ -597,6 +623,8 @@ class PolicyUpdater:
 
         def q_fwd1():
             with torch.no_grad():
+                if gate_dp:
+                    hip.call("grl_wait_flag_ge", self.lane_flag, self.step_dev_c, 1, 200000)
                 if not ow:
                     self.gflat[na:].zero_()
                 vf.train(True)

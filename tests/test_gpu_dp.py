@@ -135,6 +135,23 @@ def test_two_ranks_on_one_communicator_fallback(monkeypatch):
         assert (flat - ref_flat).abs().max().item() <= 3e-5
 
 
+def test_two_ranks_with_gated_critic_lane(monkeypatch):
+    """GRL_DP_GATE_FROM (round 6): the data-parallel program with its critic lane gated behind the actor's first edge convolution (a launch of the
+    critic's lane waiting for a flag the actor's fiber convolution raises) -- scheduling only: the same results as one rank, recorded segments included."""
+    monkeypatch.setenv("GRL_DP_GATE_FROM", "1")   # (inherited by the spawned workers: every shard size is gated)
+    B, world, n_steps = 16, 2, 3
+    ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
+    assert all(r in ret for r in range(world))
+    for r in range(world):
+        losses, flat = ret[r]
+        for k, v in ref_losses.items():
+            assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (r, k, losses[k], v)
+        assert (flat - ref_flat).abs().max().item() <= 3e-5
+
+
 def test_two_ranks_with_published_advantage_statistics():
     """The epoch-level advantage statistics (one all-reduce per epoch, carried as a per-frame column): the update has no
     ``advantage_stats`` collective any more and still equals the single-rank update of the whole minibatch."""
