@@ -122,7 +122,9 @@ class PolicyUpdater:
         # 33.5 MB slab costs 26 us wherever it is folded -- the fold is not a first-touch problem -- and the tail keeps 16 us of its own:
         # 0.619 -> 0.623 ms at 512 frames, 0.451 -> 0.468 at 256; profiles/r06_ab_earlyfold.txt): 0 = off
         self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "0")) << 20
-        self.dp_gate_from_frames = int(os.environ.get("GRL_DP_GATE_FROM", "0"))   # data parallel: gate the critic's lane from this shard size on (0: never)
+        # data parallel: gate the critic's lane behind the actor's first edge convolution from this shard size on (0: never).  One-rank RCCL
+        # group, alternating on one box (profiles/r06_ab_dp_gate.txt): -4.1 % at 4096 frames per rank, -2 % at 2048, -1.3 % at 1024, 0 at 512
+        self.dp_gate_from_frames = int(os.environ.get("GRL_DP_GATE_FROM", "1024"))
         # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
