@@ -607,20 +607,27 @@ class PolicyUpdater:
             if gate_dp:   # ... and once more at the end of the segment: the critic's lane can be late, never stuck (its wait is bounded as well)
                 copy4(self.lane_flag, self.step_dev)
             assert actor.hyper_data.bump_next is None
+            st.update(sums=fold_.sums, maxes=fold_.maxes)
             with torch.no_grad():
                 # this rank's loss sums / maxes as ONE record of float pairs in front of the flat gradient (own row, zeros in the
-                # others): the SUM all-reduce of the actor's slice delivers every rank's record -- no collective of their own
-                hip.call("grl_trpl_fold_record_pairs", fold_.slots, fold_.batch, self.rank, world, self.gbuf[:self._rec])
-            st.update(sums=fold_.sums, maxes=fold_.maxes)
-            ops.flush_deferred_grads(overwrite=ow)
+                # others): the SUM all-reduce of the actor's slice delivers every rank's record -- no collective of their own.  The
+                # record and the fold of the slabs come from ONE launch (both only feed that all-reduce)
+                if not ops.fold_record_pairs(ow, fold_.slots, fold_.batch, self.rank, world, self.gbuf[:self._rec]):
+                    hip.call("grl_trpl_fold_record_pairs", fold_.slots, fold_.batch, self.rank, world, self.gbuf[:self._rec])
+                    ops.flush_deferred_grads(overwrite=ow)
             ops.DEFERRED = None
 
         def p_tail():   # behind the lane's collective: Adam on the reduced gradient, reported values of the delivered records
             with torch.no_grad():
-                self._adam(st, 0, na, 0)
                 ent = m.entropy_coef if m.entropy_bonus else 0.0
                 o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
-                hip.call("grl_trpl_report_record_pairs", self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
+                if self.clip:   # (the clip coefficient needs the reduced gradient's norm first: the separate launches)
+                    self._adam(st, 0, na, 0)
+                    hip.call("grl_trpl_report_record_pairs", self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
+                else:           # Adam on the reduced slice + the reported values of the delivered records: ONE launch
+                    hip.call("grl_adam_report_record_pairs", self.flat[:na], self.gflat[:na], self.exp_avg[:na], self.exp_avg_sq[:na], na,
+                             self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev,
+                             self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
                 st["lv_main"] = report_dict(o14)
 
         def q_fwd1():

@@ -84,3 +84,18 @@ GRL_DEVINL void trpl_report_body(const double* __restrict__ slots, int n_blocks,
     out[13] = mc + cc;   // "constraint": the projection's own measure (= kl for the KL projection)
   }
 }
+
+// This rank's record (sh[0..13], from trpl_fold_columns) as (hi, lo) float pairs into its row of a [world][14] region, zeros in the other rows
+// (the region travels with the flat gradient in ONE float SUM all-reduce: x + 0 is exact, hi + lo restores the double to ~2^-48).
+template <int NT>
+GRL_DEVINL void trpl_write_record_pairs(const double* sh, float2* __restrict__ region, int rank, int world) {
+  for (int i = threadIdx.x; i < world * TRPL_SLOT; i += NT) {
+    float2 v = make_float2(0.f, 0.f);
+    if (i / TRPL_SLOT == rank) {
+      const double x = sh[i % TRPL_SLOT];
+      v.x = (float)x;
+      v.y = (v.x - v.x == 0.f) ? (float)(x - (double)v.x) : 0.f;   // (inf / nan stay what they are)
+    }
+    region[i] = v;
+  }
+}

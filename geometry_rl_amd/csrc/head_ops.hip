@@ -772,15 +772,7 @@ __global__ __launch_bounds__(FOLD_NT) void trpl_fold_record_pairs_kernel(const d
                                                                         int rank, int world) {
   __shared__ double sh[16], part[FOLD_NT];
   trpl_fold_columns<FOLD_NT>(slots, n_blocks, sh, part);
-  for (int i = threadIdx.x; i < world * TRPL_SLOT; i += FOLD_NT) {
-    float2 v = make_float2(0.f, 0.f);
-    if (i / TRPL_SLOT == rank) {
-      const double x = sh[i % TRPL_SLOT];
-      v.x = (float)x;
-      v.y = (v.x - v.x == 0.f) ? (float)(x - (double)v.x) : 0.f;   // (inf / nan stay what they are)
-    }
-    region[i] = v;
-  }
+  trpl_write_record_pairs<FOLD_NT>(sh, region, rank, world);
 }
 __global__ __launch_bounds__(FOLD_NT) void trpl_report_pairs_kernel(const double* __restrict__ records, int n_records, double* __restrict__ sums,
                                                                    unsigned int* __restrict__ maxes, float entropy_coef, float* __restrict__ out) {

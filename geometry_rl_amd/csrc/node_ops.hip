@@ -846,6 +846,8 @@ struct FoldTail {
   float* out14;
   int* flag_dst;                   // optional lane signal written when the launch starts (lane_signal)
   const int* flag_src;
+  float2* pairs_region;            // report == 2 (data parallel): the extra workgroup folds the slots into THIS rank's record of (hi, lo)
+  int pairs_rank, pairs_world;     // float pairs (grl_report.h trpl_write_record_pairs) instead of evaluating the reported values
 };
 GRL_DEVINL void adam_apply(float g, float* __restrict__ gp, const FoldTail& t, float lr, float bc1, float bc2_sqrt) {
   float* p = gp + t.d_param;
@@ -919,7 +921,12 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_multi_kernel(R
     lane_signal(tail.flag_dst, tail.flag_src);
     if (tail.report && (int)blockIdx.x == m.blk0[m.n_dst]) {   // the extra workgroup: reported values (its first 64 threads)
       __shared__ double sh[16], part[64 * RED_WAVES];
-      trpl_report_body<64 * RED_WAVES>(tail.slots, tail.n_slot_blocks, tail.sums, tail.maxes, tail.ent_coef, tail.out14, sh, part);
+      if (tail.report == 2) {
+        trpl_fold_columns<64 * RED_WAVES>(tail.slots, tail.n_slot_blocks, sh, part);
+        trpl_write_record_pairs<64 * RED_WAVES>(sh, tail.pairs_region, tail.pairs_rank, tail.pairs_world);
+      } else {
+        trpl_report_body<64 * RED_WAVES>(tail.slots, tail.n_slot_blocks, tail.sums, tail.maxes, tail.ent_coef, tail.out14, sh, part);
+      }
       return;
     }
     if (tail.adam) {
@@ -1241,6 +1248,23 @@ int grl_reduce_partials_multi_ow(int n_seg, const float* const* partial, const i
   if (const int rc = fold_fill(m, n_seg, partial, n_rows, ld, start, len, dst, overwrite)) return rc;
   if (m.blk0[m.n_dst] <= 0) return 0;
   hipLaunchKernelGGL(reduce_partials_multi_kernel<false>, dim3(m.blk0[m.n_dst]), dim3(64 * RED_WAVES), 0, stream, m, FoldTail{});
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+// Data parallel: the fold of a rank's slabs and, by one extra workgroup, its loss record as (hi, lo) float pairs in front of the flat gradient
+// (grl_reduce_partials_multi_ow + grl_trpl_fold_record_pairs in ONE launch: both only feed the lane's all-reduce).
+int grl_fold_record_pairs(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                          float* const* dst, int overwrite, const double* slots, int batch, int rank, int world, float* region,
+                          hipStream_t stream) {
+  if (!slots || !region || batch < 1 || world < 1 || rank < 0 || rank >= world) return -2;
+  ReduceMulti m{};
+  if (n_seg > 0)
+    if (const int rc = fold_fill(m, n_seg, partial, n_rows, ld, start, len, dst, overwrite)) return rc;
+  FoldTail t{};
+  t.report = 2;
+  t.slots = slots; t.n_slot_blocks = trpl_blocks(batch);
+  t.pairs_region = reinterpret_cast<float2*>(region); t.pairs_rank = rank; t.pairs_world = world;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel<true>, dim3(m.blk0[m.n_dst] + 1), dim3(64 * RED_WAVES), 0, stream, m, t);
   GRL_CHECK_LAUNCH();
   return 0;
 }

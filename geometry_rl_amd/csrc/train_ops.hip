@@ -4,6 +4,7 @@
 // (train.py:308-310) and the per-sample kNN topology (rigid_tasks_data.py:285-287).
 #include "grl_common.h"
 #include "grl_feat.h"
+#include "grl_report.h"
 
 namespace {
 
@@ -37,6 +38,33 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   const float scale = scale_host * (scale_dev ? scale_dev[0] : 1.f);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+// Data parallel, behind the lane's all-reduce: the Adam update of the reduced slice and, by one extra workgroup, the reported values from the
+// ranks' delivered loss records (grl_adam_step_dev + grl_trpl_report_record_pairs in ONE launch).
+__global__ __launch_bounds__(256) void adam_dev_report_pairs_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                                   float* __restrict__ v, int n, const float* __restrict__ lr_dev, float b1,
+                                                                   float b2, float eps, const int* __restrict__ step_dev, int n_adam_blocks,
+                                                                   const double* __restrict__ records, int n_records,
+                                                                   double* __restrict__ sums, unsigned int* __restrict__ maxes,
+                                                                   float entropy_coef, float* __restrict__ out14) {
+  if ((int)blockIdx.x == n_adam_blocks) {
+    __shared__ double sh[16], part[256];
+    trpl_report_body<256, true>(records, n_records, sums, maxes, entropy_coef, out14, sh, part);
+    return;
+  }
+  const float t = (float)step_dev[0];
+  const float lr = lr_dev[0];
+  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_adam_blocks * blockDim.x) {
+    const float gi = g[i] * 1.f;            // (the same arithmetic as adam_dev_kernel with scale 1: bitwise its update)
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -418,6 +446,17 @@ int grl_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
   const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
   hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1,
                      beta2, eps, step_dev, scale_dev, scale_host);
+  GRL_CHECK_LAUNCH();
+  return 0;
+}
+
+int grl_adam_report_record_pairs(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, const float* lr_dev, float beta1,
+                                 float beta2, float eps, const int* step_dev, const float* region, int n_records, double* sums,
+                                 unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream) {
+  if (n <= 0 || !lr_dev || !step_dev || !region || !sums || !maxes || !out14 || n_records < 1) return -2;
+  const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(adam_dev_report_pairs_kernel, dim3(blocks + 1), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr_dev, beta1,
+                     beta2, eps, step_dev, blocks, reinterpret_cast<const double*>(region), n_records, sums, maxes, entropy_coef, out14);
   GRL_CHECK_LAUNCH();
   return 0;
 }

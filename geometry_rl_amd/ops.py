@@ -172,6 +172,28 @@ def fold_adam_report(overwrite, adam=None, report=None, signal=None):
     return True
 
 
+def fold_record_pairs(overwrite, slots, batch, rank, world, region) -> bool:
+    """Data parallel: the queued folds AND this rank's loss record (as (hi, lo) float pairs in front of the flat gradient) in ONE launch
+    (grl_fold_record_pairs) -- both only feed the lane's all-reduce.  False (nothing launched) when the queue does not fit one launch."""
+    import ctypes
+    global DEFERRED
+    jobs = DEFERRED or []
+    if len(jobs) > 64:
+        return False
+    by_dst = {}
+    for j in jobs:
+        by_dst.setdefault(j[3].data_ptr(), []).append(j)
+    part = [j for grp in by_dst.values() for j in grp]
+    n = len(part)
+    hip.call("grl_fold_record_pairs", n, (ctypes.c_void_p * max(n, 1))(*[j[0].data_ptr() for j in part]),
+             (ctypes.c_int * max(n, 1))(*[j[0].shape[0] for j in part]), (ctypes.c_int * max(n, 1))(*[j[0].shape[1] for j in part]),
+             (ctypes.c_int * max(n, 1))(*[j[1] for j in part]), (ctypes.c_int * max(n, 1))(*[j[2] for j in part]),
+             (ctypes.c_void_p * max(n, 1))(*[j[3].data_ptr() for j in part]), 1 if overwrite else 0, slots, int(batch), int(rank), int(world), region)
+    if DEFERRED is not None:
+        DEFERRED = []
+    return True
+
+
 def flush_deferred_grads(overwrite=False, only=None):
     """Fold every queued slab into its leaf gradient.  ``overwrite``: the gradients are WRITTEN (the caller keeps no zeroed buffer; every
     leaf gradient of the pass must then come through this queue -- PolicyUpdater checks that).  ``only``: a predicate on the destination

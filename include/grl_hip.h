@@ -419,6 +419,15 @@ int grl_oneshot_allreduce_local(float* const* bufs, float* const* stages, unsign
 /* A lane gate as a launch: the stream waits (one-thread kernel, capturable into a hipGraph) until flag[0] >= count[0] + add -- both read from
  * DEVICE memory when the kernel runs -- or timeout_us microseconds have passed (a gate is a scheduling hint: the lane then simply goes on). */
 int grl_wait_flag_ge(const int* flag, const int* count, int add, int timeout_us, hipStream_t stream);
+/* Data parallel, two more merged launches (round 6): grl_fold_record_pairs = grl_reduce_partials_multi_ow (n_seg .. overwrite) + grl_trpl_fold_record_pairs
+ * (slots .. region) -- both only feed the lane's all-reduce; grl_adam_report_record_pairs = grl_adam_step_dev (params .. step_dev; scale 1) +
+ * grl_trpl_report_record_pairs (region .. out14) -- both only read what the all-reduce delivered.  Arguments and results as in those entry points. */
+int grl_fold_record_pairs(int n_seg, const float* const* partial, const int* n_rows, const int* ld, const int* start, const int* len,
+                          float* const* dst, int overwrite, const double* slots, int batch, int rank, int world, float* region,
+                          hipStream_t stream);
+int grl_adam_report_record_pairs(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, const float* lr_dev, float beta1,
+                                 float beta2, float eps, const int* step_dev, const float* region, int n_records, double* sums,
+                                 unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 /* 1 if the current device supports hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue), else 0 (host query, no stream). */
 int grl_can_stream_wait_value(void);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */
