@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the 1024-frame oracle comparison (and the CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--critic-gate", default=None, help="A/B: where the critic's lane starts: edge0 (default) | fwd_end")
+    ap.add_argument("--critic-gate", default=None, help="A/B: where the critic's lane starts: edge0 (default) | fiber0 | fwd_end")
     ap.add_argument("--no-critic-gate", action="store_true", help="A/B: the critic's lane starts with the step instead of behind the actor's first edge convolution")
     ap.add_argument("--one-stream", action="store_true", help="A/B: one rank, everything on ONE stream / in ONE hipGraph (PolicyUpdater(overlap_critic=False)): no cross-stream wait anywhere")
     ap.add_argument("--unroll", type=int, default=8, help="one rank: minibatch steps per recorded launch (PolicyUpdater.run_minibatches); 1 = one step per launch, as in round 5")

@@ -474,12 +474,20 @@ class PolicyUpdater:
                 ops.AFTER_EDGE_HOOK = signal
             if gate and gate_point == "fwd_end":
                 st["after_forward"] = lambda: copy4(self.lane_flag, self.step_dev)
+            if gate and gate_point == "fiber0":   # experiment: the critic starts behind the first FIBER convolution (beside the ConvNeXt forward)
+                def signal_f():
+                    if actor.hyper_data.bump_next is not None:
+                        return False
+                    copy4(self.lane_flag, self.step_dev)
+                    return True
+                ops.AFTER_FIBER_HOOK = signal_f
             if fuse_tail and self.early_fold_bytes > 0:   # large single-owner slabs are folded (+ Adam) right behind their producers (ops._emit_grads)
                 ops.EARLY_FOLD = dict(adam=self._tail_args(0, na, self.step_dev), overwrite=ow, min_bytes=self.early_fold_bytes, seen=set(), fed=set())
             try:
                 fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
             finally:
                 ops.AFTER_EDGE_HOOK = None
+                ops.AFTER_FIBER_HOOK = None
                 ops.EARLY_FOLD = None
                 unsent, ops.PENDING_SIGNAL = ops.PENDING_SIGNAL, None
             if unsent is not None:   # (no fiber convolution followed the edge convolution: send the signal by itself)

@@ -277,6 +277,7 @@ FUSE_TAIL_PRE = _os.environ.get("GRL_FUSE_TAIL_PRE", "1") == "1"
 SIGNAL_IN_KERNEL = _os.environ.get("GRL_SIGNAL_IN_KERNEL", "1") == "1"   # False: lane signals as 4-byte copy launches of their own
 HEAD = None            # a HeadLaunch while an actor forward that supports it is being issued (policy.GNNGaussianPolicyDiag.forward_diag)
 TAIL_PRE = None        # a dict while PolicyUpdater issues the actor's backward: the first of {lift backward, fiber-basis backward} waits here
+AFTER_FIBER_HOOK = None
 EARLY_FOLD = None      # dict(adam=..., overwrite=..., min_bytes=..., seen=set(), fed=set()) while PolicyUpdater's fused tail is in force
 PENDING_SIGNAL = None  # (flag_dst, flag_src) int32 tensors: the next FiberConv forward launch writes flag_dst[0] = flag_src[0] when it starts
 
@@ -626,6 +627,10 @@ class FiberConv(torch.autograd.Function):
             hip.call("grl_fiber_conv_fwd_sig" + prec, x1, fk, bias.contiguous(), x2, x1.shape[0], fd, fs)
         else:
             hip.call("grl_fiber_conv_fwd" + prec, x1, fk, bias.contiguous(), x2, x1.shape[0])
+        global AFTER_FIBER_HOOK
+        if AFTER_FIBER_HOOK is not None:   # experiment (bench.py --critic-gate fiber0): a one-shot hook behind the NEXT fiber convolution's launch
+            if AFTER_FIBER_HOOK():
+                AFTER_FIBER_HOOK = None
         ctx.save_for_backward(x1, fk)
         ctx.bias, ctx.prec = bias, prec
         return x2
