@@ -167,6 +167,7 @@ GRL_DEVINL void gelu_logistic_both_pair(v2f x, v2f& g, v2f& gp) {
   g = x * s_;
   gp = fma2(fma2(-s_, s_, s_), x * fma2(x2, splat2(3.f * 0.07056f), splat2(1.5976f)), s_);   // s (1 - s) as s - s^2: one packed instruction less
 }
+template <bool WITH_GRAD> GRL_DEVINL void gelu_pair_as(v2f x, v2f& g, v2f& gp);
 template <bool WITH_GRAD>
 GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
 #if GRL_GELU_LOGISTIC
@@ -174,6 +175,12 @@ GRL_DEVINL void gelu_pair(v2f x, v2f& g, v2f& gp) {
   else gelu_logistic_pair(x, g);
   return;
 #endif
+  gelu_pair_as<WITH_GRAD>(x, g, gp);
+}
+// the A&S 7.1.26 form in EVERY build (gelu_pair's form where GRL_GELU_LOGISTIC is off): parameter-only code such as the fiber basis must
+// not change its numbers with the precision of the build it happens to be compiled into (gelu_exact_f / gelu_exact_grad_f below)
+template <bool WITH_GRAD>
+GRL_DEVINL void gelu_pair_as(v2f x, v2f& g, v2f& gp) {
   const float kp = 0.3275911f * 0.70710678118654752440f;
   v2f t, e;
   t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), kp, 1.0f));
@@ -257,11 +264,15 @@ GRL_DEVINL float4 gelu4(float4 x) {
 }
 // value + derivative, scalar form: plain (unpacked) vector instructions only -- the form for code that runs beside MFMAs of the same
 // wave (packed f32 operations do not overlap with the matrix pipe: MI355X_MICROARCH.md cycle constants; DESIGN.md finding 23)
+GRL_DEVINL void gelu_both_as(float x, float& g, float& gp);
 GRL_DEVINL void gelu_both(float x, float& g, float& gp) {
 #if GRL_GELU_LOGISTIC
   gelu_logistic_both(x, g, gp);
   return;
 #endif
+  gelu_both_as(x, g, gp);
+}
+GRL_DEVINL void gelu_both_as(float x, float& g, float& gp) {   // (the A&S form in every build: see gelu_pair_as)
   const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
 #if GRL_GELU_V2
   const float e = __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170368f, -1.32574806473615910f));   // pdf(x)
@@ -305,6 +316,17 @@ GRL_DEVINL float gelu_f(float x) {   // scalar forms (tails, tests)
 GRL_DEVINL float gelu_grad_f(float x) {
   float g, gp;
   gelu_both(x, g, gp);
+  return gp;
+}
+// ... and the same two with the A&S form whatever GRL_PREC says: bitwise gelu_f / gelu_grad_f of the fp32 build
+GRL_DEVINL float gelu_exact_f(float x) {
+  v2f g, gp;
+  gelu_pair_as<false>(v2f{x, x}, g, gp);
+  return g.x;
+}
+GRL_DEVINL float gelu_exact_grad_f(float x) {
+  float g, gp;
+  gelu_both_as(x, g, gp);
   return gp;
 }
 

@@ -591,13 +591,13 @@ GRL_DEVINL void fiber_basis_fwd_body(const FbFwd& A, int blk, float* fb_smem) {
   float z1 = A.b1[c];
 #pragma unroll
   for (int k = 0; k < FB_P; ++k) z1 += A.W1[c * FB_P + k] * A.poly[r * FB_P + k];
-  const float h1 = gelu_f(z1);
+  const float h1 = gelu_exact_f(z1);
   hs[rl * 64 + c] = h1;
   __syncthreads();
   float z2 = A.b2[c];
 #pragma unroll 16
   for (int k = 0; k < 64; ++k) z2 += W2s[c * 65 + k] * hs[rl * 64 + k];
-  const float h2 = gelu_f(z2);
+  const float h2 = gelu_exact_f(z2);
   hs[(FB_RPB + rl) * 64 + c] = h2;
   // saved for the backward: [z1 | h1 | z2 | h2] each [256][64]
   A.saved[(0 * FB_ROWS + r) * 64 + c] = z1;
@@ -656,13 +656,13 @@ GRL_DEVINL void fiber_basis_bwd_body(const FbBwd& A, int blk, float* fb_smem) {
 #pragma unroll 16
     for (int k = 0; k < 64; ++k) dphi += d[k] * w[k * 65];
   }
-  const float dz2 = dphi * gelu_grad_f(z2);
+  const float dz2 = dphi * gelu_exact_grad_f(z2);
   dz2s[rl * 64 + c] = dz2;
   __syncthreads();
   float dh1 = 0.f;
 #pragma unroll 16
   for (int k = 0; k < 64; ++k) dh1 += dz2s[rl * 64 + k] * W2s[k * 65 + c];
-  const float dz1 = dh1 * gelu_grad_f(z1);
+  const float dz1 = dh1 * gelu_exact_grad_f(z1);
   dz1s[rl * 64 + c] = dz1;
   __syncthreads();
   // ---- this workgroup's partial row (sums over its FB_RPB rows)
