@@ -101,6 +101,43 @@ def test_several_steps_per_launch_equal_the_step_by_step_loop(form):
         assert torch.equal(got, want)
 
 
+def test_launch_forms_can_be_mixed_and_follow_a_changed_hyper_parameter():
+    """run_minibatches (eight-step launches), step_from (the per-step program) and a changed hyper-parameter in between: the step counts live on
+    the device, every program reads the same flat buffers, and a changed Adam epsilon drops EVERY recording (the multi-step one included) -- the
+    result must be the step-by-step loop's."""
+    from geometry_rl_amd import agent
+    from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
+    N, T = 8, 12
+    res = {}
+    for form in ("loop", "mixed"):
+        spec, cfg, loss, data, next_last = _make(N, T, seed=41)
+        upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True)
+        upd.epoch_unroll = 4
+        buf = RolloutBuffer(dict(data))
+        drv = RolloutDriver(upd, spec, ppo_epochs=1, seed=3)
+        drv.compute_advantages(buf, next_last)
+        dev = next(iter(buf.data.values())).device
+        idx = torch.stack(drv.epoch_minibatches(buf.N, buf.T, dev))     # [12, 8]
+        if form == "loop":
+            for j in range(T):
+                if j == 7:
+                    upd.eps = 1e-4
+                upd.step_from(buf, idx[j])
+        else:
+            upd.run_minibatches(buf, idx[:5])            # eager first step + one 4-step launch
+            upd.step_from(buf, idx[5])                   # the per-step program (records itself)
+            upd.step_from(buf, idx[6])
+            assert upd._epoch is not None
+            upd.eps = 1e-4                               # a recorded scalar changes: every recording is dropped
+            assert upd._epoch is None and upd._program is None
+            upd.run_minibatches(buf, idx[7:])            # five steps: one 4-step launch (recorded again) + one single step
+        torch.cuda.synchronize()
+        assert upd.steps == T and int(upd.step_dev.item()) == T and int(upd.step_dev_c.item()) == T
+        res[form] = (upd.flat.detach().clone(), upd.exp_avg_sq.detach().clone())
+    for a, b in zip(res["loop"], res["mixed"]):
+        assert torch.equal(a, b), (a - b).abs().max().item()
+
+
 def test_collect_normalise_update_round_trip():
     """One whole training iteration on the device with a synthetic environment: raw observations -> running normalisation + clip ->
     collector-side actor (sampling) -> rollout buffer -> critic values + shifted GAE -> minibatch updates.  Checks the plumbing (keys,
