@@ -43,5 +43,10 @@ for n in 2 $N; do
   [ $n -le $NMAX ] || continue
   run_line oneshot_rigid_hepi_n${n} $n rigid_hepi GRL_DP_ONESHOT=1 || echo "  -> one-shot all-reduce failed at n=$n: see $O/oneshot_rigid_hepi_n${n}.err"
 done
+# (5) the critic lane's gate (round 6: on from 1024 frames per rank; measured on a one-rank group only): the same lines without it at 2 and 4 ranks
+for n in 2 4; do
+  [ $n -le $NMAX ] || continue
+  run_line nogate_rigid_hepi_n${n} $n rigid_hepi GRL_DP_GATE_FROM=0 || true
+done
 python tools/dp_table.py $O > $O/table.txt
 cat $O/table.txt
