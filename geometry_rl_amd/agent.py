@@ -125,6 +125,7 @@ class PolicyUpdater:
         # data parallel: gate the critic's lane behind the actor's first edge convolution from this shard size on (0: never).  One-rank RCCL
         # group, alternating on one box (profiles/r06_ab_dp_gate.txt): -4.1 % at 4096 frames per rank, -2 % at 2048, -1.3 % at 1024, 0 at 512
         self.dp_gate_from_frames = int(os.environ.get("GRL_DP_GATE_FROM", "1024"))
+        self.dp_eager_tail = os.environ.get("GRL_DP_EAGER_TAIL", "0") == "1"   # experiment: the actor lane's one-launch tail issued eagerly
         # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
@@ -625,10 +626,13 @@ class PolicyUpdater:
                     ops.flush_deferred_grads(overwrite=ow)
             ops.DEFERRED = None
 
+        # (the reported values live in ONE buffer per recorded program: the tail may run as an eager launch behind the collective, below)
+        o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
+        st["lv_main"] = report_dict(o14)
+
         def p_tail():   # behind the lane's collective: Adam on the reduced gradient, reported values of the delivered records
             with torch.no_grad():
                 ent = m.entropy_coef if m.entropy_bonus else 0.0
-                o14 = torch.empty(14, device=self.flat.device, dtype=torch.float32)
                 if self.clip:   # (the clip coefficient needs the reduced gradient's norm first: the separate launches)
                     self._adam(st, 0, na, 0)
                     hip.call("grl_trpl_report_record_pairs", self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
@@ -636,7 +640,9 @@ class PolicyUpdater:
                     hip.call("grl_adam_report_record_pairs", self.flat[:na], self.gflat[:na], self.exp_avg[:na], self.exp_avg_sq[:na], na,
                              self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev,
                              self.gbuf[:self._rec], world, st["sums"], st["maxes"], float(ent), o14)
-                st["lv_main"] = report_dict(o14)
+        # ONE launch is cheaper issued eagerly than replayed as a one-node graph (a graph launch behind a collective costs ~13 us of lane time,
+        # an eager kernel launch ~4): GRL_DP_EAGER_TAIL
+        p_tail.eager = bool(self.dp_eager_tail and not self.clip)
 
         def q_fwd1():
             with torch.no_grad():
@@ -785,6 +791,12 @@ class PolicyUpdater:
         for entry in plan:
             kind, item, lane = entry[0], entry[1], (entry[2] if len(entry) > 2 else "m")
             label = entry[3] if len(entry) > 3 else None
+            if kind == "run" and getattr(item, "eager", False):   # a segment that is issued as plain launches at every step, not recorded
+                if cur:
+                    groups.append(("run", cur, cur_lane, None))
+                    cur, cur_lane = [], None
+                groups.append(("run_eager", item, lane, label))
+                continue
             if kind == "run" and (not cur or lane == cur_lane):
                 cur.append(item)
                 cur_lane = lane
@@ -806,6 +818,9 @@ class PolicyUpdater:
         for kind, item, lane, label in groups:
             if kind == "run_host_once":
                 item()
+                continue
+            if kind == "run_eager":
+                program.append(("run", item, lane, label))
                 continue
             if kind != "run":
                 program.append((kind, item, lane, label))
