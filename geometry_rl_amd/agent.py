@@ -125,7 +125,7 @@ class PolicyUpdater:
         # data parallel: gate the critic's lane behind the actor's first edge convolution from this shard size on (0: never).  One-rank RCCL
         # group, alternating on one box (profiles/r06_ab_dp_gate.txt): -4.1 % at 4096 frames per rank, -2 % at 2048, -1.3 % at 1024, 0 at 512
         self.dp_gate_from_frames = int(os.environ.get("GRL_DP_GATE_FROM", "1024"))
-        self.dp_eager_tail = os.environ.get("GRL_DP_EAGER_TAIL", "0") == "1"   # experiment: the actor lane's one-launch tail issued eagerly
+        self.dp_eager_tail = os.environ.get("GRL_DP_EAGER_TAIL", "1") == "1"   # the actor lane's one-launch tail behind the collective: a plain launch, not a one-node graph
         # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
