@@ -54,79 +54,6 @@ GRL_DEVINL f32x16 bias_acc(const float* bias, int n0, int h) {
   return acc;
 }
 
-template <int CTRL>
-GRL_DEVINL float dpp_read(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-// ---- the fiber convolution as the forward kernel's prologue (round 6).  x2[n,p,c] = bias[c] + sum_o x1[n,o,c] fk[o,p,c] / 16 (reference
-// conv.py:88-90,108-109) where the ConvNeXt block reads it: a lane of node_mlp_fwd_kernel holds 32 channels of row (n, p), and the sixteen
-// lanes of its DPP row hold the same channels of the node's sixteen orientations -- x1[n, (p - k) & 15, c] is a row rotation away
-// (row_ror:k, folded into the multiply-add), so the product costs 512 DPP multiply-adds and 128 sixteen-byte weight loads per lane and
-// 32-row tile, and x1 is read ONCE instead of x1 read + x2 written by a launch of its own and x2 read again here (403 MB and 101 us of the
-// 4096-frame step).  The weights come from the rotated table grl_fiber_basis_fwd writes behind fk (64 KB, L2-resident; no LDS left
-// beside the weight images):
-//   tab[(((k * 8 + t) * 2 + h) * 16 + p) * 4 + j] = fk[(p - k) & 15][p][8 t + 4 h + j] / 16
-// x2 is still written when the backward needs it (x2_out != NULL): 200 MB of stores under an MFMA-bound kernel.
-#ifndef GRL_FROT_NB
-#define GRL_FROT_NB 3   // weight quads in flight: rotations k .. k + NB - 1 (32 registers each)
-#endif
-template <int K>
-GRL_DEVINL void dpp_fmac(float& y, const float& x, const float& w) {
-  asm("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(x), "v"(w), "n"(K));
-}
-template <int K>
-GRL_DEVINL void fiber_rot_load(float4 (&w)[8], const float4* __restrict__ T) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t) w[t] = T[(K * 8 + t) * 32];
-}
-template <int K>
-GRL_DEVINL void fiber_rot_fma(const float4 (&x)[8], float4 (&y)[8], const float4 (&w)[8]) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    if constexpr (K == 0) {
-      y[t].x = fmaf(w[t].x, x[t].x, y[t].x); y[t].y = fmaf(w[t].y, x[t].y, y[t].y);
-      y[t].z = fmaf(w[t].z, x[t].z, y[t].z); y[t].w = fmaf(w[t].w, x[t].w, y[t].w);
-    } else {   // y += w * x[row_ror:K]: ONE instruction (the compiler leaves a v_mov_b32_dpp in front of every multiply-add)
-      dpp_fmac<K>(y[t].x, x[t].x, w[t].x); dpp_fmac<K>(y[t].y, x[t].y, w[t].y);
-      dpp_fmac<K>(y[t].z, x[t].z, w[t].z); dpp_fmac<K>(y[t].w, x[t].w, w[t].w);
-    }
-  }
-}
-template <int K>
-GRL_DEVINL void fiber_rot_step(const float4 (&x)[8], float4 (&y)[8], float4 (&w)[GRL_FROT_NB][8], const float4* __restrict__ T) {
-  if constexpr (K + GRL_FROT_NB - 1 < 16) fiber_rot_load<K + GRL_FROT_NB - 1>(w[(K + GRL_FROT_NB - 1) % GRL_FROT_NB], T);
-  fiber_rot_fma<K>(x, y, w[K % GRL_FROT_NB]);
-  __builtin_amdgcn_sched_barrier(0);   // (one region per rotation: the scheduler otherwise hoists all 128 loads and spills)
-  if constexpr (K < 15) fiber_rot_step<K + 1>(x, y, w, T);
-}
-template <int K>
-GRL_DEVINL void fiber_rot_prime(float4 (&w)[GRL_FROT_NB][8], const float4* __restrict__ T) {
-  fiber_rot_load<K>(w[K], T);
-  if constexpr (K + 1 < GRL_FROT_NB - 1) fiber_rot_prime<K + 1>(w, T);
-}
-// x (the lane's 32 channels of x1's row) -> the same channels of x2's row
-GRL_DEVINL void fiber_rot(float4 (&x)[8], const float* __restrict__ ftab, const float* __restrict__ fbias, int r, int h) {
-  // The lane's 512 weights are the same for every tile: an offset the compiler cannot see through keeps the loads inside the tile loop
-  // (hoisted, they are 512 registers: 2 KB of scratch per lane).  The same statement is the DPP hazard's wait: a VALU-written register
-  // (the bf16 build widens x just before) must be two states old when a DPP operand reads it, and inline DPP is invisible to the
-  // compiler's hazard pass -- every x register goes through an asm that starts with s_nop 1.
-  int zero = 0;
-  asm volatile("s_nop 1" : "+v"(zero), "+v"(x[0].x), "+v"(x[0].y), "+v"(x[0].z), "+v"(x[0].w), "+v"(x[1].x), "+v"(x[1].y), "+v"(x[1].z),
-               "+v"(x[1].w), "+v"(x[2].x), "+v"(x[2].y), "+v"(x[2].z), "+v"(x[2].w), "+v"(x[3].x), "+v"(x[3].y), "+v"(x[3].z), "+v"(x[3].w));
-  asm volatile("" : "+v"(x[4].x), "+v"(x[4].y), "+v"(x[4].z), "+v"(x[4].w), "+v"(x[5].x), "+v"(x[5].y), "+v"(x[5].z), "+v"(x[5].w),
-               "+v"(x[6].x), "+v"(x[6].y), "+v"(x[6].z), "+v"(x[6].w), "+v"(x[7].x), "+v"(x[7].y), "+v"(x[7].z), "+v"(x[7].w));
-  const float4* T = reinterpret_cast<const float4*>(ftab) + (h * 16 + (r & 15) + zero);
-  float4 y[8], w[GRL_FROT_NB][8];
-  fiber_rot_prime<0>(w, T);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) y[t] = *reinterpret_cast<const float4*>(fbias + 8 * t + 4 * h);
-  __builtin_amdgcn_sched_barrier(0);
-  fiber_rot_step<0>(x, y, w, T);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = y[t];
-}
-
 GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
   // a compiler-visible VALU read of the accumulator: it cannot issue before the MFMA group that produced acc has finished
   sink += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, acc[0]), 0xE4, 0xF, 0xF, false));
@@ -136,19 +63,10 @@ GRL_DEVINL void mfma_fence(const f32x16& acc, float& sink) {
 // ------------------------------------------------------------------------------------------------ forward
 // Both GEMMs run on the bf16 matrix pipe with split operands (grl_common.h): per 32-row tile 2 x 96 bf16 MFMAs of 32 cycles
 // instead of 2 x 256 fp32 MFMAs of 64 cycles.
-// FC: ``x2`` is x1, the fiber convolution runs as the prologue of every tile (fiber_rot above: table ftab, bias fbias), x2 is written to
-// x2_out unless that is NULL (inference), and a lane signal may ride on the launch (node_ops.hip lane_signal: flag_dst[0] := flag_src[0]).
-template <bool FC>
 __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restrict__ x2, const st_t* __restrict__ x_dst,
                                                            const float* W3, const float* b3, const float* W4, const float* b4,
                                                            const float* gam, const float* bet, st_t* __restrict__ out,
-                                                           int n_rows, int accumulate, const void* __restrict__ wimg,
-                                                           const float* __restrict__ ftab, const float* __restrict__ fbias,
-                                                           st_t* __restrict__ x2_out, int* flag_dst, const int* flag_src) {
-  if constexpr (FC) {
-    if (flag_dst && blockIdx.x == 0 && threadIdx.x == 0)
-      __hip_atomic_store(flag_dst, flag_src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+                                                           int n_rows, int accumulate, const void* __restrict__ wimg) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   MlpSmemBf& s = *reinterpret_cast<MlpSmemBf*>(smem_raw);
   if (wimg) {   // the whole struct, built once per forward pass by grl_weight_images (kind 2): a linear copy
@@ -197,18 +115,6 @@ __global__ __launch_bounds__(512) void node_mlp_fwd_kernel(const st_t* __restric
 #else
     load_row(x2, rr, h, x);
 #endif
-    if constexpr (FC) {
-      fiber_rot(x, ftab, fbias, r, h);
-#if GRL_PREC   // the backward re-reads x2 as stored: the LayerNorm sees the same (rounded) values in both directions
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        raw4_t u;
-        u.x = pack_rn(x[t].x, x[t].y); u.y = pack_rn(x[t].z, x[t].w);
-        x[t] = widen4(u);
-      }
-#endif
-      if (x2_out && valid) store_row(x2_out, rr, h, x);
-    }
     {  // LayerNorm over the 64 channels of the row, split across the lane pair (l, l^32)
       float sum = 0.f;
 #pragma unroll
@@ -387,6 +293,10 @@ constexpr int LDD = C + 4;        // 68 fp32: partial dA rows
 #ifndef GRL_ROW_DPP
 #define GRL_ROW_DPP 1
 #endif
+template <int CTRL>
+GRL_DEVINL float dpp_read(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 GRL_DEVINL float row16_sum(float v) {
 #if GRL_ROW_DPP
   v += dpp_read<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -783,26 +693,10 @@ int grl_node_mlp_bwd_blocks(int n_rows);
 int GRL_ENTRY(grl_node_mlp_fwd_img)(const st_t* x2, const st_t* x_dst, const float* W3, const float* b3, const float* W4, const float* b4,
                      const float* gamma, const float* beta, st_t* out, int n_rows, int accumulate, const void* wimg, hipStream_t stream) {
   if (n_rows <= 0) return 0;
-  GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
+  GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
   grl_prof_begin_replay("node_mlp_fwd_kernel", stream);
-  hipLaunchKernelGGL(node_mlp_fwd_kernel<false>, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
-                     W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate, wimg, nullptr, nullptr, nullptr, nullptr, nullptr);
-  grl_prof_end_replay(stream);
-  GRL_CHECK_LAUNCH();
-  return 0;
-}
-// The fiber convolution and the ConvNeXt block in ONE launch: out = (accumulate ? out : 0) + x_dst + MLP(LN(x2)) with
-// x2[n,p,c] = fbias[c] + 1/16 sum_o x1[n,o,c] fk[o,p,c] computed per tile from ftab -- the rotated table grl_fiber_basis_fwd writes behind
-// fk (fk + 16*16*64).  x2_out: [n_rows, 64] or NULL (inference: x2 is not kept).  flag_dst / flag_src: optional lane signal (NULL, NULL).
-int GRL_ENTRY(grl_fiber_node_mlp_fwd)(const st_t* x1, const float* ftab, const float* fbias, st_t* x2_out, const st_t* x_dst, const float* W3,
-                                      const float* b3, const float* W4, const float* b4, const float* gamma, const float* beta, st_t* out,
-                                      int n_rows, int accumulate, const void* wimg, int* flag_dst, const int* flag_src, hipStream_t stream) {
-  if (n_rows <= 0) return flag_dst ? -2 : 0;   // (a signal needs a launch to ride on)
-  if (n_rows % 16 != 0 || !ftab || !fbias || (flag_dst && !flag_src)) return -2;
-  GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
-  grl_prof_begin_replay("node_mlp_fwd_kernel", stream);
-  hipLaunchKernelGGL(node_mlp_fwd_kernel<true>, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x1, x_dst,
-                     W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate, wimg, ftab, fbias, x2_out, flag_dst, flag_src);
+  hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
+                     W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate, wimg);
   grl_prof_end_replay(stream);
   GRL_CHECK_LAUNCH();
   return 0;

@@ -616,10 +616,6 @@ GRL_DEVINL void fiber_basis_fwd_body(const FbFwd& A, int blk, float* fb_smem) {
 #pragma unroll 16
     for (int k = 0; k < 64; ++k) acc += w[k] * hs[(FB_RPB + rl) * 64 + k];
     A.fk.p[i][r * 64 + c] = acc;
-    {  // the same value / 16 in the lane layout of node_mlp.hip's fiber_rot (the table behind fk): r = o * 16 + p, k = (p - o) & 15
-      const int o = r >> 4, p = r & 15, k = (p - o) & 15, t = c >> 3, h = (c >> 2) & 1, j = c & 3;
-      A.fk.p[i][FB_ROWS * 64 + ((((k * 8 + t) * 2 + h) * 16 + p) * 4 + j)] = acc * (1.f / 16.f);
-    }
   }
 }
 __global__ __launch_bounds__(256) void fiber_basis_fwd_kernel(FbFwd A) {
@@ -1125,7 +1121,7 @@ static int fb_fwd_fill(FbFwd& A, const float* poly, const float* W1, const float
 }
 #if !GRL_PREC   // parameter-only and reduction entry points exist once (fp32)
 // poly [256,3]; W1 [64,3]; W2 [64,64]; wf: HOST array of n_conv <= 4 device pointers to fiber_kernel weights [64 channels, 64];
-// fk: HOST array of n_conv device pointers to outputs [2][256,64] (fk | the rotated table of node_mlp.hip's fiber_rot); saved: scratch [4,256,64] kept for the backward
+// fk: HOST array of n_conv device pointers to outputs [256,64]; saved: scratch [4,256,64] kept for the backward
 int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, const float* W2, const float* b2, const float* const* wf,
                         int n_conv, float* saved, float* const* fk, hipStream_t stream) {
   FbFwd A{};

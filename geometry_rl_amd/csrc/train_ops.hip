@@ -408,7 +408,7 @@ extern "C" {
 
 // ABI version of this library: major * 10000 + minor * 100 + patch.  Bumped whenever a declared signature changes
 // (include/grl_hip.h GRL_HIP_VERSION must agree: geometry_rl_amd/hip.py checks it at load time).
-int grl_version(void) { return 206; }
+int grl_version(void) { return 205; }
 // The current stream waits (a one-thread kernel: capturable) until flag[0] >= count[0] + add, at most timeout_us microseconds.
 int grl_wait_flag_ge(const int* flag, const int* count, int add, int timeout_us, hipStream_t stream) {
   if (!flag || !count) return -2;

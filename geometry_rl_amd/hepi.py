@@ -203,9 +203,10 @@ class HEPi(nn.Module):
             x1 = ops.EdgeConv.apply(x_src, graph.pos[s], graph.pos[d], grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias,
                                     conv.kernel.weight, es, self.dim, res, self._prec, wimg)
         fk = fks[id(conv)]
+        x2 = ops.FiberConv.apply(x1, fk, conv.bias, self._prec)
         m = conv.node_mlp
-        return ops.conv_block(x1, fk, conv.bias, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res,
-                              self._prec, wimg), x1, fk
+        return ops.NodeMLP.apply(x2, x_dst, m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias, prev, res,
+                                 self._prec, wimg), x1, fk
 
     # ------------------------------------------------------------------ forward
     def latent_step(self, graph: GraphBatch, u_dict) -> torch.Tensor:

@@ -274,7 +274,6 @@ import os as _os
 # module attributes (tests flip them in-process; the A/B scripts through the environment): False = every role is its own launch, as in round 5
 FUSE_HEAD = _os.environ.get("GRL_FUSE_HEAD", "1") == "1"
 FUSE_TAIL_PRE = _os.environ.get("GRL_FUSE_TAIL_PRE", "1") == "1"
-FUSE_FIBER_MLP = _os.environ.get("GRL_FUSE_FIBER_MLP", "1") == "1"   # the fiber convolution as the prologue of the ConvNeXt forward (conv_block)
 SIGNAL_IN_KERNEL = _os.environ.get("GRL_SIGNAL_IN_KERNEL", "1") == "1"   # False: lane signals as 4-byte copy launches of their own
 HEAD = None            # a HeadLaunch while an actor forward that supports it is being issued (policy.GNNGaussianPolicyDiag.forward_diag)
 TAIL_PRE = None        # a dict while PolicyUpdater issues the actor's backward: the first of {lift backward, fiber-basis backward} waits here
@@ -639,20 +638,15 @@ class FiberConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx2):
         x1, fk = ctx.saved_tensors
-        return _fiber_conv_backward(x1, fk, ctx.bias, dx2, ctx.prec) + (None,)
-
-
-def _fiber_conv_backward(x1, fk, bias, dx2, prec):
-    """-> (dx1, dfk, dbias): one launch + the deferred fold of its partial rows."""
-    n = x1.shape[0]
-    blocks = hip.query("grl_fiber_bwd_blocks", n)
-    psize = hip.query("grl_fiber_partial_size")
-    partial = torch.empty(blocks, psize, device=dx2.device, dtype=torch.float32)
-    dx1 = torch.empty_like(x1)
-    hip.check_latent(prec, dx2)
-    hip.call("grl_fiber_conv_bwd" + prec, x1, fk, dx2.contiguous(), dx1, partial, n)
-    dfk, dbias = _emit_grads(partial, [(0, 16 * 16 * 64, (16, 16, 64), None), (16 * 16 * 64, 64, (64,), bias)])
-    return dx1, dfk, dbias
+        n = x1.shape[0]
+        blocks = hip.query("grl_fiber_bwd_blocks", n)
+        psize = hip.query("grl_fiber_partial_size")
+        partial = torch.empty(blocks, psize, device=dx2.device, dtype=torch.float32)
+        dx1 = torch.empty_like(x1)
+        hip.check_latent(ctx.prec, dx2)
+        hip.call("grl_fiber_conv_bwd" + ctx.prec, x1, fk, dx2.contiguous(), dx1, partial, n)
+        dfk, dbias = _emit_grads(partial, [(0, 16 * 16 * 64, (16, 16, 64), None), (16 * 16 * 64, 64, (64,), ctx.bias)])
+        return dx1, dfk, dbias, None
 
 
 class FiberKernels(torch.autograd.Function):
@@ -669,9 +663,7 @@ class FiberKernels(torch.autograd.Function):
         P = [t.contiguous() for t in (w1, b1, w2, b2)]
         W = [t.contiguous() for t in wfs]
         saved = torch.empty(4, 256, 64, device=dev, dtype=torch.float32)
-        # every buffer is [2][16,16,64] (ABI 206): fk, and behind it the same values / 16 in the lane layout of grl_fiber_node_mlp_fwd
-        both = [torch.empty(2, 16, 16, 64, device=dev, dtype=torch.float32) for _ in range(n)]
-        fks, tabs = [b[0] for b in both], [b[1] for b in both]
+        fks = [torch.empty(16, 16, 64, device=dev, dtype=torch.float32) for _ in range(n)]
         if HEAD is not None and HEAD.fiber is None:   # rides in the merged head launch (HeadLaunch)
             HEAD.fiber = (poly2, P, W, saved, fks)
         else:
@@ -679,15 +671,13 @@ class FiberKernels(torch.autograd.Function):
                      (ctypes.c_void_p * n)(*[t.data_ptr() for t in fks]))
         ctx.save_for_backward(poly2, P[2], saved, *W)
         ctx.params = (w1, b1, w2, b2) + tuple(wfs)
-        ctx.mark_non_differentiable(*tabs)
-        return tuple(fks) + tuple(tabs)
+        return tuple(fks)
 
     @staticmethod
     def backward(ctx, *dfks):
         import ctypes
         poly2, w2, saved, *W = ctx.saved_tensors
         n = len(W)
-        dfks = dfks[:n]   # (the tables are non-differentiable outputs)
         dev = poly2.device
         d = [g.contiguous() if g is not None else None for g in dfks]
         partial = torch.empty(hip.query("grl_fiber_basis_blocks"), hip.query("grl_fiber_basis_partial_size", n), device=dev,
@@ -711,11 +701,8 @@ def fiber_kernels(poly, basis_fn, convs):
     out = {}
     for i in range(0, len(convs), 4):
         part = convs[i:i + 4]
-        res = FiberKernels.apply(poly, basis_fn[1].weight, basis_fn[1].bias, basis_fn[3].weight, basis_fn[3].bias,
+        fks = FiberKernels.apply(poly, basis_fn[1].weight, basis_fn[1].bias, basis_fn[3].weight, basis_fn[3].bias,
                                  *[c.fiber_kernel.weight for c in part])
-        fks, tabs = res[:len(part)], res[len(part):]
-        for fk, tab in zip(fks, tabs):
-            fk.ftab = tab   # the rotated table of the same launch: conv_block's fused forward reads it
         out.update({id(c): fk for c, fk in zip(part, fks)})
     return out
 
@@ -741,81 +728,26 @@ class NodeMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x2, *ws = ctx.saved_tensors
+        x2, w3, b3, w4, b4, gamma, beta = ctx.saved_tensors
+        dev = dout.device
         dout = dout.contiguous()
-        dx2, d_dst, grads = _node_mlp_backward(x2, ws, ctx.params, dout, ctx.residual, ctx.prec, ctx.wimg)
-        return (dx2, d_dst) + grads + (dout if ctx.has_prev else None, None, None, None)
-
-
-def _node_mlp_backward(x2, ws, params, dout, residual, prec, wimg):
-    """-> (dx2, d x_dst or None, (dgamma, dbeta, dw3, db3, dw4, db4)): one launch + the deferred fold of its partial rows."""
-    w3, b3, w4, b4, gamma, beta = ws
-    n_rows = x2.shape[0] * 16
-    dx2 = torch.empty_like(x2)
-    blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
-    psize = hip.query("grl_node_mlp_partial_size")
-    partial = torch.empty(blocks + 1, psize, device=dout.device, dtype=torch.float32)   # last row: scratch (shared W3 fragment image)
-    hip.call("grl_node_mlp_bwd_img" + prec, x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows, wimg.mlp_b if wimg else None,
-             rows=n_rows)
-    partial = partial[:blocks]
-    pw3, pb3, pw4, pb4, pg, pbt = params
-    dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
-                                                           (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),
-                                                           (33088, 64, (64,), pg), (33152, 64, (64,), pbt)])
-    d_dst = dout
-    if residual is not None:   # handed to the EdgeConv backward of the same layer (same tensor x feeds both)
-        residual["dres"] = dout
-        d_dst = None
-    return dx2, d_dst, (dgam, dbet, dw3, db3, dw4, db4)
-
-
-class FiberNodeMLP(torch.autograd.Function):
-    """FiberConv + NodeMLP in ONE forward launch (grl_fiber_node_mlp_fwd: the depthwise product as the ConvNeXt kernel's prologue, by DPP
-    row rotations against the rotated table FiberKernels wrote behind fk); the backward is the two launches of the separate functions.
-    x2 is written only when a backward will read it."""
-
-    @staticmethod
-    def forward(ctx, x1, fk, ftab, bias, x_dst, gamma, beta, w3, b3, w4, b4, prev: Optional[torch.Tensor], residual=None, prec: str = "",
-                wimg: Optional[WeightImages] = None):
-        hip.check_f32(fk, ftab, bias, gamma, beta, w3, b3, w4, b4)
-        hip.check_latent(prec, x1, x_dst, prev)
-        ws = [a.contiguous() for a in (w3, b3, w4, b4, gamma, beta)]
-        n_rows = x1.shape[0] * 16
-        keep = any(ctx.needs_input_grad)   # (all False under no_grad: inference does not write x2)
-        x2 = torch.empty_like(x1) if keep else None
-        out = prev.clone() if prev is not None else torch.empty_like(x1)
-        fd = fs = None
-        global PENDING_SIGNAL
-        if PENDING_SIGNAL is not None and x1.shape[0] > 0:   # a lane signal rides on this launch (PolicyUpdater._plan_lanes), as on FiberConv's
-            (fd, fs), PENDING_SIGNAL = PENDING_SIGNAL, None
-        hip.call("grl_fiber_node_mlp_fwd" + prec, x1, ftab, bias.contiguous(), x2, x_dst, *ws, out, n_rows, 1 if prev is not None else 0,
-                 wimg.mlp_f if wimg else None, fd, fs, rows=n_rows)
-        global AFTER_FIBER_HOOK
-        if AFTER_FIBER_HOOK is not None:
-            if AFTER_FIBER_HOOK():
-                AFTER_FIBER_HOOK = None
-        if keep:
-            ctx.save_for_backward(x1, fk.contiguous(), x2, *ws)
-        ctx.has_prev, ctx.prec, ctx.wimg, ctx.residual, ctx.bias = prev is not None, prec, wimg, residual, bias
-        ctx.params = (w3, b3, w4, b4, gamma, beta)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x1, fk, x2, *ws = ctx.saved_tensors
-        dout = dout.contiguous()
-        dx2, d_dst, (dgam, dbet, dw3, db3, dw4, db4) = _node_mlp_backward(x2, ws, ctx.params, dout, ctx.residual, ctx.prec, ctx.wimg)
-        dx1, dfk, dbias = _fiber_conv_backward(x1, fk, ctx.bias, dx2, ctx.prec)
-        return (dx1, dfk, None, dbias, d_dst, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None, None, None, None)
-
-
-def conv_block(x1, fk, bias, x_dst, gamma, beta, w3, b3, w4, b4, prev, residual, prec, wimg):
-    """out = [prev +] x_dst + MLP(LN(fiber_conv(x1, fk) + bias)): one launch (FiberNodeMLP) or the two separate ones."""
-    ftab = getattr(fk, "ftab", None)
-    if FUSE_FIBER_MLP and ftab is not None and x1.shape[0] > 0:
-        return FiberNodeMLP.apply(x1, fk, ftab, bias, x_dst, gamma, beta, w3, b3, w4, b4, prev, residual, prec, wimg)
-    x2 = FiberConv.apply(x1, fk, bias, prec)
-    return NodeMLP.apply(x2, x_dst, gamma, beta, w3, b3, w4, b4, prev, residual, prec, wimg)
+        n_rows = x2.shape[0] * 16
+        dx2 = torch.empty_like(x2)
+        blocks = hip.query("grl_node_mlp_bwd_blocks", n_rows)
+        psize = hip.query("grl_node_mlp_partial_size")
+        partial = torch.empty(blocks + 1, psize, device=dev, dtype=torch.float32)   # last row: scratch (shared W3 fragment image)
+        hip.call("grl_node_mlp_bwd_img" + ctx.prec, x2, dout, w3, b3, w4, b4, gamma, beta, dx2, partial, n_rows,
+                 ctx.wimg.mlp_b if ctx.wimg else None, rows=n_rows)
+        partial = partial[:blocks]
+        pw3, pb3, pw4, pb4, pg, pbt = ctx.params
+        dw3, db3, dw4, db4, dgam, dbet = _emit_grads(partial, [(0, 16384, (256, 64), pw3), (16384, 256, (256,), pb3),
+                                                               (16640, 16384, (64, 256), pw4), (33024, 64, (64,), pb4),
+                                                               (33088, 64, (64,), pg), (33152, 64, (64,), pbt)])
+        d_dst = dout
+        if ctx.residual is not None:   # handed to the EdgeConv backward of the same layer (same tensor x feeds both)
+            ctx.residual["dres"] = dout
+            d_dst = None
+        return (dx2, d_dst, dgam, dbet, dw3, db3, dw4, db4, dout if ctx.has_prev else None, None, None, None)
 
 
 class Readout(torch.autograd.Function):

@@ -146,10 +146,11 @@ class PonitaGCN(nn.Module):
         res = {} if (lo == 0 and torch.is_grad_enabled() and x.requires_grad) else None
         x1 = ops.EdgeConv.apply(x, pos, pos_dst, grid3, b[1].weight, b[1].bias, b[3].weight, b[3].bias, layer.conv.kernel.weight, es,
                                 self.dim, res, self._prec, wimg)
+        x2 = ops.FiberConv.apply(x1, fk, layer.conv.bias, self._prec)
         if collect is not None:
             collect.update(x1=x1, fk=fk)
-        return ops.conv_block(x1, fk, layer.conv.bias, x_dst, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
-                              layer.linear_2.weight, layer.linear_2.bias, None, res, self._prec, wimg)
+        return ops.NodeMLP.apply(x2, x_dst, layer.norm.weight, layer.norm.bias, layer.linear_1.weight, layer.linear_1.bias,
+                                 layer.linear_2.weight, layer.linear_2.bias, None, res, self._prec, wimg)
 
     supports_head = True   # latent_step issues the merged head launch (ops.HeadLaunch) before its first consumer
 

@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 206   /* 206 (round 6): grl_fiber_node_mlp_fwd added, grl_fiber_basis_fwd / grl_step_head write the rotated table behind fk (fk buffers are [2][256][64]); 205 (round 6): grl_source_hash added; 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
+#define GRL_HIP_VERSION 205   /* 205 (round 6): grl_source_hash added; 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
 int grl_version(void);
 /* The hash of the sources this binary was built from (16 hex digits + NUL into buf; returns the length).  geometry_rl_amd/hip.py
    source_hash() recomputes it from csrc/, this header and the build's flag tables and refuses a library that disagrees. */
@@ -184,8 +184,6 @@ int grl_node_mlp_bwd_img_bf16(const grl_bf16* x2, const grl_bf16* dout, const fl
 /* ---- fiber kernel basis (parameter-only, 256 rows): hepi.py:109-123,157 / ponita.py:246-268 + conv.py:62 ------------------------
  * Phi = GELU(W2 GELU(W1 poly + b1) + b2), fk_i = Phi Wf_i^T for n_conv <= 4 convolutions, one launch each way.
  * wf / fk / dfk: HOST arrays of device pointers; saved: scratch [4,256,64] kept for the backward;
- * (ABI 206) every fk buffer is [2][256][64]: [0] = fk[o,p,c]; [1] = the same values / 16 in the lane layout grl_fiber_node_mlp_fwd reads,
- *   tab[(((k*8 + t)*2 + h)*16 + p)*4 + j] = fk[(p - k) & 15][p][8t + 4h + j] / 16   (k: DPP row rotation, t / h / j: the lane's channel quads);
  * partial [grl_fiber_basis_blocks()][grl_fiber_basis_partial_size(n_conv)] = [dWf_0..dWf_{n-1} (4096 each) | dW2 4096 | db2 64 | dW1 192 | db1 64] */
 int grl_fiber_basis_fwd(const float* poly, const float* W1, const float* b1, const float* W2, const float* b2, const float* const* wf,
                         int n_conv, float* saved, float* const* fk, hipStream_t stream);
@@ -220,17 +218,6 @@ int grl_node_mlp_fwd_img(const float* x2, const float* x_dst, const float* W3, c
 int grl_node_mlp_bwd_img(const float* x2, const float* dout, const float* W3, const float* b3, const float* W4, const float* b4,
                          const float* gamma, const float* beta, float* dx2, float* partial, int n_rows, const void* wimg,
                          hipStream_t stream);
-/* (ABI 206) fiber convolution + ConvNeXt block in ONE launch (conv.py:88-90,108-109 + 64-69,112): x2 = fbias + 1/16 sum_o x1 fk computed per
- * 32-row tile from ftab (= fk + 256*64, see grl_fiber_basis_fwd) by DPP row rotations, then out = (accumulate ? out : 0) + x_dst + MLP(LN(x2)).
- * x2_out: [n_rows,64] (kept for grl_node_mlp_bwd) or NULL; flag_dst / flag_src: optional lane signal, flag_dst[0] := flag_src[0] when the
- * launch starts (as grl_fiber_conv_fwd_sig), or NULL, NULL.  n_rows = 16 n_nodes. */
-int grl_fiber_node_mlp_fwd(const float* x1, const float* ftab, const float* fbias, float* x2_out, const float* x_dst, const float* W3,
-                           const float* b3, const float* W4, const float* b4, const float* gamma, const float* beta, float* out, int n_rows,
-                           int accumulate, const void* wimg, int* flag_dst, const int* flag_src, hipStream_t stream);
-int grl_fiber_node_mlp_fwd_bf16(const grl_bf16* x1, const float* ftab, const float* fbias, grl_bf16* x2_out, const grl_bf16* x_dst,
-                                const float* W3, const float* b3, const float* W4, const float* b4, const float* gamma, const float* beta,
-                                grl_bf16* out, int n_rows, int accumulate, const void* wimg, int* flag_dst, const int* flag_src,
-                                hipStream_t stream);
 
 /* ---- read-out + contextual std head: hepi.py:173-190 (ponita_gcn.py:129-146),
  *      algorithms/trust_region_projections/models/policy/gnn_gaussian_policy_diag.py:65-87 ------------------------------------
