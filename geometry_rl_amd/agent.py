@@ -129,10 +129,7 @@ class PolicyUpdater:
         # gated sizes: one step per launch with the gathers inside (by device cursor).  Measured no better than the per-step program with its
         # eager gather (256 / 512 frames: -0.5 % / +0.5 %) and 1 % slower at 4096 frames (gpurun_out -> profiles/r06_ab_forms.txt): OFF
         self.epoch_cursor = os.environ.get("GRL_EPOCH_CURSOR", "0") == "1"
-        # compute units the ConvNeXt kernels leave free (grl_set_reserved_cus: process-wide; the partial-row partition follows it).  With ONE
-        # a gate's waiting wave may stay resident through the backward launches, and a gated lane fits a multi-step launch at every size
-        self.reserved_cus = int(os.environ.get("GRL_RESERVED_CUS", "0"))
-        self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64" if self.reserved_cus < 1 else str(1 << 30)))   # ... above this many frames
+        self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64"))   # ... above this many frames
         self.epoch_gated_from_frames = int(os.environ.get("GRL_EPOCH_GATED_FROM", "3072"))   # run_minibatches: the gated per-step program from here on
         self._epoch = None
         self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
@@ -151,9 +148,6 @@ class PolicyUpdater:
         n = sum(pad4(p.numel()) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        if self.flat.is_cuda and hip.query("grl_reserved_cus") != self.reserved_cus:
-            if hip.query("grl_set_reserved_cus", self.reserved_cus) != 0:
-                raise ValueError(f"GRL_RESERVED_CUS={self.reserved_cus}: 0 .. 64")
         if not self.gate_in_graph and self.flat.is_cuda and not hip.query("grl_can_stream_wait_value"):
             self.gate_in_graph = True   # (no hipStreamWaitValue32 on this device: the gate as a launch)
         # the flat gradient, with room IN FRONT of it for the ranks' loss records ([world][14] (hi, lo) float pairs, grl_trpl_fold_record_pairs):

@@ -16,8 +16,6 @@
 #define MLPB_SYNC() __syncthreads()
 #endif
 
-extern "C" int grl_reserved_cus(void);   // train_ops.hip
-
 namespace {
 
 #ifndef GRL_MLP_NT
@@ -678,10 +676,6 @@ int blocks_for(int n_rows, int rows_per_block, int cap) {
   const int b = (n_rows + rows_per_block - 1) / rows_per_block;
   return b < 1 ? 1 : (b < cap ? b : cap);
 }
-// Workgroups of the two ConvNeXt kernels at most: one per compute unit (each takes a whole one: 8 waves x 256 registers forward, 4 x 512
-// backward) minus the units left free for a lane's waiting wave (grl_set_reserved_cus, train_ops.hip) -- with 256 workgroups and one
-// register-holding wave resident anywhere on the chip the launch finds 255 units and runs twice as long (DESIGN.md finding 59).
-int mlp_cap() { return 256 - grl_reserved_cus(); }
 
 }  // namespace
 
@@ -689,7 +683,7 @@ extern "C" {
 
 #if !GRL_PREC   // shape queries: shared by both precision builds of this file
 int grl_node_mlp_partial_size() { return MLP_PARTIAL; }
-int grl_node_mlp_bwd_blocks(int n_rows) { return blocks_for(n_rows, 32, mlp_cap()); }
+int grl_node_mlp_bwd_blocks(int n_rows) { return blocks_for(n_rows, 32, 256); }
 #else
 int grl_node_mlp_bwd_blocks(int n_rows);
 #endif
@@ -701,7 +695,7 @@ int GRL_ENTRY(grl_node_mlp_fwd_img)(const st_t* x2, const st_t* x_dst, const flo
   if (n_rows <= 0) return 0;
   GRL_ONCE(hipFuncSetAttribute((const void*)node_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemBf)));
   grl_prof_begin_replay("node_mlp_fwd_kernel", stream);
-  hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, mlp_cap())), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
+  hipLaunchKernelGGL(node_mlp_fwd_kernel, dim3(blocks_for(n_rows, 256, 256)), dim3(512), sizeof(MlpSmemBf), stream, x2, x_dst,
                      W3, b3, W4, b4, gamma, beta, out, n_rows, accumulate, wimg);
   grl_prof_end_replay(stream);
   GRL_CHECK_LAUNCH();

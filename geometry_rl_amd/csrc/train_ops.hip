@@ -408,7 +408,7 @@ extern "C" {
 
 // ABI version of this library: major * 10000 + minor * 100 + patch.  Bumped whenever a declared signature changes
 // (include/grl_hip.h GRL_HIP_VERSION must agree: geometry_rl_amd/hip.py checks it at load time).
-int grl_version(void) { return 206; }
+int grl_version(void) { return 205; }
 // The current stream waits (a one-thread kernel: capturable) until flag[0] >= count[0] + add, at most timeout_us microseconds.
 int grl_wait_flag_ge(const int* flag, const int* count, int add, int timeout_us, hipStream_t stream) {
   if (!flag || !count) return -2;
@@ -417,15 +417,6 @@ int grl_wait_flag_ge(const int* flag, const int* count, int add, int timeout_us,
   GRL_CHECK_LAUNCH();
   return 0;
 }
-// Compute units the one-workgroup-per-unit kernels leave free (0 or 1 of the 256): process-wide, set once before the first step -- the
-// partial-row partition of the ConvNeXt backward depends on it (results are reproducible for a given value, not across values).
-static int g_reserved = 0;
-int grl_set_reserved_cus(int n) {
-  if (n < 0 || n > 64) return -2;
-  g_reserved = n;
-  return 0;
-}
-int grl_reserved_cus(void) { return g_reserved; }
 int grl_can_stream_wait_value(void) {
   int dev = 0, v = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GRL_LIB", os.path.join(_HERE, "libgrl_hip.so"))  # GRL_LIB: debugging builds only
-ABI_VERSION = 206   # include/grl_hip.h GRL_HIP_VERSION
+ABI_VERSION = 205   # include/grl_hip.h GRL_HIP_VERSION
 SOURCES = ["edge_conv.hip", "edge_conv16.hip", "node_ops.hip", "node_mlp.hip", "node_mlp16.hip", "head_ops.hip",
            "critic_ops.hip", "train_ops.hip", "weight_images.hip", "calib.hip", "oneshot.hip"]
 # (source, extra flags, object suffix): the two MFMA files are compiled a second time as the plain-bf16 variant (one MFMA per

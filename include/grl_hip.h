@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ABI version (major*10000 + minor*100 + patch); grl_version() returns the value the library was built with. */
-#define GRL_HIP_VERSION 206   /* 206 (round 6): grl_set_reserved_cus / grl_reserved_cus added; 205 (round 6): grl_source_hash added; 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
+#define GRL_HIP_VERSION 205   /* 205 (round 6): grl_source_hash added; 204 (round 5): grl_head_fused / grl_head_fused_rows removed, grl_calib_mfma / grl_calib_copy added; the exports are exactly this header */
 int grl_version(void);
 /* The hash of the sources this binary was built from (16 hex digits + NUL into buf; returns the length).  geometry_rl_amd/hip.py
    source_hash() recomputes it from csrc/, this header and the build's flag tables and refuses a library that disagrees. */
@@ -430,12 +430,6 @@ int grl_adam_report_record_pairs(float* params, const float* grads, float* exp_a
                                  unsigned int* maxes, float entropy_coef, float* out14, hipStream_t stream);
 /* 1 if the current device supports hipStreamWaitValue32 (hipDeviceAttributeCanUseStreamWaitValue), else 0 (host query, no stream). */
 int grl_can_stream_wait_value(void);
-/* (ABI 206) Compute units the kernels that take a whole unit per workgroup (grl_node_mlp_fwd*, grl_node_mlp_bwd*: 256 workgroups in one round)
- * leave FREE, 0 <= n <= 64, process-wide (host calls, no stream): with n = 1 a lane's waiting wave (grl_wait_flag_ge) can stay resident through
- * those launches without halving their speed -- what a gated critic lane inside a multi-step launch needs (PolicyUpdater.run_minibatches).
- * grl_node_mlp_bwd_blocks follows it (the partial-row partition: results are reproducible for a given n, not across values).  Default 0. */
-int grl_set_reserved_cus(int n);
-int grl_reserved_cus(void);
 /* n <= 24 small device-to-device copies in one launch (host arrays of device pointers / byte counts) */
 int grl_copy_many(void* const* dst, const void* const* src, const long long* bytes, int n, hipStream_t stream);
 /* minibatch assembly from a device-resident rollout (train.py:120,128,258-261): dst[k][i,:] = src[k][idx[i],:] for k < n <= 24
