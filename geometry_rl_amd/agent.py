@@ -589,7 +589,7 @@ class PolicyUpdater:
         # beside that launch the critic's kernels cost it 60-170 us at 4096 frames (finding 42; DESIGN round 6).  The wait starts with the step
         # and ends inside the actor's forward: it is never resident during a backward launch.  GRL_DP_GATE_FROM frames (0 = never).
         frames_local = next((int(v.shape[0]) for v in batch.values() if torch.is_tensor(v)), 0)
-        gate_dp = bool(self.dp_gate_from_frames) and frames_local >= self.dp_gate_from_frames
+        gate_dp = bool(self.dp_gate_from_frames) and self._work_frames(frames_local) >= self.dp_gate_from_frames   # (work-normalised, see _work_frames)
 
         def copy4(dst, src):
             import ctypes
@@ -956,10 +956,24 @@ class PolicyUpdater:
         self._epoch = dict(key=(B, U, cursor, id(buf)), idx=idx_static, base=(base_a, base_c), sts=sts, keep=(sa, sc, ga, gc, buf),
                            program=[("fork", None, "m", None), ("graph", ga_graph, "m", None), ("graph", gc_graph, "s", None)] + tail)
 
+    # The size thresholds of the lane policy (_gate_for, run_minibatches) were measured on rigid_insertion_multi HEPi, whose compact graph has
+    # this many edges per frame (kNN + task edges); every other workload is placed on that scale by ITS edge count -- the edge kernels are
+    # 60 % of every step, so a cloth minibatch of 512 frames is "a rigid minibatch of ~1900 frames" to the policy, not a small one
+    POLICY_EDGES_PER_FRAME = 64
+
+    def _work_frames(self, frames: int) -> int:
+        """``frames`` of this workload on the scale the lane policy was measured on: the cached topology's edges / POLICY_EDGES_PER_FRAME
+        (the topology of a size exists once its first, eager step has run; before that the frame count itself)."""
+        hd = getattr(self.loss_module.actor_network, "hyper_data", None)
+        topo = hd._cache.get(frames) if hd is not None else None
+        if not topo or not topo.get("edges"):
+            return frames
+        return max(1, round(sum(es.n_edges for es in topo["edges"].values()) / self.POLICY_EDGES_PER_FRAME))
+
     def _gate_for(self, frames: int) -> bool:
         """Is the critic's lane gated behind the actor's first edge convolution at this minibatch size?  (see _plan_lanes)"""
         mode = self.critic_after_first_conv
-        return bool(mode) and (isinstance(mode, str) or not (768 <= frames < 2048))
+        return bool(mode) and (isinstance(mode, str) or not (768 <= self._work_frames(frames) < 2048))
 
     def run_minibatches(self, buf, idx_rows: torch.Tensor, unroll: Optional[int] = None):
         """The updates of consecutive minibatches: ``idx_rows`` [M, B] int64 (device), row j = the rollout rows of minibatch j (what
@@ -987,8 +1001,9 @@ class PolicyUpdater:
         # (-3.7 % at 128, -1.2 % at 256 / 512, -2 % at 2048) and loses to it at 4096 (+1.7 %), where the critic's 0.25 ms of kernels beside
         # the wrong launches cost more than the boundaries of a 3 ms step; with the gate INSIDE a multi-step launch it loses everywhere
         # above 64 frames (a resident waiting wave during the previous step's one-wave-per-SIMD backward kernels).
-        gate_here = self._gate_for(B) and (B <= self.epoch_unroll_max_gated_frames or B >= self.epoch_gated_from_frames)
-        gated_big = gate_here and B > self.epoch_unroll_max_gated_frames
+        Bw = self._work_frames(B)   # (the thresholds are on the scale of the workload they were measured on)
+        gate_here = self._gate_for(B) and (Bw <= self.epoch_unroll_max_gated_frames or Bw >= self.epoch_gated_from_frames)
+        gated_big = gate_here and Bw > self.epoch_unroll_max_gated_frames
         cursor = gated_big and self.epoch_cursor
         if cursor:
             U = 1
