@@ -414,6 +414,8 @@ def main():
     for i in range(3):  # set-up steps (not warmup): the first runs eagerly and builds the cached topology, the second records the
         upd.step_from(buf, next(mb))  # hipGraph(s), the third is the first replay
     if chunked:   # (the warm-up also records the multi-step launch)
+        if getattr(upd, "autotune_form", False):   # set-up, not warm-up: the updater measures once which recorded form this size takes
+            upd.run_minibatches(buf, take(upd.tune_minibatches(args.unroll)), unroll=args.unroll)
         upd.run_minibatches(buf, take(max(args.warmup, args.unroll)), unroll=args.unroll)
     else:
         for i in range(args.warmup):
@@ -496,7 +498,8 @@ def main():
                            "reduced once per epoch ('advantage_stats_epoch', outside the update)"}
     ms = 1e3 * dt / args.steps
     n_graphs = sum(1 for p_ in (upd._program or []) if p_[0] == "graph")
-    if chunked and getattr(upd, "_epoch", None) is not None:
+    lane_form = getattr(upd, "form_by_size", {}).get(B)
+    if chunked and getattr(upd, "_epoch", None) is not None and lane_form != "per_step":
         upd.mode_timed = (f"graph ({upd._epoch['key'][1]} minibatch step(s) per launch: 2 single-stream hipGraphs on two lanes, in-graph gathers "
                           f"{'by device cursor, lanes joined once per call' if upd._epoch['key'][2] else 'of fixed index rows'}, gate as a launch)")
     else:
@@ -696,6 +699,8 @@ def main():
             "repeats": len(rep_dt_global), "repeats_ms_per_step": [1e3 * x / args.steps for x in rep_dt_global],
             # host time to ENQUEUE a step (median repeat, rank 0): a step whose enqueue time reaches its device time is launch-bound
             "host_enqueue_ms_per_step": 1e3 * sorted(rep_enq)[len(rep_enq) // 2] / args.steps,
+            # which recorded form the one-rank updater took at this size and the measurement behind it (PolicyUpdater._tune_form; null: the table)
+            "lane_form": ({"form": lane_form, **upd.form_times.get(B, {})} if lane_form else None),
             "ms_per_step_min_max": [1e3 * min(rep_dt_global) / args.steps, 1e3 * max(rep_dt_global) / args.steps],
             "value_note": "value = steps / (median over the repeats of the time of one timed region of exactly `steps` steps, max over ranks)",
             "box_calibration": calib, "box_calibration_after": calib_after,

@@ -132,6 +132,9 @@ class PolicyUpdater:
         self.epoch_unroll_max_gated_frames = int(os.environ.get("GRL_EPOCH_UNROLL_MAX_GATED", "64"))   # ... above this many frames
         self.epoch_gated_from_frames = int(os.environ.get("GRL_EPOCH_GATED_FROM", "3072"))   # run_minibatches: the gated per-step program from here on
         self._epoch = None
+        # which recorded form run_minibatches takes above 64 work-frames is measured once per size (_tune_form); GRL_AUTOTUNE_FORM=0: the table
+        self.autotune_form = os.environ.get("GRL_AUTOTUNE_FORM", "1") == "1"
+        self.form_by_size, self.form_times = {}, {}
         self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
         self._copies = []
         self.critic_first = os.environ.get("GRL_CRITIC_FIRST", "0") == "1"
@@ -1005,9 +1008,21 @@ class PolicyUpdater:
         gate_here = self._gate_for(B) and (Bw <= self.epoch_unroll_max_gated_frames or Bw >= self.epoch_gated_from_frames)
         gated_big = gate_here and Bw > self.epoch_unroll_max_gated_frames
         cursor = gated_big and self.epoch_cursor
+        # That table is ONE workload's; on the others the better of the two forms differs by 1-2 % either way (cloth and rope
+        # prefer the gated per-step program at 512 frames, the two-agent EMPN the multi-step launch: profiles/r06_ab_policy.txt).  Both forms
+        # give bitwise the same update, so above 64 work-frames the choice is MEASURED once per size on the running program (_tune_form:
+        # alternating blocks of U steps of each, HIP events) whenever a call brings enough minibatches; until then the table decides.
+        form = self.form_by_size.get(B)
+        if (form is None and self.autotune_form and not self.epoch_cursor and Bw > self.epoch_unroll_max_gated_frames
+                and M - j >= self.tune_minibatches(U)):
+            j, out = self._tune_form(buf, idx_rows, j, U)
+            form = self.form_by_size[B]
+        per_step = (form == "per_step") if form is not None else (gated_big and not cursor)
+        if form == "unrolled":
+            cursor, gate_here = False, False   # (the measured multi-step launch is the ungated one)
         if cursor:
             U = 1
-        elif gated_big:     # a gate inside a multi-step launch is a resident wave during the previous step's backward: the per-step program
+        elif per_step:     # a gate inside a multi-step launch is a resident wave during the previous step's backward: the per-step program
             while j < M:
                 out = self.step_from(buf, idx_rows[j])
                 j += 1
@@ -1052,10 +1067,68 @@ class PolicyUpdater:
             j += 1
         return out
 
+    TUNE_ROUNDS = 2   # alternating blocks per form in _tune_form
+
+    def tune_minibatches(self, U: Optional[int] = None) -> int:
+        """Minibatches one measurement of the two recorded forms consumes (they are ordinary updates, in order)."""
+        U = int(U or self.epoch_unroll)
+        return U + 3 + 2 * self.TUNE_ROUNDS * U
+
+    def _tune_form(self, buf, idx_rows, j, U):
+        """Measure, on the running program, which recorded form is faster at this minibatch size: ``U`` steps per launch with the critic's lane
+        ungated, or one step per launch with the lane gated as ``_gate_for`` says.  Both are recorded and replayed once, then TUNE_ROUNDS
+        alternating blocks of U steps of each are timed with HIP events on the caller's stream (both lanes joined at every block boundary);
+        ONE host synchronisation at the end.  Every step is an ordinary update of the next minibatch, and the two forms produce bitwise the
+        same update (tests/test_gpu_rollout.py), so the measurement changes nothing but the time.  -> (next j, last loss dict)."""
+        B = int(idx_rows.shape[1])
+        main, cs = torch.cuda.current_stream(), self._critic_stream()
+        out = None
+
+        def unrolled(rows):
+            if self._epoch is None or self._epoch["key"] != (B, U, False, id(buf)):
+                self.loss_module._global_steps = self.steps
+                self._compile_epoch(buf, rows[0], U, False, gate=False)
+            ep = self._epoch
+            ep["idx"].copy_(rows)
+            self.steps += U
+            try:
+                self._execute(ep["program"])
+            except BaseException:
+                self.steps -= U
+                raise
+            self.last_outs = [st["out"] for st in ep["sts"]]
+            return self.last_outs[-1]
+
+        def per_step(rows):
+            o = None
+            for r in rows:
+                o = self.step_from(buf, r)
+            return o
+
+        out = unrolled(idx_rows[j:j + U]); j += U          # records (and runs) the multi-step launch
+        out = per_step(idx_rows[j:j + 3]); j += 3          # records the per-step program, first replays
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * self.TUNE_ROUNDS + 1)]
+        main.wait_stream(cs)
+        ev[0].record(main)
+        for r in range(self.TUNE_ROUNDS):
+            out = unrolled(idx_rows[j:j + U]); j += U
+            main.wait_stream(cs)
+            ev[2 * r + 1].record(main)
+            out = per_step(idx_rows[j:j + U]); j += U
+            main.wait_stream(cs)
+            ev[2 * r + 2].record(main)
+        ev[-1].synchronize()
+        t_u = min(ev[2 * r].elapsed_time(ev[2 * r + 1]) for r in range(self.TUNE_ROUNDS)) / U
+        t_p = min(ev[2 * r + 1].elapsed_time(ev[2 * r + 2]) for r in range(self.TUNE_ROUNDS)) / U
+        self.form_by_size[B] = "unrolled" if t_u <= t_p else "per_step"
+        self.form_times[B] = {"unrolled_ms_per_step": t_u, "per_step_ms_per_step": t_p, "steps_per_block": U, "blocks_per_form": self.TUNE_ROUNDS}
+        return j, out
+
     def reset_graph(self):
         """Drop the recorded step (next step re-records): needed when the minibatch size changes."""
         self._program, self._static, self._copies, self._epoch = None, None, [], None
         self._eager_sizes = set()
+        self.form_by_size, self.form_times = {}, {}
 
     def _check_calibrated(self):
         """Data parallel: the first training forward of a fresh actor re-initialises the conv kernels from rank-local data

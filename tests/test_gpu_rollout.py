@@ -101,6 +101,43 @@ def test_several_steps_per_launch_equal_the_step_by_step_loop(form):
         assert torch.equal(got, want)
 
 
+def test_measured_choice_of_the_recorded_form_changes_nothing_but_the_time():
+    """Above 64 work-frames run_minibatches MEASURES which recorded form the size takes (PolicyUpdater._tune_form: the multi-step launch and the
+    per-step program in alternating blocks, HIP events, one synchronisation) as soon as a call brings enough minibatches.  The measurement is
+    made of ordinary updates of the next minibatches, and both forms are bitwise the step-by-step loop -- so is the whole call, whichever
+    form wins; a second call takes the measured form without measuring again."""
+    from geometry_rl_amd import agent
+    from geometry_rl_amd.rollout import RolloutBuffer, RolloutDriver
+    N, T = 96, 30
+    res = {}
+    for form in ("loop", "measured"):
+        spec, cfg, loss, data, next_last = _make(N, T, seed=57)
+        upd = agent.PolicyUpdater(loss, lr=cfg.lr, use_graph=True)
+        upd.epoch_unroll = 4
+        buf = RolloutBuffer(dict(data))
+        drv = RolloutDriver(upd, spec, ppo_epochs=1, seed=5)
+        drv.compute_advantages(buf, next_last)
+        dev = next(iter(buf.data.values())).device
+        idx = torch.stack(drv.epoch_minibatches(buf.N, buf.T, dev))     # [30, 96]
+        if form == "loop":
+            upd.autotune_form = False
+            for j in range(T):
+                upd.step_from(buf, idx[j])
+        else:
+            assert upd.autotune_form and upd.tune_minibatches(4) == 23
+            upd.run_minibatches(buf, idx[:25])           # eager first step, 23 measured steps, one single step
+            assert upd.form_by_size.get(N) in ("unrolled", "per_step")
+            times = dict(upd.form_times[N])
+            assert times["unrolled_ms_per_step"] > 0 and times["per_step_ms_per_step"] > 0
+            upd.run_minibatches(buf, idx[25:])           # five steps in the measured form
+            assert upd.form_times[N] == times            # (not measured again)
+        torch.cuda.synchronize()
+        assert upd.steps == T and int(upd.step_dev.item()) == T and int(upd.step_dev_c.item()) == T
+        res[form] = (upd.flat.detach().clone(), upd.exp_avg.detach().clone(), upd.exp_avg_sq.detach().clone())
+    for a, b in zip(res["loop"], res["measured"]):
+        assert torch.equal(a, b), (a - b).abs().max().item()
+
+
 def test_launch_forms_can_be_mixed_and_follow_a_changed_hyper_parameter():
     """run_minibatches (eight-step launches), step_from (the per-step program) and a changed hyper-parameter in between: the step counts live on
     the device, every program reads the same flat buffers, and a changed Adam epsilon drops EVERY recording (the multi-step one included) -- the
