@@ -5,6 +5,7 @@ replaces the inner loop of ``examples/torchrl/train.py:258-316``."""
 from dataclasses import dataclass
 from typing import Dict, Optional
 
+import contextlib
 import os
 
 import torch
@@ -90,6 +91,24 @@ def build_agent(spec: TaskSpec, cfg: AgentConfig, device="cuda", group=None):
 
 
 _CRITIC_GROUPS = {}   # (id of the actor lane's process group, its ranks) -> the critic lane's communicator
+
+
+@contextlib.contextmanager
+def _no_gc_while_capturing():
+    """Python's cyclic collector must not run while a stream is capturing: if it frees an object that owns device resources -- the hipGraphs
+    or events of an updater that went out of use -- their destruction inside the capture is an error raised from a destructor, and the
+    process aborts (seen once in six runs of tests/test_gpu_rollout.py: "Fatal Python error: Aborted ... Garbage-collecting" under
+    _compile_epoch; this torch's ``torch.cuda.graph`` no longer collects on entry).  Garbage is collected BEFORE the capture, and the
+    collector is held for its duration."""
+    import gc
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class PolicyUpdater:
@@ -831,7 +850,7 @@ class PolicyUpdater:
             g = torch.cuda.CUDAGraph()
             # one allocator pool per lane: graphs of different lanes are replayed concurrently and must not share scratch memory
             # thread_local: background threads of the process (the collectives' watchdog) may keep issuing event queries
-            with torch.cuda.graph(g, pool=pools.get(lane), stream=side, capture_error_mode="thread_local"):
+            with _no_gc_while_capturing(), torch.cuda.graph(g, pool=pools.get(lane), stream=side, capture_error_mode="thread_local"):
                 for fn in item:
                     fn()
             pools[lane] = g.pool()
@@ -944,11 +963,11 @@ class PolicyUpdater:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         ga_graph, gc_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga_graph, stream=side, capture_error_mode="thread_local"):
+        with _no_gc_while_capturing(), torch.cuda.graph(ga_graph, stream=side, capture_error_mode="thread_local"):
             for g_, main_all in mains:
                 g_()
                 main_all()
-        with torch.cuda.graph(gc_graph, stream=side, capture_error_mode="thread_local"):
+        with _no_gc_while_capturing(), torch.cuda.graph(gc_graph, stream=side, capture_error_mode="thread_local"):
             for st, g_, critic_all in critics:
                 st["critic_pre"] = g_              # (behind the lane's gate, in front of its features: critic_all runs it)
                 critic_all()

@@ -200,7 +200,7 @@ class PolicyActor:
                 g.register_generator_state(self.gen)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            with _agent._no_gc_while_capturing(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 self._out = self._pass(self._static)
             torch.cuda.current_stream().wait_stream(side)
             self._graph = g

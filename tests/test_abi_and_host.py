@@ -174,3 +174,37 @@ def test_balanced_node_order_is_a_reproducible_permutation_with_even_slots():
     cut[0], cut[-1] = 0, n
     assert int((rp0[cut[1:]] - rp0[cut[:-1]]).max()) > int(load.max())
     assert int((new_of_old - torch.arange(n)).abs().max()) < 16 * n // slots * 8                  # nodes stay inside their window
+
+
+def test_collector_is_held_while_a_stream_captures():
+    """agent._no_gc_while_capturing: garbage is collected before the capture and the cyclic collector is disabled for its duration (an object
+    with device resources freed inside a capture aborts the process); the collector's previous state comes back, also after an exception."""
+    import gc
+    from geometry_rl_amd import agent
+
+    class Cycle:
+        def __init__(self):
+            self.me = self
+    seen = []
+    import weakref
+    c = Cycle()
+    ref = weakref.ref(c, lambda _: seen.append("freed"))
+    del c
+    assert gc.isenabled()
+    with agent._no_gc_while_capturing():
+        assert seen == ["freed"]            # collected on entry ...
+        assert not gc.isenabled()           # ... and nothing is collected inside
+    assert gc.isenabled()
+    try:
+        with agent._no_gc_while_capturing():
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with agent._no_gc_while_capturing():
+            pass
+        assert not gc.isenabled()           # (a caller that runs without the collector keeps it off)
+    finally:
+        gc.enable()
