@@ -132,15 +132,10 @@ class PolicyUpdater:
         # 4-byte copy behind that launch sets to the step count: _plan_lanes).  Beside that launch the critic's kernels cost it 60-90 us at 4096
         # frames (DESIGN.md finding 42); beside the HBM-bound kernels that follow they cost less: -1.6 % on the step (finding 55).
         self.critic_after_first_conv = critic_after_first_conv
-        # experiment knobs of round 6 (tools/r06_ab_lanes.sh): host enqueue order of the two lanes, priority of the critic's stream
         # the critic lane's gate: a launch of the lane itself (grl_wait_flag_ge, default) or hipStreamWaitValue32 in front of its graph
         # (round 5; GRL_GATE_STREAMWAIT=1 -- a BETA API: taken only where the device reports support)
         self.gate_in_graph = os.environ.get("GRL_GATE_STREAMWAIT", "0") != "1"
         self.epoch_unroll = int(os.environ.get("GRL_EPOCH_UNROLL", "8"))   # minibatch steps per recorded launch of run_minibatches
-        # large single-owner slabs folded (+ Adam) right behind their producers instead of in the tail: measured SLOWER at every size (a
-        # 33.5 MB slab costs 26 us wherever it is folded -- the fold is not a first-touch problem -- and the tail keeps 16 us of its own:
-        # 0.619 -> 0.623 ms at 512 frames, 0.451 -> 0.468 at 256; profiles/r06_ab_earlyfold.txt): 0 = off
-        self.early_fold_bytes = int(os.environ.get("GRL_EARLY_FOLD_MB", "0")) << 20
         # data parallel: gate the critic's lane behind the actor's first edge convolution from this shard size on (0: never).  One-rank RCCL
         # group, alternating on one box (profiles/r06_ab_dp_gate.txt): -4.1 % at 4096 frames per rank, -2 % at 2048, -1.3 % at 1024, 0 at 512
         self.dp_gate_from_frames = int(os.environ.get("GRL_DP_GATE_FROM", "1024"))
@@ -154,10 +149,6 @@ class PolicyUpdater:
         # which recorded form run_minibatches takes above 64 work-frames is measured once per size (_tune_form); GRL_AUTOTUNE_FORM=0: the table
         self.autotune_form = os.environ.get("GRL_AUTOTUNE_FORM", "1") == "1"
         self.form_by_size, self.form_times = {}, {}
-        self.graph_copies = int(os.environ.get("GRL_GRAPH_COPIES", "1"))   # > 1: that many recordings of the step, replayed in turn
-        self._copies = []
-        self.critic_first = os.environ.get("GRL_CRITIC_FIRST", "0") == "1"
-        self.critic_prio = os.environ.get("GRL_CRITIC_PRIO", "low")
 
         self.allow_eager_fallback = allow_eager_fallback   # False: a failed hipGraph capture raises instead of degrading silently
         self.mode = "graph" if use_graph else "eager"      # what actually runs (bench.py reports it)
@@ -259,7 +250,7 @@ class PolicyUpdater:
     def _set_hyper(self, key, value):
         if self._hyper[key] != value:
             self._hyper[key] = value
-            self._program, self._epoch, self._copies = None, None, []   # recorded launches carry the old scalar
+            self._program, self._epoch = None, None   # recorded launches carry the old scalar
 
     eps = property(lambda self: self._hyper["eps"], lambda self, v: self._set_hyper("eps", v))
     betas = property(lambda self: self._hyper["betas"], lambda self, v: self._set_hyper("betas", tuple(v)))
@@ -504,14 +495,11 @@ class PolicyUpdater:
                     copy4(self.lane_flag, self.step_dev)
                     return True
                 ops.AFTER_FIBER_HOOK = signal_f
-            if fuse_tail and self.early_fold_bytes > 0:   # large single-owner slabs are folded (+ Adam) right behind their producers (ops._emit_grads)
-                ops.EARLY_FOLD = dict(adam=self._tail_args(0, na, self.step_dev), overwrite=ow, min_bytes=self.early_fold_bytes, seen=set(), fed=set())
             try:
                 fold_ = self._actor_head(st, None, bool(m.normalize_advantage and st["obs"][0].shape[0] > 1))
             finally:
                 ops.AFTER_EDGE_HOOK = None
                 ops.AFTER_FIBER_HOOK = None
-                ops.EARLY_FOLD = None
                 unsent, ops.PENDING_SIGNAL = ops.PENDING_SIGNAL, None
             if unsent is not None:   # (no fiber convolution followed the edge convolution: send the signal by itself)
                 copy4(*unsent)
@@ -568,8 +556,6 @@ class PolicyUpdater:
 
         wait = [("wait_flag", None, "s", "critic_lane_start")] if (gate and not gate_in_graph) else []
         st["lanes"] = (main_all, critic_all)
-        if self.critic_first:   # host order only: the critic's wait + graph are handed to the device BEFORE the actor's graph
-            return [("fork", None), *wait, ("run", critic_all, "s"), ("run", main_all), ("join", None), ("run_host", lambda: self._finish(st))]
         return [("fork", None), ("run", main_all), *wait, ("run", critic_all, "s"), ("join", None), ("run_host", lambda: self._finish(st))]
 
     def _plan_dp(self, batch, st):
@@ -742,7 +728,7 @@ class PolicyUpdater:
             # the LOWEST priority the device offers: the critic's small launches take the compute units the actor's kernels leave (heads,
             # tails, the latency-bound loss kernel) instead of displacing their workgroups (DESIGN.md finding 33)
             prio = 0
-            if self.critic_prio == "low" and hasattr(torch.cuda.Stream, "priority_range"):
+            if hasattr(torch.cuda.Stream, "priority_range"):
                 try:
                     prio = max(torch.cuda.Stream.priority_range())
                 except Exception:
@@ -801,10 +787,7 @@ class PolicyUpdater:
         m.actor_network.hyper_data.check_topology(*[batch[k] for k in m.in_features])
         m.critic_network._network1.hyper_data.check_topology(*[batch[k] for k in m.critic_in_features])
         self._static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
-        self._copies = []
-        for _copy in range(max(1, self.graph_copies)):   # (graph_copies > 1: the same program recorded again, replayed in turn -- an experiment knob)
-            self._compile_one()
-            self._copies.append((self._program, self._st))
+        self._compile_one()
 
     def _compile_one(self):
         st = self._st = {}
@@ -911,7 +894,7 @@ class PolicyUpdater:
     def _epoch_ok(self) -> bool:
         m = self.loss_module
         return bool(self.use_graph and m.world_size == 1 and not (self.group is not None and self.force_dp_plan) and self.overlap_critic
-                    and m.critic_coef and self.gate_in_graph and self.epoch_unroll > 1 and self.graph_copies <= 1)
+                    and m.critic_coef and self.gate_in_graph and self.epoch_unroll > 1)
 
     def _lane_keys(self, buf):
         m = self.loss_module
@@ -1145,7 +1128,7 @@ class PolicyUpdater:
 
     def reset_graph(self):
         """Drop the recorded step (next step re-records): needed when the minibatch size changes."""
-        self._program, self._static, self._copies, self._epoch = None, None, [], None
+        self._program, self._static, self._epoch = None, None, None
         self._eager_sizes = set()
         self.form_by_size, self.form_times = {}, {}
 
@@ -1228,8 +1211,6 @@ class PolicyUpdater:
                 self.use_graph, self._program, self._static, self.mode = False, None, None, "eager (graph capture failed)"
                 return self._step(batch)
         self._refresh_static(batch)
-        if len(self._copies) > 1:
-            self._program, self._st = self._copies[self.steps % len(self._copies)]
         self._execute(self._program)
         return self._st["out"]
 

@@ -238,23 +238,6 @@ def _emit_grads(partial: torch.Tensor, segments):
     now = [i for i in range(len(segments)) if i not in skip]
     for i in skip:
         outs[i] = None
-    if (EARLY_FOLD is not None and DEFERRED is not None and not any(fresh_flags) and partial.numel() * 4 >= EARLY_FOLD["min_bytes"]
-            and id(partial) not in EARLY_FOLD["seen"]):
-        # A LARGE slab whose destinations it feeds alone (the ConvNeXt block's 33.5 MB): folded -- with the Adam update of exactly those
-        # parameters -- right behind its producer, while its rows are still in the XCDs' L2s / the Infinity Cache, instead of cold in the
-        # lane's tail (the same launch, the same summation order; PolicyUpdater installs EARLY_FOLD only where the tail applies Adam)
-        jobs = [(partial, st, ln, d) for i, (st, ln, d) in enumerate(zip(starts, lens, dsts)) if i not in skip]
-        queued = {j[3].data_ptr() for j in DEFERRED}
-        if jobs and not any(j[3].data_ptr() in queued for j in jobs):
-            keep, EARLY_FOLD["seen"] = DEFERRED, EARLY_FOLD["seen"] | {id(partial)}
-            try:
-                globals()["DEFERRED"] = jobs
-                done = fold_adam_report(EARLY_FOLD["overwrite"], EARLY_FOLD["adam"])
-            finally:
-                globals()["DEFERRED"] = keep
-            if done:
-                EARLY_FOLD["fed"].update(j[3].data_ptr() for j in jobs)
-                return outs
     if DEFERRED is not None:
         jobs = [(partial, st, ln, d) for i, (st, ln, d, f) in enumerate(zip(starts, lens, dsts, fresh_flags)) if not f and i not in skip]
         now = [i for i, f in enumerate(fresh_flags) if f and i not in skip]
@@ -278,7 +261,6 @@ SIGNAL_IN_KERNEL = _os.environ.get("GRL_SIGNAL_IN_KERNEL", "1") == "1"   # False
 HEAD = None            # a HeadLaunch while an actor forward that supports it is being issued (policy.GNNGaussianPolicyDiag.forward_diag)
 TAIL_PRE = None        # a dict while PolicyUpdater issues the actor's backward: the first of {lift backward, fiber-basis backward} waits here
 AFTER_FIBER_HOOK = None
-EARLY_FOLD = None      # dict(adam=..., overwrite=..., min_bytes=..., seen=set(), fed=set()) while PolicyUpdater's fused tail is in force
 PENDING_SIGNAL = None  # (flag_dst, flag_src) int32 tensors: the next FiberConv forward launch writes flag_dst[0] = flag_src[0] when it starts
 
 
