@@ -1,5 +1,6 @@
 #!/bin/bash
 # On the GPU box: the data-parallel program (one-rank RCCL group) of THIS tree against round 5's tree (_ab/r05, its own library) at 4096 and 1024
+# (_ab/r05 = `git archive 89b724b | tar -x -C _ab/r05` + its own build; the copy is scratch and was deleted at the end of round 6)
 # frames, alternating, then a kernel timeline of one DP step of each at 4096 frames.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/dp_vs_r05.txt
