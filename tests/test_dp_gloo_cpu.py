@@ -8,16 +8,10 @@ import os
 import socket
 
 import torch
+
+from spawn_util import spawn_ranks
 import torch.distributed as dist
 import torch.multiprocessing as mp
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _global_ln_stats(x):
@@ -80,8 +74,7 @@ def test_sharded_minibatch_reproduces_full_batch_gradient():
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (ret,))
     assert len(ret) == world
     for r, w in ret.items():
         assert w < 1e-9, (r, w)
@@ -123,7 +116,7 @@ def _stats_worker(rank, world, port, ret):
 def test_epoch_advantage_statistics_two_ranks():
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_stats_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    spawn_ranks(_stats_worker, world, (world,), (ret,))
     for r in range(world):
         ok, calls = ret[r]
         assert ok and calls == ["advantage_stats_epoch"] * 2, (ok, calls)   # ONE collective per epoch

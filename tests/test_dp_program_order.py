@@ -7,16 +7,10 @@ import socket
 
 import pytest
 import torch
+
+from spawn_util import spawn_ranks
 import torch.distributed as dist
 import torch.multiprocessing as mp
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _has_cycle(nodes, edges):
@@ -123,7 +117,7 @@ def test_four_ranks_enqueue_one_sequence_per_communicator_and_no_cycle(one_comm)
     world = 4
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), one_comm, ret), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (one_comm, ret,))
     per_rank = ret["outlines"]
     for pub in (True, False):
         progs = [r[pub] for r in per_rank]

@@ -6,18 +6,12 @@ import socket
 
 import pytest
 import torch
+
+from spawn_util import spawn_ranks
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _setup(B, group):
@@ -68,7 +62,7 @@ def test_two_ranks_match_single_rank():
     ref_flat = upd.flat.detach().cpu()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (B, ret,))
     assert all(r in ret for r in range(world))
     for r in range(world):
         losses, flat = ret[r]
@@ -109,7 +103,7 @@ def test_two_ranks_with_graph_segments_match_single_rank(n_steps):
     ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (B, ret, True, n_steps,))
     assert all(r in ret for r in range(world))
     for r in range(world):
         losses, flat = ret[r]
@@ -126,7 +120,7 @@ def test_two_ranks_on_one_communicator_fallback(monkeypatch):
     ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (B, ret, True, n_steps,))
     assert all(r in ret for r in range(world))
     for r in range(world):
         losses, flat = ret[r]
@@ -143,7 +137,7 @@ def test_two_ranks_with_gated_critic_lane(monkeypatch):
     ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (B, ret, True, n_steps,))
     assert all(r in ret for r in range(world))
     for r in range(world):
         losses, flat = ret[r]
@@ -159,7 +153,7 @@ def test_two_ranks_with_published_advantage_statistics():
     ref_losses, ref_flat = _run_single(B, n_steps, use_graph=False)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret, True, n_steps, True), nprocs=world, join=True)
+    spawn_ranks(_worker, world, (world,), (B, ret, True, n_steps, True,))
     for r in range(world):
         losses, flat = ret[r]
         names = ret[f"collectives{r}"]
@@ -223,7 +217,7 @@ def test_replicas_calibrate_together_and_follow_the_lr_schedule(anneal):
     B, world = 16, 2
     ref_losses, ref_flat = _single_natural(B, anneal)
     ret = mp.Manager().dict()
-    mp.spawn(_worker_natural, args=(world, _free_port(), B, ret, "gloo", anneal), nprocs=world, join=True)
+    spawn_ranks(_worker_natural, world, (world,), (B, ret, "gloo", anneal,))
     for r in range(world):
         losses, flat = ret[r]
         for k, v in ref_losses.items():
@@ -240,7 +234,7 @@ def test_two_ranks_rccl():
     B, world = 16, 2
     ref_losses, ref_flat = _single_natural(B)
     ret = mp.Manager().dict()
-    mp.spawn(_worker_natural, args=(world, _free_port(), B, ret, "nccl"), nprocs=world, join=True)
+    spawn_ranks(_worker_natural, world, (world,), (B, ret, "nccl",))
     for r in range(world):
         losses, flat = ret[r]
         for k, v in ref_losses.items():
@@ -294,7 +288,7 @@ def test_time_batched_critic_pass_two_ranks_equals_one_rank():
         ref = critic(*[obs[k].to(dev) for k in spec.in_features], train=False).reshape(N, T).cpu()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_critic_worker, args=(world, _free_port(), N, T, ret), nprocs=world, join=True)
+    spawn_ranks(_critic_worker, world, (world,), (N, T, ret,))
     got = torch.cat([ret[r][0] for r in range(world)], dim=0)
     err = (got - ref).abs().max().item()
     print(f"time-batched critic, {world} ranks vs 1: max |dV| = {err:.3e} (|V| max {ref.abs().max().item():.3e}); all-reduces per rank: {ret[0][1]}")

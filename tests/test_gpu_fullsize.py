@@ -11,6 +11,8 @@ is not the checker:
 import pytest
 import torch
 
+from spawn_util import spawn_ranks
+
 pytestmark = pytest.mark.gpu
 B = 4096
 KEYS = ("loss_objective", "loss_trust_region", "loss_entropy", "loss_critic", "kl", "ESS", "mean_constraint", "cov_constraint", "entropy")
@@ -97,9 +99,8 @@ def test_full_size_four_shards_match_the_full_minibatch(wl):
     import torch.multiprocessing as mp
     agent, spec, cfg, actor, critic, loss, batch = _make(wl=wl)
     l0, g0, _ = _one_update(agent, loss, cfg, batch)
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_dp_worker, args=(4, port, ret, wl), nprocs=4, join=True)
+    spawn_ranks(_dp_worker, 4, (4,), (ret, wl,))
     scale = float(g0.abs().max())
     for r in range(4):
         lr_, gr = ret[r]
